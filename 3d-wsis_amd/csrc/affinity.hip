@@ -1,0 +1,364 @@
+// Inter-superpoint affinity.
+//
+//  a16  edge attention  modules/model/backbone_3D_WSIS.py:218-249
+//       logit_e = (q[u].k[v]) * scale * pos_e ; a = softmax over the out-edges of u ;
+//       res[u] = sum_e a_e v[v_e].  One wavefront owns one source superpoint (CSR over u), so the
+//       segment softmax and the weighted sum need no atomics and have a fixed order.
+//  a17  dense S x S fp64 affinity matrix, masked row-normalised transition matrix, fp64 matrix
+//       product on the f64 MFMA (v_mfma_f64_16x16x4_f64), column max / first argmax.
+//       train_scannetv2.py:562-570, modules/datasets/scannetv2_dataset.py:679-721
+#include "common.h"
+
+using namespace wsis;
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// dot of two D-vectors spread over the 64 lanes (fixed order: lane-strided partials + butterfly)
+__device__ __forceinline__ float wave_dot(const float* __restrict__ a, const float* __restrict__ b, int D,
+                                          int lane) {
+  float p = 0.0f;
+  for (int d = lane; d < D; d += 64) p += a[d] * b[d];
+  return wave_sum(p);
+}
+
+__global__ __launch_bounds__(256) void edge_affinity_fwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ pos, const int64_t* __restrict__ ev, const int32_t* __restrict__ perm_u,
+    const int32_t* __restrict__ off_u, float scale, float* __restrict__ aff, float* __restrict__ res,
+    int64_t Su, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t u = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); u < Su; u += nwaves) {
+    const int beg = off_u[u], end = off_u[u + 1];
+    const float* qu = q + u * D;
+    // pass 1: max logit
+    float mx = -INFINITY;
+    for (int j = beg; j < end; ++j) {
+      const int32_t e = perm_u[j];
+      const float lg = wave_dot(qu, k + ev[e] * D, D, lane) * scale * pos[e];
+      mx = fmaxf(mx, lg);
+    }
+    // pass 2: sum of exp
+    float tot = 0.0f;
+    for (int j = beg; j < end; ++j) {
+      const int32_t e = perm_u[j];
+      const float lg = wave_dot(qu, k + ev[e] * D, D, lane) * scale * pos[e];
+      tot += expf(lg - mx);
+    }
+    // pass 3: normalised affinity and weighted value sum
+    for (int d0 = 0; d0 < D; d0 += 64) {
+      const int d = d0 + lane;
+      float r = 0.0f;
+      for (int j = beg; j < end; ++j) {
+        const int32_t e = perm_u[j];
+        const int64_t ve = ev[e];
+        const float lg = wave_dot(qu, k + ve * D, D, lane) * scale * pos[e];
+        const float a = expf(lg - mx) / tot;
+        if (d0 == 0 && lane == 0) aff[e] = a;
+        if (d < D) r += a * v[ve * D + d];
+      }
+      if (d < D) res[u * D + d] = r;
+    }
+  }
+}
+
+// backward, pass over sources u: dq, dpos, and per-edge ds (stored in tmp[0:E])
+__global__ __launch_bounds__(256) void edge_affinity_bwd_u_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const float* __restrict__ pos, const float* __restrict__ aff, const int64_t* __restrict__ ev,
+    const int32_t* __restrict__ perm_u, const int32_t* __restrict__ off_u, float scale,
+    const float* __restrict__ daff, const float* __restrict__ dres, float* __restrict__ dq,
+    float* __restrict__ dpos, float* __restrict__ ds_out, int64_t Su, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t u = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); u < Su; u += nwaves) {
+    const int beg = off_u[u], end = off_u[u + 1];
+    const float* qu = q + u * D;
+    const float* dru = dres + u * D;
+    // sum_e a_e * da_e
+    float dotsum = 0.0f;
+    for (int j = beg; j < end; ++j) {
+      const int32_t e = perm_u[j];
+      float da = wave_dot(dru, v + ev[e] * D, D, lane);
+      if (daff) da += daff[e];
+      dotsum += aff[e] * da;
+    }
+    for (int d0 = 0; d0 < D; d0 += 64) {
+      const int d = d0 + lane;
+      float gq = 0.0f;
+      for (int j = beg; j < end; ++j) {
+        const int32_t e = perm_u[j];
+        const int64_t ve = ev[e];
+        float da = wave_dot(dru, v + ve * D, D, lane);
+        if (daff) da += daff[e];
+        const float a = aff[e];
+        const float dlogit = a * (da - dotsum);
+        const float s = wave_dot(qu, k + ve * D, D, lane) * scale;
+        const float dsv = dlogit * pos[e] * scale;
+        if (d0 == 0 && lane == 0) {
+          dpos[e] = dlogit * s;
+          ds_out[e] = dsv;
+        }
+        if (d < D) gq += dsv * k[ve * D + d];
+      }
+      if (d < D) dq[u * D + d] = gq;
+    }
+  }
+}
+
+// backward, pass over targets v: dk[v] = sum ds_e q[u_e], dv[v] = sum a_e dres[u_e]
+__global__ __launch_bounds__(256) void edge_affinity_bwd_v_kernel(
+    const float* __restrict__ q, const float* __restrict__ aff, const float* __restrict__ ds,
+    const int64_t* __restrict__ eu, const int32_t* __restrict__ perm_v, const int32_t* __restrict__ off_v,
+    const float* __restrict__ dres, float* __restrict__ dk, float* __restrict__ dv, int64_t S, int64_t Su,
+    int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t t = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); t < S; t += nwaves) {
+    const int beg = off_v[t], end = off_v[t + 1];
+    for (int d0 = 0; d0 < D; d0 += 64) {
+      const int d = d0 + lane;
+      if (d >= D) continue;
+      float gk = 0.0f, gv = 0.0f;
+      for (int j = beg; j < end; ++j) {
+        const int32_t e = perm_v[j];
+        const int64_t ue = eu[e];
+        gk += ds[e] * q[ue * D + d];
+        gv += aff[e] * dres[ue * D + d];
+      }
+      dk[t * D + d] = gk;
+      dv[t * D + d] = gv;
+    }
+  }
+}
+
+__global__ void dense_build_kernel(const int64_t* __restrict__ eu, const int64_t* __restrict__ ev,
+                                   const float* __restrict__ aff, int64_t E, double* __restrict__ A,
+                                   int64_t S) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < E;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t u = eu[e], w = ev[e];
+    if (u >= 0 && u < S && w >= 0 && w < S) A[u * S + w] = (double)aff[e];
+  }
+}
+
+// one workgroup per row: W = A*adj*sem, d = rowsum (0 -> 1), T0 = W/d
+__global__ __launch_bounds__(256) void transition_kernel(const double* __restrict__ A,
+                                                         const uint8_t* __restrict__ adj,
+                                                         const int32_t* __restrict__ pred,
+                                                         const float* __restrict__ conf,
+                                                         const int32_t* __restrict__ label, int cls, float thr,
+                                                         double* __restrict__ T0, int64_t S) {
+  __shared__ double red[256];
+  const int64_t r = blockIdx.x;
+  const bool mr = pred[r] == cls && conf[r] > thr;
+  const bool lr = label[r] == cls;
+  double part = 0.0;
+  for (int64_t j = threadIdx.x; j < S; j += blockDim.x) {
+    const bool mj = pred[j] == cls && conf[j] > thr;
+    const bool sem = (mr && mj) || (j == r && lr);
+    const double w = sem ? A[r * S + j] * (double)adj[r * S + j] : 0.0;
+    T0[r * S + j] = w;
+    part += w;
+  }
+  red[threadIdx.x] = part;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  double dsum = red[0];
+  if (dsum == 0.0) dsum = 1.0;
+  for (int64_t j = threadIdx.x; j < S; j += blockDim.x) T0[r * S + j] = T0[r * S + j] / dsum;
+}
+
+// ---- fp64 GEMM on the f64 matrix cores ----------------------------------------------------
+// block tile 64x64, BK = 16, 4 waves each owning a 32x32 quadrant (2x2 MFMA 16x16x4 tiles).
+// v_mfma_f64_16x16x4_f64: A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15],
+// C/D: col = lane&15, row = (lane>>4) + 4*reg.
+constexpr int GB = 64;
+constexpr int GK = 16;
+__global__ __launch_bounds__(256) void dgemm_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                    double* __restrict__ C, int64_t M, int64_t N, int64_t Kd) {
+  __shared__ double As[GB][GK + 1];
+  __shared__ double Bs[GK][GB + 1];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+  const int64_t row0 = (int64_t)blockIdx.y * GB, col0 = (int64_t)blockIdx.x * GB;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
+  for (int64_t k0 = 0; k0 < Kd; k0 += GK) {
+    for (int f = tid; f < GB * GK; f += 256) {
+      const int r = f / GK, c = f % GK;
+      const int64_t gr = row0 + r, gc = k0 + c;
+      As[r][c] = (gr < M && gc < Kd) ? A[gr * Kd + gc] : 0.0;
+    }
+    for (int f = tid; f < GK * GB; f += 256) {
+      const int r = f / GB, c = f % GB;
+      const int64_t gr = k0 + r, gc = col0 + c;
+      Bs[r][c] = (gr < Kd && gc < N) ? B[gr * N + gc] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 4) {
+      const int kq = kk + (lane >> 4);
+      double a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[wr + i * 16 + (lane & 15)][kq];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[kq][wc + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t gr = row0 + wr + i * 16 + (lane >> 4) + 4 * e;
+        const int64_t gc = col0 + wc + j * 16 + (lane & 15);
+        if (gr < M && gc < N) C[gr * N + gc] = acc[i][j][e];
+      }
+}
+
+__global__ void colmax_kernel(const double* __restrict__ T, const int32_t* __restrict__ label, int cls,
+                              double* __restrict__ scores, int32_t* __restrict__ arg, int64_t S) {
+  for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < S;
+       j += (int64_t)gridDim.x * blockDim.x) {
+    // np.max / np.argmax over axis 0 of a matrix whose non-class rows are zero: first max wins
+    double best = 0.0;
+    int32_t bi = -1;
+    for (int64_t r = 0; r < S; ++r) {
+      const double val = (label[r] == cls) ? T[r * S + j] : 0.0;
+      if (bi < 0 || val > best) {
+        best = val;
+        bi = (int32_t)r;
+      }
+    }
+    scores[j] = best;
+    arg[j] = bi < 0 ? 0 : bi;
+  }
+}
+
+int waves_grid(int64_t segments) {
+  int64_t g = ceil_div(segments, 4);
+  if (g < 1) g = 1;
+  if (g > 256 * 16) g = 256 * 16;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wsis_edge_affinity_fwd(const float* d_q, const float* d_k, const float* d_v, const float* d_pos,
+                           const int64_t* d_eu, const int64_t* d_ev, const int32_t* d_perm_u,
+                           const int32_t* d_off_u, float scale, float* d_aff, float* d_res, int64_t E,
+                           int64_t Su, int32_t D, void* stream) {
+  WSIS_REQUIRE(E >= 0 && Su >= 0 && D >= 1, "bad sizes");
+  if (Su == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_q && d_k && d_v && d_off_u && d_res, "null pointer");
+  WSIS_REQUIRE(E == 0 || (d_pos && d_ev && d_perm_u && d_aff), "null pointer");
+  (void)d_eu;
+  hipLaunchKernelGGL(edge_affinity_fwd_kernel, dim3(waves_grid(Su)), dim3(256), 0, as_stream(stream), d_q,
+                     d_k, d_v, d_pos, d_ev, d_perm_u, d_off_u, scale, d_aff, d_res, Su, D);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_edge_affinity_bwd(const float* d_q, const float* d_k, const float* d_v, const float* d_pos,
+                           const float* d_aff, const int64_t* d_eu, const int64_t* d_ev,
+                           const int32_t* d_perm_u, const int32_t* d_off_u, const int32_t* d_perm_v,
+                           const int32_t* d_off_v, float scale, const float* d_daff,
+                           const float* d_dres, float* d_dq, float* d_dk, float* d_dv, float* d_dpos,
+                           float* d_tmp, int64_t E, int64_t S, int64_t Su, int32_t D, void* stream) {
+  WSIS_REQUIRE(E >= 0 && S >= 0 && Su >= 0 && Su <= S && D >= 1, "bad sizes");
+  if (S == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_q && d_k && d_v && d_dres && d_dq && d_dk && d_dv && d_off_u && d_off_v, "null pointer");
+  WSIS_REQUIRE(E == 0 || (d_pos && d_aff && d_eu && d_ev && d_perm_u && d_perm_v && d_dpos && d_tmp),
+               "null pointer");
+  hipStream_t st = as_stream(stream);
+  WSIS_HIP_CHECK(hipMemsetAsync(d_dq, 0, sizeof(float) * (size_t)S * D, st));
+  if (Su > 0) {
+    hipLaunchKernelGGL(edge_affinity_bwd_u_kernel, dim3(waves_grid(Su)), dim3(256), 0, st, d_q, d_k, d_v,
+                       d_pos, d_aff, d_ev, d_perm_u, d_off_u, scale, d_daff, d_dres, d_dq, d_dpos, d_tmp, Su,
+                       D);
+    WSIS_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(edge_affinity_bwd_v_kernel, dim3(waves_grid(S)), dim3(256), 0, st, d_q, d_aff, d_tmp,
+                     d_eu, d_perm_v, d_off_v, d_dres, d_dk, d_dv, S, Su, D);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_affinity_dense_build(const int64_t* d_eu, const int64_t* d_ev, const float* d_aff, int64_t E,
+                              double* d_A, int64_t S, void* stream) {
+  WSIS_REQUIRE(E >= 0 && S >= 0, "bad sizes");
+  if (S == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_A, "null pointer");
+  hipStream_t st = as_stream(stream);
+  WSIS_HIP_CHECK(hipMemsetAsync(d_A, 0, sizeof(double) * (size_t)S * S, st));
+  if (E == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_eu && d_ev && d_aff, "null pointer");
+  hipLaunchKernelGGL(dense_build_kernel, dim3(grid_for(E, 256)), dim3(256), 0, st, d_eu, d_ev, d_aff, E, d_A,
+                     S);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_affinity_transition(const double* d_A, const uint8_t* d_adj, const int32_t* d_pred,
+                             const float* d_conf, const int32_t* d_label, int32_t cls, float thr,
+                             double* d_T0, int64_t S, void* stream) {
+  WSIS_REQUIRE(S >= 0, "bad size");
+  if (S == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_A && d_adj && d_pred && d_conf && d_label && d_T0, "null pointer");
+  hipLaunchKernelGGL(transition_kernel, dim3((unsigned)S), dim3(256), 0, as_stream(stream), d_A, d_adj,
+                     d_pred, d_conf, d_label, cls, thr, d_T0, S);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_dgemm(const double* d_A, const double* d_B, double* d_C, int64_t M, int64_t N, int64_t Kd,
+               void* stream) {
+  WSIS_REQUIRE(M >= 0 && N >= 0 && Kd >= 0, "bad sizes");
+  if (M == 0 || N == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_A && d_B && d_C, "null pointer");
+  const dim3 grid((unsigned)ceil_div(N, GB), (unsigned)ceil_div(M, GB));
+  hipLaunchKernelGGL(dgemm_kernel, grid, dim3(256), 0, as_stream(stream), d_A, d_B, d_C, M, N, Kd);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_affinity_colmax(const double* d_T, const int32_t* d_label, int32_t cls, double* d_scores,
+                         int32_t* d_arg, int64_t S, void* stream) {
+  WSIS_REQUIRE(S >= 0, "bad size");
+  if (S == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_T && d_label && d_scores && d_arg, "null pointer");
+  hipLaunchKernelGGL(colmax_kernel, dim3(grid_for(S, 64)), dim3(64), 0, as_stream(stream), d_T, d_label, cls,
+                     d_scores, d_arg, S);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+}  // extern "C"

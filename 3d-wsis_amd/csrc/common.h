@@ -1,0 +1,67 @@
+// Shared helpers for libwsis_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/wsis_hip.h"
+
+namespace wsis {
+
+std::string& err_slot();
+int fail(int code, const char* fmt, ...);
+
+#define WSIS_HIP_CHECK(expr)                                                          \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess)                                                             \
+      return ::wsis::fail(WSIS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                          __FILE__, __LINE__);                                        \
+  } while (0)
+
+#define WSIS_LAUNCH_CHECK() WSIS_HIP_CHECK(hipGetLastError())
+
+#define WSIS_REQUIRE(cond, msg)                                     \
+  do {                                                              \
+    if (!(cond)) return ::wsis::fail(WSIS_ERR_ARG, "%s: %s", __func__, msg); \
+  } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// grid size for a grid-stride memory-bound kernel: cap at 8 blocks per CU (guide: Guideline 11)
+inline int grid_for(int64_t work_items, int block) {
+  int64_t g = ceil_div(work_items, block);
+  if (g < 1) g = 1;
+  if (g > 256 * 8) g = 256 * 8;
+  return (int)g;
+}
+
+// ---- device-side hash (linear-index keys) --------------------------------------------------
+constexpr int64_t kEmptyKey = -1;
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+__device__ __forceinline__ int32_t hash_lookup(const int64_t* __restrict__ keys,
+                                               const int32_t* __restrict__ vals, uint64_t mask,
+                                               int64_t key) {
+  uint64_t h = mix64((uint64_t)key) & mask;
+  for (;;) {
+    int64_t k = keys[h];
+    if (k == key) return vals[h];
+    if (k == kEmptyKey) return -1;
+    h = (h + 1) & mask;
+  }
+}
+
+}  // namespace wsis

@@ -1,0 +1,405 @@
+// Rulebook construction: coordinate hash, SubMConv3d gather table,
+// SparseConv3d output set (ascending linear index) + coupled down/up gather tables, and the
+// mask ordering used by the implicit-GEMM tiles.  Integer work, HBM/latency bound.
+//
+// Semantics restated from [UPSTREAM] spconv v1.0 getIndicePair:
+//   pair (in p, out o) under kernel offset kappa iff p_j = o_j*s_j - pad_j + kappa_j, 0<=kappa_j<k_j,
+//   0<=o_j<out_j; flat offset = (kappa0*k1+kappa1)*k2+kappa2.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+
+#include "common.h"
+
+using namespace wsis;
+
+namespace {
+
+struct Geo {
+  int shape_in[3];
+  int shape_out[3];
+  int k[3];
+  int s[3];
+  int p[3];
+};
+
+__device__ __forceinline__ int64_t lin_key(int b, int c0, int c1, int c2, const int* S) {
+  return (((int64_t)b * S[0] + c0) * S[1] + c1) * S[2] + c2;
+}
+
+__global__ void hash_insert_kernel(const int32_t* __restrict__ indices, int64_t M, Geo g,
+                                   int64_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                   uint64_t mask) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < M;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(indices)[r];
+    const int64_t key = lin_key(c.x, c.y, c.z, c.w, g.shape_in);
+    uint64_t h = mix64((uint64_t)key) & mask;
+    for (;;) {
+      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(keys + h),
+                                         (unsigned long long)kEmptyKey, (unsigned long long)key);
+      if (old == (unsigned long long)kEmptyKey || old == (unsigned long long)key) {
+        atomicMin(vals + h, (int32_t)r);  // duplicates: smallest row wins (deterministic)
+        break;
+      }
+      h = (h + 1) & mask;
+    }
+  }
+}
+
+// one thread per output row, loop over the K offsets: writes nbr[k*M + r] (coalesced per k)
+__global__ void subm_kernel(const int32_t* __restrict__ indices, int64_t M, Geo g,
+                            const int64_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                            uint64_t mask, int32_t* __restrict__ nbr, uint32_t* __restrict__ omask) {
+  const int K = g.k[0] * g.k[1] * g.k[2];
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < M;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(indices)[r];
+    uint32_t bits = 0;
+    int kf = 0;
+    for (int a = 0; a < g.k[0]; ++a) {
+      const int x = c.y - g.p[0] + a;
+      for (int b = 0; b < g.k[1]; ++b) {
+        const int y = c.z - g.p[1] + b;
+        for (int d = 0; d < g.k[2]; ++d, ++kf) {
+          const int z = c.w - g.p[2] + d;
+          int32_t v = -1;
+          if (x >= 0 && x < g.shape_in[0] && y >= 0 && y < g.shape_in[1] && z >= 0 &&
+              z < g.shape_in[2]) {
+            if (x == c.y && y == c.z && z == c.w)
+              v = (int32_t)r;
+            else
+              v = hash_lookup(keys, vals, mask, lin_key(c.x, x, y, z, g.shape_in));
+          }
+          nbr[(int64_t)kf * M + r] = v;
+          if (v >= 0 && kf < 32) bits |= (1u << kf);
+        }
+      }
+    }
+    if (omask) omask[r] = bits;
+  }
+}
+
+// candidate output keys of every active input; invalid candidates get key == invalid
+__global__ void down_cand_kernel(const int32_t* __restrict__ indices, int64_t M, Geo g, int fast,
+                                 int64_t invalid, int64_t* __restrict__ cand) {
+  const int K = g.k[0] * g.k[1] * g.k[2];
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < M;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(indices)[r];
+    const int p[3] = {c.y, c.z, c.w};
+    if (fast) {
+      int o[3];
+      bool ok = true;
+      for (int j = 0; j < 3; ++j) {
+        o[j] = p[j] / g.s[j];
+        ok = ok && o[j] < g.shape_out[j];
+      }
+      cand[r] = ok ? lin_key(c.x, o[0], o[1], o[2], g.shape_out) : invalid;
+    } else {
+      int kf = 0;
+      for (int a = 0; a < g.k[0]; ++a)
+        for (int b = 0; b < g.k[1]; ++b)
+          for (int d = 0; d < g.k[2]; ++d, ++kf) {
+            const int kk[3] = {a, b, d};
+            int o[3];
+            bool ok = true;
+            for (int j = 0; j < 3; ++j) {
+              const int t = p[j] + g.p[j] - kk[j];
+              ok = ok && t >= 0 && (t % g.s[j]) == 0;
+              o[j] = t / g.s[j];
+              ok = ok && o[j] < g.shape_out[j];
+            }
+            cand[r * K + kf] = ok ? lin_key(c.x, o[0], o[1], o[2], g.shape_out) : invalid;
+          }
+    }
+  }
+}
+
+__global__ void down_fix_count_kernel(const int64_t* __restrict__ out_keys, int64_t invalid,
+                                      int32_t* __restrict__ count) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int32_t n = *count;
+    if (n > 0 && out_keys[n - 1] == invalid) --n;
+    *count = n;
+  }
+}
+
+// decode sorted unique keys -> out indices, insert (key -> row) into the coarse hash
+__global__ void down_decode_kernel(const int64_t* __restrict__ out_keys, int64_t M_out, Geo g,
+                                   int32_t* __restrict__ indices_out, int64_t* __restrict__ keys,
+                                   int32_t* __restrict__ vals, uint64_t mask) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < M_out;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    int64_t key = out_keys[r];
+    int64_t t = key;
+    const int c2 = (int)(t % g.shape_out[2]);
+    t /= g.shape_out[2];
+    const int c1 = (int)(t % g.shape_out[1]);
+    t /= g.shape_out[1];
+    const int c0 = (int)(t % g.shape_out[0]);
+    t /= g.shape_out[0];
+    reinterpret_cast<int4*>(indices_out)[r] = make_int4((int)t, c0, c1, c2);
+    uint64_t h = mix64((uint64_t)key) & mask;
+    for (;;) {
+      unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(keys + h),
+                                         (unsigned long long)kEmptyKey, (unsigned long long)key);
+      if (old == (unsigned long long)kEmptyKey) {
+        vals[h] = (int32_t)r;
+        break;
+      }
+      h = (h + 1) & mask;
+    }
+  }
+}
+
+__global__ void down_fill_kernel(const int32_t* __restrict__ indices, int64_t M_in, int64_t M_out,
+                                 Geo g, const int64_t* __restrict__ keys,
+                                 const int32_t* __restrict__ vals, uint64_t mask,
+                                 int32_t* __restrict__ nbr_down, int32_t* __restrict__ nbr_up,
+                                 uint32_t* __restrict__ mask_down, uint32_t* __restrict__ mask_up) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < M_in;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(indices)[r];
+    const int p[3] = {c.y, c.z, c.w};
+    uint32_t bits = 0;
+    int kf = 0;
+    for (int a = 0; a < g.k[0]; ++a)
+      for (int b = 0; b < g.k[1]; ++b)
+        for (int d = 0; d < g.k[2]; ++d, ++kf) {
+          const int kk[3] = {a, b, d};
+          int o[3];
+          bool ok = true;
+          for (int j = 0; j < 3; ++j) {
+            const int t = p[j] + g.p[j] - kk[j];
+            ok = ok && t >= 0 && (t % g.s[j]) == 0;
+            o[j] = t / g.s[j];
+            ok = ok && o[j] < g.shape_out[j];
+          }
+          if (!ok) continue;
+          const int32_t orow =
+              hash_lookup(keys, vals, mask, lin_key(c.x, o[0], o[1], o[2], g.shape_out));
+          if (orow < 0) continue;  // cannot happen: every valid candidate is an output
+          nbr_down[(int64_t)kf * M_out + orow] = (int32_t)r;
+          nbr_up[(int64_t)kf * M_in + r] = orow;
+          if (kf < 32) {
+            bits |= (1u << kf);
+            if (mask_down) atomicOr(mask_down + orow, 1u << kf);
+          }
+        }
+    if (mask_up) mask_up[r] = bits;
+  }
+}
+
+__global__ void iota_kernel(int32_t* __restrict__ p, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = (int32_t)i;
+}
+
+int fill_geo(Geo& g, const int32_t* in_shape, const int32_t* out_shape, const int32_t* k,
+             const int32_t* s, const int32_t* p) {
+  for (int j = 0; j < 3; ++j) {
+    g.shape_in[j] = in_shape ? in_shape[j] : 0;
+    g.shape_out[j] = out_shape ? out_shape[j] : 0;
+    g.k[j] = k ? k[j] : 1;
+    g.s[j] = s ? s[j] : 1;
+    g.p[j] = p ? p[j] : 0;
+    if (g.k[j] < 1 || g.s[j] < 1 || g.p[j] < 0) return -1;
+  }
+  return 0;
+}
+
+bool is_pow2(int64_t x) { return x > 0 && (x & (x - 1)) == 0; }
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int bits_for(int64_t max_value) {
+  int b = 1;
+  while (b < 63 && ((int64_t)1 << b) <= max_value) ++b;
+  return b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wsis_hash_build(const int32_t* d_indices, int64_t M, const int32_t* h_shape3, int64_t* d_keys,
+                    int32_t* d_vals, int64_t cap, void* stream) {
+  WSIS_REQUIRE(M >= 0 && h_shape3 && d_keys && d_vals, "bad args");
+  WSIS_REQUIRE(is_pow2(cap) && cap >= 2 * M && cap >= 2, "cap must be a power of two >= 2*M");
+  Geo g;
+  WSIS_REQUIRE(fill_geo(g, h_shape3, nullptr, nullptr, nullptr, nullptr) == 0, "bad geometry");
+  hipStream_t st = as_stream(stream);
+  WSIS_HIP_CHECK(hipMemsetAsync(d_keys, 0xFF, sizeof(int64_t) * (size_t)cap, st));
+  WSIS_HIP_CHECK(hipMemsetAsync(d_vals, 0x7F, sizeof(int32_t) * (size_t)cap, st));
+  if (M == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_indices, "null indices");
+  hipLaunchKernelGGL(hash_insert_kernel, dim3(grid_for(M, 256)), dim3(256), 0, st, d_indices, M, g,
+                     d_keys, d_vals, (uint64_t)(cap - 1));
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_rulebook_subm(const int32_t* d_indices, int64_t M, const int32_t* h_shape3,
+                       const int32_t* h_ksize3, const int32_t* h_pad3, const int64_t* d_keys,
+                       const int32_t* d_vals, int64_t cap, int32_t* d_nbr, uint32_t* d_mask,
+                       void* stream) {
+  WSIS_REQUIRE(M >= 0 && h_shape3 && h_ksize3 && h_pad3, "bad args");
+  if (M == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_indices && d_keys && d_vals && d_nbr && is_pow2(cap), "null pointer / bad cap");
+  Geo g;
+  WSIS_REQUIRE(fill_geo(g, h_shape3, h_shape3, h_ksize3, nullptr, h_pad3) == 0, "bad geometry");
+  hipLaunchKernelGGL(subm_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), d_indices, M,
+                     g, d_keys, d_vals, (uint64_t)(cap - 1), d_nbr, d_mask);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int64_t wsis_rulebook_down_ncand(int64_t M_in, const int32_t* k, const int32_t* s, const int32_t* p) {
+  if (!k || !s || !p || M_in < 0) return -1;
+  bool fast = true;
+  for (int j = 0; j < 3; ++j) fast = fast && k[j] == s[j] && p[j] == 0;
+  return fast ? M_in : M_in * (int64_t)k[0] * k[1] * k[2];
+}
+
+int64_t wsis_rulebook_down_workspace_bytes(int64_t n_cand) {
+  if (n_cand < 0) return -1;
+  if (n_cand == 0) return 256;
+  size_t sort_bytes = 0, uniq_bytes = 0;
+  int64_t* kp = nullptr;
+  int32_t* cp = nullptr;
+  if (rocprim::radix_sort_keys(nullptr, sort_bytes, kp, kp, (size_t)n_cand, 0, 64, (hipStream_t)0) !=
+      hipSuccess)
+    return -1;
+  if (rocprim::unique(nullptr, uniq_bytes, kp, kp, cp, (size_t)n_cand, rocprim::equal_to<int64_t>(),
+                      (hipStream_t)0) != hipSuccess)
+    return -1;
+  // layout: [sorted keys n_cand*8][temp max(sort,unique)]
+  return (int64_t)(align256((size_t)n_cand * 8) + align256(sort_bytes > uniq_bytes ? sort_bytes : uniq_bytes) +
+                   256);
+}
+
+int wsis_rulebook_down_keys(const int32_t* d_indices_in, int64_t M_in, const int32_t* h_in_shape3,
+                            const int32_t* h_out_shape3, const int32_t* h_ksize3,
+                            const int32_t* h_stride3, const int32_t* h_pad3, int64_t* d_cand,
+                            int64_t* d_out_keys, int32_t* d_count, void* d_ws, int64_t ws_bytes,
+                            void* stream) {
+  WSIS_REQUIRE(M_in >= 0 && h_in_shape3 && h_out_shape3 && h_ksize3 && h_stride3 && h_pad3 && d_count,
+               "bad args");
+  hipStream_t st = as_stream(stream);
+  WSIS_HIP_CHECK(hipMemsetAsync(d_count, 0, sizeof(int32_t), st));
+  if (M_in == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_indices_in && d_cand && d_out_keys && d_ws, "null pointer");
+  Geo g;
+  WSIS_REQUIRE(fill_geo(g, h_in_shape3, h_out_shape3, h_ksize3, h_stride3, h_pad3) == 0, "bad geometry");
+  const int64_t n_cand = wsis_rulebook_down_ncand(M_in, h_ksize3, h_stride3, h_pad3);
+  bool fast_b = true;
+  for (int j = 0; j < 3; ++j) fast_b = fast_b && h_ksize3[j] == h_stride3[j] && h_pad3[j] == 0;
+  const int fast = fast_b ? 1 : 0;
+  // invalid candidates carry the largest int64 so they sort behind every real linear index
+  const int64_t invalid = INT64_MAX;
+  hipLaunchKernelGGL(down_cand_kernel, dim3(grid_for(M_in, 256)), dim3(256), 0, st, d_indices_in, M_in, g,
+                     fast, invalid, d_cand);
+  WSIS_LAUNCH_CHECK();
+  char* ws = static_cast<char*>(d_ws);
+  int64_t* d_sorted = reinterpret_cast<int64_t*>(ws);
+  size_t off = align256((size_t)n_cand * 8);
+  WSIS_REQUIRE((int64_t)off < ws_bytes, "workspace too small");
+  void* d_temp = ws + off;
+  size_t temp_bytes = (size_t)ws_bytes - off;
+  size_t need = 0;
+  WSIS_HIP_CHECK(rocprim::radix_sort_keys(nullptr, need, d_cand, d_sorted, (size_t)n_cand, 0, 64, st));
+  WSIS_REQUIRE(need <= temp_bytes, "workspace too small for sort");
+  const int end_bit = 64;
+  WSIS_HIP_CHECK(rocprim::radix_sort_keys(d_temp, temp_bytes, d_cand, d_sorted, (size_t)n_cand, 0,
+                                          end_bit, st));
+  need = 0;
+  WSIS_HIP_CHECK(rocprim::unique(nullptr, need, d_sorted, d_out_keys, d_count, (size_t)n_cand,
+                                 rocprim::equal_to<int64_t>(), st));
+  WSIS_REQUIRE(need <= temp_bytes, "workspace too small for unique");
+  WSIS_HIP_CHECK(rocprim::unique(d_temp, temp_bytes, d_sorted, d_out_keys, d_count, (size_t)n_cand,
+                                 rocprim::equal_to<int64_t>(), st));
+  hipLaunchKernelGGL(down_fix_count_kernel, dim3(1), dim3(64), 0, st, d_out_keys, invalid, d_count);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_rulebook_down_fill(const int32_t* d_indices_in, int64_t M_in, const int32_t* h_in_shape3,
+                            const int32_t* h_out_shape3, const int32_t* h_ksize3,
+                            const int32_t* h_stride3, const int32_t* h_pad3,
+                            const int64_t* d_out_keys, int64_t M_out, int32_t* d_indices_out,
+                            int64_t* d_keys, int32_t* d_vals, int64_t cap, int32_t* d_nbr_down,
+                            int32_t* d_nbr_up, uint32_t* d_mask_down, uint32_t* d_mask_up,
+                            void* stream) {
+  WSIS_REQUIRE(M_in >= 0 && M_out >= 0 && h_in_shape3 && h_out_shape3 && h_ksize3 && h_stride3 && h_pad3,
+               "bad args");
+  WSIS_REQUIRE(d_keys && d_vals && is_pow2(cap) && cap >= 2 * M_out && cap >= 2,
+               "cap must be a power of two >= 2*M_out");
+  Geo g;
+  WSIS_REQUIRE(fill_geo(g, h_in_shape3, h_out_shape3, h_ksize3, h_stride3, h_pad3) == 0, "bad geometry");
+  const int K = g.k[0] * g.k[1] * g.k[2];
+  hipStream_t st = as_stream(stream);
+  WSIS_HIP_CHECK(hipMemsetAsync(d_keys, 0xFF, sizeof(int64_t) * (size_t)cap, st));
+  WSIS_HIP_CHECK(hipMemsetAsync(d_vals, 0x7F, sizeof(int32_t) * (size_t)cap, st));
+  if (M_out > 0) {
+    WSIS_REQUIRE(d_out_keys && d_indices_out && d_nbr_down, "null pointer");
+    WSIS_HIP_CHECK(hipMemsetAsync(d_nbr_down, 0xFF, sizeof(int32_t) * (size_t)(K * M_out), st));
+    if (d_mask_down) WSIS_HIP_CHECK(hipMemsetAsync(d_mask_down, 0, sizeof(uint32_t) * (size_t)M_out, st));
+    hipLaunchKernelGGL(down_decode_kernel, dim3(grid_for(M_out, 256)), dim3(256), 0, st, d_out_keys, M_out,
+                       g, d_indices_out, d_keys, d_vals, (uint64_t)(cap - 1));
+    WSIS_LAUNCH_CHECK();
+  }
+  if (M_in > 0) {
+    WSIS_REQUIRE(d_indices_in && d_nbr_up, "null pointer");
+    WSIS_HIP_CHECK(hipMemsetAsync(d_nbr_up, 0xFF, sizeof(int32_t) * (size_t)(K * M_in), st));
+    if (M_out > 0) {
+      hipLaunchKernelGGL(down_fill_kernel, dim3(grid_for(M_in, 256)), dim3(256), 0, st, d_indices_in, M_in,
+                         M_out, g, d_keys, d_vals, (uint64_t)(cap - 1), d_nbr_down, d_nbr_up, d_mask_down,
+                         d_mask_up);
+      WSIS_LAUNCH_CHECK();
+    } else if (d_mask_up) {
+      WSIS_HIP_CHECK(hipMemsetAsync(d_mask_up, 0, sizeof(uint32_t) * (size_t)M_in, st));
+    }
+  }
+  return WSIS_OK;
+}
+
+int64_t wsis_mask_order_workspace_bytes(int64_t M) {
+  if (M < 0) return -1;
+  if (M == 0) return 256;
+  size_t sort_bytes = 0;
+  uint32_t* kp = nullptr;
+  int32_t* vp = nullptr;
+  if (rocprim::radix_sort_pairs(nullptr, sort_bytes, kp, kp, vp, vp, (size_t)M, 0, 32, (hipStream_t)0) !=
+      hipSuccess)
+    return -1;
+  // layout: [keys_out M*4][iota M*4][temp]
+  return (int64_t)(2 * align256((size_t)M * 4) + align256(sort_bytes) + 256);
+}
+
+int wsis_mask_order(const uint32_t* d_mask, int64_t M, int32_t* d_order, void* d_ws, int64_t ws_bytes,
+                    void* stream) {
+  WSIS_REQUIRE(M >= 0, "bad M");
+  if (M == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_mask && d_order && d_ws, "null pointer");
+  hipStream_t st = as_stream(stream);
+  char* ws = static_cast<char*>(d_ws);
+  const size_t a = align256((size_t)M * 4);
+  WSIS_REQUIRE((int64_t)(2 * a) < ws_bytes, "workspace too small");
+  uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws);
+  int32_t* iota = reinterpret_cast<int32_t*>(ws + a);
+  void* temp = ws + 2 * a;
+  size_t temp_bytes = (size_t)ws_bytes - 2 * a;
+  hipLaunchKernelGGL(iota_kernel, dim3(grid_for(M, 256)), dim3(256), 0, st, iota, M);
+  WSIS_LAUNCH_CHECK();
+  size_t need = 0;
+  WSIS_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, need, d_mask, keys_out, iota, d_order, (size_t)M, 0, 32, st));
+  WSIS_REQUIRE(need <= temp_bytes, "workspace too small for sort");
+  WSIS_HIP_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, d_mask, keys_out, iota, d_order, (size_t)M, 0,
+                                           32, st));
+  return WSIS_OK;
+}
+
+}  // extern "C"

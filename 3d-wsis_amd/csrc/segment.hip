@@ -1,0 +1,235 @@
+// torch_scatter.scatter replacement: sorted-segment wavefront reductions.
+//
+// torch_scatter 2.0.x [UPSTREAM] does one atomic per element.  Here the index vector is turned
+// into a CSR once (stable radix sort => points of a segment stay in ascending position), and one
+// wavefront reduces one segment with a fixed summation order: no atomics, deterministic.
+// HBM-bound: N*C*4 + N*4 read, S*C*4 written.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
+
+#include "common.h"
+
+using namespace wsis;
+
+namespace {
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+__global__ void csr_keys_kernel(const int64_t* __restrict__ index, int64_t N, uint32_t* __restrict__ keys,
+                                int32_t* __restrict__ iota) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    keys[i] = (uint32_t)index[i];
+    iota[i] = (int32_t)i;
+  }
+}
+
+__global__ void csr_offsets_kernel(const uint32_t* __restrict__ sorted, int64_t N, int64_t S,
+                                   int32_t* __restrict__ offsets) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t cur = sorted[i];
+    const int64_t prev = i > 0 ? (int64_t)sorted[i - 1] : -1;
+    for (int64_t s = prev + 1; s <= cur && s <= S; ++s) offsets[s] = (int32_t)i;
+    if (i == N - 1)
+      for (int64_t s = cur + 1; s <= S; ++s) offsets[s] = (int32_t)N;
+  }
+}
+
+__global__ void fill_i32_kernel(int32_t* __restrict__ p, int64_t n, int32_t v) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+// One wave per segment.  Lanes cover G rows x CP channels per step (CP = channels handled per
+// pass, power of two <= 64); partial results of the G row groups are combined with a fixed
+// butterfly, so the sum order depends only on the segment's (sorted) content.
+template <int REDUCE>  // 0 sum, 1 mean, 2 max
+__global__ __launch_bounds__(256) void segment_reduce_kernel(
+    const float* __restrict__ src, const int32_t* __restrict__ perm, const int32_t* __restrict__ offsets,
+    float* __restrict__ out, int32_t* __restrict__ argmax, int64_t S, int C, int CP) {
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const int64_t waves_total = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int G = 64 / CP;     // rows in flight per step
+  const int c_in = lane % CP;
+  const int grp = lane / CP;
+  for (int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave_in_block; s < S; s += waves_total) {
+    const int beg = offsets[s], end = offsets[s + 1];
+    for (int c0 = 0; c0 < C; c0 += CP) {
+      const int c = c0 + c_in;
+      float acc = (REDUCE == 2) ? -INFINITY : 0.0f;
+      int32_t arg = -1;
+      if (c < C) {
+        for (int j = beg + grp; j < end; j += G) {
+          const int32_t p = perm[j];
+          const float v = src[(int64_t)p * C + c];
+          if (REDUCE == 2) {
+            if (v > acc || arg < 0) {  // first occurrence wins inside a group (ascending p)
+              if (v > acc || arg < 0) {
+                acc = v;
+                arg = p;
+              }
+            }
+          } else {
+            acc += v;
+          }
+        }
+      }
+      // combine the G groups: lanes with equal c_in, xor butterfly over the group bits
+      for (int off = CP; off < 64; off <<= 1) {
+        const float o = __shfl_xor(acc, off, 64);
+        const int32_t oa = __shfl_xor(arg, off, 64);
+        if (REDUCE == 2) {
+          // keep the larger value; ties -> smaller original position (first max)
+          const bool take = (oa >= 0) && (arg < 0 || o > acc || (o == acc && oa < arg));
+          if (take) {
+            acc = o;
+            arg = oa;
+          }
+        } else {
+          acc += o;
+        }
+      }
+      if (grp == 0 && c < C) {
+        const int cnt = end - beg;
+        if (REDUCE == 1) acc = acc / (float)(cnt > 0 ? cnt : 1);
+        if (REDUCE == 2) {
+          if (cnt == 0) acc = 0.0f;
+          argmax[s * C + c] = arg;
+        }
+        out[s * C + c] = acc;
+      }
+    }
+  }
+}
+
+__global__ void segment_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ index,
+                                   const int32_t* __restrict__ offsets, float* __restrict__ dsrc, int64_t N,
+                                   int C, int reduce) {
+  const int64_t total = N * C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / C;
+    const int c = (int)(t - p * C);
+    const int64_t s = index[p];
+    float g = dout[s * C + c];
+    if (reduce == 1) {
+      const int cnt = offsets[s + 1] - offsets[s];
+      g = g / (float)(cnt > 0 ? cnt : 1);
+    }
+    dsrc[t] = g;
+  }
+}
+
+__global__ void segment_max_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ argmax,
+                                       float* __restrict__ dsrc, int64_t S, int C) {
+  const int64_t total = S * C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t a = argmax[t];
+    if (a >= 0) dsrc[(int64_t)a * C + (t % C)] = dout[t];  // one writer per (row, c): a row has one segment
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t wsis_segment_csr_workspace_bytes(int64_t N, int64_t S) {
+  if (N < 0 || S < 0) return -1;
+  if (N == 0) return 256;
+  size_t sort_bytes = 0;
+  uint32_t* kp = nullptr;
+  int32_t* vp = nullptr;
+  if (rocprim::radix_sort_pairs(nullptr, sort_bytes, kp, kp, vp, vp, (size_t)N, 0, 32, (hipStream_t)0) !=
+      hipSuccess)
+    return -1;
+  return (int64_t)(3 * align256((size_t)N * 4) + align256(sort_bytes) + 256);
+}
+
+int wsis_segment_csr(const int64_t* d_index, int64_t N, int64_t S, int32_t* d_perm, int32_t* d_offsets,
+                     void* d_ws, int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(N >= 0 && S >= 0 && d_offsets, "bad args");
+  WSIS_REQUIRE(S < ((int64_t)1 << 31) && N < ((int64_t)1 << 31), "sizes exceed int32");
+  hipStream_t st = as_stream(stream);
+  if (N == 0) {
+    WSIS_HIP_CHECK(hipMemsetAsync(d_offsets, 0, sizeof(int32_t) * (size_t)(S + 1), st));
+    return WSIS_OK;
+  }
+  WSIS_REQUIRE(d_index && d_perm && d_ws, "null pointer");
+  char* ws = static_cast<char*>(d_ws);
+  const size_t a = align256((size_t)N * 4);
+  WSIS_REQUIRE((int64_t)(3 * a) < ws_bytes, "workspace too small");
+  uint32_t* keys = reinterpret_cast<uint32_t*>(ws);
+  uint32_t* keys_sorted = reinterpret_cast<uint32_t*>(ws + a);
+  int32_t* iota = reinterpret_cast<int32_t*>(ws + 2 * a);
+  void* temp = ws + 3 * a;
+  size_t temp_bytes = (size_t)ws_bytes - 3 * a;
+  hipLaunchKernelGGL(csr_keys_kernel, dim3(grid_for(N, 256)), dim3(256), 0, st, d_index, N, keys, iota);
+  WSIS_LAUNCH_CHECK();
+  int end_bit = 1;
+  while (end_bit < 32 && ((int64_t)1 << end_bit) < S + 1) ++end_bit;
+  size_t need = 0;
+  WSIS_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, need, keys, keys_sorted, iota, d_perm, (size_t)N, 0,
+                                           end_bit, st));
+  WSIS_REQUIRE(need <= temp_bytes, "workspace too small for sort");
+  WSIS_HIP_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, iota, d_perm, (size_t)N, 0,
+                                           end_bit, st));
+  hipLaunchKernelGGL(csr_offsets_kernel, dim3(grid_for(N, 256)), dim3(256), 0, st, keys_sorted, N, S,
+                     d_offsets);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_segment_reduce_fwd(const float* d_src, const int32_t* d_perm, const int32_t* d_offsets,
+                            float* d_out, int32_t* d_argmax, int64_t N, int64_t S, int32_t C,
+                            int32_t reduce, void* stream) {
+  WSIS_REQUIRE(N >= 0 && S >= 0 && C >= 1 && reduce >= 0 && reduce <= 2, "bad args");
+  if (S == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_offsets && d_out && (N == 0 || (d_src && d_perm)), "null pointer");
+  WSIS_REQUIRE(reduce != 2 || d_argmax, "max needs an argmax buffer");
+  int CP = 1;
+  while (CP < C && CP < 64) CP <<= 1;
+  const int block = 256;
+  int64_t g = ceil_div(S, block / 64);
+  if (g > 256 * 16) g = 256 * 16;
+  hipStream_t st = as_stream(stream);
+  if (reduce == 0)
+    hipLaunchKernelGGL(segment_reduce_kernel<0>, dim3((unsigned)g), dim3(block), 0, st, d_src, d_perm,
+                       d_offsets, d_out, d_argmax, S, C, CP);
+  else if (reduce == 1)
+    hipLaunchKernelGGL(segment_reduce_kernel<1>, dim3((unsigned)g), dim3(block), 0, st, d_src, d_perm,
+                       d_offsets, d_out, d_argmax, S, C, CP);
+  else
+    hipLaunchKernelGGL(segment_reduce_kernel<2>, dim3((unsigned)g), dim3(block), 0, st, d_src, d_perm,
+                       d_offsets, d_out, d_argmax, S, C, CP);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_segment_reduce_bwd(const float* d_dout, const int64_t* d_index, const int32_t* d_offsets,
+                            const int32_t* d_argmax, float* d_dsrc, int64_t N, int64_t S, int32_t C,
+                            int32_t reduce, void* stream) {
+  WSIS_REQUIRE(N >= 0 && S >= 0 && C >= 1 && reduce >= 0 && reduce <= 2, "bad args");
+  if (N == 0 || S == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_dout && d_dsrc, "null pointer");
+  hipStream_t st = as_stream(stream);
+  if (reduce == 2) {
+    WSIS_REQUIRE(d_argmax, "max backward needs argmax");
+    hipLaunchKernelGGL(segment_max_bwd_kernel, dim3(grid_for(S * C, 256)), dim3(256), 0, st, d_dout, d_argmax,
+                       d_dsrc, S, C);
+  } else {
+    WSIS_REQUIRE(d_index && d_offsets, "null pointer");
+    hipLaunchKernelGGL(segment_bwd_kernel, dim3(grid_for(N * C, 256)), dim3(256), 0, st, d_dout, d_index,
+                       d_offsets, d_dsrc, N, C, reduce);
+  }
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+}  // extern "C"

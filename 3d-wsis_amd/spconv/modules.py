@@ -1,0 +1,77 @@
+"""spconv.modules [UPSTREAM spconv v1.0 modules.py]: SparseModule marker and SparseSequential.
+
+SparseSequential semantics relied on by the reference:
+  * SparseModule children receive the SparseConvTensor;
+  * ordinary nn.Modules (BatchNorm1d, ReLU, Identity) are applied to ``.features`` and the result is
+    re-bound ON THE SAME tensor object (which is why modules/model/sparse_unet3d.py:164-169 snapshots
+    ``identity`` first), skipped when the tensor has no active voxel;
+  * children are named positionally ("0","1",...) or by the keys of one OrderedDict
+    (sparse_unet3d.py:127,254) -- this fixes the state-dict key names.
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .tensor import SparseConvTensor
+
+
+class SparseModule(nn.Module):
+    """place holder: every module subclassing this takes a SparseConvTensor"""
+    pass
+
+
+def is_spconv_module(module):
+    return isinstance(module, SparseModule)
+
+
+def is_sparse_conv(module):
+    from .conv import SparseConvolution
+    return isinstance(module, SparseConvolution)
+
+
+class SparseSequential(SparseModule):
+    def __init__(self, *args, **kwargs):
+        super(SparseSequential, self).__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError("index {} is out of range".format(idx))
+        if idx < 0:
+            idx += len(self)
+        it = iter(self._modules.values())
+        for _ in range(idx):
+            next(it)
+        return next(it)
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def forward(self, input):
+        for k, module in self._modules.items():
+            if is_spconv_module(module):
+                input = module(input)
+            else:
+                if isinstance(input, SparseConvTensor):
+                    if input.indices.shape[0] != 0:
+                        input.features = module(input.features)
+                else:
+                    input = module(input)
+        return input

@@ -1,0 +1,235 @@
+"""Rulebooks and the sparse-convolution autograd Function on top of libwsis_hip.so.
+
+Restates [UPSTREAM] spconv v1.0 ops.get_indice_pairs / functional.Sparse*ConvFunction
+ for the call sites in modules/model/sparse_unet3d.py:130,261,292.
+
+Native rulebook = gather tables ``nbr[K, rows]`` (row of the other side or -1) instead of upstream's
+per-offset pair lists; ``Rulebook.to_pairs()`` exports the upstream ``(indice_pairs, indice_pair_num)``
+form for parity tests.
+"""
+import os
+
+import numpy as np
+import torch
+from torch.autograd import Function
+
+import wsis_native as _n
+
+
+def _use_mask_order():
+    return os.environ.get("WSIS_MASK_ORDER", "1") != "0"
+
+
+def _pow2_cap(m):
+    cap = 16
+    while cap < 2 * m:
+        cap <<= 1
+    return cap
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple, np.ndarray)):
+        v = [int(x) for x in v]
+        assert len(v) == 3
+        return v
+    return [int(v)] * 3
+
+
+def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
+    out = []
+    for i in range(len(input_size)):
+        size = (input_size[i] + 2 * padding[i] - dilation[i] * (kernel_size[i] - 1) - 1) // stride[i] + 1
+        out.append(int(size))
+    return out
+
+
+def build_hash(indices, spatial_shape):
+    """coordinate hash (keys int64[cap], vals int32[cap], cap) of int32 [M,4] indices."""
+    _n.require_cuda(indices)
+    M = indices.shape[0]
+    cap = _pow2_cap(M)
+    keys = torch.empty(cap, dtype=torch.int64, device=indices.device)
+    vals = torch.empty(cap, dtype=torch.int32, device=indices.device)
+    _n.check(_n.hip().wsis_hash_build(_n.ptr(indices), M, _n.i32x3(spatial_shape), _n.ptr(keys), _n.ptr(vals),
+                                      cap, _n.stream_ptr()), "hash_build")
+    return keys, vals, cap
+
+
+def _mask_order(mask):
+    M = mask.shape[0]
+    lib = _n.hip()
+    ws_bytes = lib.wsis_mask_order_workspace_bytes(M)
+    if ws_bytes < 0:
+        raise _n.WsisError("mask_order workspace query failed")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mask.device)
+    order = torch.empty(M, dtype=torch.int32, device=mask.device)
+    _n.check(lib.wsis_mask_order(_n.ptr(mask), M, _n.ptr(order), _n.ptr(ws), ws_bytes, _n.stream_ptr()),
+             "mask_order")
+    return order
+
+
+class Rulebook(object):
+    """What ``indice_dict[indice_key]`` holds (upstream: a 5-tuple)."""
+
+    def __init__(self, kind, ksize, stride, padding, in_indices, out_indices, in_shape, out_shape):
+        self.kind = kind                # "subm" | "down"
+        self.ksize, self.stride, self.padding = ksize, stride, padding
+        self.in_indices, self.out_indices = in_indices, out_indices
+        self.in_shape, self.out_shape = in_shape, out_shape
+        self.K = int(np.prod(ksize))
+        # subm: nbr [K, M]; down: nbr (= nbr_down) [K, M_out] and nbr_up [K, M_in]
+        self.nbr = None
+        self.nbr_up = None
+        self.order = None
+        self.order_up = None
+        self.out_hash = None
+
+    # upstream-format export (tests / INTEGRATION.md): indice_pairs int32 [K,2,maxP] (-1 padded),
+    # indice_pair_num int32 [K]; pair order inside an offset = ascending output row.
+    def to_pairs(self):
+        nbr = self.nbr
+        K, M = nbr.shape
+        valid = nbr >= 0
+        num = valid.sum(1).to(torch.int32)
+        maxp = int(num.max().item()) if K > 0 and M > 0 else 0
+        pairs = torch.full((K, 2, max(maxp, 1)), -1, dtype=torch.int32, device=nbr.device)
+        for k in range(K):
+            o = torch.nonzero(valid[k], as_tuple=False).flatten()
+            pairs[k, 0, :o.numel()] = nbr[k, o]
+            pairs[k, 1, :o.numel()] = o.to(torch.int32)
+        return pairs, num
+
+
+def build_subm_rulebook(indices, spatial_shape, ksize, padding, hash_tab=None):
+    """SubMConv3d rulebook (a5): out rows == in rows, nbr[k][o] = i with coord_i = coord_o - pad + kappa."""
+    _n.require_cuda(indices)
+    M = indices.shape[0]
+    K = int(np.prod(ksize))
+    dev = indices.device
+    if hash_tab is None:
+        hash_tab = build_hash(indices, spatial_shape)
+    keys, vals, cap = hash_tab
+    rb = Rulebook("subm", ksize, [1, 1, 1], padding, indices, indices, list(spatial_shape), list(spatial_shape))
+    rb.nbr = torch.empty((K, M), dtype=torch.int32, device=dev)
+    mask = torch.empty(M, dtype=torch.int32, device=dev) if K <= 32 else None
+    _n.check(_n.hip().wsis_rulebook_subm(_n.ptr(indices), M, _n.i32x3(spatial_shape), _n.i32x3(ksize),
+                                         _n.i32x3(padding), _n.ptr(keys), _n.ptr(vals), cap, _n.ptr(rb.nbr),
+                                         _n.ptr(mask), _n.stream_ptr()), "rulebook_subm")
+    if mask is not None and _use_mask_order() and M > 0:
+        rb.order = _mask_order(mask)
+    rb.out_hash = hash_tab
+    return rb
+
+
+def build_down_rulebook(indices, spatial_shape, ksize, stride, padding):
+    """SparseConv3d rulebook (a6): output rows = ascending linear index of the reachable coarse voxels."""
+    _n.require_cuda(indices)
+    lib = _n.hip()
+    dev = indices.device
+    M_in = indices.shape[0]
+    K = int(np.prod(ksize))
+    out_shape = get_conv_output_size(list(spatial_shape), ksize, stride, padding, [1, 1, 1])
+    k3, s3, p3 = _n.i32x3(ksize), _n.i32x3(stride), _n.i32x3(padding)
+    in3, out3 = _n.i32x3(spatial_shape), _n.i32x3(out_shape)
+    st = _n.stream_ptr()
+    n_cand = lib.wsis_rulebook_down_ncand(M_in, k3, s3, p3)
+    ws_bytes = lib.wsis_rulebook_down_workspace_bytes(n_cand)
+    if ws_bytes < 0:
+        raise _n.WsisError("rulebook_down workspace query failed")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    cand = torch.empty(max(n_cand, 1), dtype=torch.int64, device=dev)
+    out_keys = torch.empty(max(n_cand, 1), dtype=torch.int64, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    _n.check(lib.wsis_rulebook_down_keys(_n.ptr(indices), M_in, in3, out3, k3, s3, p3, _n.ptr(cand),
+                                         _n.ptr(out_keys), _n.ptr(count), _n.ptr(ws), ws_bytes, st),
+             "rulebook_down_keys")
+    M_out = int(count.item())   # the one host sync per level (upstream has the same one)
+    out_indices = torch.empty((M_out, 4), dtype=torch.int32, device=dev)
+    cap = _pow2_cap(M_out)
+    keys = torch.empty(cap, dtype=torch.int64, device=dev)
+    vals = torch.empty(cap, dtype=torch.int32, device=dev)
+    rb = Rulebook("down", ksize, stride, padding, indices, out_indices, list(spatial_shape), out_shape)
+    rb.nbr = torch.empty((K, M_out), dtype=torch.int32, device=dev)
+    rb.nbr_up = torch.empty((K, M_in), dtype=torch.int32, device=dev)
+    use_mask = K <= 32
+    mask_down = torch.empty(M_out, dtype=torch.int32, device=dev) if use_mask else None
+    mask_up = torch.empty(M_in, dtype=torch.int32, device=dev) if use_mask else None
+    _n.check(lib.wsis_rulebook_down_fill(_n.ptr(indices), M_in, in3, out3, k3, s3, p3, _n.ptr(out_keys), M_out,
+                                         _n.ptr(out_indices), _n.ptr(keys), _n.ptr(vals), cap, _n.ptr(rb.nbr),
+                                         _n.ptr(rb.nbr_up), _n.ptr(mask_down), _n.ptr(mask_up), st),
+             "rulebook_down_fill")
+    if use_mask and _use_mask_order():
+        if M_out > 0:
+            rb.order = _mask_order(mask_down)
+        if M_in > 0:
+            rb.order_up = _mask_order(mask_up)
+    rb.out_hash = (keys, vals, cap)
+    return rb
+
+
+def _conv(X, nbr, order, W, bias, residual, M_out):
+    """out[r] = sum_k X[nbr[k][r]] @ W[k]  (W [K,Cin,Cout] contiguous)."""
+    K, Cin, Cout = W.shape
+    out = torch.empty((M_out, Cout), dtype=torch.float32, device=X.device)
+    _n.check(_n.hip().wsis_spconv_fwd(_n.ptr(X), _n.ptr(nbr), _n.ptr(order), _n.ptr(W), _n.ptr(bias),
+                                      _n.ptr(residual), _n.ptr(out), X.shape[0], M_out, K, Cin, Cout,
+                                      _n.stream_ptr()), "spconv_fwd")
+    return out
+
+
+def _weight_t(W, flip):
+    K, Cin, Cout = W.shape
+    WT = torch.empty((K, Cout, Cin), dtype=torch.float32, device=W.device)
+    _n.check(_n.hip().wsis_weight_transpose(_n.ptr(W), _n.ptr(WT), K, Cin, Cout, int(flip), _n.stream_ptr()),
+             "weight_transpose")
+    return WT
+
+
+def _dw(X, nbr, dY, K, Cin, Cout):
+    lib = _n.hip()
+    M_out = dY.shape[0]
+    ws_bytes = lib.wsis_spconv_dw_workspace_bytes(M_out, K, Cin, Cout)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
+    dW = torch.empty((K, Cin, Cout), dtype=torch.float32, device=X.device)
+    _n.check(lib.wsis_spconv_dw(_n.ptr(X), _n.ptr(nbr), _n.ptr(dY), _n.ptr(dW), X.shape[0], M_out, K, Cin, Cout,
+                                _n.ptr(ws), ws_bytes, _n.stream_ptr()), "spconv_dw")
+    return dW
+
+
+class SparseConvFunction(Function):
+    """features [M_in,Cin], weight [k0,k1,k2,Cin,Cout] -> [M_out,Cout].
+
+    nbr_f/order_f: gather table of the forward pass (rows = outputs);
+    nbr_b/order_b: gather table of the dIn pass (rows = inputs); flip: subm dIn uses W[K-1-k]^T."""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, nbr_f, order_f, nbr_b, order_b, flip, M_out):
+        _n.require_cuda(features, weight)
+        X = features.contiguous().float()
+        Cin, Cout = weight.shape[-2], weight.shape[-1]
+        W = weight.contiguous().float().view(-1, Cin, Cout)
+        b = bias.contiguous().float() if bias is not None else None
+        out = _conv(X, nbr_f, order_f, W, b, None, M_out)
+        ctx.save_for_backward(X, W)
+        ctx.aux = (nbr_f, nbr_b, order_b, flip, weight.shape, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        X, W = ctx.saved_tensors
+        nbr_f, nbr_b, order_b, flip, wshape, has_bias = ctx.aux
+        dY = grad_out.contiguous().float()
+        K, Cin, Cout = W.shape
+        dX = dW = db = None
+        if ctx.needs_input_grad[0]:
+            WT = _weight_t(W, flip)
+            dX = _conv(dY, nbr_b, order_b, WT, None, None, X.shape[0])
+        if ctx.needs_input_grad[1]:
+            dW = _dw(X, nbr_f, dY, K, Cin, Cout).view(wshape)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dY.sum(0)
+        return dX, dW, db, None, None, None, None, None, None
+
+
+def sparse_conv(features, weight, bias, nbr_f, order_f, nbr_b, order_b, flip, M_out):
+    return SparseConvFunction.apply(features, weight, bias, nbr_f, order_f, nbr_b, order_b, flip, M_out)

@@ -1,0 +1,148 @@
+"""ctypes binding of the C ABI declared in include/wsis_hip.h.
+
+Two libraries (built in-tree by ``3d-wsis_amd/csrc/Makefile`` / ``__graft_entry__.build()``):
+
+* ``libwsis_host.so`` -- host-only operators (voxelization_idx, bfs_cluster); safe in forked
+  DataLoader workers, never initialises HIP.
+* ``libwsis_hip.so``  -- every device operator (hipcc, gfx950).
+
+There is NO fallback: if a library is missing the accessor raises, and device operators refuse CPU
+tensors.  Only ``tests/``, ``bench.py``'s cpu_baseline leg and ``__graft_entry__.smoke()`` may
+import ``oracle/``.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+
+_host = None
+_hip = None
+
+I32 = c_int32
+I64 = c_int64
+F32 = c_float
+P = c_void_p
+
+
+class WsisError(RuntimeError):
+    pass
+
+
+def _load(name):
+    path = os.path.join(_PKG, name)
+    if not os.path.exists(path):
+        raise WsisError(
+            f"{name} not found at {path}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C 3d-wsis_amd/csrc` (no CPU fallback exists for this path)")
+    return ctypes.CDLL(path)
+
+
+_HOST_SIGS = {
+    "wsis_host_version": (I32, []),
+    "wsis_host_last_error": (c_char_p, []),
+    "wsis_host_voxelize_idx_map": (I32, [P, I64, P, P, P]),
+    "wsis_host_voxelize_idx_fill": (I32, [P, I64, P, I64, I32, P, P]),
+    "wsis_host_bfs_cluster_count": (I32, [P, P, P, I64, I32, P, P, P, P]),
+    "wsis_host_bfs_cluster_fill": (I32, [P, P, I64, I64, I64, P, P]),
+}
+
+_HIP_SIGS = {
+    "wsis_version": (I32, []),
+    "wsis_last_error": (c_char_p, []),
+    "wsis_device_count": (I32, []),
+    "wsis_voxelize_fwd": (I32, [P, P, P, I64, I32, I32, I32, P]),
+    "wsis_voxelize_bwd": (I32, [P, P, P, I64, I32, I32, I32, P]),
+    "wsis_hash_build": (I32, [P, I64, P, P, P, I64, P]),
+    "wsis_rulebook_subm": (I32, [P, I64, P, P, P, P, P, I64, P, P, P]),
+    "wsis_rulebook_down_ncand": (I64, [I64, P, P, P]),
+    "wsis_rulebook_down_workspace_bytes": (I64, [I64]),
+    "wsis_rulebook_down_keys": (I32, [P, I64, P, P, P, P, P, P, P, P, P, I64, P]),
+    "wsis_rulebook_down_fill": (I32, [P, I64, P, P, P, P, P, P, I64, P, P, P, I64, P, P, P, P, P]),
+    "wsis_mask_order_workspace_bytes": (I64, [I64]),
+    "wsis_mask_order": (I32, [P, I64, P, P, I64, P]),
+    "wsis_spconv_fwd": (I32, [P, P, P, P, P, P, P, I64, I64, I32, I32, I32, P]),
+    "wsis_weight_transpose": (I32, [P, P, I32, I32, I32, I32, P]),
+    "wsis_spconv_dw_workspace_bytes": (I64, [I64, I32, I32, I32]),
+    "wsis_spconv_dw": (I32, [P, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
+    "wsis_segment_csr_workspace_bytes": (I64, [I64, I64]),
+    "wsis_segment_csr": (I32, [P, I64, I64, P, P, P, I64, P]),
+    "wsis_segment_reduce_fwd": (I32, [P, P, P, P, P, I64, I64, I32, I32, P]),
+    "wsis_segment_reduce_bwd": (I32, [P, P, P, P, P, I64, I64, I32, I32, P]),
+    "wsis_gather_rows": (I32, [P, P, I32, P, I64, I32, P]),
+    "wsis_edge_affinity_fwd": (I32, [P, P, P, P, P, P, P, P, F32, P, P, I64, I64, I32, P]),
+    "wsis_edge_affinity_bwd": (I32, [P] * 11 + [F32] + [P] * 7 + [I64, I64, I64, I32, P]),
+    "wsis_affinity_dense_build": (I32, [P, P, P, I64, P, I64, P]),
+    "wsis_affinity_transition": (I32, [P, P, P, P, P, I32, F32, P, I64, P]),
+    "wsis_dgemm": (I32, [P, P, P, I64, I64, I64, P]),
+    "wsis_affinity_colmax": (I32, [P, P, I32, P, P, I64, P]),
+    "wsis_ballquery_workspace_bytes": (I64, [I64]),
+    "wsis_ballquery_count": (I32, [P, P, P, I64, I32, F32, P, P, P, I64, P]),
+    "wsis_ballquery_fill": (I32, [P, P, P, I64, I32, F32, P, P, I64, P, I64, P]),
+}
+
+
+def _bind(lib, sigs):
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def host():
+    """libwsis_host.so (never touches the GPU runtime)."""
+    global _host
+    if _host is None:
+        _host = _bind(_load("libwsis_host.so"), _HOST_SIGS)
+    return _host
+
+
+def hip():
+    """libwsis_hip.so (device operators)."""
+    global _hip
+    if _hip is None:
+        _hip = _bind(_load("libwsis_hip.so"), _HIP_SIGS)
+    return _hip
+
+
+def declared_symbols():
+    return sorted(_HOST_SIGS), sorted(_HIP_SIGS)
+
+
+def check_host(status, what):
+    if status != 0:
+        raise WsisError(f"{what} failed ({status}): {host().wsis_host_last_error().decode()}")
+
+
+def check(status, what):
+    if status != 0:
+        raise WsisError(f"{what} failed ({status}): {hip().wsis_last_error().decode()}")
+
+
+# ---- torch helpers ------------------------------------------------------------------------------
+
+def ptr(t):
+    """data_ptr of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise WsisError("this operator runs on the MI355X only: got a CPU tensor (there is no CPU fallback)")
+
+
+def i32x3(v):
+    """host int32[3] array from an int or a 3-sequence."""
+    if isinstance(v, int):
+        v = (v, v, v)
+    v = [int(x) for x in v]
+    assert len(v) == 3
+    return (c_int32 * 3)(*v)

@@ -1,0 +1,149 @@
+"""Fused operators of the hot path that have no third-party name in the reference:
+
+* ``edge_affinity``      -- modules/model/backbone_3D_WSIS.py:218-244 (q.k dot, pos-enc scaling, segment
+                            softmax over the out-edges of u, weighted V sum) as one HIP kernel + backward.
+* ``affinity_matrix`` / ``propagate_class`` / ``weak_label_propagation`` -- the dense S x S fp64 affinity
+  product of train_scannetv2.py:562-570 and modules/datasets/scannetv2_dataset.py:664-736 on the f64 MFMA.
+"""
+import numpy as np
+import torch
+from torch.autograd import Function
+
+import wsis_native as _n
+from torch_scatter import SegmentCSR
+
+
+class EdgeGraph(object):
+    """CSR over sources and over targets of a directed edge list (built once per batch)."""
+
+    def __init__(self, edge_u, edge_v, num_nodes):
+        _n.require_cuda(edge_u, edge_v)
+        self.eu = edge_u.contiguous().long()
+        self.ev = edge_v.contiguous().long()
+        self.E = self.eu.numel()
+        self.S = int(num_nodes)
+        self.Su = int(self.eu.max().item()) + 1 if self.E > 0 else 0
+        self.csr_u = SegmentCSR(self.eu, self.Su)
+        self.csr_v = SegmentCSR(self.ev, self.S)
+
+
+class _EdgeAffinity(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, pos, graph, scale):
+        _n.require_cuda(q, k, v, pos)
+        q, k, v = q.contiguous().float(), k.contiguous().float(), v.contiguous().float()
+        pos = pos.contiguous().float().view(-1)
+        S, D = q.shape
+        assert S == graph.S and pos.numel() == graph.E
+        aff = torch.empty(graph.E, dtype=torch.float32, device=q.device)
+        res = torch.empty((graph.Su, D), dtype=torch.float32, device=q.device)
+        _n.check(_n.hip().wsis_edge_affinity_fwd(_n.ptr(q), _n.ptr(k), _n.ptr(v), _n.ptr(pos), _n.ptr(graph.eu),
+                                                 _n.ptr(graph.ev), _n.ptr(graph.csr_u.perm),
+                                                 _n.ptr(graph.csr_u.offsets), float(scale), _n.ptr(aff),
+                                                 _n.ptr(res), graph.E, graph.Su, D, _n.stream_ptr()),
+                 "edge_affinity_fwd")
+        ctx.save_for_backward(q, k, v, pos, aff)
+        ctx.graph, ctx.scale = graph, float(scale)
+        return aff, res
+
+    @staticmethod
+    def backward(ctx, d_aff, d_res):
+        q, k, v, pos, aff = ctx.saved_tensors
+        g = ctx.graph
+        S, D = q.shape
+        dev = q.device
+        d_res = d_res.contiguous().float() if d_res is not None else torch.zeros((g.Su, D), device=dev)
+        d_aff = d_aff.contiguous().float() if d_aff is not None else None
+        dq = torch.empty((S, D), dtype=torch.float32, device=dev)
+        dk = torch.empty((S, D), dtype=torch.float32, device=dev)
+        dv = torch.empty((S, D), dtype=torch.float32, device=dev)
+        dpos = torch.empty(max(g.E, 1), dtype=torch.float32, device=dev)
+        tmp = torch.empty(max(2 * g.E, 1), dtype=torch.float32, device=dev)
+        _n.check(_n.hip().wsis_edge_affinity_bwd(
+            _n.ptr(q), _n.ptr(k), _n.ptr(v), _n.ptr(pos), _n.ptr(aff), _n.ptr(g.eu), _n.ptr(g.ev),
+            _n.ptr(g.csr_u.perm), _n.ptr(g.csr_u.offsets), _n.ptr(g.csr_v.perm), _n.ptr(g.csr_v.offsets),
+            ctx.scale, _n.ptr(d_aff), _n.ptr(d_res), _n.ptr(dq), _n.ptr(dk), _n.ptr(dv), _n.ptr(dpos),
+            _n.ptr(tmp), g.E, S, g.Su, D, _n.stream_ptr()), "edge_affinity_bwd")
+        return dq, dk, dv, dpos[:g.E], None, None
+
+
+def edge_affinity(q, k, v, pos_enc, graph, scale):
+    """returns (edge_affinity [E], res [max(u)+1, D])."""
+    return _EdgeAffinity.apply(q, k, v, pos_enc, graph, scale)
+
+
+# ---- a17: dense affinity matrix + label propagation -------------------------------------------------
+
+def affinity_matrix(edge_u, edge_v, edge_affinity_vals, S):
+    """A [S,S] float64 with A[u,v] = affinity of edge (u,v) (train_scannetv2.py:567-570)."""
+    _n.require_cuda(edge_u, edge_v, edge_affinity_vals)
+    eu, ev = edge_u.contiguous().long(), edge_v.contiguous().long()
+    aff = edge_affinity_vals.detach().contiguous().float()
+    A = torch.empty((S, S), dtype=torch.float64, device=aff.device)
+    _n.check(_n.hip().wsis_affinity_dense_build(_n.ptr(eu), _n.ptr(ev), _n.ptr(aff), eu.numel(), _n.ptr(A), S,
+                                                _n.stream_ptr()), "affinity_dense_build")
+    return A
+
+
+def dgemm(A, B):
+    _n.require_cuda(A, B)
+    assert A.dtype == torch.float64 and B.dtype == torch.float64
+    A, B = A.contiguous(), B.contiguous()
+    M, Kd = A.shape
+    N = B.shape[1]
+    C = torch.empty((M, N), dtype=torch.float64, device=A.device)
+    _n.check(_n.hip().wsis_dgemm(_n.ptr(A), _n.ptr(B), _n.ptr(C), M, N, Kd, _n.stream_ptr()), "dgemm")
+    return C
+
+
+def propagate_class(A, adj_u8, pred, conf, label, cls, iterations_num, thr=0.7):
+    """One class of modules/datasets/scannetv2_dataset.py:689-721 on the device.
+    returns (instance_scores fp64 [S], instance_pseudo_label int32 [S])."""
+    S = A.shape[0]
+    lib = _n.hip()
+    st = _n.stream_ptr()
+    T0 = torch.empty_like(A)
+    _n.check(lib.wsis_affinity_transition(_n.ptr(A), _n.ptr(adj_u8), _n.ptr(pred), _n.ptr(conf), _n.ptr(label),
+                                          int(cls), float(thr), _n.ptr(T0), S, st), "affinity_transition")
+    T = T0
+    for _ in range(int(iterations_num)):
+        T = dgemm(T, T0)
+    scores = torch.empty(S, dtype=torch.float64, device=A.device)
+    arg = torch.empty(S, dtype=torch.int32, device=A.device)
+    _n.check(lib.wsis_affinity_colmax(_n.ptr(T), _n.ptr(label), int(cls), _n.ptr(scores), _n.ptr(arg), S, st),
+             "affinity_colmax")
+    return scores, arg
+
+
+def weak_label_propagation(A, adjacency, sp_semantic_value, superpoint_pred_semantic, superpoint_semantic_label,
+                           iterations_num, class_num):
+    """Device version of ScanNetV2Inst_spg.weak_label_propagation up to ``pseudo_label_final``
+    (modules/datasets/scannetv2_dataset.py:664-736).  ``adjacency`` is the [S,S] adjacency (without the
+    identity; it is added here like ``:681-682``).  Returns (pseudo_label_final [S] float64 numpy with -100
+    for unknown, pseudo_label_scores [S])."""
+    dev = A.device
+    S = A.shape[0]
+    adj = torch.as_tensor(adjacency, device=dev)
+    adj_u8 = (adj.to(torch.int32) + torch.eye(S, dtype=torch.int32, device=dev)).to(torch.uint8).contiguous()
+    pred = torch.as_tensor(superpoint_pred_semantic, device=dev).to(torch.int32).contiguous()
+    conf = torch.as_tensor(sp_semantic_value, device=dev).to(torch.float32).contiguous()
+    label_np = np.asarray(superpoint_semantic_label)
+    label = torch.as_tensor(label_np, device=dev).to(torch.int32).contiguous()
+    scores_list, pseudo_list = [], []
+    for c in range(class_num):
+        if (label_np == c).sum() == 0:
+            continue
+        s, a = propagate_class(A, adj_u8, pred, conf, label, c, iterations_num)
+        scores_list.append(s)
+        pseudo_list.append(a)
+    if not scores_list:
+        return np.ones(S) * -100, np.zeros(S)
+    scores = torch.stack(scores_list).cpu().numpy()
+    pseudo = torch.stack(pseudo_list).cpu().numpy()
+    _ind = np.argmax(scores, axis=0)
+    pseudo_label = np.choose(_ind, pseudo)
+    pseudo_label_scores = np.choose(_ind, scores)
+    final = np.ones(S) * -100
+    unknown = (pseudo_label_scores != 0) & (label_np == -100)
+    final[unknown] = pseudo_label[unknown]
+    return final, pseudo_label_scores

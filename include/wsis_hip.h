@@ -1,0 +1,229 @@
+/*
+ * wsis_hip.h -- C ABI of the MI355X (gfx950) hot path of 3D-WSIS.
+ *
+ * This is the drop-in boundary.  Two shared libraries export it:
+ *
+ *   libwsis_host.so  (g++ only, never touches the HIP runtime -- safe in forked DataLoader workers)
+ *       wsis_host_*   : voxelization_idx, bfs_cluster, reference-order helpers
+ *   libwsis_hip.so   (hipcc --offload-arch=gfx950)
+ *       wsis_*        : every device operator
+ *
+ * Conventions
+ *   - every pointer named d_* is DEVICE memory, h_* is HOST memory; the caller (PyTorch) allocates
+ *     every input, output and workspace buffer and passes raw pointers + sizes.  The library never
+ *     allocates device memory that outlives a call and never frees caller memory.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *   - every function returns int: 0 = ok, <0 = error; wsis_last_error()/wsis_host_last_error()
+ *     return a thread-local message.  No C++ exception crosses the ABI.
+ *   - variable-size outputs use count-then-fill or documented upper bounds with the true count
+ *     written to a device int32 the caller reads back.
+ *   - feature rows are row-major fp32 [rows, C]; indices are int32 [M,4] = (batch, c0, c1, c2).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * fpthink/3D-WSIS tree).  [UPSTREAM] marks semantics of an un-vendored dependency (spconv v1.0
+ * llijiang fork, PointGroup lib/pointgroup_ops, torch_scatter 2.0.x) restated in SURVEY.md App. A.
+ */
+#ifndef WSIS_HIP_H_
+#define WSIS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WSIS_ABI_VERSION 1
+
+/* error codes */
+#define WSIS_OK 0
+#define WSIS_ERR_ARG (-1)      /* bad argument (null pointer, bad size, unsupported shape) */
+#define WSIS_ERR_HIP (-2)      /* a HIP runtime call failed (message has hipGetErrorString) */
+#define WSIS_ERR_OVERFLOW (-3) /* a caller-provided capacity was too small */
+
+/* ------------------------------------------------------------------------------------------ */
+/* libwsis_host.so : host-only operators                                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+int wsis_host_version(void);
+const char* wsis_host_last_error(void);
+
+/* pointgroup_ops.voxelization_idx(coords, batchsize, mode)  [UPSTREAM PG_OP.voxelize_idx]
+ * call sites: modules/datasets/scannetv2_dataset.py:449,528  test_scannetv2.py:389
+ * Pass 1: scan points in order, voxel id = order of first occurrence of the (b,x,y,z) row.
+ *   h_coords int64 [N,4]; writes h_p2v int32 [N]; *M = #voxels; *max_active = longest point list. */
+int wsis_host_voxelize_idx_map(const int64_t* h_coords, int64_t N, int32_t* h_p2v, int64_t* M,
+                               int32_t* max_active);
+/* Pass 2: h_voxel_locs int64 [M,4] = coords of each voxel's first point;
+ *   h_v2p int32 [M, 1+max_active] = [count, p0, p1, ... ascending, 0 padded]. */
+int wsis_host_voxelize_idx_fill(const int64_t* h_coords, int64_t N, const int32_t* h_p2v, int64_t M,
+                                int32_t max_active, int64_t* h_voxel_locs, int32_t* h_v2p);
+
+/* pointgroup_ops.bfs_cluster(semantic_label, ball_query_idxs, start_len, threshold)
+ * [UPSTREAM PG_OP.bfs_cluster; no call site in the reference, named by BASELINE.json north_star]
+ * Pass 1: FIFO BFS, seeds ascending, neighbour accepted iff same label & unvisited.  Writes
+ *   h_point_cluster int32 [N] = kept-cluster id or -1 and h_order int32 [N] = discovery rank of the
+ *   point inside its cluster; *n_clusters, *n_points = totals over kept clusters (size >= threshold). */
+int wsis_host_bfs_cluster_count(const int32_t* h_semantic, const int32_t* h_ball_idx,
+                                const int32_t* h_start_len, int64_t N, int32_t threshold,
+                                int32_t* h_point_cluster, int32_t* h_order, int64_t* n_clusters,
+                                int64_t* n_points);
+/* Pass 2: h_cluster_idxs int32 [n_points,2] = (cluster id, point idx) in discovery order,
+ *   h_cluster_offsets int32 [n_clusters+1]. */
+int wsis_host_bfs_cluster_fill(const int32_t* h_point_cluster, const int32_t* h_order, int64_t N,
+                               int64_t n_clusters, int64_t n_points, int32_t* h_cluster_idxs,
+                               int32_t* h_cluster_offsets);
+
+/* ------------------------------------------------------------------------------------------ */
+/* libwsis_hip.so : device operators                                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+int wsis_version(void);
+const char* wsis_last_error(void);
+/* number of visible HIP devices (0 when none) -- does not create a context */
+int wsis_device_count(void);
+
+/* ---- a2: pointgroup_ops.voxelization(feats, map_rule, mode)  train_scannetv2.py:189 ---------
+ * out[m,:] = sum_{i<n_m} w * feats[v2p[m,1+i],:], w = 1/n_m for mode 4 else 1, accumulated in
+ * list order in fp32.  d_v2p int32 [M, stride] with stride = 1+max_active. */
+int wsis_voxelize_fwd(const float* d_feats, const int32_t* d_v2p, float* d_out, int64_t M, int32_t C,
+                      int32_t stride, int32_t mode, void* stream);
+/* d_dfeats [N,C] must be zero-initialised by the caller; dfeats[p,:] = w * dout[m,:]. */
+int wsis_voxelize_bwd(const float* d_dout, const int32_t* d_v2p, float* d_dfeats, int64_t M, int32_t C,
+                      int32_t stride, int32_t mode, void* stream);
+
+/* ---- a5/a6: rulebooks [UPSTREAM spconv getIndicePair]  sparse_unet3d.py:130,261,292 ---------
+ * Native rulebook format = gather table nbr int32 [K, M_rows]: nbr[k][r] = row of the OTHER side
+ * paired with row r under flat kernel offset k (row-major over the 3 kernel dims), or -1.
+ * Hash table: open addressing, d_keys int64 [cap] (cap power of two >= 2*M), d_vals int32 [cap];
+ * key = linear index ((b*S0+c0)*S1+c1)*S2+c2. */
+int wsis_hash_build(const int32_t* d_indices, int64_t M, const int32_t* h_shape3, int64_t* d_keys,
+                    int32_t* d_vals, int64_t cap, void* stream);
+/* SubMConv3d: out rows == in rows.  nbr[k][o] = i with coord[i] = coord[o] - pad + kappa.
+ * d_mask uint32 [M] (optional, may be null, needs K<=32): bit k set iff nbr[k][o] >= 0. */
+int wsis_rulebook_subm(const int32_t* d_indices, int64_t M, const int32_t* h_shape3,
+                       const int32_t* h_ksize3, const int32_t* h_pad3, const int64_t* d_keys,
+                       const int32_t* d_vals, int64_t cap, int32_t* d_nbr, uint32_t* d_mask,
+                       void* stream);
+/* SparseConv3d (stride s, pad p, dilation 1): out_shape_j = floor((in_j + 2p_j - (k_j-1) - 1)/s_j)+1.
+ * Step 1: candidate keys + sort + unique -> d_out_keys int64 [<= n_cand] ascending linear index,
+ * count in d_count int32[1].  n_cand = M_in when k==s && p==0, else M_in*K. */
+int64_t wsis_rulebook_down_ncand(int64_t M_in, const int32_t* h_ksize3, const int32_t* h_stride3,
+                                 const int32_t* h_pad3);
+int64_t wsis_rulebook_down_workspace_bytes(int64_t n_cand);
+int wsis_rulebook_down_keys(const int32_t* d_indices_in, int64_t M_in, const int32_t* h_in_shape3,
+                            const int32_t* h_out_shape3, const int32_t* h_ksize3,
+                            const int32_t* h_stride3, const int32_t* h_pad3, int64_t* d_cand,
+                            int64_t* d_out_keys, int32_t* d_count, void* d_ws, int64_t ws_bytes,
+                            void* stream);
+/* Step 2 (after the caller read M_out): decode out indices [M_out,4], build the coarse hash table,
+ * fill nbr_down int32 [K, M_out] (coarse row -> fine row) and nbr_up int32 [K, M_in]
+ * (fine row -> coarse row); optional masks as in wsis_rulebook_subm. */
+int wsis_rulebook_down_fill(const int32_t* d_indices_in, int64_t M_in, const int32_t* h_in_shape3,
+                            const int32_t* h_out_shape3, const int32_t* h_ksize3,
+                            const int32_t* h_stride3, const int32_t* h_pad3,
+                            const int64_t* d_out_keys, int64_t M_out, int32_t* d_indices_out,
+                            int64_t* d_keys, int32_t* d_vals, int64_t cap, int32_t* d_nbr_down,
+                            int32_t* d_nbr_up, uint32_t* d_mask_down, uint32_t* d_mask_up,
+                            void* stream);
+/* Tile ordering for the implicit GEMM: d_order int32 [M] = stable argsort of d_mask (rows with the
+ * same set of active offsets become neighbours so whole tiles skip inactive offsets). */
+int64_t wsis_mask_order_workspace_bytes(int64_t M);
+int wsis_mask_order(const uint32_t* d_mask, int64_t M, int32_t* d_order, void* d_ws, int64_t ws_bytes,
+                    void* stream);
+
+/* ---- a7-a11: sparse convolution [UPSTREAM spconv indiceConv / indiceConvBackward] -----------
+ * out[r,:] = sum_k X[nbr[k][r],:] @ W[k]  (rows with nbr<0 contribute nothing), fp32.
+ *   SubMConv3d fwd      : X=in,   nbr=subm table,  W=weight [K,Cin,Cout]
+ *   SubMConv3d dIn      : X=dOut, nbr=subm table,  W=wsis_weight_transpose(weight, flip=1)
+ *   SparseConv3d fwd    : X=in,   nbr=nbr_down,    W=weight
+ *   SparseConv3d dIn    : X=dOut, nbr=nbr_up,      W=transpose(weight, flip=0)
+ *   SparseInverseConv3d : X=in,   nbr=nbr_up,      W=weight ; dIn: X=dOut, nbr=nbr_down, W^T
+ * d_order (optional int32 [M_out]) = tile ordering from wsis_mask_order; d_bias optional [Cout];
+ * d_residual optional [M_out,Cout] added in the epilogue (sparse_unet3d.py:170 fused).
+ * K==1 with d_nbr==null is the dense 1x1 shortcut (sparse_unet3d.py:115-119). */
+int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_W,
+                    const float* d_bias, const float* d_residual, float* d_out, int64_t M_in,
+                    int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* stream);
+/* WT[k'] = W[k]^T with k' = (flip ? K-1-k : k); W [K,Cin,Cout] -> WT [K,Cout,Cin]. */
+int wsis_weight_transpose(const float* d_W, float* d_WT, int32_t K, int32_t Cin, int32_t Cout,
+                          int32_t flip, void* stream);
+/* dW[k] = sum_r X[nbr[k][r],:]^T (x) dY[r,:]   -> d_dW [K,Cin,Cout] (overwritten).
+ * Deterministic: per-workgroup partial slabs in d_ws reduced in a fixed order. */
+int64_t wsis_spconv_dw_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout);
+int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const float* d_dY, float* d_dW, int64_t M_in,
+                   int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
+                   void* stream);
+
+/* ---- a14/a15: row gather and torch_scatter.scatter  backbone_3D_WSIS.py:179,188,225,232,244 --
+ * CSR of a (possibly unsorted) index vector: d_perm int32 [N] = stable argsort(index),
+ * d_offsets int32 [S+1].  d_index is int64 [N] (torch_scatter takes LongTensor). */
+int64_t wsis_segment_csr_workspace_bytes(int64_t N, int64_t S);
+int wsis_segment_csr(const int64_t* d_index, int64_t N, int64_t S, int32_t* d_perm, int32_t* d_offsets,
+                     void* d_ws, int64_t ws_bytes, void* stream);
+/* reduce: 0 = sum, 1 = mean (sum / max(count,1)), 2 = max (empty segments -> 0).
+ * out [S,C]; d_argmax int32 [S,C] only for max (row index into src, -1 for empty). Points are
+ * accumulated in ascending original position => deterministic. */
+int wsis_segment_reduce_fwd(const float* d_src, const int32_t* d_perm, const int32_t* d_offsets,
+                            float* d_out, int32_t* d_argmax, int64_t N, int64_t S, int32_t C,
+                            int32_t reduce, void* stream);
+/* dsrc [N,C]: sum -> dout[index[p]]; mean -> dout[index[p]]/max(cnt,1); max -> scattered to argmax
+ * rows (dsrc must be zero-initialised for max). */
+int wsis_segment_reduce_bwd(const float* d_dout, const int64_t* d_index, const int32_t* d_offsets,
+                            const int32_t* d_argmax, float* d_dsrc, int64_t N, int64_t S, int32_t C,
+                            int32_t reduce, void* stream);
+/* out[p,:] = src[idx[p],:] (int32 or int64 index selected by idx_is_64). */
+int wsis_gather_rows(const float* d_src, const void* d_idx, int32_t idx_is_64, float* d_out, int64_t N,
+                     int32_t C, void* stream);
+
+/* ---- a16: edge affinity attention  backbone_3D_WSIS.py:218-249 ------------------------------
+ * logit_e = (q[u_e].k[v_e]) * scale * pos_enc_e ; a = segment softmax over edges sharing u ;
+ * res[u,:] = sum_e a_e v[v_e,:].  CSR over u: d_perm_u/d_off_u from wsis_segment_csr(edge_u).
+ * res [Su,D] with Su = max(u)+1 (rows without edges -> 0). */
+int wsis_edge_affinity_fwd(const float* d_q, const float* d_k, const float* d_v, const float* d_pos,
+                           const int64_t* d_eu, const int64_t* d_ev, const int32_t* d_perm_u,
+                           const int32_t* d_off_u, float scale, float* d_aff, float* d_res, int64_t E,
+                           int64_t Su, int32_t D, void* stream);
+/* backward: inputs dAff [E] (may be null), dRes [Su,D].  Outputs dq [S,D] (rows >= Su and rows
+ * without edges zero), dk, dv [S,D], dpos [E].  Needs CSR over v as well.  d_tmp float [2*E]. */
+int wsis_edge_affinity_bwd(const float* d_q, const float* d_k, const float* d_v, const float* d_pos,
+                           const float* d_aff, const int64_t* d_eu, const int64_t* d_ev,
+                           const int32_t* d_perm_u, const int32_t* d_off_u, const int32_t* d_perm_v,
+                           const int32_t* d_off_v, float scale, const float* d_daff,
+                           const float* d_dres, float* d_dq, float* d_dk, float* d_dv, float* d_dpos,
+                           float* d_tmp, int64_t E, int64_t S, int64_t Su, int32_t D, void* stream);
+
+/* ---- a17: dense inter-superpoint affinity + label propagation -------------------------------
+ * train_scannetv2.py:562-570, modules/datasets/scannetv2_dataset.py:664-721 (fp64, host numpy).
+ * A [S,S] fp64 zero-filled then A[u_e, v_e] = aff_e (edge order, later edges win). */
+int wsis_affinity_dense_build(const int64_t* d_eu, const int64_t* d_ev, const float* d_aff, int64_t E,
+                              double* d_A, int64_t S, void* stream);
+/* T0 = rownorm(A * adj * sem_c) for one class c:
+ *   sem[r][j] = (m[r] && m[j]) || (r==j && label[r]==c), m[r] = (pred[r]==c && conf[r]>thr);
+ *   adj [S,S] uint8 (adjacency + I); rows summing to 0 are divided by 1. */
+int wsis_affinity_transition(const double* d_A, const uint8_t* d_adj, const int32_t* d_pred,
+                             const float* d_conf, const int32_t* d_label, int32_t cls, float thr,
+                             double* d_T0, int64_t S, void* stream);
+/* C = A @ B, fp64 [S,S] row-major on the f64 matrix cores (v_mfma_f64_16x16x4_f64). */
+int wsis_dgemm(const double* d_A, const double* d_B, double* d_C, int64_t M, int64_t N, int64_t Kd,
+               void* stream);
+/* column-wise max / first argmax of T restricted to rows with label[r]==c (other rows count as 0):
+ * scores fp64 [S], arg int32 [S]  (np.max/np.argmax(axis=0) semantics, first max wins). */
+int wsis_affinity_colmax(const double* d_T, const int32_t* d_label, int32_t cls, double* d_scores,
+                         int32_t* d_arg, int64_t S, void* stream);
+
+/* ---- a19/a20: ballquery_batch_p / bfs_cluster [UPSTREAM PG_OP] ------------------------------
+ * For point p: ascending indices k of same-batch points with |x_p-x_k|^2 < r^2 (strict, incl. p),
+ * capped at 1000.  Deterministic offsets = exclusive prefix sum of the counts.
+ * Pass 1 writes d_start_len int32 [N,2] and d_total int32[1]; pass 2 fills d_idx int32 [total].
+ * Uniform-grid acceleration: workspace sized by the query. */
+int64_t wsis_ballquery_workspace_bytes(int64_t N);
+int wsis_ballquery_count(const float* d_xyz, const int32_t* d_batch_idx, const int32_t* d_batch_off,
+                         int64_t N, int32_t B, float radius, int32_t* d_start_len, int32_t* d_total,
+                         void* d_ws, int64_t ws_bytes, void* stream);
+int wsis_ballquery_fill(const float* d_xyz, const int32_t* d_batch_idx, const int32_t* d_batch_off,
+                        int64_t N, int32_t B, float radius, const int32_t* d_start_len, int32_t* d_idx,
+                        int64_t total, void* d_ws, int64_t ws_bytes, void* stream);
+#ifdef __cplusplus
+}
+#endif
+#endif /* WSIS_HIP_H_ */

@@ -1,0 +1,46 @@
+"""CPU: the two C-ABI libraries load and export every symbol include/wsis_hip.h declares."""
+import ctypes
+import os
+import re
+
+import wsis_native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "wsis_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wsis_\w+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    names = _declared()
+    assert len(names) >= 30
+    host = ctypes.CDLL(os.path.join(ROOT, "3d-wsis_amd", "libwsis_host.so"))
+    hip = ctypes.CDLL(os.path.join(ROOT, "3d-wsis_amd", "libwsis_hip.so"))
+    for n in names:
+        lib = host if n.startswith("wsis_host_") else hip
+        assert hasattr(lib, n), f"{n} declared in include/wsis_hip.h but not exported"
+
+
+def test_binding_table_matches_header():
+    host_names, hip_names = wsis_native.declared_symbols()
+    assert sorted(host_names + hip_names) == _declared()
+
+
+def test_libraries_load_and_report_version():
+    assert wsis_native.host().wsis_host_version() == 1
+    assert wsis_native.hip().wsis_version() == 1
+    assert wsis_native.hip().wsis_device_count() >= 0
+
+
+def test_device_ops_refuse_cpu_tensors():
+    import pytest
+    import torch
+    import pointgroup_ops
+    import torch_scatter
+    with pytest.raises(wsis_native.WsisError):
+        pointgroup_ops.voxelization(torch.zeros(4, 3), torch.zeros((2, 3), dtype=torch.int32), 4)
+    with pytest.raises(wsis_native.WsisError):
+        torch_scatter.scatter(torch.zeros(4, 3), torch.zeros(4, dtype=torch.long), dim=0, reduce="mean")

@@ -1,0 +1,333 @@
+"""GPU parity tests: every HIP operator (called through the C ABI via the drop-in packages) against the
+CPU oracle on the same seeded inputs.  Integer outputs bit-exact; fp32 tensors within the stated
+tolerance (rtol 1e-4 / atol 1e-5 per operator output, SURVEY 8a notes)."""
+import numpy as np
+import pytest
+import torch
+
+import pointgroup_ops
+import spconv
+import torch_scatter
+import wsis_ops
+from oracle import affinity_ref, pg_ops, scatter_ref
+from oracle import spconv_ref as ref
+from tests.util import random_sparse_coords
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    scale = max(1.0, float(b.abs().max())) if b.numel() else 1.0
+    ok = torch.allclose(a, b, rtol=rtol, atol=atol * scale)
+    if not ok:
+        print("max abs err", float((a - b).abs().max()), "scale", scale)
+    return ok
+
+
+# ---------------------------------------------------------------- voxelization (a1 + a2)
+@pytest.mark.parametrize("N,C", [(1, 6), (5000, 6), (3000, 3)])
+def test_voxelization_fwd_bwd(N, C):
+    rng = np.random.default_rng(N)
+    coords = np.concatenate([rng.integers(0, 2, (N, 1)), rng.integers(0, 14, (N, 3))], 1).astype(np.int64)
+    feats = rng.standard_normal((N, C)).astype(np.float32)
+    locs, p2v, v2p = pointgroup_ops.voxelization_idx(torch.from_numpy(coords), 2, 4)
+    f = torch.from_numpy(feats).to(DEV).requires_grad_(True)
+    out = pointgroup_ops.voxelization(f, v2p.to(DEV), 4)
+    expect = pg_ops.voxelization(feats, v2p.numpy(), 4)
+    assert np.array_equal(out.detach().cpu().numpy(), expect), "sequential fp32 mean must be bit-exact"
+    g = rng.standard_normal(expect.shape).astype(np.float32)
+    out.backward(torch.from_numpy(g).to(DEV))
+    assert np.array_equal(f.grad.cpu().numpy(), pg_ops.voxelization_backward(g, v2p.numpy(), N, 4))
+
+
+# ---------------------------------------------------------------- rulebooks (a5, a6)
+def _pairs_sets(pairs_t, num_t):
+    pairs_t, num_t = pairs_t.cpu().numpy(), num_t.cpu().numpy()
+    return [set(zip(pairs_t[k, 0, :num_t[k]].tolist(), pairs_t[k, 1, :num_t[k]].tolist())) for k in range(len(num_t))]
+
+
+@pytest.mark.parametrize("ksize,pad", [(3, 1), ((1, 3, 3), (0, 1, 1)), ((3, 1, 3), (1, 0, 1))])
+@pytest.mark.parametrize("shape,density", [((9, 8, 7), 0.3), ((24, 20, 16), 0.05)])
+def test_rulebook_subm(ksize, pad, shape, density):
+    idx = random_sparse_coords(11, 2, shape, density)
+    t = torch.from_numpy(idx).to(DEV)
+    rb = spconv.ops.build_subm_rulebook(t, list(shape), spconv.ops._triple(ksize), spconv.ops._triple(pad))
+    got = _pairs_sets(*rb.to_pairs())
+    exp = ref.subm_pairs(idx, shape, ksize, pad)
+    assert len(got) == len(exp)
+    for k, (i_rows, o_rows) in enumerate(exp):
+        assert got[k] == set(zip(i_rows.tolist(), o_rows.tolist())), f"offset {k}"
+    if rb.order is not None:
+        assert sorted(rb.order.cpu().tolist()) == list(range(idx.shape[0]))
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 8), (9, 7, 8), (33, 20, 17)])
+@pytest.mark.parametrize("k,s,p", [(2, 2, 0), (3, 2, 1), (3, 1, 1)])
+def test_rulebook_down(shape, k, s, p):
+    idx = random_sparse_coords(12, 3, shape, 0.1)
+    t = torch.from_numpy(idx).to(DEV)
+    rb = spconv.ops.build_down_rulebook(t, list(shape), [k] * 3, [s] * 3, [p] * 3)
+    out_idx, out_shape, exp = ref.down_pairs(idx, shape, k, s, p)
+    assert rb.out_shape == out_shape
+    assert np.array_equal(rb.out_indices.cpu().numpy(), out_idx), "output rows = ascending linear index, exact"
+    got = _pairs_sets(*rb.to_pairs())
+    for kk, (i_rows, o_rows) in enumerate(exp):
+        assert got[kk] == set(zip(i_rows.tolist(), o_rows.tolist()))
+    # nbr_up is the transposed table
+    up = rb.nbr_up.cpu().numpy()
+    down = rb.nbr.cpu().numpy()
+    for kk in range(down.shape[0]):
+        o = np.nonzero(down[kk] >= 0)[0]
+        assert np.array_equal(up[kk][down[kk][o]], o)
+        assert (up[kk] >= 0).sum() == len(o)
+
+
+def test_rulebook_empty_and_single():
+    t = torch.zeros((0, 4), dtype=torch.int32, device=DEV)
+    rb = spconv.ops.build_subm_rulebook(t, [8, 8, 8], [3, 3, 3], [1, 1, 1])
+    assert rb.nbr.shape == (27, 0)
+    one = torch.tensor([[0, 3, 3, 3]], dtype=torch.int32, device=DEV)
+    rb = spconv.ops.build_subm_rulebook(one, [8, 8, 8], [3, 3, 3], [1, 1, 1])
+    n = rb.nbr.cpu().numpy().ravel()
+    assert n[13] == 0 and (np.delete(n, 13) == -1).all()
+    rbd = spconv.ops.build_down_rulebook(one, [8, 8, 8], [2] * 3, [2] * 3, [0] * 3)
+    assert rbd.out_indices.cpu().tolist() == [[0, 1, 1, 1]]
+
+
+# ---------------------------------------------------------------- sparse conv fwd/bwd (a7-a11)
+def _conv_case(kind, cin, cout, shape, density, seed, bias=False, surface=False):
+    idx = random_sparse_coords(seed, 2, shape, density, surface=surface)
+    M = idx.shape[0]
+    g = torch.Generator().manual_seed(seed)
+    t_idx = torch.from_numpy(idx).to(DEV)
+    if kind == "subm":
+        mod = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=bias, indice_key="k").to(DEV)
+        pairs = ref.subm_pairs(idx, shape, 3, 1)
+        M_out, x_rows = M, M
+    elif kind == "subm1":
+        mod = spconv.SubMConv3d(cin, cout, 1, bias=bias).to(DEV)
+        pairs = [(np.arange(M), np.arange(M))]
+        M_out, x_rows = M, M
+    elif kind == "down":
+        mod = spconv.SparseConv3d(cin, cout, 2, stride=2, bias=bias, indice_key="k").to(DEV)
+        out_idx, _, pairs = ref.down_pairs(idx, shape, 2, 2, 0)
+        M_out, x_rows = out_idx.shape[0], M
+    else:
+        raise ValueError(kind)
+    x = torch.randn(x_rows, cin, generator=g)
+    xg = x.clone().to(DEV).requires_grad_(True)
+    inp = spconv.SparseConvTensor(xg, t_idx, np.array(shape), 2)
+    out = mod(inp)
+    w = mod.weight.detach().cpu().double().requires_grad_(True)
+    b = mod.bias.detach().cpu().double() if bias else None
+    xr = x.double().requires_grad_(True)
+    expect = ref.pairs_conv(xr, w, pairs, M_out, b)
+    assert out.features.shape == expect.shape
+    assert close(out.features, expect), f"forward {kind} {cin}->{cout}"
+    go = torch.randn(expect.shape, generator=g)
+    out.features.backward(go.to(DEV))
+    expect.backward(go.double())
+    assert close(xg.grad, xr.grad), f"dIn {kind} {cin}->{cout}"
+    assert close(mod.weight.grad, w.grad), f"dW {kind} {cin}->{cout}"
+    return out, inp, mod
+
+
+@pytest.mark.parametrize("cin,cout", [(6, 32), (32, 32), (64, 32), (96, 96), (160, 160), (5, 7), (33, 70), (256, 128)])
+def test_subm_conv(cin, cout):
+    _conv_case("subm", cin, cout, (12, 11, 10), 0.25, 21)
+
+
+def test_subm_conv_bias_and_surface_tiles():
+    _conv_case("subm", 32, 64, (40, 40, 12), 0.9, 22, bias=True, surface=True)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 64), (128, 160), (64, 96)])
+def test_down_conv(cin, cout):
+    _conv_case("down", cin, cout, (13, 12, 11), 0.3, 23)
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 32), (256, 128), (192, 96)])
+def test_1x1_conv(cin, cout):
+    _conv_case("subm1", cin, cout, (10, 10, 10), 0.3, 24)
+
+
+def test_inverse_conv_roundtrip_shapes_and_values():
+    shape = (13, 12, 11)
+    idx = random_sparse_coords(25, 2, shape, 0.3)
+    M = idx.shape[0]
+    g = torch.Generator().manual_seed(25)
+    x = torch.randn(M, 32, generator=g)
+    down = spconv.SparseConv3d(32, 64, 2, stride=2, bias=False, indice_key="sp").to(DEV)
+    up = spconv.SparseInverseConv3d(64, 32, 2, indice_key="sp", bias=False).to(DEV)
+    xg = x.clone().to(DEV).requires_grad_(True)
+    t = spconv.SparseConvTensor(xg, torch.from_numpy(idx).to(DEV), np.array(shape), 2)
+    mid = down(t)
+    back = up(mid)
+    assert back.indices.data_ptr() == t.indices.data_ptr() and list(back.spatial_shape) == list(shape)
+    out_idx, _, pairs = ref.down_pairs(idx, shape, 2, 2, 0)
+    wd = down.weight.detach().cpu().double().requires_grad_(True)
+    wu = up.weight.detach().cpu().double().requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    e_mid = ref.pairs_conv(xr, wd, pairs, out_idx.shape[0])
+    e_back = ref.pairs_conv(e_mid, wu, ref.inverse_pairs(pairs), M)
+    assert close(back.features, e_back)
+    go = torch.randn(e_back.shape, generator=g)
+    back.features.backward(go.to(DEV))
+    e_back.backward(go.double())
+    assert close(xg.grad, xr.grad) and close(down.weight.grad, wd.grad) and close(up.weight.grad, wu.grad)
+    # inputs on the dropped odd plane get exactly zero rows
+    dropped = (idx[:, 1] // 2 >= 6) | (idx[:, 2] // 2 >= 6) | (idx[:, 3] // 2 >= 5)
+    if dropped.any():
+        assert float(back.features[torch.from_numpy(dropped).to(DEV)].abs().max()) == 0.0
+
+
+def test_conv_is_deterministic_and_order_independent(monkeypatch):
+    shape = (30, 30, 10)
+    idx = random_sparse_coords(26, 2, shape, 0.8, surface=True)
+    g = torch.Generator().manual_seed(26)
+    x = torch.randn(idx.shape[0], 32, generator=g).to(DEV)
+    mod = spconv.SubMConv3d(32, 32, 3, padding=1, bias=False, indice_key="k").to(DEV)
+    outs = []
+    for flag in ("1", "1", "0"):
+        monkeypatch.setenv("WSIS_MASK_ORDER", flag)
+        t = spconv.SparseConvTensor(x, torch.from_numpy(idx).to(DEV), np.array(shape), 2)
+        outs.append(mod(t).features.clone())
+    assert torch.equal(outs[0], outs[1]), "run-to-run bit-exact"
+    assert torch.equal(outs[0], outs[2]), "tile ordering must not change any value (same per-row sum order)"
+
+
+# ---------------------------------------------------------------- scatter (a15)
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max", "min"])
+@pytest.mark.parametrize("N,S,C", [(5000, 300, 32), (777, 50, 3), (1000, 400, 1), (300, 7, 70)])
+def test_scatter(reduce, N, S, C):
+    g = torch.Generator().manual_seed(N + C)
+    index = torch.randint(0, S, (N,), generator=g)
+    index[0] = S - 1
+    src = torch.randn(N, C, generator=g) if C > 1 else torch.randn(N, generator=g)
+    xs = src.clone().to(DEV).requires_grad_(True)
+    out = torch_scatter.scatter(xs, index.to(DEV), dim=0, reduce=reduce)
+    xr = src.clone().double().requires_grad_(True)
+    expect = scatter_ref.scatter(xr, index, 0, None, reduce)
+    assert out.shape == expect.shape
+    assert close(out, expect)
+    go = torch.randn(expect.shape, generator=g)
+    out.backward(go.to(DEV))
+    expect.backward(go.double())
+    assert close(xs.grad, xr.grad)
+
+
+def test_scatter_empty_segments_and_determinism():
+    index = torch.tensor([5, 5, 0, 9], device=DEV)
+    src = torch.tensor([[1.0], [3.0], [-2.0], [4.0]], device=DEV)
+    assert torch_scatter.scatter(src, index, 0, reduce="mean").flatten().tolist() == [-2, 0, 0, 0, 0, 2, 0, 0, 0, 4]
+    assert torch_scatter.scatter(src, index, 0, reduce="max").flatten().tolist() == [-2, 0, 0, 0, 0, 3, 0, 0, 0, 4]
+    big = torch.randn(20000, 32, device=DEV)
+    idx = torch.randint(0, 500, (20000,), device=DEV)
+    a = torch_scatter.scatter(big, idx, 0, reduce="mean")
+    b = torch_scatter.scatter(big, idx, 0, reduce="mean")
+    assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------- edge affinity (a16)
+def _graph(seed, S, deg):
+    rng = np.random.default_rng(seed)
+    edges = set()
+    for u in range(S - 3):          # last nodes have no out-edges: res is shorter than S
+        for v in rng.choice(S, size=rng.integers(1, deg + 1), replace=False):
+            if u != v:
+                edges.add((u, int(v)))
+    e = np.array(sorted(edges), dtype=np.int64)
+    return e[:, 0], e[:, 1]
+
+
+@pytest.mark.parametrize("S,deg,D", [(64, 6, 64), (300, 12, 64), (40, 5, 32)])
+def test_edge_affinity_fwd_bwd(S, deg, D):
+    eu, ev = _graph(S, S, deg)
+    g = torch.Generator().manual_seed(S)
+    q, k, v = (torch.randn(S, D, generator=g) for _ in range(3))
+    pos = torch.randn(len(eu), generator=g)
+    tq, tk, tv, tp = (t.clone().to(DEV).requires_grad_(True) for t in (q, k, v, pos))
+    graph = wsis_ops.EdgeGraph(torch.from_numpy(eu).to(DEV), torch.from_numpy(ev).to(DEV), S)
+    aff, res = wsis_ops.edge_affinity(tq, tk, tv, tp, graph, 1.0 / np.sqrt(D))
+    rq, rk, rv, rp = (t.clone().double().requires_grad_(True) for t in (q, k, v, pos))
+    e_aff, e_res = affinity_ref.edge_affinity(rq, rk, rv, rp, torch.from_numpy(eu), torch.from_numpy(ev))
+    assert res.shape == e_res.shape and res.shape[0] == eu.max() + 1 < S
+    assert close(aff, e_aff) and close(res, e_res)
+    ga, gr = torch.randn(e_aff.shape, generator=g), torch.randn(e_res.shape, generator=g)
+    (aff * ga.to(DEV)).sum().add((res * gr.to(DEV)).sum()).backward()
+    (e_aff * ga.double()).sum().add((e_res * gr.double()).sum()).backward()
+    for a, b, name in ((tq, rq, "dq"), (tk, rk, "dk"), (tv, rv, "dv"), (tp, rp, "dpos")):
+        assert close(a.grad, b.grad, rtol=1e-3, atol=1e-4), name
+
+
+# ---------------------------------------------------------------- dense affinity + propagation (a17)
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (100, 70, 33), (257, 130, 5)])
+def test_dgemm_f64_mfma(M, N, K):
+    g = torch.Generator().manual_seed(M)
+    A, B = torch.randn(M, K, generator=g, dtype=torch.float64), torch.randn(K, N, generator=g, dtype=torch.float64)
+    C = wsis_ops.dgemm(A.to(DEV), B.to(DEV))
+    assert torch.allclose(C.cpu(), A @ B, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("iterations", [0, 1, 2])
+def test_label_propagation(iterations):
+    S, classes = 180, 6
+    eu, ev = _graph(5, S, 8)
+    both = np.unique(np.concatenate([np.stack([eu, ev], 1), np.stack([ev, eu], 1)]), axis=0)
+    eu, ev = both[:, 0], both[:, 1]
+    rng = np.random.default_rng(7)
+    aff = rng.random(len(eu)).astype(np.float32)
+    adjacency = np.zeros((S, S), dtype=np.int64)
+    adjacency[eu, ev] = 1
+    pred = rng.integers(0, classes, S)
+    conf = rng.random(S).astype(np.float32)
+    label = np.full(S, -100)
+    lab_ids = rng.choice(S, 20, replace=False)
+    label[lab_ids] = pred[lab_ids] = rng.integers(0, classes - 1, 20)   # one class absent
+    A_ref = affinity_ref.affinity_matrix(eu, ev, aff, S)
+    e_final, e_scores, _ = affinity_ref.weak_label_propagation(A_ref, adjacency, conf, pred, label, iterations, classes)
+    A = wsis_ops.affinity_matrix(torch.from_numpy(eu).to(DEV), torch.from_numpy(ev).to(DEV),
+                                 torch.from_numpy(aff).to(DEV), S)
+    assert np.array_equal(A.cpu().numpy(), A_ref)
+    final, scores = wsis_ops.weak_label_propagation(A, adjacency, conf, pred, label, iterations, classes)
+    assert np.allclose(scores, e_scores, rtol=1e-10, atol=1e-14)
+    assert np.array_equal(final, e_final)
+
+
+# ---------------------------------------------------------------- ball query (a19) + clustering (a20)
+@pytest.mark.parametrize("N,B,r", [(1, 1, 0.05), (700, 2, 0.05), (3000, 3, 0.03)])
+def test_ballquery_and_bfs(N, B, r):
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(N)
+    sizes = [N // B] * B
+    sizes[-1] += N - sum(sizes)
+    xyz = (rng.random((N, 3)) * 0.4).astype(np.float32)
+    bi = np.repeat(np.arange(B), sizes).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    idx, sl = pointgroup_ops.ballquery_batch_p(torch.from_numpy(xyz).to(DEV), torch.from_numpy(bi).to(DEV),
+                                               torch.from_numpy(off).to(DEV), r, 50)
+    e_idx, e_sl = pg_ops.ballquery_batch_p(xyz, bi, off, r)
+    assert np.array_equal(sl.cpu().numpy(), e_sl) and np.array_equal(idx.cpu().numpy(), e_idx)
+    # independent: cKDTree per batch item (strict radius: allow boundary-equal pairs to differ)
+    for b in range(B):
+        tree = cKDTree(xyz[off[b]:off[b + 1]].astype(np.float64))
+        cnt = np.array([len(x) for x in tree.query_ball_point(xyz[off[b]:off[b + 1]].astype(np.float64), r)])
+        assert np.abs(cnt - e_sl[off[b]:off[b + 1], 1]).max() <= 1
+    sem = rng.integers(0, 2, N).astype(np.int32)
+    ci, co = pointgroup_ops.bfs_cluster(torch.from_numpy(sem), idx.cpu(), sl.cpu(), 3)
+    ri, ro = pg_ops.bfs_cluster(sem, e_idx, e_sl, 3)
+    assert np.array_equal(ci.numpy(), ri) and np.array_equal(co.numpy(), ro)
+
+
+def test_ballquery_cap_1000():
+    N = 1500
+    xyz = np.zeros((N, 3), dtype=np.float32)
+    bi = np.zeros(N, dtype=np.int32)
+    off = np.array([0, N], dtype=np.int32)
+    idx, sl = pointgroup_ops.ballquery_batch_p(torch.from_numpy(xyz).to(DEV), torch.from_numpy(bi).to(DEV),
+                                               torch.from_numpy(off).to(DEV), 0.01, 50)
+    assert (sl[:, 1] == 1000).all() and idx.numel() == 1000 * N
+    assert idx[:1000].cpu().tolist() == list(range(1000))
