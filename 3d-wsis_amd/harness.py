@@ -1,0 +1,279 @@
+"""Synthetic ScanNet-shaped scenes, batch assembly and the per-iteration hot path of 3D-WSIS.
+
+* ``make_scene``   -- seeded generator specified in SURVEY.md 8d (room = floor + 4 walls + boxes sampled at one
+                      point per occupied 2 cm voxel plus ~30 % duplicates, 0.25 m superpoints, <0.3 m
+                      superpoint graph, weak labels: one labelled superpoint per instance).
+* ``collate``      -- the batch dict of modules/datasets/scannetv2_dataset.py:343-474, built
+                      with the host ``pointgroup_ops.voxelization_idx``.
+* ``to_device`` / ``train_step`` -- the iteration of train_scannetv2.py:143-252: H2D, superpoint centres,
+                      ``voxelization`` -> ``SparseConvTensor`` -> ``Network`` -> ``MultiTaskLoss`` -> backward ->
+                      ECC grad clamp -> AdamW step.
+"""
+import types
+
+import numpy as np
+import torch
+
+SCALE = 50            # config/ScanNet_v2_3D_WSIS.yaml:31 (2 cm voxels)
+FULL_SCALE_MIN = 128  # :30 full_scale[0]
+
+
+def default_cfg():
+    model = types.SimpleNamespace(input_channel=3, use_coords=True, blocks=5, block_reps=2, media=32, classes=20,
+                                  fix_module="[]")          # config/ScanNet_v2_3D_WSIS.yaml:37-45
+    loss = types.SimpleNamespace(ignore_label=-100, supervise_instance_size=True, joint_training_epoch=0,
+                                 semantic_dice=True, supervise_sp_offset=True)   # stage-3 switches (8d)
+    return types.SimpleNamespace(model=model, loss=loss, mode=4, batch_size=1)
+
+
+# -------------------------------------------------------------------------------------------------------------
+def _face_voxels(origin, u, v, lu, lv, voxel):
+    """voxel-centre samples of the rectangle origin + a*u + b*v, 0<=a<lu, 0<=b<lv (metres)."""
+    na, nb = max(int(round(lu / voxel)), 1), max(int(round(lv / voxel)), 1)
+    a, b = np.meshgrid((np.arange(na) + 0.5) * voxel, (np.arange(nb) + 0.5) * voxel, indexing="ij")
+    return origin[None, :] + a.reshape(-1, 1) * u[None, :] + b.reshape(-1, 1) * v[None, :]
+
+
+def make_scene(seed, room=(4.6, 3.6, 2.2), n_box=8, dup=0.3, voxel=0.02, sp_cell=0.25, classes=20,
+               max_points=None):
+    """returns a dict of numpy arrays describing one scene (all host side)."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    L, W, H = room
+    ex, ey, ez = np.eye(3)
+    faces = [(np.zeros(3), ex, ey, L, W),                                   # floor
+             (np.zeros(3), ex, ez, L, H), (np.array([0, W, 0.]), ex, ez, L, H),   # walls y=0 / y=W
+             (np.zeros(3), ey, ez, W, H), (np.array([L, 0, 0.]), ey, ez, W, H)]   # walls x=0 / x=L
+    inst_of_face = [0, 1, 2, 3, 4]
+    n_inst = 5
+    for _ in range(n_box):
+        sx, sy, sz = rng.uniform(0.3, 0.7), rng.uniform(0.3, 0.7), rng.uniform(0.3, 0.7)
+        ox, oy = rng.uniform(0.1, L - sx - 0.1), rng.uniform(0.1, W - sy - 0.1)
+        o = np.array([ox, oy, 0.0])
+        box = [(o + np.array([0, 0, sz]), ex, ey, sx, sy),                 # top
+               (o, ex, ez, sx, sz), (o + np.array([0, sy, 0]), ex, ez, sx, sz),
+               (o, ey, ez, sy, sz), (o + np.array([sx, 0, 0]), ey, ez, sy, sz)]
+        faces += box
+        inst_of_face += [n_inst] * 5
+        n_inst += 1
+    pts, face_id = [], []
+    for f, (o, u, v, lu, lv) in enumerate(faces):
+        p = _face_voxels(np.asarray(o, float), u, v, lu, lv, voxel)
+        pts.append(p)
+        face_id.append(np.full(len(p), f))
+    pts = np.concatenate(pts)
+    face_id = np.concatenate(face_id)
+    # one point per occupied voxel
+    vox = np.floor(pts / voxel + 1e-6).astype(np.int64)
+    _, first = np.unique(vox, axis=0, return_index=True)
+    first.sort()
+    pts, face_id, vox = pts[first], face_id[first], vox[first]
+    jitter = (rng.random(pts.shape) - 0.5) * 0.6 * voxel
+    base = (vox + 0.5) * voxel
+    pts = base + jitter
+    n_dup = int(dup * len(pts))
+    d = rng.choice(len(pts), n_dup, replace=False)
+    pts = np.concatenate([pts, base[d] + (rng.random((n_dup, 3)) - 0.5) * 0.6 * voxel])
+    face_id = np.concatenate([face_id, face_id[d]])
+    perm = rng.permutation(len(pts))
+    if max_points is not None:
+        perm = perm[:max_points]
+    pts, face_id = pts[perm].astype(np.float32), face_id[perm]
+    N = len(pts)
+    rgb = rng.uniform(-1, 1, (N, 3)).astype(np.float32)
+
+    # superpoints = 0.25 m cell x surface patch, dense renumbered
+    cell = np.floor(pts / sp_cell).astype(np.int64)
+    key = np.concatenate([face_id[:, None], cell], 1)
+    _, superpoint = np.unique(key, axis=0, return_inverse=True)
+    superpoint = superpoint.reshape(-1).astype(np.int64)
+    S = int(superpoint.max()) + 1
+    cnt = np.bincount(superpoint, minlength=S).astype(np.float64)
+    centre = np.stack([np.bincount(superpoint, pts[:, j], S) / cnt for j in range(3)], 1)
+    sp_face = np.zeros(S, dtype=np.int64)
+    sp_face[superpoint] = face_id
+    sp_inst = np.asarray(inst_of_face)[sp_face]
+
+    # superpoint graph: both directions between centres closer than 0.3 m (<= 8 nearest), sorted tuples
+    tree = cKDTree(centre)
+    dist, nbr = tree.query(centre, k=min(9, S), distance_upper_bound=0.3)
+    und = set()
+    for s in range(S):
+        for dd, t in zip(dist[s][1:], nbr[s][1:]):
+            if np.isfinite(dd) and t < S and t != s:
+                und.add((min(s, int(t)), max(s, int(t))))
+    if not und:
+        und.add((0, min(1, S - 1)))
+    edges = np.array(sorted(list(und) + [(b, a) for a, b in und]), dtype=np.int64)
+    edge_feats = rng.standard_normal((len(edges), 13)).astype(np.float32)
+
+    # labels: semantic per instance, weak supervision = one labelled superpoint per instance
+    inst_sem = rng.integers(0, classes, n_inst)
+    sp_sem_full = inst_sem[sp_inst]
+    sp_sem = np.full(S, -100, dtype=np.int64)
+    sp_ins = np.full(S, -100, dtype=np.int64)
+    for i in range(n_inst):
+        members = np.nonzero(sp_inst == i)[0]
+        if len(members):
+            c = members[rng.integers(len(members))]
+            sp_sem[c], sp_ins[c] = sp_sem_full[c], i
+    inst_centre = np.stack([np.array([pts[(sp_inst[superpoint] == i)].mean(0) if (sp_inst == i).any() else np.zeros(3)
+                                      for i in range(n_inst)])])[0]
+    sp_offset = (inst_centre[sp_inst] - centre).astype(np.float32)
+    inst_vox = np.array([max(int(((sp_inst[superpoint]) == i).sum()), 1) for i in range(n_inst)])
+    inst_size = np.array([np.linalg.norm(pts[sp_inst[superpoint] == i].max(0) - pts[sp_inst[superpoint] == i].min(0))
+                          if (sp_inst == i).any() else 0.0 for i in range(n_inst)])
+    return dict(xyz=pts, rgb=rgb, superpoint=superpoint, edges=edges, edge_feats=edge_feats,
+                sem_label=sp_sem[superpoint], ins_label=sp_ins[superpoint], sp_sem=sp_sem, sp_ins=sp_ins,
+                sp_offset=sp_offset, sp_voxnum=inst_vox[sp_inst].astype(np.float32),
+                sp_size=inst_size[sp_inst].astype(np.float32), n_inst=n_inst, S=S)
+
+
+# -------------------------------------------------------------------------------------------------------------
+def collate(scenes, mode=4):
+    """Batch dict with the schema of scannetv2_dataset.py:460-474; host tensors."""
+    import pointgroup_ops
+    from graphnet import GraphConvInfo
+    locs, locs_float, feats, sem, ins, sps = [], [], [], [], [], []
+    sp_sem, sp_ins, sp_off, sp_vox, sp_size = [], [], [], [], []
+    edge_sorted, edge_feats_sorted, edges_ext = [], [], []
+    batch_offsets, sp_batch_offsets = [0], [0]
+    sp_bias, inst_bias = 0, 0
+    for b, sc in enumerate(scenes):
+        xyz = sc["xyz"]
+        v = np.floor(xyz.astype(np.float64) * SCALE).astype(np.int64)
+        v = v - v.min(0)
+        locs.append(torch.cat([torch.full((len(v), 1), b, dtype=torch.int64), torch.from_numpy(v)], 1))
+        locs_float.append(torch.from_numpy(xyz))
+        feats.append(torch.from_numpy(sc["rgb"]))
+        sem.append(torch.from_numpy(sc["sem_label"]))
+        il = sc["ins_label"].copy()
+        il[il != -100] += inst_bias
+        ins.append(torch.from_numpy(il))
+        sps.append(torch.from_numpy(sc["superpoint"] + sp_bias))
+        sp_sem.append(torch.from_numpy(sc["sp_sem"]))
+        si = sc["sp_ins"].copy()
+        si[si != -100] += inst_bias
+        sp_ins.append(torch.from_numpy(si))
+        sp_off.append(torch.from_numpy(sc["sp_offset"]))
+        sp_vox.append(torch.from_numpy(sc["sp_voxnum"]))
+        sp_size.append(torch.from_numpy(sc["sp_size"]))
+        E = sc["edges"]
+        order = np.argsort(E[:, 1], kind="stable")          # ecc/GraphConvInfo.py:54 (sorted by target)
+        edge_sorted.append(torch.from_numpy(E[order] + sp_bias))
+        edge_feats_sorted.append(torch.from_numpy(sc["edge_feats"][order]))
+        edges_ext.append(torch.from_numpy(E + sp_bias))     # original (sorted-tuple) order, :455-457
+        sp_bias += sc["S"]
+        inst_bias += sc["n_inst"]
+        batch_offsets.append(batch_offsets[-1] + len(v))
+        sp_batch_offsets.append(sp_bias)
+    locs = torch.cat(locs, 0)
+    spatial_shape = np.clip((locs.max(0)[0][1:] + 1).numpy(), FULL_SCALE_MIN, None)
+    voxel_locs, p2v_map, v2p_map = pointgroup_ops.voxelization_idx(locs, len(scenes), mode)
+    edge_indexes = torch.cat(edge_sorted, 0).t().contiguous()
+    GIs = [GraphConvInfo(edge_indexes, torch.cat(edge_feats_sorted, 0), sp_bias)]
+    edges = torch.cat(edges_ext, 0)
+    return {
+        "locs": locs, "voxel_locs": voxel_locs, "p2v_map": p2v_map, "v2p_map": v2p_map,
+        "locs_float": torch.cat(locs_float, 0).float(), "feats": torch.cat(feats, 0).float(),
+        "semantic_labels": torch.cat(sem, 0).long(), "instance_labels": torch.cat(ins, 0).long(),
+        "offsets": torch.tensor(batch_offsets, dtype=torch.int32), "spatial_shape": spatial_shape,
+        "superpoint": torch.cat(sps, 0).long(), "GIs": GIs,
+        "sp_batch_offsets": torch.tensor(sp_batch_offsets, dtype=torch.int32),
+        "edge_u_list": edges[:, 0].contiguous().long(), "edge_v_list": edges[:, 1].contiguous().long(),
+        "superpoint_semantic_labels": torch.cat(sp_sem, 0).long(),
+        "superpoint_instance_labels": torch.cat(sp_ins, 0).long(),
+        "superpoint_offset_vector": torch.cat(sp_off, 0).float(),
+        "superpoint_instance_voxel_num": torch.log(torch.cat(sp_vox, 0).float()),
+        "superpoint_instance_size": torch.cat(sp_size, 0).float(),
+        "scene_list": [f"synthetic_{i}" for i in range(len(scenes))],
+    }
+
+
+_DEVICE_KEYS = ("voxel_locs", "p2v_map", "v2p_map", "locs_float", "feats", "semantic_labels", "instance_labels",
+                "superpoint", "edge_u_list", "edge_v_list", "superpoint_semantic_labels",
+                "superpoint_instance_labels", "superpoint_offset_vector", "superpoint_instance_voxel_num",
+                "superpoint_instance_size")
+
+
+def to_device(batch, device):
+    """H2D of train_scannetv2.py:149-172 plus the per-batch graph structures (CSR of the superpoint ids and of
+    the edge lists) that are constant for the batch."""
+    from torch_scatter import SegmentCSR
+    import wsis_ops
+    out = dict(batch)
+    for k in _DEVICE_KEYS:
+        out[k] = batch[k].to(device)
+    out["voxel_coords_int"] = out["voxel_locs"].int().contiguous()
+    out["GIs"][0].cuda()
+    S = int(batch["sp_batch_offsets"][-1])
+    out["superpoint_csr"] = SegmentCSR(out["superpoint"], S)
+    out["edge_graph"] = wsis_ops.EdgeGraph(out["edge_u_list"], out["edge_v_list"], S)
+    return out
+
+
+def forward_loss(model, criterion, batch, cfg, epoch=5):
+    """train_scannetv2.py:174-232 on a device batch -> (loss, ret)"""
+    import pointgroup_ops
+    import spconv
+    from torch_scatter import scatter
+    coords_float = batch["locs_float"]
+    superpoint = batch["superpoint"]
+    centre = scatter(coords_float, superpoint, dim=0, reduce="mean", csr=batch.get("superpoint_csr"))
+    extra = {"superpoint": superpoint, "GIs": batch["GIs"], "edge_u_list": batch["edge_u_list"],
+             "edge_v_list": batch["edge_v_list"], "superpoint_cenetr_xyz": centre,
+             "superpoint_csr": batch.get("superpoint_csr"), "edge_graph": batch.get("edge_graph")}
+    feats = batch["feats"]
+    if cfg.model.use_coords:
+        feats = torch.cat((feats, coords_float), 1)
+    voxel_feats = pointgroup_ops.voxelization(feats, batch["v2p_map"], cfg.mode)
+    input_ = spconv.SparseConvTensor(voxel_feats, batch["voxel_coords_int"], batch["spatial_shape"], cfg.batch_size)
+    ret = model(input_, batch["p2v_map"], extra)
+    loss_inp = {
+        "point_labels": (batch["semantic_labels"], batch["instance_labels"]),
+        "semantic_scores": ret["semantic_scores"],
+        "superpoint_labels": (batch["superpoint_semantic_labels"], batch["superpoint_instance_labels"]),
+        "sp_semantic": ret["sp_semantic_scores"],
+        "sp_offset_vector": (ret["pred_sp_offset_vectors"], batch["superpoint_offset_vector"]),
+        "sp_occupancy": (ret["pred_sp_occupancy"], batch["superpoint_instance_voxel_num"]),
+        "sp_instance_size": (ret["pred_sp_ins_size"], batch["superpoint_instance_size"]),
+        "sp_discriminative_features": (ret["sp_discriminative_feats"], batch["sp_batch_offsets"]),
+    }
+    loss, loss_out = criterion(loss_inp, epoch)
+    return loss, ret
+
+
+def train_step(model, criterion, optimizer, batch, cfg, epoch=5, grad_sync=None):
+    """one iteration of train_scannetv2.py:143-252 (forward, loss, backward, ECC grad clamp, AdamW step)."""
+    loss, ret = forward_loss(model, criterion, batch, cfg, epoch)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync(model)
+    for p in model.ecc.parameters():
+        if p.grad is not None:
+            p.grad.data.clamp_(-1, 1)
+    optimizer.step()
+    return loss.detach(), ret
+
+
+def build_model(cfg, device, seed=123):
+    import backbone_3D_WSIS
+    import losses_3D_WSIS
+    torch.manual_seed(seed)   # config/ScanNet_v2_3D_WSIS.yaml:3
+    model = backbone_3D_WSIS.Network(cfg.model).to(device)
+    criterion = losses_3D_WSIS.MultiTaskLoss(None, cfg.loss, cfg.model)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)   # yaml:58-61
+    return model, criterion, optimizer
+
+
+def train_step_smoke(device="cuda:0"):
+    """tiny fwd+bwd+step of the whole path (used by __graft_entry__.smoke)."""
+    cfg = default_cfg()
+    scene = make_scene(0, room=(1.2, 1.0, 0.8), n_box=1)
+    batch = to_device(collate([scene]), device)
+    model, crit, opt = build_model(cfg, device)
+    loss, ret = train_step(model, crit, opt, batch, cfg)
+    assert torch.isfinite(loss).item(), "non-finite loss in smoke step"
+    assert ret["edge_affinity"].shape[0] == batch["edge_u_list"].shape[0]
+    return float(loss)

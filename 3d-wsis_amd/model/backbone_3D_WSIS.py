@@ -1,0 +1,136 @@
+"""``Network`` of 3D-WSIS on the MI355X operator surface.
+
+Same constructor argument (``param`` with input_channel/use_coords/blocks/block_reps/media/classes/
+fix_module), same ``forward(input, input_map, extra_data)`` signature, same ``ret`` keys and the same module
+tree / state-dict names as the reference's modules/model/backbone_3D_WSIS.py:24-255, so the reference's
+train/test scripts and checkpoints can use it as a drop-in.
+
+Differences, all inside the hot path: sparse convs, voxel->point gather, superpoint scatter-mean and the
+edge-affinity attention run as HIP kernels from libwsis_hip.so; the attention block (:218-244) is ONE fused
+kernel (fwd + bwd) instead of ~10 elementwise/scatter launches.
+"""
+import ast
+import functools
+import math
+
+import torch
+import torch.nn as nn
+
+import spconv
+import graphnet
+import wsis_ops
+from sparse_unet3d import ResidualBlock, UBlock
+from torch_scatter import SegmentCSR, scatter
+
+__all__ = ["Network"]
+
+
+class Network(nn.Module):
+    def __init__(self, param):
+        super().__init__()
+        self.input_channel = param.input_channel
+        self.use_coords = param.use_coords
+        self.blocks = param.blocks
+        self.block_reps = param.block_reps
+        self.media = param.media
+        self.classes = param.classes
+        fix = getattr(param, "fix_module", "[]")
+        self.fix_module = ast.literal_eval(fix) if isinstance(fix, str) else list(fix)
+
+        if self.use_coords:
+            self.input_channel += 3
+
+        self.input_conv = spconv.SparseSequential(
+            spconv.SubMConv3d(self.input_channel, self.media, kernel_size=3, padding=1, bias=False,
+                              indice_key="subm1"))
+        norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+        block_list = [self.media * (i + 1) for i in range(self.blocks)]
+        self.unet = UBlock(block_list, norm_fn, self.block_reps, ResidualBlock, indice_key_id=1)
+        self.output_layer = spconv.SparseSequential(norm_fn(self.media), nn.ReLU(inplace=True))
+
+        def head(cin, cout):
+            return nn.Sequential(nn.Linear(cin, cin, bias=True), norm_fn(cin), nn.ReLU(inplace=True),
+                                 nn.Linear(cin, cout))
+
+        self.linear = head(self.media, self.classes)                       # point semantic
+        self.ecc = graphnet.GraphNetwork("gru_7_0,f_64,b,r", nfeat=self.media, fnet_widths=[13, 32, 128, 64],
+                                         fnet_orthoinit=True, fnet_llbias=True, fnet_bnidx=2, use_pyg=True,
+                                         cuda=True)
+        sp_feat_dim = 64
+        self.sp_sem_seg = head(sp_feat_dim, self.classes)
+        self.sp_offset_vector_head = head(sp_feat_dim, 3)
+        self.sp_occupancy_head = head(sp_feat_dim, 1)
+        self.sp_ins_size_head = head(sp_feat_dim, 1)
+
+        d_model = 64
+        self.fc_position = nn.Sequential(nn.Linear(3, 16), nn.ReLU(), nn.Linear(16, 1))
+        self.w_qs = nn.Linear(d_model, d_model, bias=False)
+        self.w_ks = nn.Linear(d_model, d_model, bias=False)
+        self.w_vs = nn.Linear(d_model, d_model, bias=False)
+        self.feature_term = head(d_model, 7)
+
+        for name in self.fix_module:
+            module = getattr(self, name)
+            module.eval()
+            for p in module.parameters():
+                p.requires_grad = False
+
+    @staticmethod
+    def freeze_bn(module):
+        for child in module.modules():
+            if isinstance(child, nn.BatchNorm1d):
+                child.weight.requires_grad_(False)
+                child.bias.requires_grad_(False)
+
+    @staticmethod
+    def set_bn_init(m):
+        if m.__class__.__name__.find("BatchNorm") != -1:
+            try:
+                m.weight.data.fill_(1.0)
+                m.bias.data.fill_(0.0)
+            except Exception:
+                pass
+
+    def forward(self, input, input_map, extra_data):
+        ret = {}
+        for name in self.fix_module:
+            getattr(self, name).eval()
+
+        output = self.input_conv(input)
+        output = self.unet(output)
+        output = self.output_layer(output)
+        output_feats = output.features[input_map.long()]            # [N, m] voxel -> point
+
+        ret["semantic_scores"] = self.linear(output_feats)          # [N, nClass]
+
+        superpoint = extra_data["superpoint"].long()
+        sp_csr = extra_data.get("superpoint_csr")                   # optional reuse (extension)
+        embeddings = scatter(output_feats, superpoint, dim=0, reduce="mean", csr=sp_csr)
+
+        self.ecc.set_info(extra_data["GIs"], cuda=True)
+        ecc_outputs = self.ecc(embeddings)
+
+        ret["sp_semantic_scores"] = self.sp_sem_seg(ecc_outputs)
+        ret["pred_sp_offset_vectors"] = self.sp_offset_vector_head(ecc_outputs)
+        ret["pred_sp_occupancy"] = self.sp_occupancy_head(ecc_outputs).squeeze(-1)
+        ret["pred_sp_ins_size"] = self.sp_ins_size_head(ecc_outputs).squeeze(-1)
+
+        # ---- affinity between adjacent superpoints (backbone_3D_WSIS.py:207-253) ----
+        centre = extra_data["superpoint_cenetr_xyz"]
+        q, k, v = self.w_qs(ecc_outputs), self.w_ks(ecc_outputs), self.w_vs(ecc_outputs)
+        edge_u, edge_v = extra_data["edge_u_list"], extra_data["edge_v_list"]
+        graph = extra_data.get("edge_graph")
+        if graph is None:
+            graph = wsis_ops.EdgeGraph(edge_u, edge_v, ecc_outputs.shape[0])
+        pos_enc = self.fc_position(centre[edge_u] - centre[edge_v]).reshape(-1)
+        affinity, res = wsis_ops.edge_affinity(q, k, v, pos_enc, graph, 1.0 / math.sqrt(k.size(-1)))
+        ret["edge_affinity"] = affinity
+
+        if res.shape[0] == ecc_outputs.shape[0]:
+            sp_feat = ecc_outputs + res
+        else:
+            pad = torch.zeros((ecc_outputs.shape[0] - res.shape[0], res.shape[1]), dtype=res.dtype,
+                              device=res.device)
+            sp_feat = ecc_outputs + torch.cat((res, pad), 0)
+        ret["sp_discriminative_feats"] = self.feature_term(sp_feat)
+        return ret

@@ -1,0 +1,181 @@
+"""Superpoint graph network 'gru_7_0,f_64,b,r' of 3D-WSIS ("next" row 8f-1): plain-torch
+restatement on top of the HIP segmented mean, same parameter names as the reference so its checkpoints load
+(modules/model/graphnet.py:19-114, modules/model/spg_modules.py:61-121,128-185,207-253; state-dict grammar
+in SURVEY App. B: ``ecc.0._cell.*``, ``ecc.0._fnet.{0,2,4,5,7}``, ``ecc.1``, ``ecc.2``).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.nn.init as init
+
+from torch_scatter import SegmentCSR, scatter
+
+
+class GraphConvInfo(object):
+    """Vectorised graph structure of a batch (replaces modules/model/ecc/GraphConvInfo.py:34-87, without
+    igraph): ``edge_indexes`` int64 [2,E] = (source, target) SORTED BY TARGET within each graph and
+    ``edgefeats`` fp32 [E,13] in that same order."""
+
+    def __init__(self, edge_indexes, edgefeats, num_nodes):
+        self._edge_indexes = edge_indexes
+        self._edgefeats = edgefeats
+        self.num_nodes = int(num_nodes)
+        self._csr = None
+
+    def cuda(self):
+        if not self._edge_indexes.is_cuda:
+            self._edge_indexes = self._edge_indexes.cuda()
+            self._edgefeats = self._edgefeats.cuda()
+        return self
+
+    def get_buffers(self):
+        return self._edgefeats
+
+    def get_pyg_buffers(self):
+        return self._edge_indexes
+
+    def csr(self):
+        if self._csr is None:
+            self._csr = SegmentCSR(self._edge_indexes[0], self.num_nodes)
+        return self._csr
+
+
+def create_fnet(widths, orthoinit, llbias, bnidx=-1):
+    """filter-generating MLP (graphnet.py:19-36)"""
+    mods = []
+    for k in range(len(widths) - 2):
+        mods.append(nn.Linear(widths[k], widths[k + 1]))
+        if orthoinit:
+            init.orthogonal_(mods[-1].weight, gain=init.calculate_gain("relu"))
+        if bnidx == k:
+            mods.append(nn.BatchNorm1d(widths[k + 1]))
+        mods.append(nn.ReLU(True))
+    mods.append(nn.Linear(widths[-2], widths[-1], bias=llbias))
+    if orthoinit:
+        init.orthogonal_(mods[-1].weight)
+    if bnidx == len(widths) - 1:
+        mods.append(nn.BatchNorm1d(mods[-1].weight.size(0)))
+    return nn.Sequential(*mods)
+
+
+class GRUCellEx(nn.GRUCell):
+    """GRU cell with per-row normalisation of the gate pre-activations and an input gate
+    (spg_modules.py:207-253).  The reference's InstanceNorm1d(1) over [S,1,3H] is a per-row
+    (x-mean)/sqrt(var+1e-5) without affine parameters."""
+
+    def __init__(self, input_size, hidden_size, bias=True, layernorm=True, ingate=True):
+        super().__init__(input_size, hidden_size, bias)
+        self._layernorm = layernorm
+        self._ingate = ingate
+        if ingate:
+            self.add_module("ig", nn.Linear(hidden_size, input_size, bias=True))
+
+    @staticmethod
+    def _rownorm(x):
+        mu = x.mean(dim=1, keepdim=True)
+        var = x.var(dim=1, unbiased=False, keepdim=True)
+        return (x - mu) / torch.sqrt(var + 1e-5)
+
+    def forward(self, input, hidden):
+        if self._ingate:
+            input = torch.sigmoid(self._modules["ig"](hidden)) * input
+        gi = F.linear(input, self.weight_ih)
+        gh = F.linear(hidden, self.weight_hh)
+        if self._layernorm:
+            gi, gh = self._rownorm(gi), self._rownorm(gh)
+        i_r, i_i, i_n = gi.chunk(3, 1)
+        h_r, h_i, h_n = gh.chunk(3, 1)
+        bih_r, bih_i, bih_n = self.bias_ih.chunk(3)
+        bhh_r, bhh_i, bhh_n = self.bias_hh.chunk(3)
+        resetgate = torch.sigmoid(i_r + bih_r + h_r + bhh_r)
+        inputgate = torch.sigmoid(i_i + bih_i + h_i + bhh_i)
+        newgate = torch.tanh(i_n + bih_n + resetgate * (h_n + bhh_n))
+        return newgate + inputgate * (hidden - newgate)
+
+
+class RNNGraphConvModule(nn.Module):
+    """7 x { edge-conditioned message passing (mean over out-edges of x[target] @ W_e) -> GRUCellEx }
+    (spg_modules.py:152-185 with the PyG NNConv of :61-121: flow=target_to_source, aggr=mean)."""
+
+    def __init__(self, cell, filter_net, nfeat, vv=True, nrepeats=1, cat_all=False):
+        super().__init__()
+        self._cell = cell
+        self._fnet = filter_net
+        self._nrepeats = nrepeats
+        self._cat_all = cat_all
+        self._vv = vv
+        self._gci = None
+
+    def set_info(self, gc_info):
+        self._gci = gc_info
+
+    def forward(self, hx):
+        edgefeats = self._gci.get_buffers()
+        edge_indexes = self._gci.get_pyg_buffers()
+        src, dst = edge_indexes[0], edge_indexes[1]
+        weights = self._fnet(edgefeats)
+        nc = hx.size(1)
+        assert weights.size(1) in (nc, nc * nc)
+        if weights.size(1) != nc:
+            weights = weights.view(-1, nc, nc)
+        csr = self._gci.csr()
+        hxs = [hx]
+        for _ in range(self._nrepeats):
+            x_j = hx[dst]
+            if weights.dim() == 3:
+                msg = torch.bmm(x_j.unsqueeze(1), weights).squeeze(1)
+            else:
+                msg = x_j * weights
+            inp = scatter(msg, src, dim=0, dim_size=hx.size(0), reduce="mean", csr=csr)
+            hx = self._cell(inp, hx)
+            hxs.append(hx)
+        return torch.cat(hxs, 1) if self._cat_all else hx
+
+
+class GraphNetwork(nn.Module):
+    """config-string driven container (graphnet.py:39-114); supports the tokens the reference uses:
+    gru_R_vv, f_N, b, r, d_p."""
+
+    def __init__(self, config, nfeat, fnet_widths, fnet_orthoinit=True, fnet_llbias=True, fnet_bnidx=-1,
+                 edge_mem_limit=1e20, use_pyg=True, cuda=True):
+        super().__init__()
+        self.gconvs = []
+        for d, conf in enumerate(config.split(",")):
+            conf = conf.strip().split("_")
+            if conf[0] == "f":
+                self.add_module(str(d), nn.Linear(nfeat, int(conf[1])))
+                nfeat = int(conf[1])
+            elif conf[0] == "b":
+                self.add_module(str(d), nn.BatchNorm1d(nfeat, eps=1e-5, affine=len(conf) == 1))
+            elif conf[0] == "r":
+                self.add_module(str(d), nn.ReLU(True))
+            elif conf[0] == "d":
+                self.add_module(str(d), nn.Dropout(p=float(conf[1]), inplace=False))
+            elif conf[0] == "gru":
+                nrepeats = int(conf[1])
+                vv = bool(int(conf[2])) if len(conf) > 2 else True
+                layernorm = bool(int(conf[3])) if len(conf) > 3 else True
+                ingate = bool(int(conf[4])) if len(conf) > 4 else True
+                cat_all = bool(int(conf[5])) if len(conf) > 5 else True
+                fnet = create_fnet(fnet_widths + [nfeat ** 2 if not vv else nfeat], fnet_orthoinit, fnet_llbias,
+                                   fnet_bnidx)
+                cell = GRUCellEx(nfeat, nfeat, bias=True, layernorm=layernorm, ingate=ingate)
+                gconv = RNNGraphConvModule(cell, fnet, nfeat, vv=vv, nrepeats=nrepeats, cat_all=cat_all)
+                self.add_module(str(d), gconv)
+                self.gconvs.append(gconv)
+                if cat_all:
+                    nfeat *= nrepeats + 1
+            elif len(conf[0]) > 0:
+                raise NotImplementedError("Unknown module: " + conf[0])
+
+    def set_info(self, gc_infos, cuda=True):
+        gc_infos = gc_infos if isinstance(gc_infos, (list, tuple)) else [gc_infos]
+        for i, gc in enumerate(self.gconvs):
+            if cuda:
+                gc_infos[i].cuda()
+            gc.set_info(gc_infos[i])
+
+    def forward(self, input):
+        for module in self._modules.values():
+            input = module(input)
+        return input

@@ -1,0 +1,147 @@
+"""``MultiTaskLoss`` of 3D-WSIS (caller side of the hot path) -- same constructor, forward
+signature, ``loss_inp`` keys and returned ``(loss, loss_out)`` as the reference's
+modules/model/losses_3D_WSIS.py:13-253; pinned against the imported reference by tests/golden/loss_golden.npz.
+
+Pure torch; ``device`` follows the inputs instead of the reference's hard-coded 'cuda' attribute (:33)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _NullLogger(object):
+    def info(self, *a, **k):
+        pass
+
+
+class MultiTaskLoss(nn.Module):
+    def __init__(self, logger, param_loss, param_model):
+        super().__init__()
+        self.logger = logger if logger is not None else _NullLogger()
+        self.ignore_label = param_loss.ignore_label
+        self.supervise_instance_size = param_loss.supervise_instance_size
+        self.joint_training_epoch = param_loss.joint_training_epoch
+        self.semantic_dice = param_loss.semantic_dice
+        self.semantic_class_num = param_model.classes
+        self.discriminative_feature_dim = 7
+        self.delta_v = 0.1
+        self.delta_d = 1.5
+        self.param_var = 1.
+        self.param_dist = 1.
+        self.param_reg = 0.001
+        self.supervise_sp_offset = getattr(param_loss, "supervise_sp_offset", True)
+        self.log_values = getattr(param_loss, "log_values", False)   # the reference logs (= syncs) every term
+        self.semantic_criterion = nn.CrossEntropyLoss(ignore_index=self.ignore_label)
+        self.occupany_L1loss = nn.L1Loss()
+        self.instance_size_L1loss = nn.L1Loss()
+        self.superpoint_semantic_criterion = nn.CrossEntropyLoss(ignore_index=self.ignore_label)
+
+    def _log(self, name, value):
+        if self.log_values:
+            self.logger.info("{}: {:.4f}".format(name, value))
+
+    def forward(self, loss_inp, epoch):
+        loss_out = {}
+        semantic_labels, instance_labels = loss_inp["point_labels"]
+        semantic_scores = loss_inp["semantic_scores"]
+        semantic_loss = self.semantic_criterion(semantic_scores, semantic_labels)
+        if self.semantic_dice:
+            keep = semantic_labels != self.ignore_label
+            semantic_scores = F.softmax(semantic_scores[keep], dim=-1)
+            one_hot = F.one_hot(semantic_labels[keep], num_classes=self.semantic_class_num)
+            semantic_loss = semantic_loss + dice_loss_multi_classes(semantic_scores, one_hot).mean()
+        loss_out["semantic_loss"] = (semantic_loss, semantic_scores.sum())
+
+        joint = epoch > self.joint_training_epoch
+        if joint:
+            sp_sem_labels, sp_ins_labels = loss_inp["superpoint_labels"]
+            sp_valid = (sp_ins_labels != self.ignore_label) & (sp_sem_labels != self.ignore_label)
+            n_valid = sp_valid.sum()
+
+            sp_semantic_scores = loss_inp["sp_semantic"]
+            superpoint_semantic_loss = self.superpoint_semantic_criterion(sp_semantic_scores, sp_sem_labels)
+            loss_out["superpoint_semantic_loss"] = (superpoint_semantic_loss, sp_semantic_scores.sum())
+
+            if self.supervise_sp_offset:
+                pred_off, gt_off = loss_inp["sp_offset_vector"]
+                pt_dist = torch.sum(torch.abs(pred_off - gt_off), dim=-1)
+                offset_norm_loss = torch.sum(pt_dist * sp_valid) / (n_valid + 1e-6)
+                gt_dir = gt_off / (torch.norm(gt_off, p=2, dim=1).unsqueeze(-1) + 1e-8)
+                pt_dir = pred_off / (torch.norm(pred_off, p=2, dim=1).unsqueeze(-1) + 1e-8)
+                direction_diff = -(gt_dir * pt_dir).sum(-1)
+                offset_dir_loss = torch.sum(direction_diff * sp_valid) / (n_valid + 1e-6)
+                loss_out["offset_norm_loss"] = (offset_norm_loss, n_valid)
+                loss_out["offset_dir_loss"] = (offset_dir_loss, n_valid)
+
+            feats, sp_batch_offsets = loss_inp["sp_discriminative_features"]
+            offs = [int(o) for o in sp_batch_offsets]
+            d_losses = []
+            for i in range(1, len(offs)):
+                b, e = offs[i - 1], offs[i]
+                valid = sp_valid[b:e]
+                d_loss, _, _, _ = self.discriminative_loss(feats[b:e][valid], sp_ins_labels[b:e][valid])
+                d_losses.append(d_loss.view(-1))
+            sp_d_loss = torch.mean(torch.cat(d_losses))
+            loss_out["superpoint_discriminative_loss"] = (sp_d_loss, feats.shape[0])
+
+            if self.supervise_instance_size:
+                pred_occ, gt_occ = loss_inp["sp_occupancy"]
+                occupancy_loss = self.occupany_L1loss(pred_occ[sp_valid], gt_occ[sp_valid])
+                loss_out["occupancy_loss"] = (occupancy_loss, n_valid)
+                pred_size, gt_size = loss_inp["sp_instance_size"]
+                instance_size_loss = self.instance_size_L1loss(pred_size[sp_valid], gt_size[sp_valid])
+                loss_out["instance_size_loss"] = (instance_size_loss, n_valid)
+
+        loss = 0.0
+        loss = loss + 1.0 * semantic_loss
+        self._log("point semantic loss", semantic_loss)
+        if joint:
+            loss = loss + 1.0 * superpoint_semantic_loss
+            self._log("sp semantic loss", superpoint_semantic_loss)
+            if self.supervise_sp_offset:
+                loss = loss + (1.0 * offset_norm_loss + 1.0 * offset_dir_loss)
+                self._log("sp offset norm loss", offset_norm_loss)
+                self._log("sp offset dir loss", offset_dir_loss)
+            loss = loss + 1.0 * sp_d_loss
+            self._log("sp discriminative loss", sp_d_loss)
+            if self.supervise_instance_size:
+                loss = loss + 1.0 * occupancy_loss + 1.0 * instance_size_loss
+                self._log("sp occupancy loss", occupancy_loss)
+                self._log("sp instance size loss", instance_size_loss)
+        return loss, loss_out
+
+    def discriminative_loss(self, prediction, correct_label):
+        """pull (delta_v) / push (L1 cdist, delta_d) / reg terms over the instances of one scene
+        (losses_3D_WSIS.py:157-230)."""
+        dev = prediction.device
+        pred = torch.reshape(prediction, [-1, self.discriminative_feature_dim])
+        unique_labels, unique_id, counts = torch.unique(correct_label, sorted=False, return_inverse=True,
+                                                        return_counts=True)
+        counts = counts.float()
+        n = unique_labels.size(0)
+        seg_sum = torch.zeros(n, self.discriminative_feature_dim, device=dev).index_add_(0, unique_id, pred)
+        mu = seg_sum / counts.reshape(-1, 1)
+        dist = torch.norm(pred - mu[unique_id], p=2, dim=1)
+        dist = torch.square(torch.clamp(dist - self.delta_v, min=0.))
+        l_var = torch.zeros(n, device=dev).index_add_(0, unique_id, dist)
+        l_var = torch.sum(l_var / counts) / n
+        if n <= 1:
+            l_dist = torch.tensor(0., device=dev)
+        else:
+            d = 2. * self.delta_d - torch.cdist(mu, mu, p=1)
+            d = d - torch.diagflat(torch.diag(d, 0))
+            l_dist = torch.sum(torch.square(torch.clamp(d, min=0.))) / (n * (n - 1))
+        l_reg = torch.sum(torch.norm(mu, p=2, dim=1))
+        l_var = self.param_var * l_var
+        l_dist = self.param_dist * l_dist
+        l_reg = self.param_reg * l_reg
+        return l_var + l_dist + l_reg, l_var, l_dist, l_reg
+
+
+def dice_loss_multi_classes(input, target, epsilon=1e-5, weight=None):
+    """per-class dice on [N, nClass] probabilities / one-hot targets (losses_3D_WSIS.py:233-253)"""
+    assert input.size() == target.size()
+    input = input.transpose(0, 1)
+    target = target.transpose(0, 1).float()
+    dice = (2 * torch.sum(input * target, dim=1) + epsilon) / \
+           (torch.sum(input * input, dim=1) + torch.sum(target * target, dim=1) + 1e-4 + epsilon)
+    return 1. - dice

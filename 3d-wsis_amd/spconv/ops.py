@@ -43,9 +43,15 @@ def get_conv_output_size(input_size, kernel_size, stride, padding, dilation):
     return out
 
 
+def _check_indices(indices):
+    if indices.dtype != torch.int32 or indices.dim() != 2 or indices.shape[1] != 4 or not indices.is_contiguous():
+        raise _n.WsisError("indices must be a contiguous int32 [M,4] tensor")
+
+
 def build_hash(indices, spatial_shape):
     """coordinate hash (keys int64[cap], vals int32[cap], cap) of int32 [M,4] indices."""
     _n.require_cuda(indices)
+    _check_indices(indices)
     M = indices.shape[0]
     cap = _pow2_cap(M)
     keys = torch.empty(cap, dtype=torch.int64, device=indices.device)
@@ -103,6 +109,7 @@ class Rulebook(object):
 def build_subm_rulebook(indices, spatial_shape, ksize, padding, hash_tab=None):
     """SubMConv3d rulebook (a5): out rows == in rows, nbr[k][o] = i with coord_i = coord_o - pad + kappa."""
     _n.require_cuda(indices)
+    _check_indices(indices)
     M = indices.shape[0]
     K = int(np.prod(ksize))
     dev = indices.device
@@ -124,6 +131,7 @@ def build_subm_rulebook(indices, spatial_shape, ksize, padding, hash_tab=None):
 def build_down_rulebook(indices, spatial_shape, ksize, stride, padding):
     """SparseConv3d rulebook (a6): output rows = ascending linear index of the reachable coarse voxels."""
     _n.require_cuda(indices)
+    _check_indices(indices)
     lib = _n.hip()
     dev = indices.device
     M_in = indices.shape[0]

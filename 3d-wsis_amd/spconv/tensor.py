@@ -17,6 +17,8 @@ class SparseConvTensor(object):
         self.indices = indices
         if self.indices.dtype != torch.int32:
             self.indices = self.indices.int()
+        if not self.indices.is_contiguous():
+            self.indices = self.indices.contiguous()   # the kernels read raw [M,4] rows
         self.spatial_shape = spatial_shape
         self.batch_size = batch_size
         self.indice_dict = {}   # rulebook cache, shared by reference with outputs of spconv modules
