@@ -29,7 +29,8 @@ template <int NB>
 __global__ __launch_bounds__(256) void spconv_fwd_kernel(
     const float* __restrict__ X, const int32_t* __restrict__ nbr, const int32_t* __restrict__ order,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ residual,
-    float* __restrict__ out, int64_t M_in, int64_t M_out, int K, int Cin, int Cout) {
+    float* __restrict__ out, float* __restrict__ partial, int64_t M_in, int64_t M_out, int K, int Cin, int Cout,
+    int k_per) {
   __shared__ __attribute__((aligned(16))) float As[TM * A_STRIDE];
   __shared__ __attribute__((aligned(16))) float Bs[CK * NB * 32];
   __shared__ int32_t rowId[TM];
@@ -60,7 +61,12 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
 
   const bool vec4 = (Cin & 3) == 0;
 
-  for (int k = 0; k < K; ++k) {
+  // kernel-offset split: blockIdx.z owns offsets [k_begin, k_end); with gridDim.z > 1 the raw sums go to a
+  // partial slab that spconv_reduce_kernel adds in a fixed order (small levels have too few tiles to fill
+  // 256 CUs otherwise -- the per-offset stage->MFMA chain is latency bound).
+  const int k_begin = blockIdx.z * k_per;
+  const int k_end = min(K, k_begin + k_per);
+  for (int k = k_begin; k < k_end; ++k) {
     // neighbour row of every tile row under offset k
     int32_t nb = -1;
     if (tid < TM) {
@@ -143,6 +149,21 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
   }
 
   // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*half
+  if (gridDim.z > 1) {
+    float* dst = partial + (int64_t)blockIdx.z * M_out * Cout;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      const int c = cb * 32 + l31;
+      if (c >= ncols) continue;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        const int32_t r = rowId[wave * 32 + rr];
+        if (r >= 0) dst[(int64_t)r * Cout + col0 + c] = acc[cb][reg];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) {
     const int c = cb * 32 + l31;
@@ -159,6 +180,30 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
       out[o] = v;
     }
   }
+}
+
+__global__ void spconv_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                     const float* __restrict__ residual, float* __restrict__ out, int64_t M_out,
+                                     int Cout, int ksplit) {
+  const int64_t total = M_out * Cout;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.0f;
+    for (int z = 0; z < ksplit; ++z) s += partial[(int64_t)z * total + t];
+    if (bias) s += bias[t % Cout];
+    if (residual) s += residual[t];
+    out[t] = s;
+  }
+}
+
+int fwd_ksplit(int64_t M_out, int K, int Cout) {
+  const int nblk = (Cout + 31) / 32;
+  const int NB = nblk <= 5 ? nblk : 4;
+  const int64_t wgs = ceil_div(M_out, TM) * ceil_div(Cout, NB * 32);
+  if (wgs >= 512 || K == 1) return 1;
+  int64_t ks = ceil_div(1024, wgs);
+  if (ks > K) ks = K;
+  return (int)ks;
 }
 
 __global__ void weight_transpose_kernel(const float* __restrict__ W, float* __restrict__ WT, int K,
@@ -300,9 +345,16 @@ int dw_rows_per_chunk(int64_t M_out) {
 
 extern "C" {
 
+int64_t wsis_spconv_fwd_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout) {
+  if (M_out < 0 || K < 1 || Cin < 1 || Cout < 1) return -1;
+  const int ks = fwd_ksplit(M_out, K, Cout);
+  return ks <= 1 ? 256 : (int64_t)ks * M_out * Cout * (int64_t)sizeof(float) + 256;
+}
+
 int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_W,
                     const float* d_bias, const float* d_residual, float* d_out, int64_t M_in,
-                    int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* stream) {
+                    int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
+                    void* stream) {
   WSIS_REQUIRE(M_in >= 0 && M_out >= 0 && K >= 1 && Cin >= 1 && Cout >= 1, "bad sizes");
   if (M_out == 0) return WSIS_OK;
   WSIS_REQUIRE(d_X && d_W && d_out, "null pointer");
@@ -310,12 +362,20 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
   WSIS_REQUIRE(M_out < (int64_t)1 << 31 && M_in < (int64_t)1 << 31, "row count exceeds int32");
   const int nblk = (Cout + 31) / 32;
   const int NB = nblk <= 5 ? nblk : 4;
-  const dim3 grid((unsigned)ceil_div(M_out, TM), (unsigned)ceil_div(Cout, NB * 32));
+  const int ksplit = fwd_ksplit(M_out, K, Cout);
+  const int k_per = (K + ksplit - 1) / ksplit;
+  const int kz = (K + k_per - 1) / k_per;   // blocks along z that own at least one offset
+  float* partial = nullptr;
+  if (kz > 1) {
+    WSIS_REQUIRE(d_ws && ws_bytes >= (int64_t)kz * M_out * Cout * (int64_t)sizeof(float), "workspace too small");
+    partial = static_cast<float*>(d_ws);
+  }
+  const dim3 grid((unsigned)ceil_div(M_out, TM), (unsigned)ceil_div(Cout, NB * 32), (unsigned)kz);
   hipStream_t st = as_stream(stream);
 #define WSIS_FWD_CASE(n)                                                                          \
   case n:                                                                                         \
     hipLaunchKernelGGL(spconv_fwd_kernel<n>, grid, dim3(256), 0, st, d_X, d_nbr, d_order, d_W,    \
-                       d_bias, d_residual, d_out, M_in, M_out, K, Cin, Cout);                     \
+                       d_bias, d_residual, d_out, partial, M_in, M_out, K, Cin, Cout, k_per);     \
     break;
   switch (NB) {
     WSIS_FWD_CASE(1)
@@ -328,6 +388,11 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
   }
 #undef WSIS_FWD_CASE
   WSIS_LAUNCH_CHECK();
+  if (kz > 1) {
+    hipLaunchKernelGGL(spconv_reduce_kernel, dim3(grid_for(M_out * Cout, 256)), dim3(256), 0, st, partial, d_bias,
+                       d_residual, d_out, M_out, Cout, kz);
+    WSIS_LAUNCH_CHECK();
+  }
   return WSIS_OK;
 }
 

@@ -1,0 +1,85 @@
+"""Scene-sharded data parallelism: one process per GPU, independent scenes per rank, one
+bucketed gradient all-reduce per step over RCCL/xGMI (backend "nccl" on ROCm; "gloo" in the CPU tests).
+
+The reference only wraps the model in DistributedDataParallel and never initialises a process group
+(train_scannetv2.py:734-738); this is the working replacement.  Buckets are flat fp32 buffers in
+reverse parameter order (gradients become ready in roughly that order), so a few large collectives replace
+361 small ones -- sized for xGMI's per-link bandwidth rather than for launch count."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_scenes(scene_ids, rank, world):
+    """round-robin scene -> rank assignment (independent batch items, no data-path collective)"""
+    return [s for i, s in enumerate(scene_ids) if i % world == rank]
+
+
+class GradSync(object):
+    """Averages gradients across ranks with flat buckets (default 16 MiB; 11.1 M fp32 parameters -> 3 buckets)."""
+
+    def __init__(self, model, bucket_bytes=16 << 20, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        params = [p for p in model.parameters() if p.requires_grad]
+        params.reverse()
+        self.buckets, cur, size = [], [], 0
+        for p in params:
+            nbytes = p.numel() * p.element_size()
+            if cur and size + nbytes > bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self.buckets.append(cur)
+        self._flat = [None] * len(self.buckets)
+
+    def __call__(self, model=None):
+        if self.world == 1:
+            return
+        handles = []
+        for b, bucket in enumerate(self.buckets):
+            n = sum(p.numel() for p in bucket)
+            flat = self._flat[b]
+            if flat is None or flat.numel() != n or flat.device != bucket[0].device:
+                flat = torch.zeros(n, dtype=bucket[0].dtype, device=bucket[0].device)
+                self._flat[b] = flat
+            off = 0
+            for p in bucket:
+                k = p.numel()
+                if p.grad is None:      # unused parameter on this rank still takes part with zeros
+                    flat[off:off + k].zero_()
+                else:
+                    flat[off:off + k].copy_(p.grad.reshape(-1))
+                off += k
+            handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for b, bucket in enumerate(self.buckets):
+            handles[b].wait()
+            flat = self._flat[b]
+            flat.div_(self.world)
+            off = 0
+            for p in bucket:
+                k = p.numel()
+                if p.grad is None:
+                    p.grad = flat[off:off + k].view_as(p).clone()
+                else:
+                    p.grad.copy_(flat[off:off + k].view_as(p))
+                off += k

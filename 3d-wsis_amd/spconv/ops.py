@@ -175,13 +175,62 @@ def build_down_rulebook(indices, spatial_shape, ksize, stride, padding):
     return rb
 
 
+class KernelProfiler(object):
+    """Live per-launch timing of the conv kernels with HIP events on the launch stream (bench.py roofline).
+    Algorithmic bytes per launch follow SURVEY.md 8d: P*(Cin+Cout)*4 + P*8, flops 2*P*Cin*Cout, with P = number
+    of rulebook pairs of the launch (entries >= 0 of its gather table; M rows for the dense 1x1 case)."""
+
+    def __init__(self):
+        self.records = {}      # kernel name -> list of (start_event, end_event, bytes, flops)
+        self._pairs = {}
+
+    def pairs(self, nbr, M_out):
+        if nbr is None:
+            return int(M_out)
+        key = (nbr.data_ptr(), tuple(nbr.shape))
+        if key not in self._pairs:
+            self._pairs[key] = int((nbr >= 0).sum().item())
+        return self._pairs[key]
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, name, start, nbytes, flops):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.records.setdefault(name, []).append((start, ev, nbytes, flops))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
+            out[name] = {"launches": len(recs), "ms": ms, "bytes": sum(r[2] for r in recs),
+                         "flops": sum(r[3] for r in recs)}
+        return out
+
+
+PROFILER = None
+
+
 def _conv(X, nbr, order, W, bias, residual, M_out):
     """out[r] = sum_k X[nbr[k][r]] @ W[k]  (W [K,Cin,Cout] contiguous)."""
     K, Cin, Cout = W.shape
     out = torch.empty((M_out, Cout), dtype=torch.float32, device=X.device)
-    _n.check(_n.hip().wsis_spconv_fwd(_n.ptr(X), _n.ptr(nbr), _n.ptr(order), _n.ptr(W), _n.ptr(bias),
-                                      _n.ptr(residual), _n.ptr(out), X.shape[0], M_out, K, Cin, Cout,
-                                      _n.stream_ptr()), "spconv_fwd")
+    prof = PROFILER
+    if prof is not None:
+        P = prof.pairs(nbr, M_out)
+        t0 = prof.begin()
+    lib = _n.hip()
+    ws_bytes = lib.wsis_spconv_fwd_workspace_bytes(M_out, K, Cin, Cout)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device) if ws_bytes > 256 else None
+    _n.check(lib.wsis_spconv_fwd(_n.ptr(X), _n.ptr(nbr), _n.ptr(order), _n.ptr(W), _n.ptr(bias),
+                                 _n.ptr(residual), _n.ptr(out), X.shape[0], M_out, K, Cin, Cout, _n.ptr(ws),
+                                 ws_bytes, _n.stream_ptr()), "spconv_fwd")
+    if prof is not None:
+        prof.end("spconv_fwd_kernel", t0, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout)
     return out
 
 
@@ -199,8 +248,14 @@ def _dw(X, nbr, dY, K, Cin, Cout):
     ws_bytes = lib.wsis_spconv_dw_workspace_bytes(M_out, K, Cin, Cout)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device)
     dW = torch.empty((K, Cin, Cout), dtype=torch.float32, device=X.device)
+    prof = PROFILER
+    if prof is not None:
+        P = prof.pairs(nbr, M_out)
+        t0 = prof.begin()
     _n.check(lib.wsis_spconv_dw(_n.ptr(X), _n.ptr(nbr), _n.ptr(dY), _n.ptr(dW), X.shape[0], M_out, K, Cin, Cout,
                                 _n.ptr(ws), ws_bytes, _n.stream_ptr()), "spconv_dw")
+    if prof is not None:
+        prof.end("spconv_dw_kernel", t0, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout)
     return dW
 
 

@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py -- scenes/s, forward+backward(+AdamW step) of the 3D-WSIS per-scene hot path on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): one synthetic ScanNet-shaped scene per GPU
+(~150 k active voxels at 2 cm, seed 1 + rank), inputs resident in HBM before the timed region; one step =
+superpoint centres -> voxelization -> SparseConvTensor -> Network (SubMConv3d UNet + ECC GNN + edge affinity) ->
+MultiTaskLoss (stage-3 switches) -> backward -> [RCCL gradient all-reduce when N > 1] -> ECC grad clamp ->
+AdamW step (train_scannetv2.py:143-252).  N > 1: weak scaling, one scene per rank, no data-path collective.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      -- dominant kernel (spconv_fwd_kernel: every forward and dIn pass of the 49 sparse convs):
+                   algorithmic gather/scatter bytes (P*(Cin+Cout)*4 + P*8 per launch) / HIP-event
+                   time of those launches, against the 8 TB/s HBM peak.
+  cpu_baseline  -- the oracle (torch-CPU restatement mirroring upstream's gather -> mm -> scatter-add) timed on
+                   this box's host cores on the same scene (rank 0, N = 1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+importlib.import_module("3d-wsis_amd")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--profile-steps", type=int, default=2, help="extra event-instrumented steps for the roofline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--scene-seed", type=int, default=1)
+    ap.add_argument("--small", action="store_true", help="debug: a small room instead of the C2 scene")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch_host, cfg, iters):
+    """oracle fwd+bwd on the host cores, same scene; bounded: 1 warm-up + `iters` timed passes."""
+    from oracle import network_ref
+    import losses_3D_WSIS
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(123)
+    ref = network_ref.RefNetwork()
+    crit = losses_3D_WSIS.MultiTaskLoss(None, cfg.loss, cfg.model)
+
+    def one():
+        ref.zero_grad(set_to_none=True)
+        loss, _ = network_ref.forward_loss_cpu(ref, crit, batch_host)
+        loss.backward()
+
+    t0 = time.time()
+    one()                       # warm-up (first-touch page faults dominate it)
+    warm = time.time() - t0
+    if warm > 90:
+        iters = 1
+    t0 = time.time()
+    for _ in range(iters):
+        one()
+    dt = (time.time() - t0) / iters
+    model_name = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model_name = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": 1.0 / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} fwd+bwd pass(es) of the same {batch_host['voxel_locs'].shape[0]}-voxel scene after 1 "
+                      f"warm-up pass ({warm:.1f} s), torch-CPU oracle, {cores} threads, {model_name}"}
+
+
+def main():
+    args = parse()
+    import harness
+    import parallel
+    from spconv import ops as sp_ops
+
+    rank, local_rank, world = parallel.init_distributed()
+    assert world == max(args.gpus, 1) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    cfg = harness.default_cfg()
+    if args.small:
+        scene = harness.make_scene(args.scene_seed + rank, room=(2.0, 1.6, 1.2), n_box=2)
+    else:
+        scene = harness.make_scene(args.scene_seed + rank)
+    batch_host = harness.collate([scene])
+    batch = harness.to_device(batch_host, device)
+    model, criterion, optimizer = harness.build_model(cfg, device)
+    grad_sync = parallel.GradSync(model) if world > 1 else None
+    if world > 1:   # identical initial weights on every rank
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+        for b in model.buffers():
+            dist.broadcast(b.data, 0)
+
+    def step():
+        return harness.train_step(model, criterion, optimizer, batch, cfg, grad_sync=grad_sync)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    scenes_per_s = world * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: event-instrumented extra steps (same inputs, same process) ----
+    roof = None
+    extra = {}
+    if rank == 0 and args.profile_steps > 0:
+        sp_ops.PROFILER = sp_ops.KernelProfiler()
+        for _ in range(args.profile_steps):
+            step()
+        summ = sp_ops.PROFILER.summary()
+        sp_ops.PROFILER = None
+        k = summ.get("spconv_fwd_kernel")
+        if k and k["ms"] > 0:
+            gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+            roof = {"kernel": "spconv_fwd_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches_per_step": k["launches"] // args.profile_steps,
+                    "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 2),
+                    "alg_bytes_per_step": k["bytes"] // args.profile_steps,
+                    "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2)}
+        d = summ.get("spconv_dw_kernel")
+        if d and d["ms"] > 0:
+            extra["dw_kernel"] = {"achieved_GBs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
+                                  "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+                                  "launches_per_step": d["launches"] // args.profile_steps,
+                                  "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)}
+        if k and d:
+            extra["conv_ms_per_step"] = round((k["ms"] + d["ms"]) / args.profile_steps, 3)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(batch_host, cfg, args.cpu_iters)
+
+    if rank == 0:
+        M = int(batch_host["voxel_locs"].shape[0])
+        out = {
+            "metric": "scenes/sec fwd+bwd ScanNet 2cm (~150k voxels) @1/8 GPU; HBM GB/s vs roofline",
+            "value": round(scenes_per_s, 3), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: 1 synthetic ScanNet-shaped scene per GPU, 2 cm voxels, fwd+bwd+AdamW step "
+                                   "(SubMConv3d UNet 32..160 + ECC GNN + edge affinity + MultiTaskLoss)",
+                       "active_voxels": M, "points": int(batch_host["locs"].shape[0]),
+                       "superpoints": int(batch_host["sp_batch_offsets"][-1]),
+                       "edges": int(batch_host["edge_u_list"].shape[0]), "scenes_per_gpu": 1,
+                       "parallelism": f"scene-sharded dp{world}", "loss": float(loss)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        out.update(extra)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

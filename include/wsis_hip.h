@@ -141,9 +141,13 @@ int wsis_mask_order(const uint32_t* d_mask, int64_t M, int32_t* d_order, void* d
  * d_order (optional int32 [M_out]) = tile ordering from wsis_mask_order; d_bias optional [Cout];
  * d_residual optional [M_out,Cout] added in the epilogue (sparse_unet3d.py:170 fused).
  * K==1 with d_nbr==null is the dense 1x1 shortcut (sparse_unet3d.py:115-119). */
+/* Small levels split the K offsets over blockIdx.z and reduce partial slabs from d_ws in a fixed order
+ * (size from the query; 256 bytes when no split is used). */
+int64_t wsis_spconv_fwd_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout);
 int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_W,
                     const float* d_bias, const float* d_residual, float* d_out, int64_t M_in,
-                    int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* stream);
+                    int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
+                    void* stream);
 /* WT[k'] = W[k]^T with k' = (flip ? K-1-k : k); W [K,Cin,Cout] -> WT [K,Cout,Cin]. */
 int wsis_weight_transpose(const float* d_W, float* d_WT, int32_t K, int32_t Cin, int32_t Cout,
                           int32_t flip, void* stream);

@@ -10,10 +10,10 @@ def scatter(src, index, dim=0, dim_size=None, reduce="sum"):
     S = int(index.max()) + 1 if dim_size is None else int(dim_size)
     shape = (S,) + tuple(src.shape[1:])
     if reduce in ("sum", "add"):
-        return torch.zeros(shape, dtype=src.dtype).index_add(0, index, src)
+        return torch.zeros(shape, dtype=src.dtype).index_add_(0, index, src)
     if reduce == "mean":
-        s = torch.zeros(shape, dtype=src.dtype).index_add(0, index, src)
-        cnt = torch.zeros(S, dtype=src.dtype).index_add(0, index, torch.ones_like(index, dtype=src.dtype))
+        s = torch.zeros(shape, dtype=src.dtype).index_add_(0, index, src)
+        cnt = torch.zeros(S, dtype=src.dtype).index_add_(0, index, torch.ones_like(index, dtype=src.dtype))
         cnt = cnt.clamp(min=1)
         return s / cnt.view((S,) + (1,) * (src.dim() - 1))
     if reduce in ("max", "min"):

@@ -92,7 +92,7 @@ def pairs_conv(features, weight, pairs, M_out, bias=None):
             continue
         i_t = torch.as_tensor(i_rows, device=features.device)
         o_t = torch.as_tensor(o_rows, device=features.device)
-        out = out.index_add(0, o_t, features.index_select(0, i_t) @ W[kf])
+        out.index_add_(0, o_t, features.index_select(0, i_t) @ W[kf])
     if bias is not None:
         out = out + bias
     return out
@@ -109,3 +109,60 @@ def pairs_to_table(pairs, M_rows):
     for kf, (i_rows, o_rows) in enumerate(pairs):
         nbr[kf, o_rows] = i_rows
     return nbr
+
+
+# ---- vectorised rulebooks (same results as the dict versions above, used for large scenes / CPU baseline) ----
+def _lin(idx, shape):
+    return ((idx[:, 0] * shape[0] + idx[:, 1]) * shape[1] + idx[:, 2]) * shape[2] + idx[:, 3]
+
+
+def subm_pairs_fast(indices, spatial_shape, ksize, padding):
+    idx = np.asarray(indices, dtype=np.int64)
+    k, p = _triple(ksize), _triple(padding)
+    S = [int(s) for s in spatial_shape]
+    lin = _lin(idx, S)
+    order = np.argsort(lin, kind="stable")
+    slin = lin[order]
+    pairs = []
+    rows = np.arange(idx.shape[0])
+    for a in range(k[0]):
+        for b in range(k[1]):
+            for c in range(k[2]):
+                q = idx[:, 1:] + np.array([a - p[0], b - p[1], c - p[2]])
+                ok = np.all((q >= 0) & (q < np.array(S)), axis=1)
+                qlin = ((idx[:, 0] * S[0] + q[:, 0]) * S[1] + q[:, 1]) * S[2] + q[:, 2]
+                pos = np.searchsorted(slin, qlin)
+                pos_c = np.minimum(pos, len(slin) - 1) if len(slin) else pos
+                hit = ok & (pos < len(slin))
+                if len(slin):
+                    hit &= slin[pos_c] == qlin
+                pairs.append((order[pos_c[hit]].astype(np.int64), rows[hit].astype(np.int64)))
+    return pairs
+
+
+def down_pairs_fast(indices, spatial_shape, ksize, stride, padding):
+    idx = np.asarray(indices, dtype=np.int64)
+    k, s, p = _triple(ksize), _triple(stride), _triple(padding)
+    out_shape = conv_output_size(spatial_shape, k, s, p)
+    sa, oa = np.array(s), np.array(out_shape)
+    cand = []
+    for a in range(k[0]):
+        for b in range(k[1]):
+            for c in range(k[2]):
+                t = idx[:, 1:] + np.array([p[0] - a, p[1] - b, p[2] - c])
+                ok = np.all((t >= 0) & (t % sa == 0) & (t // sa < oa), axis=1)
+                o = t // sa
+                olin = ((idx[:, 0] * oa[0] + o[:, 0]) * oa[1] + o[:, 1]) * oa[2] + o[:, 2]
+                cand.append((np.nonzero(ok)[0], olin[ok]))
+    all_lin = np.concatenate([c[1] for c in cand]) if cand else np.zeros(0, np.int64)
+    lins = np.unique(all_lin)
+    out_idx = np.zeros((len(lins), 4), dtype=np.int64)
+    l = lins.copy()
+    out_idx[:, 3] = l % oa[2]
+    l //= oa[2]
+    out_idx[:, 2] = l % oa[1]
+    l //= oa[1]
+    out_idx[:, 1] = l % oa[0]
+    out_idx[:, 0] = l // oa[0]
+    pairs = [(rows.astype(np.int64), np.searchsorted(lins, ol).astype(np.int64)) for rows, ol in cand]
+    return out_idx, out_shape, pairs
