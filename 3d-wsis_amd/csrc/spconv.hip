@@ -3,12 +3,14 @@
 //   out[r,:] = sum_k X[nbr[k][r],:] @ W[k]          (wsis_spconv_fwd; also every dIn pass)
 //   dW[k]    = sum_r X[nbr[k][r],:]^T (x) dY[r,:]   (wsis_spconv_dw)
 //
-// Output-stationary implicit GEMM: a workgroup owns a tile of 128 output rows, walks the K kernel
-// offsets, gathers the needed input rows straight into LDS (no per-offset gather buffer in HBM,
-// no scatter-add atomics -- upstream spconv does both), and accumulates in MFMA registers with
-// the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32.  Offsets that no row of the tile
-// uses are skipped (the tile ordering from wsis_mask_order makes that frequent).
-// The reduction order is fixed => results are run-to-run deterministic.
+// Output-stationary implicit GEMM.  A workgroup owns a tile of 128 output rows *in tile order* (rows
+// sorted by their set of active kernel offsets, wsis_mask_order), reads the tile's slice of the packed
+// gather table once, derives which offsets the tile (and each 32-row wave slice) uses, and walks only
+// those.  Per (offset, 32-channel chunk) step the gathered input rows and the weight chunk are fetched
+// into registers while the previous step's MFMAs run (issue-early / write-late staging), written to LDS,
+// and consumed by the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32.  No per-offset gather
+// buffer in HBM and no scatter-add atomics (upstream spconv does both); the reduction order is fixed,
+// so results are run-to-run deterministic and independent of the tile order.
 #include "common.h"
 
 using namespace wsis;
@@ -21,20 +23,22 @@ namespace {
 constexpr int TM = 128;       // output rows per workgroup
 constexpr int CK = 32;        // input channels staged per step
 constexpr int A_STRIDE = 36;  // words; 16-B aligned rows, conflict-free ds_read_b128
+constexpr int KG = 32;        // kernel offsets handled per group (bit masks are 32 bit)
 
 // ------------------------------------------------------------------------------------------
 // forward / dIn kernel
 // ------------------------------------------------------------------------------------------
 template <int NB>
 __global__ __launch_bounds__(256) void spconv_fwd_kernel(
-    const float* __restrict__ X, const int32_t* __restrict__ nbr, const int32_t* __restrict__ order,
+    const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ residual,
     float* __restrict__ out, float* __restrict__ partial, int64_t M_in, int64_t M_out, int K, int Cin, int Cout,
     int k_per) {
   __shared__ __attribute__((aligned(16))) float As[TM * A_STRIDE];
   __shared__ __attribute__((aligned(16))) float Bs[CK * NB * 32];
+  __shared__ int32_t nbT[KG * TM];   // [offset in group][tile row] -> input row or -1
   __shared__ int32_t rowId[TM];
-  __shared__ int32_t nbId[TM];
+  __shared__ uint32_t grpMask[4];    // per 32-row slice: bit k set iff some row of the slice uses offset k
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -44,14 +48,15 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
   const int64_t tile0 = (int64_t)blockIdx.x * TM;
   const int col0 = blockIdx.y * (NB * 32);
   const int ncols = min(NB * 32, Cout - col0);
+  const bool vec4 = (Cin & 3) == 0;
+  const bool wvec4 = (Cout & 3) == 0;
 
+  int32_t my_row = -1;
   if (tid < TM) {
     const int64_t t = tile0 + tid;
-    int32_t r = -1;
-    if (t < M_out) r = order ? order[t] : (int32_t)t;
-    rowId[tid] = r;
+    if (t < M_out) my_row = order ? order[t] : (int32_t)t;
+    rowId[tid] = my_row;
   }
-  __syncthreads();
 
   f32x16 acc[NB];
 #pragma unroll
@@ -59,34 +64,49 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[cb][i] = 0.0f;
 
-  const bool vec4 = (Cin & 3) == 0;
-
   // kernel-offset split: blockIdx.z owns offsets [k_begin, k_end); with gridDim.z > 1 the raw sums go to a
   // partial slab that spconv_reduce_kernel adds in a fixed order (small levels have too few tiles to fill
-  // 256 CUs otherwise -- the per-offset stage->MFMA chain is latency bound).
+  // 256 CUs otherwise).
   const int k_begin = blockIdx.z * k_per;
   const int k_end = min(K, k_begin + k_per);
-  for (int k = k_begin; k < k_end; ++k) {
-    // neighbour row of every tile row under offset k
-    int32_t nb = -1;
-    if (tid < TM) {
-      const int32_t r = rowId[tid];
-      if (r >= 0) nb = nbr ? nbr[(int64_t)k * M_out + r] : r;
-      nbId[tid] = nb;
-    }
-    if (!__syncthreads_or(nb >= 0)) continue;  // whole tile inactive for this offset
-    const bool wave_active = __ballot(nbId[wave * 32 + l31] >= 0) != 0ull;
-    const float* Wk = W + (int64_t)k * Cin * Cout;
 
-    for (int ci0 = 0; ci0 < Cin; ci0 += CK) {
+  for (int kg0 = k_begin; kg0 < k_end; kg0 += KG) {
+    const int kcount = min(KG, k_end - kg0);
+    __syncthreads();  // previous group's nbT / grpMask readers are done
+    if (tid < 4) grpMask[tid] = 0u;
+    __syncthreads();
+    // ---- tile slice of the packed gather table: nbrS[k][tile0 + t], coalesced 512-B pieces
+    if (tid < TM) {
+      uint32_t bits_lo = 0u, bits_hi = 0u;  // which offsets are active in my 32-row slice (lo/hi half of the wave)
+      for (int kk = 0; kk < kcount; ++kk) {
+        int32_t v = -1;
+        if (my_row >= 0) v = nbrS ? nbrS[(int64_t)(kg0 + kk) * M_out + tile0 + tid] : my_row;
+        nbT[kk * TM + tid] = v;
+        const unsigned long long b = __ballot(v >= 0);
+        if ((uint32_t)b) bits_lo |= 1u << kk;
+        if ((uint32_t)(b >> 32)) bits_hi |= 1u << kk;
+      }
+      if (lane == 0) {
+        grpMask[wave * 2] = bits_lo;
+        grpMask[wave * 2 + 1] = bits_hi;
+      }
+    }
+    __syncthreads();
+    const uint32_t my_mask = grpMask[wave];
+    uint32_t tile_mask = grpMask[0] | grpMask[1] | grpMask[2] | grpMask[3];
+    if (tile_mask == 0u) continue;
+
+    // ---- pipelined walk over (active offset, channel chunk) steps
+    f32x4 ra[4];
+    f32x4 rb[NB];
+    auto fetch = [&](int kk, int ci0) {
       const int cin_here = min(CK, Cin - ci0);
-      // ---- stage A: gathered rows [TM x CK] (zero rows where the neighbour is missing)
 #pragma unroll
-      for (int j = 0; j < (TM * CK / 4) / 256; ++j) {
+      for (int j = 0; j < 4; ++j) {
         const int f = tid + 256 * j;
         const int row = f >> 3;
         const int c4 = (f & 7) * 4;
-        const int32_t g = nbId[row];
+        const int32_t g = nbT[kk * TM + row];
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (g >= 0) {
           const float* src = X + (int64_t)g * Cin + ci0 + c4;
@@ -98,16 +118,18 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
               if (c4 + e < cin_here) v[e] = src[e];
           }
         }
-        *reinterpret_cast<f32x4*>(&As[row * A_STRIDE + c4]) = v;
+        ra[j] = v;
       }
-      // ---- stage B: W[k][ci0:ci0+CK][col0:col0+NB*32]
-      for (int f = tid; f < CK * NB * 8; f += 256) {
-        const int kk = f / (NB * 8);
-        const int c4 = (f - kk * (NB * 8)) * 4;
+      const float* Wk = W + (int64_t)(kg0 + kk) * Cin * Cout;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int f = tid + 256 * j;
+        const int kr = f / (NB * 8);
+        const int c4 = (f - kr * (NB * 8)) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (kk < cin_here) {
-          const float* src = Wk + (int64_t)(ci0 + kk) * Cout + col0 + c4;
-          if ((Cout & 3) == 0 && c4 + 3 < ncols) {
+        if (kr < cin_here) {
+          const float* src = Wk + (int64_t)(ci0 + kr) * Cout + col0 + c4;
+          if (wvec4 && c4 + 3 < ncols) {
             v = *reinterpret_cast<const f32x4*>(src);
           } else {
 #pragma unroll
@@ -115,10 +137,44 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
               if (c4 + e < ncols) v[e] = src[e];
           }
         }
-        *reinterpret_cast<f32x4*>(&Bs[kk * (NB * 32) + c4]) = v;
+        rb[j] = v;
+      }
+    };
+
+    int kk = __builtin_ctz(tile_mask);
+    tile_mask &= tile_mask - 1;
+    int ci0 = 0;
+    fetch(kk, ci0);
+    for (;;) {
+      // write the fetched step to LDS
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int f = tid + 256 * j;
+        *reinterpret_cast<f32x4*>(&As[(f >> 3) * A_STRIDE + (f & 7) * 4]) = ra[j];
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int f = tid + 256 * j;
+        const int kr = f / (NB * 8);
+        *reinterpret_cast<f32x4*>(&Bs[kr * (NB * 32) + (f - kr * (NB * 8)) * 4]) = rb[j];
       }
       __syncthreads();
-      if (wave_active) {
+      // next step (issue its loads now, they land while the MFMAs below run)
+      const int cur_kk = kk;
+      const int cin_here = min(CK, Cin - ci0);
+      int nkk = kk, nci = ci0 + CK;
+      bool more = true;
+      if (nci >= Cin) {
+        nci = 0;
+        if (tile_mask) {
+          nkk = __builtin_ctz(tile_mask);
+          tile_mask &= tile_mask - 1;
+        } else {
+          more = false;
+        }
+      }
+      if (more) fetch(nkk, nci);
+      if ((my_mask >> cur_kk) & 1u) {
         // MFMA k index (step s, half h) <-> staged channel h*16 + s, so a lane reads 16 contiguous
         // floats of its A row with four ds_read_b128.
         const float* arow = &As[(wave * 32 + l31) * A_STRIDE + half * 16];
@@ -144,7 +200,10 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
           }
         }
       }
+      if (!more) break;
       __syncthreads();
+      kk = nkk;
+      ci0 = nci;
     }
   }
 
@@ -221,16 +280,30 @@ __global__ void weight_transpose_kernel(const float* __restrict__ W, float* __re
   }
 }
 
+// nbrS[k][t] = nbr[k][order[t]]  (gather table with its columns in tile order)
+__global__ void rulebook_pack_kernel(const int32_t* __restrict__ nbr, const int32_t* __restrict__ order,
+                                     int32_t* __restrict__ nbrS, int64_t M, int K) {
+  const int64_t total = M * K;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t k = t / M;
+    const int64_t c = t - k * M;
+    nbrS[t] = nbr[k * M + order[c]];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
-// dW kernel: grid (chunk, k, ci-block).  Each wave streams rows of its chunk; the MFMA A operand
-// is X^T (lane = input channel, the two k-slots = two consecutive rows), B is dY -- both are
-// coalesced 128-B row segments loaded straight from global memory, no LDS transposition.
+// dW kernel: grid (chunk, k, ci-block).  Each wave streams the rows of its chunk in tile order; the MFMA
+// A operand is X^T (lane = input channel, the two k-slots = two consecutive tile rows), B is dY -- both
+// are coalesced 128-B row segments loaded straight from global memory, no LDS transposition.  Row pairs
+// whose offset k is inactive are skipped (tile order groups equal offset sets, so most steps are either
+// fully active or fully skipped).
 // ------------------------------------------------------------------------------------------
 template <int NBO>
 __global__ __launch_bounds__(256) void spconv_dw_kernel(
-    const float* __restrict__ X, const int32_t* __restrict__ nbr, const float* __restrict__ dY,
-    float* __restrict__ partial, int64_t M_in, int64_t M_out, int K, int Cin, int Cout, int rows_per_chunk,
-    int n_cib, int co0) {
+    const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
+    const float* __restrict__ dY, float* __restrict__ partial, int64_t M_in, int64_t M_out, int K, int Cin,
+    int Cout, int rows_per_chunk, int n_cib, int co0) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4][NBO][1024]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -257,7 +330,7 @@ __global__ __launch_bounds__(256) void spconv_dw_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[cb][i] = 0.0f;
 
-  const int32_t* nbk = nbr ? nbr + (int64_t)k * M_out : nullptr;
+  const int32_t* nbk = nbrS ? nbrS + (int64_t)k * M_out : nullptr;
   bool cob_ok[NBO];
 #pragma unroll
   for (int cb = 0; cb < NBO; ++cb) cob_ok[cb] = (co0 + cb * 32 + l31) < Cout;
@@ -265,12 +338,16 @@ __global__ __launch_bounds__(256) void spconv_dw_kernel(
   constexpr int U = 4;  // steps (pairs of rows) in flight
   for (int64_t r0 = w_begin; r0 < w_end; r0 += 2 * U) {
     int32_t g[U];
-    int64_t rr[U];
+    int64_t yr[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      rr[u] = r0 + 2 * u + half;
+      const int64_t t = r0 + 2 * u + half;
       g[u] = -1;
-      if (rr[u] < w_end) g[u] = nbk ? nbk[rr[u]] : (int32_t)rr[u];
+      yr[u] = 0;
+      if (t < w_end) {
+        yr[u] = order ? order[t] : t;
+        g[u] = nbk ? nbk[t] : (int32_t)yr[u];
+      }
     }
     float a[U];
     float b[U][NBO];
@@ -281,7 +358,7 @@ __global__ __launch_bounds__(256) void spconv_dw_kernel(
 #pragma unroll
       for (int cb = 0; cb < NBO; ++cb) {
         b[u][cb] = 0.0f;
-        if (g[u] >= 0 && cob_ok[cb]) b[u][cb] = dY[rr[u] * Cout + co0 + cb * 32 + l31];
+        if (g[u] >= 0 && cob_ok[cb]) b[u][cb] = dY[yr[u] * Cout + co0 + cb * 32 + l31];
       }
     }
 #pragma unroll
@@ -344,6 +421,17 @@ int dw_rows_per_chunk(int64_t M_out) {
 }  // namespace
 
 extern "C" {
+
+int wsis_rulebook_pack(const int32_t* d_nbr, const int32_t* d_order, int32_t* d_nbr_packed, int64_t M,
+                       int32_t K, void* stream) {
+  WSIS_REQUIRE(M >= 0 && K >= 1, "bad sizes");
+  if (M == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_nbr && d_order && d_nbr_packed, "null pointer");
+  hipLaunchKernelGGL(rulebook_pack_kernel, dim3(grid_for(M * K, 256)), dim3(256), 0, as_stream(stream), d_nbr,
+                     d_order, d_nbr_packed, M, K);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
 
 int64_t wsis_spconv_fwd_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout) {
   if (M_out < 0 || K < 1 || Cin < 1 || Cout < 1) return -1;
@@ -414,9 +502,9 @@ int64_t wsis_spconv_dw_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, in
   return n_chunks * K * ci_pad * Cout * (int64_t)sizeof(float) + 256;
 }
 
-int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const float* d_dY, float* d_dW, int64_t M_in,
-                   int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
-                   void* stream) {
+int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY,
+                   float* d_dW, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws,
+                   int64_t ws_bytes, void* stream) {
   WSIS_REQUIRE(M_in >= 0 && M_out >= 0 && K >= 1 && Cin >= 1 && Cout >= 1 && d_dW, "bad args");
   hipStream_t st = as_stream(stream);
   if (M_out == 0) {
@@ -438,12 +526,12 @@ int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const float* d_dY, fl
     const int nbo = min(5, nblk - cb0);
     const int co0 = cb0 * 32;
     const size_t lds = (size_t)4 * nbo * 1024 * sizeof(float);
-#define WSIS_DW_CASE(n)                                                                               \
-  case n:                                                                                             \
-    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_dw_kernel<n>,                              \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
-    hipLaunchKernelGGL(spconv_dw_kernel<n>, grid, dim3(256), lds, st, d_X, d_nbr, d_dY, partial, M_in, \
-                       M_out, K, Cin, Cout, rpc, n_cib, co0);                                         \
+#define WSIS_DW_CASE(n)                                                                                  \
+  case n:                                                                                                \
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_dw_kernel<n>,                                 \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+    hipLaunchKernelGGL(spconv_dw_kernel<n>, grid, dim3(256), lds, st, d_X, d_nbr, d_order, d_dY, partial, \
+                       M_in, M_out, K, Cin, Cout, rpc, n_cib, co0);                                      \
     break;
     switch (nbo) {
       WSIS_DW_CASE(1)

@@ -92,7 +92,7 @@ class SparseConvolution(SparseModule):
             assert rb is not None and rb.kind == "down", "SparseInverseConv3d needs the rulebook of its SparseConv3d"
             assert rb.out_indices.shape[0] == indices.shape[0], "inverse conv input rows != coupled conv output rows"
             M_out = rb.in_indices.shape[0]
-            out_features = ops.sparse_conv(features, self.weight, self.bias, rb.nbr_up, rb.order_up, rb.nbr,
+            out_features = ops.sparse_conv(features, self.weight, self.bias, rb.nbr_up_p, rb.order_up, rb.nbr_p,
                                            rb.order, 0, M_out)
             out_tensor = SparseConvTensor(out_features, rb.in_indices, np.array(rb.in_shape), batch_size)
             out_tensor.indice_dict = input.indice_dict
@@ -109,7 +109,7 @@ class SparseConvolution(SparseModule):
                 if self.indice_key is not None:
                     input.indice_dict[self.indice_key] = rb
             M = indices.shape[0]
-            out_features = ops.sparse_conv(features, self.weight, self.bias, rb.nbr, rb.order, rb.nbr, rb.order,
+            out_features = ops.sparse_conv(features, self.weight, self.bias, rb.nbr_p, rb.order, rb.nbr_p, rb.order,
                                            1, M)
             out_tensor = SparseConvTensor(out_features, indices, input.spatial_shape, batch_size)
             out_tensor.indice_dict = input.indice_dict
@@ -123,8 +123,8 @@ class SparseConvolution(SparseModule):
             if self.indice_key is not None:
                 input.indice_dict[self.indice_key] = rb
         M_out = rb.out_indices.shape[0]
-        out_features = ops.sparse_conv(features, self.weight, self.bias, rb.nbr, rb.order, rb.nbr_up, rb.order_up,
-                                       0, M_out)
+        out_features = ops.sparse_conv(features, self.weight, self.bias, rb.nbr_p, rb.order, rb.nbr_up_p,
+                                       rb.order_up, 0, M_out)
         out_tensor = SparseConvTensor(out_features, rb.out_indices, np.array(out_spatial_shape), batch_size)
         out_tensor.indice_dict = input.indice_dict
         out_tensor.grid = input.grid

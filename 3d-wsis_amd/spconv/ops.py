@@ -74,6 +74,16 @@ def _mask_order(mask):
     return order
 
 
+def _pack(nbr, order):
+    if order is None or nbr.shape[1] == 0:
+        return nbr
+    K, M = nbr.shape
+    packed = torch.empty_like(nbr)
+    _n.check(_n.hip().wsis_rulebook_pack(_n.ptr(nbr), _n.ptr(order), _n.ptr(packed), M, K, _n.stream_ptr()),
+             "rulebook_pack")
+    return packed
+
+
 class Rulebook(object):
     """What ``indice_dict[indice_key]`` holds (upstream: a 5-tuple)."""
 
@@ -88,7 +98,14 @@ class Rulebook(object):
         self.nbr_up = None
         self.order = None
         self.order_up = None
+        self.nbr_p = None       # packed tables (columns in tile order) fed to the kernels
+        self.nbr_up_p = None
         self.out_hash = None
+
+    def pack(self):
+        self.nbr_p = _pack(self.nbr, self.order)
+        if self.nbr_up is not None:
+            self.nbr_up_p = _pack(self.nbr_up, self.order_up)
 
     # upstream-format export (tests / INTEGRATION.md): indice_pairs int32 [K,2,maxP] (-1 padded),
     # indice_pair_num int32 [K]; pair order inside an offset = ascending output row.
@@ -124,6 +141,7 @@ def build_subm_rulebook(indices, spatial_shape, ksize, padding, hash_tab=None):
                                          _n.ptr(mask), _n.stream_ptr()), "rulebook_subm")
     if mask is not None and _use_mask_order() and M > 0:
         rb.order = _mask_order(mask)
+    rb.pack()
     rb.out_hash = hash_tab
     return rb
 
@@ -171,6 +189,7 @@ def build_down_rulebook(indices, spatial_shape, ksize, stride, padding):
             rb.order = _mask_order(mask_down)
         if M_in > 0:
             rb.order_up = _mask_order(mask_up)
+    rb.pack()
     rb.out_hash = (keys, vals, cap)
     return rb
 
@@ -242,7 +261,7 @@ def _weight_t(W, flip):
     return WT
 
 
-def _dw(X, nbr, dY, K, Cin, Cout):
+def _dw(X, nbr, order, dY, K, Cin, Cout):
     lib = _n.hip()
     M_out = dY.shape[0]
     ws_bytes = lib.wsis_spconv_dw_workspace_bytes(M_out, K, Cin, Cout)
@@ -252,8 +271,8 @@ def _dw(X, nbr, dY, K, Cin, Cout):
     if prof is not None:
         P = prof.pairs(nbr, M_out)
         t0 = prof.begin()
-    _n.check(lib.wsis_spconv_dw(_n.ptr(X), _n.ptr(nbr), _n.ptr(dY), _n.ptr(dW), X.shape[0], M_out, K, Cin, Cout,
-                                _n.ptr(ws), ws_bytes, _n.stream_ptr()), "spconv_dw")
+    _n.check(lib.wsis_spconv_dw(_n.ptr(X), _n.ptr(nbr), _n.ptr(order), _n.ptr(dY), _n.ptr(dW), X.shape[0], M_out,
+                                K, Cin, Cout, _n.ptr(ws), ws_bytes, _n.stream_ptr()), "spconv_dw")
     if prof is not None:
         prof.end("spconv_dw_kernel", t0, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout)
     return dW
@@ -262,8 +281,9 @@ def _dw(X, nbr, dY, K, Cin, Cout):
 class SparseConvFunction(Function):
     """features [M_in,Cin], weight [k0,k1,k2,Cin,Cout] -> [M_out,Cout].
 
-    nbr_f/order_f: gather table of the forward pass (rows = outputs);
-    nbr_b/order_b: gather table of the dIn pass (rows = inputs); flip: subm dIn uses W[K-1-k]^T."""
+    nbr_f/order_f: PACKED gather table + tile order of the forward pass (rows = outputs);
+    nbr_b/order_b: packed gather table + tile order of the dIn pass (rows = inputs);
+    flip: subm dIn uses W[K-1-k]^T."""
 
     @staticmethod
     def forward(ctx, features, weight, bias, nbr_f, order_f, nbr_b, order_b, flip, M_out):
@@ -274,13 +294,13 @@ class SparseConvFunction(Function):
         b = bias.contiguous().float() if bias is not None else None
         out = _conv(X, nbr_f, order_f, W, b, None, M_out)
         ctx.save_for_backward(X, W)
-        ctx.aux = (nbr_f, nbr_b, order_b, flip, weight.shape, bias is not None)
+        ctx.aux = (nbr_f, order_f, nbr_b, order_b, flip, weight.shape, bias is not None)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         X, W = ctx.saved_tensors
-        nbr_f, nbr_b, order_b, flip, wshape, has_bias = ctx.aux
+        nbr_f, order_f, nbr_b, order_b, flip, wshape, has_bias = ctx.aux
         dY = grad_out.contiguous().float()
         K, Cin, Cout = W.shape
         dX = dW = db = None
@@ -288,7 +308,7 @@ class SparseConvFunction(Function):
             WT = _weight_t(W, flip)
             dX = _conv(dY, nbr_b, order_b, WT, None, None, X.shape[0])
         if ctx.needs_input_grad[1]:
-            dW = _dw(X, nbr_f, dY, K, Cin, Cout).view(wshape)
+            dW = _dw(X, nbr_f, order_f, dY, K, Cin, Cout).view(wshape)
         if has_bias and ctx.needs_input_grad[2]:
             db = dY.sum(0)
         return dX, dW, db, None, None, None, None, None, None

@@ -66,7 +66,8 @@ _HIP_SIGS = {
     "wsis_spconv_fwd": (I32, [P, P, P, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
     "wsis_weight_transpose": (I32, [P, P, I32, I32, I32, I32, P]),
     "wsis_spconv_dw_workspace_bytes": (I64, [I64, I32, I32, I32]),
-    "wsis_spconv_dw": (I32, [P, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
+    "wsis_spconv_dw": (I32, [P, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
+    "wsis_rulebook_pack": (I32, [P, P, P, I64, I32, P]),
     "wsis_segment_csr_workspace_bytes": (I64, [I64, I64]),
     "wsis_segment_csr": (I32, [P, I64, I64, P, P, P, I64, P]),
     "wsis_segment_reduce_fwd": (I32, [P, P, P, P, P, I64, I64, I32, I32, P]),

@@ -131,6 +131,12 @@ int64_t wsis_mask_order_workspace_bytes(int64_t M);
 int wsis_mask_order(const uint32_t* d_mask, int64_t M, int32_t* d_order, void* d_ws, int64_t ws_bytes,
                     void* stream);
 
+/* Packed gather table for the convolution kernels: nbr_packed[k][t] = nbr[k][order[t]] (columns in tile
+ * order, so a 128-row tile reads K coalesced 512-byte pieces).  With d_order == NULL the kernels take the
+ * unpacked table as is. */
+int wsis_rulebook_pack(const int32_t* d_nbr, const int32_t* d_order, int32_t* d_nbr_packed, int64_t M,
+                       int32_t K, void* stream);
+
 /* ---- a7-a11: sparse convolution [UPSTREAM spconv indiceConv / indiceConvBackward] -----------
  * out[r,:] = sum_k X[nbr[k][r],:] @ W[k]  (rows with nbr<0 contribute nothing), fp32.
  *   SubMConv3d fwd      : X=in,   nbr=subm table,  W=weight [K,Cin,Cout]
@@ -138,7 +144,8 @@ int wsis_mask_order(const uint32_t* d_mask, int64_t M, int32_t* d_order, void* d
  *   SparseConv3d fwd    : X=in,   nbr=nbr_down,    W=weight
  *   SparseConv3d dIn    : X=dOut, nbr=nbr_up,      W=transpose(weight, flip=0)
  *   SparseInverseConv3d : X=in,   nbr=nbr_up,      W=weight ; dIn: X=dOut, nbr=nbr_down, W^T
- * d_order (optional int32 [M_out]) = tile ordering from wsis_mask_order; d_bias optional [Cout];
+ * d_nbr is the PACKED table when d_order (int32 [M_out], tile ordering from wsis_mask_order) is given,
+ * the plain table when d_order is NULL; d_bias optional [Cout];
  * d_residual optional [M_out,Cout] added in the epilogue (sparse_unet3d.py:170 fused).
  * K==1 with d_nbr==null is the dense 1x1 shortcut (sparse_unet3d.py:115-119). */
 /* Small levels split the K offsets over blockIdx.z and reduce partial slabs from d_ws in a fixed order
@@ -151,12 +158,12 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
 /* WT[k'] = W[k]^T with k' = (flip ? K-1-k : k); W [K,Cin,Cout] -> WT [K,Cout,Cin]. */
 int wsis_weight_transpose(const float* d_W, float* d_WT, int32_t K, int32_t Cin, int32_t Cout,
                           int32_t flip, void* stream);
-/* dW[k] = sum_r X[nbr[k][r],:]^T (x) dY[r,:]   -> d_dW [K,Cin,Cout] (overwritten).
+/* dW[k] = sum_r X[nbr[k][r],:]^T (x) dY[r,:]   -> d_dW [K,Cin,Cout] (overwritten); d_nbr/d_order as above.
  * Deterministic: per-workgroup partial slabs in d_ws reduced in a fixed order. */
 int64_t wsis_spconv_dw_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout);
-int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const float* d_dY, float* d_dW, int64_t M_in,
-                   int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
-                   void* stream);
+int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY,
+                   float* d_dW, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws,
+                   int64_t ws_bytes, void* stream);
 
 /* ---- a14/a15: row gather and torch_scatter.scatter  backbone_3D_WSIS.py:179,188,225,232,244 --
  * CSR of a (possibly unsorted) index vector: d_perm int32 [N] = stable argsort(index),
