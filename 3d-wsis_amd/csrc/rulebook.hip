@@ -193,6 +193,31 @@ __global__ void down_fill_kernel(const int32_t* __restrict__ indices, int64_t M_
   }
 }
 
+__device__ __forceinline__ uint32_t spread3(uint32_t x) {  // 8 bits -> every third bit
+  x &= 0xffu;
+  x = (x | (x << 16)) & 0x0300F00Fu;
+  x = (x | (x << 8)) & 0x0300F00Fu;
+  x = (x | (x << 4)) & 0x030C30C3u;
+  x = (x | (x << 2)) & 0x09249249u;
+  return x;
+}
+
+// sort key of a row: (batch, Morton code of its block of 2^bs voxels per side, set of active offsets).
+// Rows of one spatial block become neighbours (their gathers hit the same L1/L2 lines), and inside a block
+// rows with the same offset set are adjacent (whole 32-row MFMA slices skip inactive offsets).
+__global__ void tile_key_kernel(const int32_t* __restrict__ indices, const uint32_t* __restrict__ mask,
+                                int64_t M, int bs, uint64_t* __restrict__ keys, int32_t* __restrict__ iota) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < M;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(indices)[r];
+    const uint32_t mort = spread3((uint32_t)c.y >> bs) | (spread3((uint32_t)c.z >> bs) << 1) |
+                          (spread3((uint32_t)c.w >> bs) << 2);
+    keys[r] = ((uint64_t)((uint32_t)c.x & 0xffu) << 56) | ((uint64_t)(mort & 0xffffffu) << 32) |
+              (uint64_t)(mask ? mask[r] : 0u);
+    iota[r] = (int32_t)r;
+  }
+}
+
 __global__ void iota_kernel(int32_t* __restrict__ p, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x)
@@ -363,6 +388,43 @@ int wsis_rulebook_down_fill(const int32_t* d_indices_in, int64_t M_in, const int
       WSIS_HIP_CHECK(hipMemsetAsync(d_mask_up, 0, sizeof(uint32_t) * (size_t)M_in, st));
     }
   }
+  return WSIS_OK;
+}
+
+int64_t wsis_tile_order_workspace_bytes(int64_t M) {
+  if (M < 0) return -1;
+  if (M == 0) return 256;
+  size_t sort_bytes = 0;
+  uint64_t* kp = nullptr;
+  int32_t* vp = nullptr;
+  if (rocprim::radix_sort_pairs(nullptr, sort_bytes, kp, kp, vp, vp, (size_t)M, 0, 64, (hipStream_t)0) !=
+      hipSuccess)
+    return -1;
+  // layout: [keys M*8][keys_out M*8][iota M*4][temp]
+  return (int64_t)(2 * align256((size_t)M * 8) + align256((size_t)M * 4) + align256(sort_bytes) + 256);
+}
+
+int wsis_tile_order(const int32_t* d_indices, const uint32_t* d_mask, int64_t M, int32_t block_shift,
+                    int32_t* d_order, void* d_ws, int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(M >= 0 && block_shift >= 0 && block_shift < 16, "bad args");
+  if (M == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_indices && d_order && d_ws, "null pointer");
+  hipStream_t st = as_stream(stream);
+  char* ws = static_cast<char*>(d_ws);
+  const size_t a8 = align256((size_t)M * 8), a4 = align256((size_t)M * 4);
+  WSIS_REQUIRE((int64_t)(2 * a8 + a4) < ws_bytes, "workspace too small");
+  uint64_t* keys = reinterpret_cast<uint64_t*>(ws);
+  uint64_t* keys_out = reinterpret_cast<uint64_t*>(ws + a8);
+  int32_t* iota = reinterpret_cast<int32_t*>(ws + 2 * a8);
+  void* temp = ws + 2 * a8 + a4;
+  size_t temp_bytes = (size_t)ws_bytes - (2 * a8 + a4);
+  hipLaunchKernelGGL(tile_key_kernel, dim3(grid_for(M, 256)), dim3(256), 0, st, d_indices, d_mask, M,
+                     (int)block_shift, keys, iota);
+  WSIS_LAUNCH_CHECK();
+  size_t need = 0;
+  WSIS_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, need, keys, keys_out, iota, d_order, (size_t)M, 0, 64, st));
+  WSIS_REQUIRE(need <= temp_bytes, "workspace too small for sort");
+  WSIS_HIP_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_out, iota, d_order, (size_t)M, 0, 64, st));
   return WSIS_OK;
 }
 

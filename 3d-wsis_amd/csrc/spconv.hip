@@ -11,6 +11,8 @@
 // and consumed by the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32.  No per-offset gather
 // buffer in HBM and no scatter-add atomics (upstream spconv does both); the reduction order is fixed,
 // so results are run-to-run deterministic and independent of the tile order.
+#include <cstdlib>
+
 #include "common.h"
 
 using namespace wsis;
@@ -28,8 +30,8 @@ constexpr int KG = 32;        // kernel offsets handled per group (bit masks are
 // ------------------------------------------------------------------------------------------
 // forward / dIn kernel
 // ------------------------------------------------------------------------------------------
-template <int NB>
-__global__ __launch_bounds__(256) void spconv_fwd_kernel(
+template <int NB, bool VEC4>
+__global__ __launch_bounds__(256, (NB <= 1 ? 4 : (NB <= 3 ? 3 : 2))) void spconv_fwd_kernel(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ residual,
     float* __restrict__ out, float* __restrict__ partial, int64_t M_in, int64_t M_out, int K, int Cin, int Cout,
@@ -48,8 +50,6 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
   const int64_t tile0 = (int64_t)blockIdx.x * TM;
   const int col0 = blockIdx.y * (NB * 32);
   const int ncols = min(NB * 32, Cout - col0);
-  const bool vec4 = (Cin & 3) == 0;
-  const bool wvec4 = (Cout & 3) == 0;
 
   int32_t my_row = -1;
   if (tid < TM) {
@@ -70,19 +70,40 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
   const int k_begin = blockIdx.z * k_per;
   const int k_end = min(K, k_begin + k_per);
 
+  // per-thread staging coordinates (constant over the walk)
+  int a_row[4], a_c4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int f = tid + 256 * j;
+    a_row[j] = f >> 3;
+    a_c4[j] = (f & 7) * 4;
+  }
+  int b_kr[NB], b_c4[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int f = tid + 256 * j;
+    b_kr[j] = f / (NB * 8);
+    b_c4[j] = (f - b_kr[j] * (NB * 8)) * 4;
+  }
+
   for (int kg0 = k_begin; kg0 < k_end; kg0 += KG) {
     const int kcount = min(KG, k_end - kg0);
-    __syncthreads();  // previous group's nbT / grpMask readers are done
-    if (tid < 4) grpMask[tid] = 0u;
-    __syncthreads();
-    // ---- tile slice of the packed gather table: nbrS[k][tile0 + t], coalesced 512-B pieces
+    __syncthreads();  // previous group's nbT / grpMask readers are done (also publishes rowId)
+    // ---- tile slice of the packed gather table: nbrS[k][tile0 + t], coalesced 512-B pieces.  All loads are
+    //      issued before any of them is consumed: one memory latency for the whole slice.
     if (tid < TM) {
-      uint32_t bits_lo = 0u, bits_hi = 0u;  // which offsets are active in my 32-row slice (lo/hi half of the wave)
-      for (int kk = 0; kk < kcount; ++kk) {
-        int32_t v = -1;
-        if (my_row >= 0) v = nbrS ? nbrS[(int64_t)(kg0 + kk) * M_out + tile0 + tid] : my_row;
-        nbT[kk * TM + tid] = v;
-        const unsigned long long b = __ballot(v >= 0);
+      int32_t v[KG];
+#pragma unroll
+      for (int kk = 0; kk < KG; ++kk) {
+        const bool ok = kk < kcount && my_row >= 0 && nbrS != nullptr;
+        v[kk] = nbrS ? nbrS[ok ? (int64_t)(kg0 + kk) * M_out + tile0 + tid : 0] : 0;
+        if (!ok) v[kk] = (nbrS == nullptr && kk < kcount) ? my_row : -1;
+      }
+      uint32_t bits_lo = 0u, bits_hi = 0u;
+#pragma unroll
+      for (int kk = 0; kk < KG; ++kk) {
+        nbT[kk * TM + tid] = v[kk];
+        const unsigned long long b = __ballot(v[kk] >= 0);
         if ((uint32_t)b) bits_lo |= 1u << kk;
         if ((uint32_t)(b >> 32)) bits_hi |= 1u << kk;
       }
@@ -96,48 +117,51 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
     uint32_t tile_mask = grpMask[0] | grpMask[1] | grpMask[2] | grpMask[3];
     if (tile_mask == 0u) continue;
 
-    // ---- pipelined walk over (active offset, channel chunk) steps
+    // ---- pipelined walk over (active offset, channel chunk) steps.
+    // fetch(): branch-free -- every lane always issues its loads (row 0 / channel 0 when masked) so that the
+    // gathers of a step are independent and in flight together; masking to zero happens when the registers are
+    // written to LDS one step later, which keeps the loads in flight under the MFMAs of the current step.
     f32x4 ra[4];
     f32x4 rb[NB];
+    uint32_t ok_bits = 0u;   // bit j: ra[j] valid, bit 8+j: rb[j] valid
     auto fetch = [&](int kk, int ci0) {
       const int cin_here = min(CK, Cin - ci0);
+      ok_bits = 0u;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int f = tid + 256 * j;
-        const int row = f >> 3;
-        const int c4 = (f & 7) * 4;
-        const int32_t g = nbT[kk * TM + row];
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (g >= 0) {
-          const float* src = X + (int64_t)g * Cin + ci0 + c4;
-          if (vec4) {
-            if (c4 < cin_here) v = *reinterpret_cast<const f32x4*>(src);
-          } else {
+        const int32_t g = nbT[kk * TM + a_row[j]];
+        const bool ok = g >= 0 && a_c4[j] < cin_here;
+        const float* src = X + (int64_t)(ok ? g : 0) * Cin + ci0 + (ok ? a_c4[j] : 0);
+        if (VEC4) {
+          ra[j] = *reinterpret_cast<const f32x4*>(src);
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (c4 + e < cin_here) v[e] = src[e];
+          for (int e = 0; e < 4; ++e) {
+            const bool oke = ok && a_c4[j] + e < cin_here;
+            const float t = src[oke ? e : 0];
+            ra[j][e] = oke ? t : 0.0f;
           }
         }
-        ra[j] = v;
+        ok_bits |= (ok ? 1u : 0u) << j;
       }
-      const float* Wk = W + (int64_t)(kg0 + kk) * Cin * Cout;
+      const float* Wk = W + (int64_t)(kg0 + kk) * Cin * Cout + col0;
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const int f = tid + 256 * j;
-        const int kr = f / (NB * 8);
-        const int c4 = (f - kr * (NB * 8)) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (kr < cin_here) {
-          const float* src = Wk + (int64_t)(ci0 + kr) * Cout + col0 + c4;
-          if (wvec4 && c4 + 3 < ncols) {
-            v = *reinterpret_cast<const f32x4*>(src);
-          } else {
+        const bool okr = b_kr[j] < cin_here;
+        const float* src = Wk + (int64_t)(ci0 + (okr ? b_kr[j] : 0)) * Cout;
+        if (VEC4) {
+          const bool okc = b_c4[j] + 3 < ncols;
+          rb[j] = *reinterpret_cast<const f32x4*>(src + (okc ? b_c4[j] : 0));
+          ok_bits |= ((okr && okc) ? 1u : 0u) << (8 + j);
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (c4 + e < ncols) v[e] = src[e];
+          for (int e = 0; e < 4; ++e) {
+            const bool okc = okr && b_c4[j] + e < ncols;
+            const float t = src[okc ? b_c4[j] + e : 0];
+            rb[j][e] = okc ? t : 0.0f;
           }
+          ok_bits |= 1u << (8 + j);
         }
-        rb[j] = v;
       }
     };
 
@@ -146,20 +170,15 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
     int ci0 = 0;
     fetch(kk, ci0);
     for (;;) {
-      // write the fetched step to LDS
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int f = tid + 256 * j;
-        *reinterpret_cast<f32x4*>(&As[(f >> 3) * A_STRIDE + (f & 7) * 4]) = ra[j];
-      }
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(&As[a_row[j] * A_STRIDE + a_c4[j]]) = ((ok_bits >> j) & 1u) ? ra[j] : zero4;
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        const int f = tid + 256 * j;
-        const int kr = f / (NB * 8);
-        *reinterpret_cast<f32x4*>(&Bs[kr * (NB * 32) + (f - kr * (NB * 8)) * 4]) = rb[j];
-      }
+      for (int j = 0; j < NB; ++j)
+        *reinterpret_cast<f32x4*>(&Bs[b_kr[j] * (NB * 32) + b_c4[j]]) = ((ok_bits >> (8 + j)) & 1u) ? rb[j] : zero4;
       __syncthreads();
-      // next step (issue its loads now, they land while the MFMAs below run)
+      // next step: issue its loads now, they land while the MFMAs below run
       const int cur_kk = kk;
       const int cin_here = min(CK, Cin - ci0);
       int nkk = kk, nci = ci0 + CK;
@@ -208,26 +227,13 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
   }
 
   // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*half
-  if (gridDim.z > 1) {
-    float* dst = partial + (int64_t)blockIdx.z * M_out * Cout;
-#pragma unroll
-    for (int cb = 0; cb < NB; ++cb) {
-      const int c = cb * 32 + l31;
-      if (c >= ncols) continue;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-        const int32_t r = rowId[wave * 32 + rr];
-        if (r >= 0) dst[(int64_t)r * Cout + col0 + c] = acc[cb][reg];
-      }
-    }
-    return;
-  }
+  float* dst = (gridDim.z > 1) ? partial + (int64_t)blockIdx.z * M_out * Cout : out;
+  const bool final_pass = gridDim.z == 1;
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) {
     const int c = cb * 32 + l31;
     if (c >= ncols) continue;
-    const float bv = bias ? bias[col0 + c] : 0.0f;
+    const float bv = (final_pass && bias) ? bias[col0 + c] : 0.0f;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
@@ -235,8 +241,8 @@ __global__ __launch_bounds__(256) void spconv_fwd_kernel(
       if (r < 0) continue;
       const int64_t o = (int64_t)r * Cout + col0 + c;
       float v = acc[cb][reg] + bv;
-      if (residual) v += residual[o];
-      out[o] = v;
+      if (final_pass && residual) v += residual[o];
+      dst[o] = v;
     }
   }
 }
@@ -293,12 +299,11 @@ __global__ void rulebook_pack_kernel(const int32_t* __restrict__ nbr, const int3
 }
 
 // ------------------------------------------------------------------------------------------
-// dW kernel: grid (chunk, k, ci-block).  Each wave streams the rows of its chunk in tile order; the MFMA
-// A operand is X^T (lane = input channel, the two k-slots = two consecutive tile rows), B is dY -- both
-// are coalesced 128-B row segments loaded straight from global memory, no LDS transposition.  Row pairs
-// whose offset k is inactive are skipped (tile order groups equal offset sets, so most steps are either
-// fully active or fully skipped).
-// ------------------------------------------------------------------------------------------
+// dW kernel: grid (row chunk, offset k, ci-block).  The MFMA A operand is X^T (lane = input channel, the two
+// k-slots = two tile rows), B is dY -- both are coalesced 128-B row segments loaded straight from global
+// memory, no LDS transposition.
+// A wave scans 64 tile rows at a time (one coalesced table read + ballot), then
+// walks only the ACTIVE rows two at a time (scalar bit scan + v_readlane), so inactive rows cost no vector work.
 template <int NBO>
 __global__ __launch_bounds__(256) void spconv_dw_kernel(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
@@ -318,9 +323,8 @@ __global__ __launch_bounds__(256) void spconv_dw_kernel(
 
   const int64_t row_begin = (int64_t)chunk * rows_per_chunk;
   const int64_t row_end = min(M_out, row_begin + rows_per_chunk);
-  // each wave takes a contiguous quarter (multiple of 2 rows)
   const int64_t span = row_end - row_begin;
-  int64_t per_wave = ((span + 3) / 4 + 1) & ~(int64_t)1;
+  const int64_t per_wave = (((span + 3) / 4) + 63) & ~(int64_t)63;
   const int64_t w_begin = row_begin + wave * per_wave;
   const int64_t w_end = min(row_end, w_begin + per_wave);
 
@@ -335,47 +339,64 @@ __global__ __launch_bounds__(256) void spconv_dw_kernel(
 #pragma unroll
   for (int cb = 0; cb < NBO; ++cb) cob_ok[cb] = (co0 + cb * 32 + l31) < Cout;
 
-  constexpr int U = 4;  // steps (pairs of rows) in flight
-  for (int64_t r0 = w_begin; r0 < w_end; r0 += 2 * U) {
-    int32_t g[U];
-    int64_t yr[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t t = r0 + 2 * u + half;
-      g[u] = -1;
-      yr[u] = 0;
-      if (t < w_end) {
-        yr[u] = order ? order[t] : t;
-        g[u] = nbk ? nbk[t] : (int32_t)yr[u];
-      }
+  constexpr int U = 4;
+  for (int64_t tb = w_begin; tb < w_end; tb += 64) {
+    const int64_t t = tb + lane;
+    int32_t yr = 0, nb = -1;
+    if (t < w_end) {
+      yr = order ? order[t] : (int32_t)t;
+      nb = nbk ? nbk[t] : yr;
     }
-    float a[U];
-    float b[U][NBO];
+    unsigned long long m = __ballot(nb >= 0);
+    while (m) {
+      int32_t g[U], y[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      a[u] = 0.0f;
-      if (g[u] >= 0 && ci_ok) a[u] = X[(int64_t)g[u] * Cin + ci];
-#pragma unroll
-      for (int cb = 0; cb < NBO; ++cb) {
-        b[u][cb] = 0.0f;
-        if (g[u] >= 0 && cob_ok[cb]) b[u][cb] = dY[yr[u] * Cout + co0 + cb * 32 + l31];
+      for (int u = 0; u < U; ++u) {
+        int32_t g0 = -1, g1 = -1, y0 = 0, y1 = 0;
+        if (m) {
+          const int i0 = __builtin_ctzll(m);
+          m &= m - 1;
+          g0 = __builtin_amdgcn_readlane(nb, i0);
+          y0 = __builtin_amdgcn_readlane(yr, i0);
+          if (m) {
+            const int i1 = __builtin_ctzll(m);
+            m &= m - 1;
+            g1 = __builtin_amdgcn_readlane(nb, i1);
+            y1 = __builtin_amdgcn_readlane(yr, i1);
+          }
+        }
+        g[u] = half ? g1 : g0;
+        y[u] = half ? y1 : y0;
       }
-    }
+      float a[U];
+      float b[U][NBO];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (__ballot(g[u] >= 0) == 0ull) continue;  // both rows of the step have no pair
+      for (int u = 0; u < U; ++u) {
+        const bool oka = g[u] >= 0 && ci_ok;
+        const float ta = X[oka ? (int64_t)g[u] * Cin + ci : 0];
+        a[u] = oka ? ta : 0.0f;
 #pragma unroll
-      for (int cb = 0; cb < NBO; ++cb)
-        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][cb], acc[cb], 0, 0, 0);
+        for (int cb = 0; cb < NBO; ++cb) {
+          const bool okb = g[u] >= 0 && cob_ok[cb];
+          const float tb = dY[okb ? (int64_t)y[u] * Cout + co0 + cb * 32 + l31 : 0];
+          b[u][cb] = okb ? tb : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (__ballot(g[u] >= 0) == 0ull) continue;
+#pragma unroll
+        for (int cb = 0; cb < NBO; ++cb)
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][cb], acc[cb], 0, 0, 0);
+      }
     }
   }
 
-  // cross-wave reduction in a fixed order, then one plain store of the partial slab
 #pragma unroll
   for (int cb = 0; cb < NBO; ++cb)
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;  // ci within block
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
       red[(wave * NBO + cb) * 1024 + row * 32 + l31] = acc[cb][reg];
     }
   __syncthreads();
@@ -458,12 +479,18 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
     WSIS_REQUIRE(d_ws && ws_bytes >= (int64_t)kz * M_out * Cout * (int64_t)sizeof(float), "workspace too small");
     partial = static_cast<float*>(d_ws);
   }
-  const dim3 grid((unsigned)ceil_div(M_out, TM), (unsigned)ceil_div(Cout, NB * 32), (unsigned)kz);
   hipStream_t st = as_stream(stream);
+  const bool vec_ok = (Cin % 4 == 0) && (Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(d_W) & 15) == 0);
+  const dim3 grid((unsigned)ceil_div(M_out, TM), (unsigned)ceil_div(Cout, NB * 32), (unsigned)kz);
 #define WSIS_FWD_CASE(n)                                                                          \
   case n:                                                                                         \
-    hipLaunchKernelGGL(spconv_fwd_kernel<n>, grid, dim3(256), 0, st, d_X, d_nbr, d_order, d_W,    \
-                       d_bias, d_residual, d_out, partial, M_in, M_out, K, Cin, Cout, k_per);     \
+    if (vec_ok)                                                                                   \
+      hipLaunchKernelGGL((spconv_fwd_kernel<n, true>), grid, dim3(256), 0, st, d_X, d_nbr, d_order, d_W,  \
+                         d_bias, d_residual, d_out, partial, M_in, M_out, K, Cin, Cout, k_per); \
+    else                                                                                          \
+      hipLaunchKernelGGL((spconv_fwd_kernel<n, false>), grid, dim3(256), 0, st, d_X, d_nbr, d_order, d_W, \
+                         d_bias, d_residual, d_out, partial, M_in, M_out, K, Cin, Cout, k_per); \
     break;
   switch (NB) {
     WSIS_FWD_CASE(1)

@@ -61,6 +61,27 @@ def build_hash(indices, spatial_shape):
     return keys, vals, cap
 
 
+def _tile_block_shift():
+    return int(os.environ.get("WSIS_TILE_BLOCK_SHIFT", "4"))
+
+
+def _tile_order(indices, mask):
+    """stable sort of the rows by (batch, Morton block, offset mask) -> int32 [M] tile order"""
+    bs = _tile_block_shift()
+    if bs < 0:
+        return _mask_order(mask)
+    M = indices.shape[0]
+    lib = _n.hip()
+    ws_bytes = lib.wsis_tile_order_workspace_bytes(M)
+    if ws_bytes < 0:
+        raise _n.WsisError("tile_order workspace query failed")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=indices.device)
+    order = torch.empty(M, dtype=torch.int32, device=indices.device)
+    _n.check(lib.wsis_tile_order(_n.ptr(indices), _n.ptr(mask), M, bs, _n.ptr(order), _n.ptr(ws), ws_bytes,
+                                 _n.stream_ptr()), "tile_order")
+    return order
+
+
 def _mask_order(mask):
     M = mask.shape[0]
     lib = _n.hip()
@@ -140,7 +161,7 @@ def build_subm_rulebook(indices, spatial_shape, ksize, padding, hash_tab=None):
                                          _n.i32x3(padding), _n.ptr(keys), _n.ptr(vals), cap, _n.ptr(rb.nbr),
                                          _n.ptr(mask), _n.stream_ptr()), "rulebook_subm")
     if mask is not None and _use_mask_order() and M > 0:
-        rb.order = _mask_order(mask)
+        rb.order = _tile_order(indices, mask)
     rb.pack()
     rb.out_hash = hash_tab
     return rb
@@ -186,9 +207,9 @@ def build_down_rulebook(indices, spatial_shape, ksize, stride, padding):
              "rulebook_down_fill")
     if use_mask and _use_mask_order():
         if M_out > 0:
-            rb.order = _mask_order(mask_down)
+            rb.order = _tile_order(out_indices, mask_down)
         if M_in > 0:
-            rb.order_up = _mask_order(mask_up)
+            rb.order_up = _tile_order(indices, mask_up)
     rb.pack()
     rb.out_hash = (keys, vals, cap)
     return rb

@@ -128,6 +128,12 @@ int wsis_rulebook_down_fill(const int32_t* d_indices_in, int64_t M_in, const int
 /* Tile ordering for the implicit GEMM: d_order int32 [M] = stable argsort of d_mask (rows with the
  * same set of active offsets become neighbours so whole tiles skip inactive offsets). */
 int64_t wsis_mask_order_workspace_bytes(int64_t M);
+/* Spatial + mask tile ordering: stable sort by (batch, Morton code of the row's block of 2^block_shift voxels
+ * per side, offset mask).  Rows of one block become neighbours, so the gathers of a tile hit the same L1/L2
+ * lines; inside a block equal offset sets stay adjacent.  d_mask may be NULL (pure spatial order). */
+int64_t wsis_tile_order_workspace_bytes(int64_t M);
+int wsis_tile_order(const int32_t* d_indices, const uint32_t* d_mask, int64_t M, int32_t block_shift,
+                    int32_t* d_order, void* d_ws, int64_t ws_bytes, void* stream);
 int wsis_mask_order(const uint32_t* d_mask, int64_t M, int32_t* d_order, void* d_ws, int64_t ws_bytes,
                     void* stream);
 
