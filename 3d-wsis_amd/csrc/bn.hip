@@ -1,0 +1,398 @@
+// BatchNorm1d (+ReLU) over the active voxels: modules/model/sparse_unet3d.py:128-137,
+// modules/model/backbone_3D_WSIS.py:47,52-55.  The reference runs BN and ReLU as separate torch ops
+// (several elementwise passes + atomics-free but multi-kernel reductions); here
+//   forward  = stats (one read of x, fixed-order tree)  + apply(+ReLU) (one read, one write)
+//   backward = reduce (dgamma, dbeta; reads x, dy)      + apply (reads x, dy; writes dx)
+// All reductions use per-workgroup partials combined in a fixed order (Chan's formula for mean/M2), so the
+// result is run-to-run deterministic.  HBM-bound: 2*M*C*4 bytes per pass.
+#include "common.h"
+
+using namespace wsis;
+
+namespace {
+
+constexpr int BN_ROWS = 512;   // rows reduced by one workgroup
+constexpr int BN_THREADS = 256;
+
+struct f4 {
+  float v[4];
+};
+__device__ __forceinline__ f4 ld4(const float* p, bool vec) {
+  f4 r;
+  if (vec) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else {
+    r.v[0] = p[0]; r.v[1] = p[1]; r.v[2] = p[2]; r.v[3] = p[3];
+  }
+  return r;
+}
+
+// Thread layout of the reductions: channels are handled in groups of 4 (one 16-byte load per row);
+// 256 threads = G channel groups x R row lanes.  C is padded to C4*4 logically; tail channels are masked.
+// pass 1 (forward): per-workgroup (sum, sumsq) per channel from ONE read of x.  partial [nblk][2][Cp]
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_partial_kernel(const float* __restrict__ x, int64_t M, int C,
+                                                                      int Cp, float* __restrict__ partial) {
+  __shared__ float s_a[BN_THREADS * 4];
+  __shared__ float s_b[BN_THREADS * 4];
+  const int G = Cp >> 2;                       // channel groups
+  const int R = max(BN_THREADS / G, 1);        // row lanes
+  const bool vec = (C & 3) == 0;
+  const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS;
+  const int64_t r1 = min(M, r0 + BN_ROWS);
+  for (int g0 = 0; g0 < G; g0 += BN_THREADS) {  // G <= 256 in practice: one trip
+    const int g = g0 + (threadIdx.x % min(G, BN_THREADS));
+    const int rl = threadIdx.x / min(G, BN_THREADS);
+    float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g < G && rl < R) {
+      const int c = g * 4;
+      for (int64_t r = r0 + rl; r < r1; r += R) {
+        float v[4];
+        if (vec) {
+          const f4 t = ld4(x + r * C + c, true);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = t.v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (c + e < C) ? x[r * C + c + e] : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sa[e] += v[e];
+          sb[e] += v[e] * v[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s_a[threadIdx.x * 4 + e] = sa[e];
+      s_b[threadIdx.x * 4 + e] = sb[e];
+    }
+    __syncthreads();
+    if (g < G && rl == 0) {
+      const int gw = min(G, BN_THREADS);
+      float ta[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < R; ++j)   // fixed order
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ta[e] += s_a[(j * gw + (threadIdx.x % gw)) * 4 + e];
+          tb[e] += s_b[(j * gw + (threadIdx.x % gw)) * 4 + e];
+        }
+      float* p = partial + (int64_t)blockIdx.x * 2 * Cp;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p[g * 4 + e] = ta[e];
+        p[Cp + g * 4 + e] = tb[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// pass 2: combine the partials in a fixed order in fp64, write mean / biased var, update running stats.
+// 256 threads = 64 channels x 4 partial lanes.
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                             int Cp, int64_t M, float* __restrict__ mean,
+                                                             float* __restrict__ var,
+                                                             float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, float momentum) {
+  __shared__ double s_s[256];
+  __shared__ double s_q[256];
+  const int cl = threadIdx.x & 63;
+  const int pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int b = pl; b < nblk; b += 4) {
+      s += partial[(int64_t)b * 2 * Cp + c];
+      q += partial[(int64_t)b * 2 * Cp + Cp + c];
+    }
+  s_s[threadIdx.x] = s;
+  s_q[threadIdx.x] = q;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    const double S = ((s_s[cl] + s_s[64 + cl]) + s_s[128 + cl]) + s_s[192 + cl];
+    const double Q = ((s_q[cl] + s_q[64 + cl]) + s_q[128 + cl]) + s_q[192 + cl];
+    const double n = (double)M;
+    const double mu = S / n;
+    double v = Q / n - mu * mu;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)mu;
+    var[c] = (float)v;
+    if (running_mean) {
+      const double unb = n > 1 ? v * n / (n - 1) : v;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+  }
+}
+
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                const float* __restrict__ var, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float eps, int relu, float* __restrict__ y,
+                                int64_t M, int C) {
+  const int64_t total = M * C;
+  if ((C & 3) == 0) {
+    const int64_t total4 = total >> 2;
+    const unsigned C4 = (unsigned)(C >> 2);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool fixed_c = (stride % C4) == 0;      // then the channel group of a thread never changes
+    unsigned cg = (unsigned)(t % C4);
+    float sc[4], sh[4];
+    auto coef = [&](unsigned g) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = (int)g * 4 + e;
+        sc[e] = (gamma ? gamma[c] : 1.0f) * rsqrtf(var[c] + eps);
+        sh[e] = (beta ? beta[c] : 0.0f) - mean[c] * sc[e];
+      }
+    };
+    coef(cg);
+    for (; t < total4; t += stride) {
+      if (!fixed_c) {
+        cg = (unsigned)(t % C4);
+        coef(cg);
+      }
+      float4 v = reinterpret_cast<const float4*>(x)[t];
+      float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // (x - mean)*sc + beta, written as x*sc + (beta - mean*sc) would change rounding: keep the torch order
+        float z = (o[e] - mean[(int)cg * 4 + e]) * sc[e] + (beta ? beta[(int)cg * 4 + e] : 0.0f);
+        if (relu) z = fmaxf(z, 0.0f);
+        o[e] = z;
+      }
+      reinterpret_cast<float4*>(y)[t] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    (void)sh;
+  } else {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+      const int c = (int)(t % C);
+      const float sc = (gamma ? gamma[c] : 1.0f) * rsqrtf(var[c] + eps);
+      float z = (x[t] - mean[c]) * sc + (beta ? beta[c] : 0.0f);
+      if (relu) z = fmaxf(z, 0.0f);
+      y[t] = z;
+    }
+  }
+}
+
+// backward pass 1: per-workgroup partial (sum dz, sum dz*xhat) per channel.  partial [nblk][2][Cp]
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    int relu, int64_t M, int C, int Cp, float* __restrict__ partial) {
+  __shared__ float s_a[BN_THREADS * 4];
+  __shared__ float s_b[BN_THREADS * 4];
+  const int G = Cp >> 2;
+  const int gw = min(G, BN_THREADS);
+  const int R = max(BN_THREADS / G, 1);
+  const bool vec = (C & 3) == 0;
+  const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS;
+  const int64_t r1 = min(M, r0 + BN_ROWS);
+  for (int g0 = 0; g0 < G; g0 += BN_THREADS) {
+    const int g = g0 + (threadIdx.x % gw);
+    const int rl = threadIdx.x / gw;
+    float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g < G && rl < R) {
+      const int c = g * 4;
+      float mu[4], rstd[4], gm[4], bt[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int cc = min(c + e, C - 1);
+        mu[e] = mean[cc];
+        rstd[e] = rsqrtf(var[cc] + eps);
+        gm[e] = gamma ? gamma[cc] : 1.0f;
+        bt[e] = beta ? beta[cc] : 0.0f;
+      }
+      for (int64_t r = r0 + rl; r < r1; r += R) {
+        float xv[4], dv[4];
+        if (vec) {
+          const f4 tx = ld4(x + r * C + c, true), td = ld4(dy + r * C + c, true);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xv[e] = tx.v[e];
+            dv[e] = td.v[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = c + e < C;
+            xv[e] = ok ? x[r * C + c + e] : 0.0f;
+            dv[e] = ok ? dy[r * C + c + e] : 0.0f;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xv[e] - mu[e]) * rstd[e];
+          float dz = dv[e];
+          if (relu && xh * gm[e] + bt[e] <= 0.0f) dz = 0.0f;
+          sa[e] += dz;
+          sb[e] += dz * xh;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s_a[threadIdx.x * 4 + e] = sa[e];
+      s_b[threadIdx.x * 4 + e] = sb[e];
+    }
+    __syncthreads();
+    if (g < G && rl == 0) {
+      float ta[4] = {0.f, 0.f, 0.f, 0.f}, tb[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < R; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ta[e] += s_a[(j * gw + (threadIdx.x % gw)) * 4 + e];
+          tb[e] += s_b[(j * gw + (threadIdx.x % gw)) * 4 + e];
+        }
+      float* p = partial + (int64_t)blockIdx.x * 2 * Cp;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p[g * 4 + e] = ta[e];
+        p[Cp + g * 4 + e] = tb[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk, int C, int Cp,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double s_s[256];
+  __shared__ double s_q[256];
+  const int cl = threadIdx.x & 63;
+  const int pl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int k = pl; k < nblk; k += 4) {
+      a += partial[(int64_t)k * 2 * Cp + c];
+      b += partial[(int64_t)k * 2 * Cp + Cp + c];
+    }
+  s_s[threadIdx.x] = a;
+  s_q[threadIdx.x] = b;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    dbeta[c] = (float)(((s_s[cl] + s_s[64 + cl]) + s_s[128 + cl]) + s_s[192 + cl]);
+    dgamma[c] = (float)(((s_q[cl] + s_q[64 + cl]) + s_q[128 + cl]) + s_q[192 + cl]);
+  }
+}
+
+// backward pass 2: dx = gamma*rstd*(dz - dbeta/M - xhat*dgamma/M)  (training);  gamma*rstd*dz (eval)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                    const float* __restrict__ mean, const float* __restrict__ var,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta, float eps,
+                                    int relu, int training, float* __restrict__ dx, int64_t M, int C) {
+  const int64_t total = M * C;
+  const float inv_m = 1.0f / (float)M;
+  const bool vec = (C & 3) == 0;
+  const int W = vec ? 4 : 1;
+  const int64_t totalw = total / W;
+  const unsigned Cw = (unsigned)(C / W);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < totalw; t += stride) {
+    const int c0 = (int)(t % Cw) * W;
+    float xv[4], dv[4], ov[4];
+    if (vec) {
+      const f4 tx = ld4(x + t * 4, true), td = ld4(dy + t * 4, true);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xv[e] = tx.v[e];
+        dv[e] = td.v[e];
+      }
+    } else {
+      xv[0] = x[t];
+      dv[0] = dy[t];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e < W) {
+        const int c = c0 + e;
+        const float rstd = rsqrtf(var[c] + eps);
+        const float g = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+        const float xh = (xv[e] - mean[c]) * rstd;
+        float dz = dv[e];
+        if (relu && xh * g + bt <= 0.0f) dz = 0.0f;
+        float r = dz;
+        if (training) r = dz - dbeta[c] * inv_m - xh * dgamma[c] * inv_m;
+        ov[e] = g * rstd * r;
+      }
+    }
+    if (vec)
+      reinterpret_cast<float4*>(dx)[t] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    else
+      dx[t] = ov[0];
+  }
+}
+
+int bn_nblk(int64_t M) { return (int)ceil_div(M > 0 ? M : 1, BN_ROWS); }
+
+}  // namespace
+
+extern "C" {
+
+int64_t wsis_bn_workspace_bytes(int64_t M, int32_t C) {
+  if (M < 0 || C < 1) return -1;
+  const int64_t Cp = (C + 3) / 4 * 4;
+  return (int64_t)bn_nblk(M) * 2 * Cp * (int64_t)sizeof(float) + 256;
+}
+
+int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* d_var, float* d_running_mean,
+                  float* d_running_var, float momentum, void* d_ws, int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(M >= 1 && C >= 1 && d_x && d_mean && d_var && d_ws, "bad args");
+  WSIS_REQUIRE(ws_bytes >= wsis_bn_workspace_bytes(M, C), "workspace too small");
+  WSIS_REQUIRE((d_running_mean == nullptr) == (d_running_var == nullptr), "running stats come in pairs");
+  const int nblk = bn_nblk(M);
+  float* partial = static_cast<float*>(d_ws);
+  hipStream_t st = as_stream(stream);
+  const int Cp = (C + 3) / 4 * 4;
+  WSIS_REQUIRE(Cp / 4 <= BN_THREADS, "C > 1024 is not supported");
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk), dim3(BN_THREADS), 0, st, d_x, M, C, Cp, partial);
+  WSIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, nblk, C, Cp, M, d_mean,
+                     d_var, d_running_mean, d_running_var, momentum);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_bn_apply(const float* d_x, const float* d_mean, const float* d_var, const float* d_gamma,
+                  const float* d_beta, float eps, int32_t relu, float* d_y, int64_t M, int32_t C, void* stream) {
+  WSIS_REQUIRE(M >= 0 && C >= 1, "bad sizes");
+  if (M == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_x && d_mean && d_var && d_y, "null pointer");
+  const int64_t work = (C & 3) == 0 ? (M * C) >> 2 : M * C;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(work, 256)), dim3(256), 0, as_stream(stream), d_x, d_mean, d_var,
+                     d_gamma, d_beta, eps, relu, d_y, M, C);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_bn_bwd(const float* d_x, const float* d_dy, const float* d_mean, const float* d_var,
+                const float* d_gamma, const float* d_beta, float eps, int32_t relu, int32_t training,
+                float* d_dx, float* d_dgamma, float* d_dbeta, int64_t M, int32_t C, void* d_ws, int64_t ws_bytes,
+                void* stream) {
+  WSIS_REQUIRE(M >= 1 && C >= 1 && d_x && d_dy && d_mean && d_var && d_dgamma && d_dbeta && d_ws, "bad args");
+  WSIS_REQUIRE(ws_bytes >= wsis_bn_workspace_bytes(M, C), "workspace too small");
+  const int nblk = bn_nblk(M);
+  float* partial = static_cast<float*>(d_ws);
+  hipStream_t st = as_stream(stream);
+  const int Cp = (C + 3) / 4 * 4;
+  WSIS_REQUIRE(Cp / 4 <= BN_THREADS, "C > 1024 is not supported");
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(BN_THREADS), 0, st, d_x, d_dy, d_mean, d_var, d_gamma,
+                     d_beta, eps, relu, M, C, Cp, partial);
+  WSIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, nblk, C, Cp, d_dgamma,
+                     d_dbeta);
+  WSIS_LAUNCH_CHECK();
+  if (d_dx) {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((C & 3) == 0 ? (M * C) >> 2 : M * C, 256)), dim3(256), 0, st, d_x, d_dy, d_mean, d_var,
+                       d_gamma, d_beta, d_dgamma, d_dbeta, eps, relu, training, d_dx, M, C);
+    WSIS_LAUNCH_CHECK();
+  }
+  return WSIS_OK;
+}
+
+}  // extern "C"

@@ -30,12 +30,23 @@ constexpr int KG = 32;        // kernel offsets handled per group (bit masks are
 // ------------------------------------------------------------------------------------------
 // forward / dIn kernel
 // ------------------------------------------------------------------------------------------
-template <int NB, bool VEC4>
+template <int NB, bool VEC4, bool DIAG = false>
 __global__ __launch_bounds__(256, (NB <= 1 ? 4 : (NB <= 3 ? 3 : 2))) void spconv_fwd_kernel(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ residual,
     float* __restrict__ out, float* __restrict__ partial, int64_t M_in, int64_t M_out, int K, int Cin, int Cout,
-    int k_per) {
+    int k_per, unsigned long long* __restrict__ dbg = nullptr) {
+  // DIAG build only: per-phase cycle sums of wave 0 (s_memtime), written to dbg[blockIdx.x*8 + phase]
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = 0;
+  auto stamp = [&](int ph) {
+    if (DIAG) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tph[ph] += now - tlast;
+      tlast = now;
+    }
+  };
+  if (DIAG) tlast = __builtin_amdgcn_s_memtime();
   __shared__ __attribute__((aligned(16))) float As[TM * A_STRIDE];
   __shared__ __attribute__((aligned(16))) float Bs[CK * NB * 32];
   __shared__ int32_t nbT[KG * TM];   // [offset in group][tile row] -> input row or -1
@@ -113,36 +124,42 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 4 : (NB <= 3 ? 3 : 2))) void spconv
       }
     }
     __syncthreads();
+    stamp(0);   // prologue: table slice
     const uint32_t my_mask = grpMask[wave];
     uint32_t tile_mask = grpMask[0] | grpMask[1] | grpMask[2] | grpMask[3];
     if (tile_mask == 0u) continue;
 
-    // ---- pipelined walk over (active offset, channel chunk) steps.
+    // ---- pipelined walk over (active offset, channel chunk) steps, register prefetch TWO steps ahead.
     // fetch(): branch-free -- every lane always issues its loads (row 0 / channel 0 when masked) so that the
     // gathers of a step are independent and in flight together; masking to zero happens when the registers are
-    // written to LDS one step later, which keeps the loads in flight under the MFMAs of the current step.
-    f32x4 ra[4];
-    f32x4 rb[NB];
-    uint32_t ok_bits = 0u;   // bit j: ra[j] valid, bit 8+j: rb[j] valid
-    auto fetch = [&](int kk, int ci0) {
+    // written to LDS, which keeps the loads in flight under the MFMAs of the two steps before.
+    struct Stage {
+      f32x4 ra[4];
+      f32x4 rb[NB];
+      uint32_t ok_bits;   // bit j: ra[j] valid, bit 8+j: rb[j] valid
+      int kk, cin_here;
+    };
+    auto fetch = [&](Stage& st, int kk, int ci0) {
       const int cin_here = min(CK, Cin - ci0);
-      ok_bits = 0u;
+      st.kk = kk;
+      st.cin_here = cin_here;
+      uint32_t okb = 0u;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int32_t g = nbT[kk * TM + a_row[j]];
         const bool ok = g >= 0 && a_c4[j] < cin_here;
         const float* src = X + (int64_t)(ok ? g : 0) * Cin + ci0 + (ok ? a_c4[j] : 0);
         if (VEC4) {
-          ra[j] = *reinterpret_cast<const f32x4*>(src);
+          st.ra[j] = *reinterpret_cast<const f32x4*>(src);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const bool oke = ok && a_c4[j] + e < cin_here;
             const float t = src[oke ? e : 0];
-            ra[j][e] = oke ? t : 0.0f;
+            st.ra[j][e] = oke ? t : 0.0f;
           }
         }
-        ok_bits |= (ok ? 1u : 0u) << j;
+        okb |= (ok ? 1u : 0u) << j;
       }
       const float* Wk = W + (int64_t)(kg0 + kk) * Cin * Cout + col0;
 #pragma unroll
@@ -151,48 +168,56 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 4 : (NB <= 3 ? 3 : 2))) void spconv
         const float* src = Wk + (int64_t)(ci0 + (okr ? b_kr[j] : 0)) * Cout;
         if (VEC4) {
           const bool okc = b_c4[j] + 3 < ncols;
-          rb[j] = *reinterpret_cast<const f32x4*>(src + (okc ? b_c4[j] : 0));
-          ok_bits |= ((okr && okc) ? 1u : 0u) << (8 + j);
+          st.rb[j] = *reinterpret_cast<const f32x4*>(src + (okc ? b_c4[j] : 0));
+          okb |= ((okr && okc) ? 1u : 0u) << (8 + j);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const bool okc = okr && b_c4[j] + e < ncols;
             const float t = src[okc ? b_c4[j] + e : 0];
-            rb[j][e] = okc ? t : 0.0f;
+            st.rb[j][e] = okc ? t : 0.0f;
           }
-          ok_bits |= 1u << (8 + j);
+          okb |= 1u << (8 + j);
+        }
+      }
+      st.ok_bits = okb;
+    };
+    // step iterator over (active offset, chunk)
+    int it_kk = __builtin_ctz(tile_mask);
+    uint32_t it_mask = tile_mask & (tile_mask - 1);
+    int it_ci = 0;
+    bool it_valid = true;
+    auto advance = [&]() {
+      it_ci += CK;
+      if (it_ci >= Cin) {
+        it_ci = 0;
+        if (it_mask) {
+          it_kk = __builtin_ctz(it_mask);
+          it_mask &= it_mask - 1;
+        } else {
+          it_valid = false;
         }
       }
     };
-
-    int kk = __builtin_ctz(tile_mask);
-    tile_mask &= tile_mask - 1;
-    int ci0 = 0;
-    fetch(kk, ci0);
-    for (;;) {
+    auto compute = [&](Stage& st, bool prefetch_more) {
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4*>(&As[a_row[j] * A_STRIDE + a_c4[j]]) = ((ok_bits >> j) & 1u) ? ra[j] : zero4;
+        *reinterpret_cast<f32x4*>(&As[a_row[j] * A_STRIDE + a_c4[j]]) = ((st.ok_bits >> j) & 1u) ? st.ra[j] : zero4;
 #pragma unroll
       for (int j = 0; j < NB; ++j)
-        *reinterpret_cast<f32x4*>(&Bs[b_kr[j] * (NB * 32) + b_c4[j]]) = ((ok_bits >> (8 + j)) & 1u) ? rb[j] : zero4;
+        *reinterpret_cast<f32x4*>(&Bs[b_kr[j] * (NB * 32) + b_c4[j]]) =
+            ((st.ok_bits >> (8 + j)) & 1u) ? st.rb[j] : zero4;
+      const int cur_kk = st.kk;
+      const int cin_here = st.cin_here;
+      stamp(1);   // wait for the stage's loads + LDS write
       __syncthreads();
-      // next step: issue its loads now, they land while the MFMAs below run
-      const int cur_kk = kk;
-      const int cin_here = min(CK, Cin - ci0);
-      int nkk = kk, nci = ci0 + CK;
-      bool more = true;
-      if (nci >= Cin) {
-        nci = 0;
-        if (tile_mask) {
-          nkk = __builtin_ctz(tile_mask);
-          tile_mask &= tile_mask - 1;
-        } else {
-          more = false;
-        }
+      stamp(2);   // barrier 1
+      if (prefetch_more) {   // refill this register stage with the step two ahead
+        fetch(st, it_kk, it_ci);
+        advance();
       }
-      if (more) fetch(nkk, nci);
+      stamp(3);   // issue prefetch
       if ((my_mask >> cur_kk) & 1u) {
         // MFMA k index (step s, half h) <-> staged channel h*16 + s, so a lane reads 16 contiguous
         // floats of its A row with four ds_read_b128.
@@ -219,13 +244,37 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 4 : (NB <= 3 ? 3 : 2))) void spconv
           }
         }
       }
-      if (!more) break;
+      stamp(4);   // fragment reads + MFMA issue
       __syncthreads();
-      kk = nkk;
-      ci0 = nci;
+      stamp(5);   // barrier 2
+      if (DIAG) tph[7] += 1;
+    };
+
+    Stage s0, s1;
+    bool have1 = false;
+    fetch(s0, it_kk, it_ci);
+    advance();
+    if (it_valid) {
+      fetch(s1, it_kk, it_ci);
+      advance();
+      have1 = true;
+    }
+    for (;;) {
+      bool pf = it_valid;
+      compute(s0, pf);
+      const bool have0 = pf;
+      if (!have1) break;
+      pf = it_valid;
+      compute(s1, pf);
+      have1 = pf;
+      if (!have0) break;
     }
   }
 
+  if (DIAG && dbg && tid == 0) {
+    stamp(6);
+    for (int i = 0; i < 8; ++i) dbg[(int64_t)blockIdx.x * 8 + i] = tph[i];
+  }
   // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*half
   float* dst = (gridDim.z > 1) ? partial + (int64_t)blockIdx.z * M_out * Cout : out;
   const bool final_pass = gridDim.z == 1;
@@ -339,7 +388,7 @@ __global__ __launch_bounds__(256) void spconv_dw_kernel(
 #pragma unroll
   for (int cb = 0; cb < NBO; ++cb) cob_ok[cb] = (co0 + cb * 32 + l31) < Cout;
 
-  constexpr int U = 4;
+  constexpr int U = (NBO <= 2) ? 8 : 4;   // row pairs in flight per wave
   for (int64_t tb = w_begin; tb < w_end; tb += 64) {
     const int64_t t = tb + lane;
     int32_t yr = 0, nb = -1;
@@ -433,9 +482,10 @@ __global__ void dw_reduce_kernel(const float* __restrict__ partial, float* __res
 }
 
 int dw_rows_per_chunk(int64_t M_out) {
-  int64_t rpc = ceil_div(M_out, 64);
-  if (rpc < 512) rpc = 512;
-  rpc = (rpc + 7) & ~(int64_t)7;
+  // ~256 row chunks at the large levels: short waves (the loop is latency bound), still only a few MB of slabs
+  int64_t rpc = ceil_div(M_out, 256);
+  if (rpc < 256) rpc = 256;
+  rpc = (rpc + 63) & ~(int64_t)63;
   return (int)rpc;
 }
 
@@ -508,6 +558,30 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
                        d_residual, d_out, M_out, Cout, kz);
     WSIS_LAUNCH_CHECK();
   }
+  return WSIS_OK;
+}
+
+// diagnostic (not part of the ABI header): NB=1 VEC4 kernel with phase stamps, dbg[tiles*8]
+int wsis_debug_spconv_diag(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_W,
+                           float* d_out, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout,
+                           unsigned long long* d_dbg, void* stream) {
+  WSIS_REQUIRE(Cout <= 32 && Cin % 4 == 0, "diag supports Cout<=32, Cin%4==0");
+  {
+    int nb1 = -1, nb2 = -1, nb3 = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, (const void*)spconv_fwd_kernel<1, true, false>, 256, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, (const void*)spconv_fwd_kernel<2, true, false>, 256, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, (const void*)spconv_fwd_kernel<5, true, false>, 256, 0);
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    fprintf(stderr, "[diag] occupancy API blocks/CU: NB1=%d NB2=%d NB5=%d; sharedMemPerMultiprocessor=%zu maxSharedPerBlock=%zu CUs=%d\n",
+            nb1, nb2, nb3, (size_t)prop.maxSharedMemoryPerMultiProcessor, (size_t)prop.sharedMemPerBlock,
+            prop.multiProcessorCount);
+  }
+  const dim3 grid((unsigned)ceil_div(M_out, TM), 1, 1);
+  hipLaunchKernelGGL((spconv_fwd_kernel<1, true, true>), grid, dim3(256), 0, as_stream(stream), d_X, d_nbr, d_order,
+                     d_W, (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, M_out, K, Cin,
+                     Cout, K, d_dbg);
+  WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }
 

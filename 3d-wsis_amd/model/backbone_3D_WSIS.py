@@ -25,6 +25,18 @@ from torch_scatter import SegmentCSR, scatter
 __all__ = ["Network"]
 
 
+class _Head(nn.Sequential):
+    """Linear -> BatchNorm1d -> ReLU -> Linear with the reference's child names (0,1,2,3); BN+ReLU run fused."""
+
+    def forward(self, x):
+        import os
+        if not x.is_cuda or os.environ.get("WSIS_FUSE_BN", "1") == "0":
+            return super().forward(x)
+        x = self[0](x)
+        x = wsis_ops.batch_norm_relu(x, self[1], relu=True)
+        return self[3](x)
+
+
 class Network(nn.Module):
     def __init__(self, param):
         super().__init__()
@@ -49,8 +61,8 @@ class Network(nn.Module):
         self.output_layer = spconv.SparseSequential(norm_fn(self.media), nn.ReLU(inplace=True))
 
         def head(cin, cout):
-            return nn.Sequential(nn.Linear(cin, cin, bias=True), norm_fn(cin), nn.ReLU(inplace=True),
-                                 nn.Linear(cin, cout))
+            return _Head(nn.Linear(cin, cin, bias=True), norm_fn(cin), nn.ReLU(inplace=True),
+                         nn.Linear(cin, cout))
 
         self.linear = head(self.media, self.classes)                       # point semantic
         self.ecc = graphnet.GraphNetwork("gru_7_0,f_64,b,r", nfeat=self.media, fnet_widths=[13, 32, 128, 64],

@@ -39,6 +39,11 @@ class GraphConvInfo(object):
             self._csr = SegmentCSR(self._edge_indexes[0], self.num_nodes)
         return self._csr
 
+    def csr_dst(self):
+        if getattr(self, "_csr_dst", None) is None:
+            self._csr_dst = SegmentCSR(self._edge_indexes[1], self.num_nodes)
+        return self._csr_dst
+
 
 def create_fnet(widths, orthoinit, llbias, bnidx=-1):
     """filter-generating MLP (graphnet.py:19-36)"""
@@ -119,14 +124,20 @@ class RNNGraphConvModule(nn.Module):
         if weights.size(1) != nc:
             weights = weights.view(-1, nc, nc)
         csr = self._gci.csr()
+        fused = weights.dim() == 3 and nc <= 32 and hx.is_cuda
+        if fused:
+            import wsis_ops
+            src_c, dst_c = src.contiguous(), dst.contiguous()
+            csr_dst = self._gci.csr_dst()
         hxs = [hx]
         for _ in range(self._nrepeats):
-            x_j = hx[dst]
-            if weights.dim() == 3:
-                msg = torch.bmm(x_j.unsqueeze(1), weights).squeeze(1)
+            if fused:
+                # gather + per-edge mat-vec + mean over the out-edges in ONE kernel (and one for the backward)
+                inp = wsis_ops.ecc_message(hx, weights, src_c, dst_c, csr, csr_dst)
             else:
-                msg = x_j * weights
-            inp = scatter(msg, src, dim=0, dim_size=hx.size(0), reduce="mean", csr=csr)
+                x_j = hx[dst]
+                msg = torch.bmm(x_j.unsqueeze(1), weights).squeeze(1) if weights.dim() == 3 else x_j * weights
+                inp = scatter(msg, src, dim=0, dim_size=hx.size(0), reduce="mean", csr=csr)
             hx = self._cell(inp, hx)
             hxs.append(hx)
         return torch.cat(hxs, 1) if self._cat_all else hx

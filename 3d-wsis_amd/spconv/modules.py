@@ -16,6 +16,11 @@ from torch import nn
 from .tensor import SparseConvTensor
 
 
+def _fuse_bn_relu():
+    import os
+    return os.environ.get("WSIS_FUSE_BN", "1") != "0"
+
+
 class SparseModule(nn.Module):
     """place holder: every module subclassing this takes a SparseConvTensor"""
     pass
@@ -65,13 +70,25 @@ class SparseSequential(SparseModule):
         self.add_module(name, module)
 
     def forward(self, input):
-        for k, module in self._modules.items():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
             if is_spconv_module(module):
                 input = module(input)
-            else:
-                if isinstance(input, SparseConvTensor):
-                    if input.indices.shape[0] != 0:
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    # peephole: BatchNorm1d followed by ReLU runs as ONE fused HIP operator (same module
+                    # objects, parameters and state-dict; only the execution is fused)
+                    nxt = mods[i + 1] if i + 1 < len(mods) else None
+                    if (isinstance(module, nn.BatchNorm1d) and type(nxt) is nn.ReLU and input.features.is_cuda
+                            and _fuse_bn_relu()):
+                        import wsis_ops
+                        input.features = wsis_ops.batch_norm_relu(input.features, module, relu=True)
+                        i += 1
+                    else:
                         input.features = module(input.features)
-                else:
-                    input = module(input)
+            else:
+                input = module(input)
+            i += 1
         return input

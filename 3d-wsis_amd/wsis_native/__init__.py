@@ -70,6 +70,10 @@ _HIP_SIGS = {
     "wsis_spconv_dw_workspace_bytes": (I64, [I64, I32, I32, I32]),
     "wsis_spconv_dw": (I32, [P, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
     "wsis_rulebook_pack": (I32, [P, P, P, I64, I32, P]),
+    "wsis_bn_workspace_bytes": (I64, [I64, I32]),
+    "wsis_bn_stats": (I32, [P, I64, I32, P, P, P, P, F32, P, I64, P]),
+    "wsis_bn_apply": (I32, [P, P, P, P, P, F32, I32, P, I64, I32, P]),
+    "wsis_bn_bwd": (I32, [P, P, P, P, P, P, F32, I32, I32, P, P, P, I64, I32, P, I64, P]),
     "wsis_segment_csr_workspace_bytes": (I64, [I64, I64]),
     "wsis_segment_csr": (I32, [P, I64, I64, P, P, P, I64, P]),
     "wsis_segment_reduce_fwd": (I32, [P, P, P, P, P, I64, I64, I32, I32, P]),
@@ -77,6 +81,8 @@ _HIP_SIGS = {
     "wsis_gather_rows": (I32, [P, P, I32, P, I64, I32, P]),
     "wsis_edge_affinity_fwd": (I32, [P, P, P, P, P, P, P, P, F32, P, P, I64, I64, I32, P]),
     "wsis_edge_affinity_bwd": (I32, [P] * 11 + [F32] + [P] * 7 + [I64, I64, I64, I32, P]),
+    "wsis_ecc_message_fwd": (I32, [P, P, P, P, P, P, I64, I64, I32, P]),
+    "wsis_ecc_message_bwd": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I32, P]),
     "wsis_affinity_dense_build": (I32, [P, P, P, I64, P, I64, P]),
     "wsis_affinity_transition": (I32, [P, P, P, P, P, I32, F32, P, I64, P]),
     "wsis_dgemm": (I32, [P, P, P, I64, I64, I64, P]),

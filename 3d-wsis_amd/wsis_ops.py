@@ -147,3 +147,110 @@ def weak_label_propagation(A, adjacency, sp_semantic_value, superpoint_pred_sema
     unknown = (pseudo_label_scores != 0) & (label_np == -100)
     final[unknown] = pseudo_label[unknown]
     return final, pseudo_label_scores
+
+
+# ---- a12: fused BatchNorm1d(+ReLU) -------------------------------------------------------------------------
+
+class _BatchNormReLU(Function):
+    """y = relu?(batch_norm(x)) with torch.nn.BatchNorm1d semantics (training: batch statistics + running-stat
+    update; eval: running statistics).  sparse_unet3d.py:128-137 runs these as separate torch modules."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, relu):
+        _n.require_cuda(x)
+        x = x.contiguous().float()
+        M, C = x.shape
+        lib = _n.hip()
+        st = _n.stream_ptr()
+        dev = x.device
+        use_batch_stats = training or running_mean is None
+        ws = None
+        if use_batch_stats:
+            assert M >= 1
+            ws_bytes = lib.wsis_bn_workspace_bytes(M, C)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            var = torch.empty(C, dtype=torch.float32, device=dev)
+            upd = training and running_mean is not None
+            _n.check(lib.wsis_bn_stats(_n.ptr(x), M, C, _n.ptr(mean), _n.ptr(var),
+                                       _n.ptr(running_mean) if upd else None,
+                                       _n.ptr(running_var) if upd else None, float(momentum), _n.ptr(ws),
+                                       ws_bytes, st), "bn_stats")
+        else:
+            mean, var = running_mean, running_var
+        y = torch.empty_like(x)
+        _n.check(lib.wsis_bn_apply(_n.ptr(x), _n.ptr(mean), _n.ptr(var), _n.ptr(weight), _n.ptr(bias), float(eps),
+                                   int(relu), _n.ptr(y), M, C, st), "bn_apply")
+        ctx.save_for_backward(x, mean, var, weight, bias)
+        ctx.cfg = (float(eps), int(relu), int(use_batch_stats))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, var, weight, bias = ctx.saved_tensors
+        eps, relu, batch_stats = ctx.cfg
+        dy = dy.contiguous().float()
+        M, C = x.shape
+        lib = _n.hip()
+        dev = x.device
+        ws_bytes = lib.wsis_bn_workspace_bytes(M, C)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        _n.check(lib.wsis_bn_bwd(_n.ptr(x), _n.ptr(dy), _n.ptr(mean), _n.ptr(var), _n.ptr(weight), _n.ptr(bias), eps,
+                                 relu, batch_stats, _n.ptr(dx), _n.ptr(dgamma), _n.ptr(dbeta), M, C, _n.ptr(ws),
+                                 ws_bytes, _n.stream_ptr()), "bn_bwd")
+        gw = dgamma if (weight is not None and ctx.needs_input_grad[1]) else None
+        gb = dbeta if (bias is not None and ctx.needs_input_grad[2]) else None
+        return dx, gw, gb, None, None, None, None, None, None
+
+
+def batch_norm_relu(x, bn, relu=True):
+    """fused forward of an nn.BatchNorm1d module (its parameters/buffers) optionally followed by ReLU"""
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                                bn.running_var if bn.track_running_stats else None, bn.training, momentum, bn.eps,
+                                relu)
+
+
+# ---- a21: edge-conditioned message passing (ECC GNN) ----------------------------------------------------------
+
+class _EccMessage(Function):
+    """inp[s] = mean over edges (s -> t) of x[t] @ W_(s->t)   (spg_modules.py:97-121, aggr='mean')"""
+
+    @staticmethod
+    def forward(ctx, x, weights, src, dst, csr_src, csr_dst):
+        _n.require_cuda(x, weights)
+        x = x.contiguous().float()
+        w = weights.contiguous().float()
+        S, C = x.shape
+        E = src.numel()
+        assert w.shape == (E, C, C) and csr_src.S == S and csr_dst.S == S
+        out = torch.empty((S, C), dtype=torch.float32, device=x.device)
+        _n.check(_n.hip().wsis_ecc_message_fwd(_n.ptr(x), _n.ptr(w), _n.ptr(dst), _n.ptr(csr_src.perm),
+                                               _n.ptr(csr_src.offsets), _n.ptr(out), S, E, C, _n.stream_ptr()),
+                 "ecc_message_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.graph = (src, dst, csr_src, csr_dst)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        src, dst, csr_src, csr_dst = ctx.graph
+        S, C = x.shape
+        E = src.numel()
+        dout = dout.contiguous().float()
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        _n.check(_n.hip().wsis_ecc_message_bwd(_n.ptr(x), _n.ptr(w), _n.ptr(dout), _n.ptr(src), _n.ptr(csr_dst.perm),
+                                               _n.ptr(csr_dst.offsets), _n.ptr(csr_src.offsets), _n.ptr(dx),
+                                               _n.ptr(dw), S, E, C, _n.stream_ptr()), "ecc_message_bwd")
+        return dx, dw, None, None, None, None
+
+
+def ecc_message(x, weights, src, dst, csr_src, csr_dst):
+    return _EccMessage.apply(x, weights, src, dst, csr_src, csr_dst)

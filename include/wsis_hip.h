@@ -171,6 +171,23 @@ int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_orde
                    float* d_dW, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws,
                    int64_t ws_bytes, void* stream);
 
+/* ---- a12: BatchNorm1d(+ReLU) over the active voxels  sparse_unet3d.py:128-137, backbone_3D_WSIS.py:47,52-55 ---
+ * Training statistics with a fixed reduction tree (deterministic).  d_ws from wsis_bn_workspace_bytes.
+ * wsis_bn_stats: d_mean/d_var [C] (biased var); running stats (optional pair) updated with `momentum` and the
+ * unbiased variance, as torch.nn.BatchNorm1d does. */
+int64_t wsis_bn_workspace_bytes(int64_t M, int32_t C);
+int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* d_var, float* d_running_mean,
+                  float* d_running_var, float momentum, void* d_ws, int64_t ws_bytes, void* stream);
+/* y = relu?( (x-mean)*rsqrt(var+eps)*gamma + beta )   (gamma/beta may be NULL = 1/0) */
+int wsis_bn_apply(const float* d_x, const float* d_mean, const float* d_var, const float* d_gamma,
+                  const float* d_beta, float eps, int32_t relu, float* d_y, int64_t M, int32_t C, void* stream);
+/* backward of the fused BN(+ReLU): dgamma = sum dz*xhat, dbeta = sum dz (dz = dy masked by the ReLU),
+ * dx = gamma*rstd*(dz - dbeta/M - xhat*dgamma/M) when training, gamma*rstd*dz otherwise; d_dx may be NULL. */
+int wsis_bn_bwd(const float* d_x, const float* d_dy, const float* d_mean, const float* d_var,
+                const float* d_gamma, const float* d_beta, float eps, int32_t relu, int32_t training,
+                float* d_dx, float* d_dgamma, float* d_dbeta, int64_t M, int32_t C, void* d_ws, int64_t ws_bytes,
+                void* stream);
+
 /* ---- a14/a15: row gather and torch_scatter.scatter  backbone_3D_WSIS.py:179,188,225,232,244 --
  * CSR of a (possibly unsorted) index vector: d_perm int32 [N] = stable argsort(index),
  * d_offsets int32 [S+1].  d_index is int64 [N] (torch_scatter takes LongTensor). */
@@ -208,6 +225,17 @@ int wsis_edge_affinity_bwd(const float* d_q, const float* d_k, const float* d_v,
                            const int32_t* d_off_v, float scale, const float* d_daff,
                            const float* d_dres, float* d_dq, float* d_dk, float* d_dv, float* d_dpos,
                            float* d_tmp, int64_t E, int64_t S, int64_t Su, int32_t D, void* stream);
+
+/* ---- a21: edge-conditioned message passing of the superpoint GNN --------------------------
+ * modules/model/spg_modules.py:97-121,168-183 (PyG NNConv, flow=target_to_source, aggr='mean', vv=False):
+ *   out[s,:] = mean_{e: src_e = s} x[dst_e,:] @ W_e,  W_e = d_w[e] in R^{C x C}, C <= 32.
+ * CSR over the sources (forward) and over the targets (backward) from wsis_segment_csr.  Backward writes
+ * dx [S,C] and the per-edge filter gradient dw [E,C,C] (every entry written). */
+int wsis_ecc_message_fwd(const float* d_x, const float* d_w, const int64_t* d_dst, const int32_t* d_perm_src,
+                         const int32_t* d_off_src, float* d_out, int64_t S, int64_t E, int32_t C, void* stream);
+int wsis_ecc_message_bwd(const float* d_x, const float* d_w, const float* d_dout, const int64_t* d_src,
+                         const int32_t* d_perm_dst, const int32_t* d_off_dst, const int32_t* d_off_src,
+                         float* d_dx, float* d_dw, int64_t S, int64_t E, int32_t C, void* stream);
 
 /* ---- a17: dense inter-superpoint affinity + label propagation -------------------------------
  * train_scannetv2.py:562-570, modules/datasets/scannetv2_dataset.py:664-721 (fp64, host numpy).

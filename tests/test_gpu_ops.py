@@ -331,3 +331,63 @@ def test_ballquery_cap_1000():
                                                torch.from_numpy(off).to(DEV), 0.01, 50)
     assert (sl[:, 1] == 1000).all() and idx.numel() == 1000 * N
     assert idx[:1000].cpu().tolist() == list(range(1000))
+
+
+# ---------------------------------------------------------------- fused BatchNorm1d(+ReLU) (a12)
+@pytest.mark.parametrize("M,C", [(5000, 32), (1300, 96), (1, 32), (777, 20), (4097, 160)])
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("training", [True, False])
+def test_fused_batchnorm_relu(M, C, relu, training):
+    if M == 1 and training:
+        pytest.skip("torch refuses a single value per channel in training mode")
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g) * 2 + 0.5
+    bn = torch.nn.BatchNorm1d(C, eps=1e-4, momentum=0.1)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    import copy
+    ref = copy.deepcopy(bn).double()
+    bn = bn.to(DEV)
+    bn.train(training)
+    ref.train(training)
+    xg = x.clone().to(DEV).requires_grad_(True)
+    y = wsis_ops.batch_norm_relu(xg, bn, relu=relu)
+    xr = x.clone().double().requires_grad_(True)
+    yr = ref(xr)
+    if relu:
+        yr = torch.relu(yr)
+    assert close(y, yr)
+    go = torch.randn(M, C, generator=g)
+    y.backward(go.to(DEV))
+    yr.backward(go.double())
+    assert close(xg.grad, xr.grad, rtol=1e-3, atol=1e-4)
+    assert close(bn.weight.grad, ref.weight.grad, rtol=1e-3, atol=1e-4) and close(bn.bias.grad, ref.bias.grad, rtol=1e-3, atol=1e-4)
+    assert close(bn.running_mean, ref.running_mean) and close(bn.running_var, ref.running_var)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+# ---------------------------------------------------------------- ECC message passing (a21)
+@pytest.mark.parametrize("S,deg", [(50, 4), (400, 9)])
+def test_ecc_message_fwd_bwd(S, deg):
+    from torch_scatter import SegmentCSR
+    eu, ev = _graph(S + 1, S, deg)
+    order = np.argsort(ev, kind="stable")          # GraphConvInfo order: sorted by target
+    src, dst = torch.from_numpy(eu[order]), torch.from_numpy(ev[order])
+    E, C = len(eu), 32
+    g = torch.Generator().manual_seed(S)
+    x = torch.randn(S, C, generator=g)
+    w = torch.randn(E, C, C, generator=g) * 0.2
+    xg, wg = x.clone().to(DEV).requires_grad_(True), w.clone().to(DEV).requires_grad_(True)
+    csr_s, csr_d = SegmentCSR(src.to(DEV), S), SegmentCSR(dst.to(DEV), S)
+    out = wsis_ops.ecc_message(xg, wg, src.to(DEV), dst.to(DEV), csr_s, csr_d)
+    xr, wr = x.clone().double().requires_grad_(True), w.clone().double().requires_grad_(True)
+    msg = torch.matmul(xr[dst].unsqueeze(1), wr).squeeze(1)
+    ref_out = scatter_ref.scatter(msg, src, 0, S, "mean")
+    assert close(out, ref_out)
+    go = torch.randn(S, C, generator=g)
+    out.backward(go.to(DEV))
+    ref_out.backward(go.double())
+    assert close(xg.grad, xr.grad, rtol=1e-3, atol=1e-4) and close(wg.grad, wr.grad, rtol=1e-3, atol=1e-4)
