@@ -11,7 +11,7 @@ using namespace wsis;
 
 namespace {
 
-constexpr int BN_ROWS = 512;   // rows reduced by one workgroup
+constexpr int BN_ROWS = 256;   // rows reduced by one workgroup
 constexpr int BN_THREADS = 256;
 
 struct f4 {
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_partial_kernel(const floa
     float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
     if (g < G && rl < R) {
       const int c = g * 4;
+#pragma unroll 4
       for (int64_t r = r0 + rl; r < r1; r += R) {
         float v[4];
         if (vec) {
@@ -89,30 +90,26 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_partial_kernel(const floa
   }
 }
 
-// pass 2: combine the partials in a fixed order in fp64, write mean / biased var, update running stats.
-// 256 threads = 64 channels x 4 partial lanes.
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ partial, int nblk, int C,
-                                                             int Cp, int64_t M, float* __restrict__ mean,
-                                                             float* __restrict__ var,
-                                                             float* __restrict__ running_mean,
-                                                             float* __restrict__ running_var, float momentum) {
-  __shared__ double s_s[256];
-  __shared__ double s_q[256];
-  const int cl = threadIdx.x & 63;
-  const int pl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+// pass 2: one wavefront per channel: lanes stride over the partials (fp64), fixed butterfly => deterministic.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(64) void bn_stats_final_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                            int Cp, int64_t M, float* __restrict__ mean,
+                                                            float* __restrict__ var,
+                                                            float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var, float momentum) {
+  const int c = blockIdx.x;
   double s = 0.0, q = 0.0;
-  if (c < C)
-    for (int b = pl; b < nblk; b += 4) {
-      s += partial[(int64_t)b * 2 * Cp + c];
-      q += partial[(int64_t)b * 2 * Cp + Cp + c];
-    }
-  s_s[threadIdx.x] = s;
-  s_q[threadIdx.x] = q;
-  __syncthreads();
-  if (pl == 0 && c < C) {
-    const double S = ((s_s[cl] + s_s[64 + cl]) + s_s[128 + cl]) + s_s[192 + cl];
-    const double Q = ((s_q[cl] + s_q[64 + cl]) + s_q[128 + cl]) + s_q[192 + cl];
+  for (int b = threadIdx.x; b < nblk; b += 64) {
+    s += partial[(int64_t)b * 2 * Cp + c];
+    q += partial[(int64_t)b * 2 * Cp + Cp + c];
+  }
+  const double S = wave_sum_f64(s), Q = wave_sum_f64(q);
+  if (threadIdx.x == 0) {
     const double n = (double)M;
     const double mu = S / n;
     double v = Q / n - mu * mu;
@@ -206,6 +203,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(
         gm[e] = gamma ? gamma[cc] : 1.0f;
         bt[e] = beta ? beta[cc] : 0.0f;
       }
+#pragma unroll 4
       for (int64_t r = r0 + rl; r < r1; r += R) {
         float xv[4], dv[4];
         if (vec) {
@@ -258,25 +256,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk, int C, int Cp,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double s_s[256];
-  __shared__ double s_q[256];
-  const int cl = threadIdx.x & 63;
-  const int pl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+__global__ __launch_bounds__(64) void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk, int C, int Cp,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x;
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int k = pl; k < nblk; k += 4) {
-      a += partial[(int64_t)k * 2 * Cp + c];
-      b += partial[(int64_t)k * 2 * Cp + Cp + c];
-    }
-  s_s[threadIdx.x] = a;
-  s_q[threadIdx.x] = b;
-  __syncthreads();
-  if (pl == 0 && c < C) {
-    dbeta[c] = (float)(((s_s[cl] + s_s[64 + cl]) + s_s[128 + cl]) + s_s[192 + cl]);
-    dgamma[c] = (float)(((s_q[cl] + s_q[64 + cl]) + s_q[128 + cl]) + s_q[192 + cl]);
+  for (int k = threadIdx.x; k < nblk; k += 64) {
+    a += partial[(int64_t)k * 2 * Cp + c];
+    b += partial[(int64_t)k * 2 * Cp + Cp + c];
+  }
+  const double A = wave_sum_f64(a), B = wave_sum_f64(b);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)A;
+    dgamma[c] = (float)B;
   }
 }
 
@@ -352,7 +343,7 @@ int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* 
   WSIS_REQUIRE(Cp / 4 <= BN_THREADS, "C > 1024 is not supported");
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk), dim3(BN_THREADS), 0, st, d_x, M, C, Cp, partial);
   WSIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, nblk, C, Cp, M, d_mean,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, st, partial, nblk, C, Cp, M, d_mean,
                      d_var, d_running_mean, d_running_var, momentum);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
@@ -384,7 +375,7 @@ int wsis_bn_bwd(const float* d_x, const float* d_dy, const float* d_mean, const 
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(BN_THREADS), 0, st, d_x, d_dy, d_mean, d_var, d_gamma,
                      d_beta, eps, relu, M, C, Cp, partial);
   WSIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(256), 0, st, partial, nblk, C, Cp, d_dgamma,
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, st, partial, nblk, C, Cp, d_dgamma,
                      d_dbeta);
   WSIS_LAUNCH_CHECK();
   if (d_dx) {

@@ -568,11 +568,11 @@ int wsis_debug_spconv_diag(const float* d_X, const int32_t* d_nbr, const int32_t
   WSIS_REQUIRE(Cout <= 32 && Cin % 4 == 0, "diag supports Cout<=32, Cin%4==0");
   {
     int nb1 = -1, nb2 = -1, nb3 = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, (const void*)spconv_fwd_kernel<1, true, false>, 256, 0);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, (const void*)spconv_fwd_kernel<2, true, false>, 256, 0);
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, (const void*)spconv_fwd_kernel<5, true, false>, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, (const void*)spconv_fwd_kernel<1, true, false>, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, (const void*)spconv_fwd_kernel<2, true, false>, 256, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, (const void*)spconv_fwd_kernel<5, true, false>, 256, 0);
     hipDeviceProp_t prop;
-    hipGetDeviceProperties(&prop, 0);
+    (void)hipGetDeviceProperties(&prop, 0);
     fprintf(stderr, "[diag] occupancy API blocks/CU: NB1=%d NB2=%d NB5=%d; sharedMemPerMultiprocessor=%zu maxSharedPerBlock=%zu CUs=%d\n",
             nb1, nb2, nb3, (size_t)prop.maxSharedMemoryPerMultiProcessor, (size_t)prop.sharedMemPerBlock,
             prop.multiProcessorCount);

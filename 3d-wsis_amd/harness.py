@@ -250,9 +250,10 @@ def train_step(model, criterion, optimizer, batch, cfg, epoch=5, grad_sync=None)
     loss.backward()
     if grad_sync is not None:
         grad_sync(model)
-    for p in model.ecc.parameters():
-        if p.grad is not None:
-            p.grad.data.clamp_(-1, 1)
+    grads = [p.grad for p in model.ecc.parameters() if p.grad is not None]
+    if grads:   # train_scannetv2.py:247-249 as two multi-tensor launches instead of one per parameter
+        torch._foreach_clamp_min_(grads, -1.0)
+        torch._foreach_clamp_max_(grads, 1.0)
     optimizer.step()
     return loss.detach(), ret
 

@@ -30,7 +30,7 @@ class _Head(nn.Sequential):
 
     def forward(self, x):
         import os
-        if not x.is_cuda or os.environ.get("WSIS_FUSE_BN", "1") == "0":
+        if not x.is_cuda or os.environ.get("WSIS_FUSE_BN", "0") == "0":
             return super().forward(x)
         x = self[0](x)
         x = wsis_ops.batch_norm_relu(x, self[1], relu=True)
@@ -108,6 +108,10 @@ class Network(nn.Module):
         for name in self.fix_module:
             getattr(self, name).eval()
 
+        import os
+        if input.features.is_cuda and os.environ.get("WSIS_PREBUILD", "1") != "0":
+            # all 5 + 4 rulebooks up front: their host syncs happen before the first conv is queued
+            spconv.ops.prebuild_unet_rulebooks(input, self.blocks)
         output = self.input_conv(input)
         output = self.unet(output)
         output = self.output_layer(output)

@@ -255,6 +255,20 @@ class KernelProfiler(object):
 PROFILER = None
 
 
+_WS_CACHE = {}
+
+
+def _fwd_ws_bytes(lib, M_out, K, Cin, Cout):
+    key = (M_out, K, Cin, Cout)
+    v = _WS_CACHE.get(key)
+    if v is None:
+        v = lib.wsis_spconv_fwd_workspace_bytes(M_out, K, Cin, Cout)
+        if len(_WS_CACHE) > 4096:
+            _WS_CACHE.clear()
+        _WS_CACHE[key] = v
+    return v
+
+
 def _conv(X, nbr, order, W, bias, residual, M_out):
     """out[r] = sum_k X[nbr[k][r]] @ W[k]  (W [K,Cin,Cout] contiguous)."""
     K, Cin, Cout = W.shape
@@ -264,7 +278,7 @@ def _conv(X, nbr, order, W, bias, residual, M_out):
         P = prof.pairs(nbr, M_out)
         t0 = prof.begin()
     lib = _n.hip()
-    ws_bytes = lib.wsis_spconv_fwd_workspace_bytes(M_out, K, Cin, Cout)
+    ws_bytes = _fwd_ws_bytes(lib, M_out, K, Cin, Cout)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device) if ws_bytes > 256 else None
     _n.check(lib.wsis_spconv_fwd(_n.ptr(X), _n.ptr(nbr), _n.ptr(order), _n.ptr(W), _n.ptr(bias),
                                  _n.ptr(residual), _n.ptr(out), X.shape[0], M_out, K, Cin, Cout, _n.ptr(ws),
@@ -309,9 +323,12 @@ class SparseConvFunction(Function):
     @staticmethod
     def forward(ctx, features, weight, bias, nbr_f, order_f, nbr_b, order_b, flip, M_out):
         _n.require_cuda(features, weight)
-        X = features.contiguous().float()
+        X = features if (features.dtype == torch.float32 and features.is_contiguous()) else features.contiguous().float()
         Cin, Cout = weight.shape[-2], weight.shape[-1]
-        W = weight.contiguous().float().view(-1, Cin, Cout)
+        W = weight.detach()
+        if W.dtype != torch.float32 or not W.is_contiguous():
+            W = W.contiguous().float()
+        W = W.view(-1, Cin, Cout)
         b = bias.contiguous().float() if bias is not None else None
         out = _conv(X, nbr_f, order_f, W, b, None, M_out)
         ctx.save_for_backward(X, W)
@@ -322,7 +339,7 @@ class SparseConvFunction(Function):
     def backward(ctx, grad_out):
         X, W = ctx.saved_tensors
         nbr_f, order_f, nbr_b, order_b, flip, wshape, has_bias = ctx.aux
-        dY = grad_out.contiguous().float()
+        dY = grad_out if (grad_out.dtype == torch.float32 and grad_out.is_contiguous()) else grad_out.contiguous().float()
         K, Cin, Cout = W.shape
         dX = dW = db = None
         if ctx.needs_input_grad[0]:
@@ -337,3 +354,28 @@ class SparseConvFunction(Function):
 
 def sparse_conv(features, weight, bias, nbr_f, order_f, nbr_b, order_b, flip, M_out):
     return SparseConvFunction.apply(features, weight, bias, nbr_f, order_f, nbr_b, order_b, flip, M_out)
+
+
+def prebuild_unet_rulebooks(tensor, n_levels, subm_key="subm{}", down_key="spconv{}", first_id=1):
+    """Builds every rulebook of a UBlock pyramid (SubM k3 p1 per level, k2 s2 between levels) up front and
+    stores them in ``tensor.indice_dict`` under the keys the modules will look up.  The rulebook chain only
+    depends on the coordinates, so the per-level host syncs (output row counts) happen before the first
+    convolution is queued and the rest of the forward/backward can be issued without stalling the host."""
+    indices, shape = tensor.indices, [int(s) for s in tensor.spatial_shape]
+    hash_tab = tensor._hash
+    for lvl in range(n_levels):
+        kid = first_id + lvl
+        key = subm_key.format(kid)
+        if key not in tensor.indice_dict:
+            if hash_tab is None:
+                hash_tab = build_hash(indices, shape)
+                if lvl == 0:
+                    tensor._hash = hash_tab
+            tensor.indice_dict[key] = build_subm_rulebook(indices, shape, [3, 3, 3], [1, 1, 1], hash_tab)
+        if lvl + 1 < n_levels:
+            dkey = down_key.format(kid)
+            rb = tensor.indice_dict.get(dkey)
+            if rb is None:
+                rb = build_down_rulebook(indices, shape, [2, 2, 2], [2, 2, 2], [0, 0, 0])
+                tensor.indice_dict[dkey] = rb
+            indices, shape, hash_tab = rb.out_indices, rb.out_shape, rb.out_hash

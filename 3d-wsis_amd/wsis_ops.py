@@ -206,10 +206,35 @@ class _BatchNormReLU(Function):
         return dx, gw, gb, None, None, None, None, None, None
 
 
+def _flush_batch_count(bn, *args):
+    n = getattr(bn, "_wsis_pending_batches", 0)
+    if n:
+        bn.num_batches_tracked += n
+        bn._wsis_pending_batches = 0
+
+
+def _defer_batch_count(bn):
+    """num_batches_tracked only feeds momentum=None; with a fixed momentum it is bookkeeping, so the +1 is
+    accumulated on the host and written back when the module's state is read (state_dict) or on demand."""
+    if not hasattr(bn, "_wsis_pending_batches"):
+        bn._wsis_pending_batches = 0
+        bn.register_state_dict_pre_hook(lambda module, prefix, keep_vars: _flush_batch_count(module))
+    bn._wsis_pending_batches += 1
+
+
+def flush_bn_counters(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            _flush_batch_count(m)
+
+
 def batch_norm_relu(x, bn, relu=True):
     """fused forward of an nn.BatchNorm1d module (its parameters/buffers) optionally followed by ReLU"""
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+        if bn.momentum is None:
+            bn.num_batches_tracked += 1          # the cumulative-average mode needs the live value
+        else:
+            _defer_batch_count(bn)               # one tiny kernel per BN per step otherwise: flushed lazily
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                                 bn.running_var if bn.track_running_stats else None, bn.training, momentum, bn.eps,
