@@ -12,6 +12,7 @@
 // buffer in HBM and no scatter-add atomics (upstream spconv does both); the reduction order is fixed,
 // so results are run-to-run deterministic and independent of the tile order.
 #include <cstdlib>
+#include <vector>
 
 #include "common.h"
 
@@ -310,6 +311,33 @@ __global__ void spconv_reduce_kernel(const float* __restrict__ partial, const fl
   }
 }
 
+// ---- live kernel timing for bench.py's roofline: HIP events recorded on the launch stream directly around
+// the dominant kernels (not around the host wrapper), enabled by wsis_prof_enable().
+struct ProfRec {
+  hipEvent_t a, b;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof[2];   // 0 = spconv_fwd_kernel, 1 = spconv_dw_kernel
+
+struct ProfScope {
+  int which;
+  hipStream_t st;
+  ProfRec r{};
+  bool live = false;
+  ProfScope(int w, hipStream_t s) : which(w), st(s) {
+    if (g_prof_on && hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess) {
+      live = hipEventRecord(r.a, st) == hipSuccess;
+    }
+  }
+  void stop() {
+    if (live) {
+      (void)hipEventRecord(r.b, st);
+      g_prof[which].push_back(r);
+      live = false;
+    }
+  }
+};
+
 int fwd_ksplit(int64_t M_out, int K, int Cout) {
   const int nblk = (Cout + 31) / 32;
   const int NB = nblk <= 5 ? nblk : 4;
@@ -533,6 +561,7 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
   const bool vec_ok = (Cin % 4 == 0) && (Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(d_W) & 15) == 0);
   const dim3 grid((unsigned)ceil_div(M_out, TM), (unsigned)ceil_div(Cout, NB * 32), (unsigned)kz);
+  ProfScope prof(0, st);
 #define WSIS_FWD_CASE(n)                                                                          \
   case n:                                                                                         \
     if (vec_ok)                                                                                   \
@@ -552,12 +581,35 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
       return fail(WSIS_ERR_ARG, "spconv_fwd: unsupported NB");
   }
 #undef WSIS_FWD_CASE
+  prof.stop();
   WSIS_LAUNCH_CHECK();
   if (kz > 1) {
     hipLaunchKernelGGL(spconv_reduce_kernel, dim3(grid_for(M_out * Cout, 256)), dim3(256), 0, st, partial, d_bias,
                        d_residual, d_out, M_out, Cout, kz);
     WSIS_LAUNCH_CHECK();
   }
+  return WSIS_OK;
+}
+
+int wsis_prof_enable(int32_t on) {
+  g_prof_on = on != 0;
+  return WSIS_OK;
+}
+
+int wsis_prof_summary(int32_t which, double* total_ms, int64_t* launches) {
+  WSIS_REQUIRE(which >= 0 && which < 2 && total_ms && launches, "bad args");
+  double ms = 0.0;
+  for (ProfRec& r : g_prof[which]) {
+    WSIS_HIP_CHECK(hipEventSynchronize(r.b));
+    float t = 0.0f;
+    WSIS_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+    ms += t;
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  *total_ms = ms;
+  *launches = (int64_t)g_prof[which].size();
+  g_prof[which].clear();
   return WSIS_OK;
 }
 
@@ -623,6 +675,7 @@ int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_orde
   const int nblk = (Cout + 31) / 32;
   const dim3 grid((unsigned)n_chunks, (unsigned)K, (unsigned)n_cib);
   // output-channel blocks are processed in groups of <= 5 per launch (register budget)
+  ProfScope prof(1, st);
   for (int cb0 = 0; cb0 < nblk; cb0 += 5) {
     const int nbo = min(5, nblk - cb0);
     const int co0 = cb0 * 32;
@@ -644,6 +697,7 @@ int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_orde
 #undef WSIS_DW_CASE
     WSIS_LAUNCH_CHECK();
   }
+  prof.stop();
   const int64_t total = (int64_t)K * Cin * Cout;
   hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, partial, d_dW, n_chunks,
                      K, Cin, Cout, ci_pad);

@@ -216,13 +216,18 @@ def build_down_rulebook(indices, spatial_shape, ksize, stride, padding):
 
 
 class KernelProfiler(object):
-    """Live per-launch timing of the conv kernels with HIP events on the launch stream (bench.py roofline).
-    Algorithmic bytes per launch follow SURVEY.md 8d: P*(Cin+Cout)*4 + P*8, flops 2*P*Cin*Cout, with P = number
-    of rulebook pairs of the launch (entries >= 0 of its gather table; M rows for the dense 1x1 case)."""
+    """Live per-launch timing of the conv kernels for bench.py's roofline.  The durations come from HIP events
+    that libwsis_hip.so records on the launch stream directly around each spconv_fwd_kernel / spconv_dw_kernel
+    launch (wsis_prof_enable / wsis_prof_summary); the algorithmic bytes per launch follow SURVEY.md 8d:
+    P*(Cin+Cout)*4 + P*8, flops 2*P*Cin*Cout, with P = number of rulebook pairs of the launch (entries >= 0 of
+    its gather table; M rows for the dense 1x1 case)."""
+
+    NAMES = ("spconv_fwd_kernel", "spconv_dw_kernel")
 
     def __init__(self):
-        self.records = {}      # kernel name -> list of (start_event, end_event, bytes, flops)
+        self.acc = {n: [0, 0, 0] for n in self.NAMES}   # launches, bytes, flops
         self._pairs = {}
+        _n.check(_n.hip().wsis_prof_enable(1), "prof_enable")
 
     def pairs(self, nbr, M_out):
         if nbr is None:
@@ -233,22 +238,27 @@ class KernelProfiler(object):
         return self._pairs[key]
 
     def begin(self):
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        return ev
+        return None
 
     def end(self, name, start, nbytes, flops):
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
-        self.records.setdefault(name, []).append((start, ev, nbytes, flops))
+        a = self.acc[name]
+        a[0] += 1
+        a[1] += nbytes
+        a[2] += flops
 
     def summary(self):
+        import ctypes
         torch.cuda.synchronize()
+        lib = _n.hip()
+        _n.check(lib.wsis_prof_enable(0), "prof_enable")
         out = {}
-        for name, recs in self.records.items():
-            ms = sum(a.elapsed_time(b) for a, b, _, _ in recs)
-            out[name] = {"launches": len(recs), "ms": ms, "bytes": sum(r[2] for r in recs),
-                         "flops": sum(r[3] for r in recs)}
+        for which, name in enumerate(self.NAMES):
+            ms = ctypes.c_double(0.0)
+            n = ctypes.c_int64(0)
+            _n.check(lib.wsis_prof_summary(which, ctypes.addressof(ms), ctypes.addressof(n)), "prof_summary")
+            launches, nbytes, flops = self.acc[name]
+            assert n.value == launches, (name, n.value, launches)
+            out[name] = {"launches": launches, "ms": ms.value, "bytes": nbytes, "flops": flops}
         return out
 
 

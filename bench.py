@@ -30,6 +30,18 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "conv_traffic.json")   # written by profiles/collect_traffic.py
+
+
+def measured_traffic():
+    """HBM bytes per spconv_fwd_kernel launch from rocprofv3 PMC passes of this same command (FETCH_SIZE doubled
+    per the gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE as is), or None when no counter run is on file."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+        return float(t["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def parse():
@@ -40,17 +52,28 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=2, help="extra event-instrumented steps for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=8)
+    ap.add_argument("--cpu-timeout", type=int, default=150)
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--scene-seed", type=int, default=1)
     ap.add_argument("--small", action="store_true", help="debug: a small room instead of the C2 scene")
     return ap.parse_args()
 
 
-def cpu_baseline(batch_host, cfg, iters):
-    """oracle fwd+bwd on the host cores, same scene; bounded: 1 warm-up + `iters` timed passes."""
+CPU_SAMPLE_ROOM = (2.3, 1.8, 2.2)   # quarter-area room of the C2 scene: the bounded cpu_baseline sample
+CPU_SAMPLE_BOXES = 2
+
+
+def cpu_worker(args):
+    """child process: oracle fwd+bwd on the host cores (never touches the GPU); prints one JSON line."""
+    import harness
     from oracle import network_ref
     import losses_3D_WSIS
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = args.cpu_threads
+    torch.set_num_threads(threads)
+    cfg = harness.default_cfg()
+    scene = harness.make_scene(args.scene_seed, room=CPU_SAMPLE_ROOM, n_box=CPU_SAMPLE_BOXES)
+    batch_host = harness.collate([scene])
     torch.manual_seed(123)
     ref = network_ref.RefNetwork()
     crit = losses_3D_WSIS.MultiTaskLoss(None, cfg.loss, cfg.model)
@@ -63,12 +86,27 @@ def cpu_baseline(batch_host, cfg, iters):
     t0 = time.time()
     one()                       # warm-up (first-touch page faults dominate it)
     warm = time.time() - t0
-    if warm > 90:
-        iters = 1
+    iters = args.cpu_iters if warm < 40 else 1
     t0 = time.time()
     for _ in range(iters):
         one()
     dt = (time.time() - t0) / iters
+    print(json.dumps({"dt": dt, "warm": warm, "iters": iters, "voxels": int(batch_host["voxel_locs"].shape[0]),
+                      "threads": threads}), flush=True)
+
+
+def cpu_baseline(full_voxels, args):
+    """The oracle (torch-CPU port of the upstream gather -> mm -> scatter-add algorithm, oracle/network_ref.py)
+    timed on this box's host cores in a child process with a hard time limit, on a bounded sample: a
+    quarter-area room generated like the C2 scene; the rate is scaled to C2 scenes by the voxel ratio."""
+    import subprocess
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 32))
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-threads", str(threads),
+           "--cpu-iters", str(args.cpu_iters), "--scene-seed", str(args.scene_seed)]
+    env = dict(os.environ)
+    env["HIP_VISIBLE_DEVICES"] = ""      # the child must not open the GPU
+    env["OMP_NUM_THREADS"] = str(threads)
     model_name = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -78,13 +116,26 @@ def cpu_baseline(batch_host, cfg, iters):
                     break
     except OSError:
         pass
-    return {"value": 1.0 / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} fwd+bwd pass(es) of the same {batch_host['voxel_locs'].shape[0]}-voxel scene after 1 "
-                      f"warm-up pass ({warm:.1f} s), torch-CPU oracle, {cores} threads, {model_name}"}
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
+        line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+        r = json.loads(line)
+    except Exception as e:   # noqa: BLE001 -- a failed/timed-out baseline must not take the GPU result down
+        return {"value": None, "unit": "scenes/s", "cores": threads, "kind": "port",
+                "sample": f"cpu baseline child failed or exceeded {args.cpu_timeout} s: {type(e).__name__}"}
+    scale = r["voxels"] / float(full_voxels)
+    return {"value": round(scale / r["dt"], 5), "unit": "scenes/s", "cores": r["threads"], "kind": "port",
+            "sample": f"{r['iters']} fwd+bwd pass(es) of a {r['voxels']}-voxel quarter-area room (same generator) "
+                      f"after a {r['warm']:.1f} s warm-up pass, {r['dt']:.2f} s per pass, scaled to the "
+                      f"{full_voxels}-voxel C2 scene by the voxel ratio; torch-CPU oracle, {r['threads']} threads of "
+                      f"{cores} logical cores, {model_name}"}
 
 
 def main():
     args = parse()
+    if args.cpu_worker:
+        cpu_worker(args)
+        return
     import harness
     import parallel
     from spconv import ops as sp_ops
@@ -147,7 +198,8 @@ def main():
         if k and k["ms"] > 0:
             gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
             roof = {"kernel": "spconv_fwd_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
+                    "alg_bytes_per_launch": k["bytes"] // k["launches"],
                     "launches_per_step": k["launches"] // args.profile_steps,
                     "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 2),
                     "alg_bytes_per_step": k["bytes"] // args.profile_steps,
@@ -163,7 +215,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(batch_host, cfg, args.cpu_iters)
+        cpu = cpu_baseline(int(batch_host["voxel_locs"].shape[0]), args)
 
     if rank == 0:
         M = int(batch_host["voxel_locs"].shape[0])

@@ -171,6 +171,12 @@ int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_orde
                    float* d_dW, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws,
                    int64_t ws_bytes, void* stream);
 
+/* Live timing of the dominant kernels (bench.py roofline): with profiling enabled every spconv_fwd_kernel
+ * (which = 0) and spconv_dw_kernel (which = 1) launch is bracketed by HIP events on its launch stream;
+ * wsis_prof_summary synchronises them, returns the summed duration and the launch count, and clears the list. */
+int wsis_prof_enable(int32_t on);
+int wsis_prof_summary(int32_t which, double* total_ms, int64_t* launches);
+
 /* ---- a12: BatchNorm1d(+ReLU) over the active voxels  sparse_unet3d.py:128-137, backbone_3D_WSIS.py:47,52-55 ---
  * Training statistics with a fixed reduction tree (deterministic).  d_ws from wsis_bn_workspace_bytes.
  * wsis_bn_stats: d_mean/d_var [C] (biased var); running stats (optional pair) updated with `momentum` and the
