@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 4 : (NB <= 3 ? 3 : 2))) void spconv
 
   if (DIAG && dbg && tid == 0) {
     stamp(6);
-    for (int i = 0; i < 8; ++i) dbg[(int64_t)blockIdx.x * 8 + i] = tph[i];
+    for (int i = 0; i < 8; ++i) dbg[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + i] = tph[i];
   }
   // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*half
   float* dst = (gridDim.z > 1) ? partial + (int64_t)blockIdx.z * M_out * Cout : out;
@@ -613,26 +613,29 @@ int wsis_prof_summary(int32_t which, double* total_ms, int64_t* launches) {
   return WSIS_OK;
 }
 
-// diagnostic (not part of the ABI header): NB=1 VEC4 kernel with phase stamps, dbg[tiles*8]
+// diagnostic (not part of the ABI header): VEC4 kernels with phase stamps, dbg[tiles*kz*8]
 int wsis_debug_spconv_diag(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_W,
-                           float* d_out, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout,
-                           unsigned long long* d_dbg, void* stream) {
-  WSIS_REQUIRE(Cout <= 32 && Cin % 4 == 0, "diag supports Cout<=32, Cin%4==0");
-  {
-    int nb1 = -1, nb2 = -1, nb3 = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, (const void*)spconv_fwd_kernel<1, true, false>, 256, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, (const void*)spconv_fwd_kernel<2, true, false>, 256, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, (const void*)spconv_fwd_kernel<5, true, false>, 256, 0);
-    hipDeviceProp_t prop;
-    (void)hipGetDeviceProperties(&prop, 0);
-    fprintf(stderr, "[diag] occupancy API blocks/CU: NB1=%d NB2=%d NB5=%d; sharedMemPerMultiprocessor=%zu maxSharedPerBlock=%zu CUs=%d\n",
-            nb1, nb2, nb3, (size_t)prop.maxSharedMemoryPerMultiProcessor, (size_t)prop.sharedMemPerBlock,
-            prop.multiProcessorCount);
+                           float* d_out, float* d_partial, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout,
+                           int32_t kz, unsigned long long* d_dbg, void* stream) {
+  WSIS_REQUIRE(Cin % 4 == 0 && Cout % 32 == 0 && Cout <= 160, "diag supports Cout in {32..160}, Cin%4==0");
+  const int nb = Cout / 32;
+  const int k_per = (K + kz - 1) / kz;
+  const dim3 grid((unsigned)ceil_div(M_out, TM), 1, (unsigned)kz);
+  hipStream_t st = as_stream(stream);
+#define WSIS_DIAG_CASE(n)                                                                                   \
+  case n:                                                                                                   \
+    hipLaunchKernelGGL((spconv_fwd_kernel<n, true, true>), grid, dim3(256), 0, st, d_X, d_nbr, d_order, d_W, \
+                       (const float*)nullptr, (const float*)nullptr, d_out, d_partial, M_out, M_out, K, Cin, Cout, \
+                       k_per, d_dbg);                                                                       \
+    break;
+  switch (nb) {
+    WSIS_DIAG_CASE(1)
+    WSIS_DIAG_CASE(2)
+    WSIS_DIAG_CASE(3)
+    WSIS_DIAG_CASE(4)
+    WSIS_DIAG_CASE(5)
   }
-  const dim3 grid((unsigned)ceil_div(M_out, TM), 1, 1);
-  hipLaunchKernelGGL((spconv_fwd_kernel<1, true, true>), grid, dim3(256), 0, as_stream(stream), d_X, d_nbr, d_order,
-                     d_W, (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, M_out, K, Cin,
-                     Cout, K, d_dbg);
+#undef WSIS_DIAG_CASE
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

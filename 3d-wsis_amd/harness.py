@@ -205,6 +205,9 @@ def to_device(batch, device):
     for k in _DEVICE_KEYS:
         out[k] = batch[k].to(device)
     out["voxel_coords_int"] = out["voxel_locs"].int().contiguous()
+    ev = torch.cuda.Event()
+    ev.record()
+    out["coords_ready_event"] = ev
     out["GIs"][0].cuda()
     S = int(batch["sp_batch_offsets"][-1])
     out["superpoint_csr"] = SegmentCSR(out["superpoint"], S)
@@ -228,6 +231,7 @@ def forward_loss(model, criterion, batch, cfg, epoch=5):
         feats = torch.cat((feats, coords_float), 1)
     voxel_feats = pointgroup_ops.voxelization(feats, batch["v2p_map"], cfg.mode)
     input_ = spconv.SparseConvTensor(voxel_feats, batch["voxel_coords_int"], batch["spatial_shape"], cfg.batch_size)
+    input_._ready_event = batch.get("coords_ready_event")
     ret = model(input_, batch["p2v_map"], extra)
     loss_inp = {
         "point_labels": (batch["semantic_labels"], batch["instance_labels"]),

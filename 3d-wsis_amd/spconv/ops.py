@@ -366,26 +366,77 @@ def sparse_conv(features, weight, bias, nbr_f, order_f, nbr_b, order_b, flip, M_
     return SparseConvFunction.apply(features, weight, bias, nbr_f, order_f, nbr_b, order_b, flip, M_out)
 
 
-def prebuild_unet_rulebooks(tensor, n_levels, subm_key="subm{}", down_key="spconv{}", first_id=1):
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[key] = st
+    return st
+
+
+def _rulebook_tensors(rb):
+    out = [rb.nbr, rb.nbr_up, rb.order, rb.order_up, rb.nbr_p, rb.nbr_up_p, rb.out_indices]
+    if rb.out_hash is not None:
+        out += [rb.out_hash[0], rb.out_hash[1]]
+    return [t for t in out if t is not None]
+
+
+def prebuild_unet_rulebooks(tensor, n_levels, subm_key="subm{}", down_key="spconv{}", first_id=1, side_stream=None):
     """Builds every rulebook of a UBlock pyramid (SubM k3 p1 per level, k2 s2 between levels) up front and
-    stores them in ``tensor.indice_dict`` under the keys the modules will look up.  The rulebook chain only
-    depends on the coordinates, so the per-level host syncs (output row counts) happen before the first
-    convolution is queued and the rest of the forward/backward can be issued without stalling the host."""
-    indices, shape = tensor.indices, [int(s) for s in tensor.spatial_shape]
-    hash_tab = tensor._hash
-    for lvl in range(n_levels):
-        kid = first_id + lvl
-        key = subm_key.format(kid)
-        if key not in tensor.indice_dict:
-            if hash_tab is None:
-                hash_tab = build_hash(indices, shape)
-                if lvl == 0:
-                    tensor._hash = hash_tab
-            tensor.indice_dict[key] = build_subm_rulebook(indices, shape, [3, 3, 3], [1, 1, 1], hash_tab)
-        if lvl + 1 < n_levels:
-            dkey = down_key.format(kid)
-            rb = tensor.indice_dict.get(dkey)
-            if rb is None:
-                rb = build_down_rulebook(indices, shape, [2, 2, 2], [2, 2, 2], [0, 0, 0])
-                tensor.indice_dict[dkey] = rb
-            indices, shape, hash_tab = rb.out_indices, rb.out_shape, rb.out_hash
+    stores them in ``tensor.indice_dict`` under the keys the modules will look up.
+
+    The rulebook chain only depends on the coordinates.  It runs on a SIDE stream: its per-level host syncs
+    (output row counts) then wait for that stream only, while the main stream keeps executing whatever is still
+    queued (the previous step's backward / optimizer), so the pipeline is never drained; the main stream joins
+    the side stream before the first convolution.  ``tensor.indices`` must be complete before the call
+    (``tensor._ready_event``, if set, is waited for on the side stream)."""
+    if side_stream is None:
+        side_stream = os.environ.get("WSIS_RULEBOOK_STREAM", "1") != "0"
+    dev = tensor.indices.device
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev) if side_stream else None
+    ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
+    built = []
+    if side is not None:
+        ev = getattr(tensor, "_ready_event", None)
+        if ev is not None:
+            side.wait_event(ev)
+    with ctx:
+        indices, shape = tensor.indices, [int(s) for s in tensor.spatial_shape]
+        hash_tab = tensor._hash
+        for lvl in range(n_levels):
+            kid = first_id + lvl
+            key = subm_key.format(kid)
+            if key not in tensor.indice_dict:
+                if hash_tab is None:
+                    hash_tab = build_hash(indices, shape)
+                    if lvl == 0:
+                        tensor._hash = hash_tab
+                        built += [hash_tab[0], hash_tab[1]]
+                rb = build_subm_rulebook(indices, shape, [3, 3, 3], [1, 1, 1], hash_tab)
+                tensor.indice_dict[key] = rb
+                built += _rulebook_tensors(rb)
+            if lvl + 1 < n_levels:
+                dkey = down_key.format(kid)
+                rb = tensor.indice_dict.get(dkey)
+                if rb is None:
+                    rb = build_down_rulebook(indices, shape, [2, 2, 2], [2, 2, 2], [0, 0, 0])
+                    tensor.indice_dict[dkey] = rb
+                    built += _rulebook_tensors(rb)
+                indices, shape, hash_tab = rb.out_indices, rb.out_shape, rb.out_hash
+    if side is not None:
+        main.wait_stream(side)
+        for t in built:          # allocated on the side stream, consumed on the main stream
+            t.record_stream(main)
+
+
+class _NullCtx(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False

@@ -1,0 +1,184 @@
+"""GPU: BASELINE.json's full sizes (C2 ~150 k voxels, C3 batch of 4, C4 ~1 M points) through size-independent
+properties -- the CPU oracle cannot finish these sizes in seconds, so the checks are algebraic:
+
+  rulebook    offset-flip symmetry of the SubM table, transposition of the coupled down/up tables, strictly
+              ascending linear index of strided-conv outputs, every fine voxel maps to its parent
+  conv        linearity in the input and in the weights, dIn = adjoint of the forward (<conv(x), y> = <x, dIn(y)>),
+              dW consistent with the same bilinear form, bit-exact determinism
+  scatter     mean * count == sum, max >= mean, gather(scatter_sum) adjoint identity
+  voxelize    p2v/v2p consistency, mean of a constant is the constant
+"""
+import numpy as np
+import pytest
+import torch
+
+import harness
+import pointgroup_ops
+import spconv
+import torch_scatter
+from spconv import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def c2_batch():
+    scene = harness.make_scene(1)
+    return harness.collate([scene])
+
+
+@pytest.fixture(scope="module")
+def c3_batch():
+    scenes = [harness.make_scene(s, room=(3.2, 2.6, 2.2), n_box=4) for s in (1, 2, 3, 4)]
+    return harness.collate(scenes)
+
+
+def _check_subm(indices, shape):
+    rb = ops.build_subm_rulebook(indices, shape, [3, 3, 3], [1, 1, 1])
+    nbr = rb.nbr
+    K, M = nbr.shape
+    ar = torch.arange(M, device=DEV, dtype=torch.int32)
+    assert torch.equal(nbr[13], ar), "centre offset pairs every voxel with itself"
+    for k in range(K):
+        o = torch.nonzero(nbr[k] >= 0).flatten()
+        i = nbr[k][o].long()
+        assert torch.equal(nbr[K - 1 - k][i].long(), o), f"offset {k}: table must be symmetric under the flip"
+        # geometry: coord[i] - coord[o] == kappa - 1, same batch
+        kappa = torch.tensor([k // 9 - 1, (k // 3) % 3 - 1, k % 3 - 1], device=DEV)
+        d = indices[i].long() - indices[o].long()
+        assert int(d[:, 0].abs().max() if len(o) else 0) == 0
+        assert len(o) == 0 or bool((d[:, 1:] == kappa).all())
+    assert sorted(rb.order.cpu().tolist()) == list(range(M))
+    assert torch.equal(rb.nbr_p, nbr[:, rb.order.long()])
+    return rb
+
+
+def _check_down(indices, shape):
+    rb = ops.build_down_rulebook(indices, shape, [2] * 3, [2] * 3, [0] * 3)
+    out = rb.out_indices.long()
+    S = rb.out_shape
+    lin = ((out[:, 0] * S[0] + out[:, 1]) * S[1] + out[:, 2]) * S[2] + out[:, 3]
+    assert bool((lin[1:] > lin[:-1]).all()), "strided-conv outputs in strictly ascending linear index"
+    up, down = rb.nbr_up, rb.nbr
+    per_fine = (up >= 0).sum(0)
+    assert int(per_fine.max()) <= 1, "k2 s2: every fine voxel has at most one parent"
+    inside = ((indices[:, 1:].long() // 2) < torch.tensor(S, device=DEV)).all(1)
+    assert torch.equal(per_fine == 1, inside), "exactly the voxels inside the floor-divided extent have a parent"
+    for k in range(8):
+        f = torch.nonzero(up[k] >= 0).flatten()
+        o = up[k][f].long()
+        assert torch.equal(down[k][o].long(), f), "down table is the transpose of the up table"
+        assert torch.equal(indices[f, 1:].long() // 2, out[o, 1:]) and torch.equal(indices[f, 0].long(), out[o, 0])
+        kappa = torch.tensor([k // 4, (k // 2) % 2, k % 2], device=DEV)
+        assert len(f) == 0 or bool((indices[f, 1:].long() % 2 == kappa).all())
+    assert int((down >= 0).sum()) == int(inside.sum())
+    return rb
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+def _check_conv_algebra(rb_nbr, rb_order, M_in, M_out, K, cin, cout, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x1, x2 = (torch.randn(M_in, cin, generator=g).to(DEV) for _ in range(2))
+    W1, W2 = (torch.randn(K, cin, cout, generator=g).to(DEV) * 0.1 for _ in range(2))
+    y = torch.randn(M_out, cout, generator=g).to(DEV)
+    f = lambda x, W: ops._conv(x, rb_nbr, rb_order, W, None, None, M_out)
+    o11 = f(x1, W1)
+    assert torch.equal(o11, f(x1, W1)), "bit-exact run-to-run"
+    scale = float(o11.abs().max()) + 1e-6
+    assert float((f(x1 + 2 * x2, W1) - (o11 + 2 * f(x2, W1))).abs().max()) < 2e-4 * scale, "linear in x"
+    assert float((f(x1, W1 - 3 * W2) - (o11 - 3 * f(x1, W2))).abs().max()) < 2e-4 * scale, "linear in W"
+    return x1, W1, y, o11
+
+
+def test_c2_full_scene_rulebooks_and_conv_properties(c2_batch):
+    b = c2_batch
+    idx = b["voxel_locs"].int().to(DEV).contiguous()
+    shape = [int(s) for s in b["spatial_shape"]]
+    M = idx.shape[0]
+    assert 140_000 < M < 175_000, M
+    rb = _check_subm(idx, shape)
+    x1, W1, y, o = _check_conv_algebra(rb.nbr_p, rb.order, M, M, 27, 32, 32, 0)
+    # adjoint: <conv(x,W), y> == <x, dIn(y)> with dIn = conv(y, same table, flipped transposed weights)
+    WT = ops._weight_t(W1, 1)
+    dx = ops._conv(y, rb.nbr_p, rb.order, WT, None, None, M)
+    lhs, rhs = _dot(o, y), _dot(x1, dx)
+    assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), 1.0)
+    dW = ops._dw(x1, rb.nbr_p, rb.order, y, 27, 32, 32)
+    assert abs(_dot(dW, W1) - lhs) < 1e-4 * max(abs(lhs), 1.0), "<dW, W> equals the same bilinear form"
+    assert torch.equal(dW, ops._dw(x1, rb.nbr_p, rb.order, y, 27, 32, 32)), "dW bit-exact run-to-run (no atomics)"
+    # strided level
+    rd = _check_down(idx, shape)
+    Mo = rd.out_indices.shape[0]
+    xd, Wd, yd, od = _check_conv_algebra(rd.nbr_p, rd.order, M, Mo, 8, 32, 64, 1)
+    WTd = ops._weight_t(Wd, 0)
+    dxd = ops._conv(yd, rd.nbr_up_p, rd.order_up, WTd, None, None, M)
+    lhs, rhs = _dot(od, yd), _dot(xd, dxd)
+    assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), 1.0)
+
+
+def test_c3_batch_of_four_never_mixes_scenes(c3_batch):
+    b = c3_batch
+    idx = b["voxel_locs"].int().to(DEV).contiguous()
+    shape = [int(s) for s in b["spatial_shape"]]
+    rb = ops.build_subm_rulebook(idx, shape, [3, 3, 3], [1, 1, 1])
+    for k in (0, 5, 13, 20, 26):
+        o = torch.nonzero(rb.nbr[k] >= 0).flatten()
+        assert torch.equal(idx[rb.nbr[k][o].long(), 0], idx[o, 0]), "pairs stay inside a batch item"
+    rd = ops.build_down_rulebook(idx, shape, [2] * 3, [2] * 3, [0] * 3)
+    assert set(rd.out_indices[:, 0].unique().cpu().tolist()) == {0, 1, 2, 3}
+
+
+def test_c2_voxelization_and_scatter_properties(c2_batch):
+    b = c2_batch
+    N, M = b["locs"].shape[0], b["voxel_locs"].shape[0]
+    p2v, v2p = b["p2v_map"], b["v2p_map"]
+    assert int(v2p[:, 0].sum()) == N and int(p2v.max()) == M - 1
+    cnt = torch.bincount(p2v.long(), minlength=M)
+    assert torch.equal(cnt.int(), v2p[:, 0])
+    first = v2p[:, 1].long()
+    assert torch.equal(b["voxel_locs"], b["locs"][first]), "voxel coords = coords of the voxel's first point"
+    const = torch.full((N, 6), 0.37, device=DEV)
+    out = pointgroup_ops.voxelization(const, v2p.to(DEV), 4)
+    assert float((out - 0.37).abs().max()) < 1e-6
+    feats = torch.randn(N, 32, device=DEV)
+    sp = b["superpoint"].to(DEV)
+    csr = torch_scatter.SegmentCSR(sp)
+    s = torch_scatter.scatter(feats, sp, 0, reduce="sum", csr=csr)
+    m = torch_scatter.scatter(feats, sp, 0, reduce="mean", csr=csr)
+    mx = torch_scatter.scatter(feats, sp, 0, reduce="max", csr=csr)
+    counts = torch.bincount(sp, minlength=s.shape[0]).float().unsqueeze(1)
+    assert float((m * counts - s).abs().max()) < 1e-3 and bool((mx >= m - 1e-6).all())
+    y = torch.randn_like(s)
+    assert abs(_dot(s, y) - _dot(feats, y[sp])) < 1e-4 * abs(_dot(s, y)), "gather is the adjoint of scatter-sum"
+
+
+def test_c4_one_million_points_inference_slice():
+    """S3DIS-room sized input (~1 M points): host voxelization, all rulebooks of the pyramid, one forward of the
+    first two layers; checks shapes, table symmetry on samples and determinism, and that nothing overflows."""
+    scene = harness.make_scene(5, room=(13.0, 10.0, 3.0), n_box=36)
+    b = harness.collate([scene])
+    N, M = b["locs"].shape[0], b["voxel_locs"].shape[0]
+    assert N > 900_000 and M > 600_000, (N, M)
+    idx = b["voxel_locs"].int().to(DEV).contiguous()
+    shape = [int(s) for s in b["spatial_shape"]]
+    t = spconv.SparseConvTensor(torch.randn(M, 6, device=DEV), idx, b["spatial_shape"], 1)
+    ops.prebuild_unet_rulebooks(t, 5)
+    sizes = []
+    for lvl in range(1, 6):
+        rb = t.indice_dict[f"subm{lvl}"]
+        K, Ml = rb.nbr.shape
+        sizes.append(Ml)
+        for k in (0, 13, 26):
+            o = torch.nonzero(rb.nbr[k] >= 0).flatten()[:50000]
+            assert torch.equal(rb.nbr[K - 1 - k][rb.nbr[k][o].long()].long(), o)
+    assert sizes[0] == M and all(a > b_ for a, b_ in zip(sizes, sizes[1:]))
+    conv1 = spconv.SubMConv3d(6, 32, 3, padding=1, bias=False, indice_key="subm1").to(DEV)
+    conv2 = spconv.SubMConv3d(32, 32, 3, padding=1, bias=False, indice_key="subm1").to(DEV)
+    with torch.no_grad():
+        o1 = conv2(conv1(t)).features
+        o2 = conv2(conv1(t)).features
+    assert o1.shape == (M, 32) and torch.isfinite(o1).all() and torch.equal(o1, o2)
