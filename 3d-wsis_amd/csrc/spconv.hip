@@ -104,20 +104,35 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 4 : (NB <= 3 ? 3 : 2))) void spconv
     // ---- tile slice of the packed gather table: nbrS[k][tile0 + t], coalesced 512-B pieces.  All loads are
     //      issued before any of them is consumed: one memory latency for the whole slice.
     if (tid < TM) {
+      // loads in batches of 8 offsets (independent, one latency per batch); batches beyond kcount are skipped,
+      // which matters when the offsets are split over blockIdx.z (kcount is 1..6 there)
       int32_t v[KG];
 #pragma unroll
-      for (int kk = 0; kk < KG; ++kk) {
-        const bool ok = kk < kcount && my_row >= 0 && nbrS != nullptr;
-        v[kk] = nbrS ? nbrS[ok ? (int64_t)(kg0 + kk) * M_out + tile0 + tid : 0] : 0;
-        if (!ok) v[kk] = (nbrS == nullptr && kk < kcount) ? my_row : -1;
+      for (int g8 = 0; g8 < KG; g8 += 8) {
+        if (g8 < kcount) {
+#pragma unroll
+          for (int kk = g8; kk < g8 + 8; ++kk) {
+            const bool ok = kk < kcount && my_row >= 0 && nbrS != nullptr;
+            v[kk] = nbrS ? nbrS[ok ? (int64_t)(kg0 + kk) * M_out + tile0 + tid : 0] : 0;
+            if (!ok) v[kk] = (nbrS == nullptr && kk < kcount) ? my_row : -1;
+          }
+        } else {
+#pragma unroll
+          for (int kk = g8; kk < g8 + 8; ++kk) v[kk] = -1;
+        }
       }
       uint32_t bits_lo = 0u, bits_hi = 0u;
 #pragma unroll
-      for (int kk = 0; kk < KG; ++kk) {
-        nbT[kk * TM + tid] = v[kk];
-        const unsigned long long b = __ballot(v[kk] >= 0);
-        if ((uint32_t)b) bits_lo |= 1u << kk;
-        if ((uint32_t)(b >> 32)) bits_hi |= 1u << kk;
+      for (int g8 = 0; g8 < KG; g8 += 8) {
+        if (g8 < kcount) {
+#pragma unroll
+          for (int kk = g8; kk < g8 + 8; ++kk) {
+            nbT[kk * TM + tid] = v[kk];
+            const unsigned long long b = __ballot(v[kk] >= 0);
+            if ((uint32_t)b) bits_lo |= 1u << kk;
+            if ((uint32_t)(b >> 32)) bits_hi |= 1u << kk;
+          }
+        }
       }
       if (lane == 0) {
         grpMask[wave * 2] = bits_lo;

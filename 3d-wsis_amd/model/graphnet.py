@@ -82,6 +82,14 @@ class GRUCellEx(nn.GRUCell):
         return (x - mu) / torch.sqrt(var + 1e-5)
 
     def forward(self, input, hidden):
+        import os
+        if (input.is_cuda and self._ingate and self._layernorm and self.bias and input.shape[1] == 32
+                and self.hidden_size == 32 and input.shape[0] > 0 and os.environ.get("WSIS_FUSE_GRU", "1") != "0"):
+            import wsis_ops
+            return wsis_ops.gru_cell_ex(input, hidden, self)   # one HIP kernel instead of ~30 launches
+        return self.forward_reference(input, hidden)
+
+    def forward_reference(self, input, hidden):
         if self._ingate:
             input = torch.sigmoid(self._modules["ig"](hidden)) * input
         gi = F.linear(input, self.weight_ih)

@@ -279,3 +279,45 @@ class _EccMessage(Function):
 
 def ecc_message(x, weights, src, dst, csr_src, csr_dst):
     return _EccMessage.apply(x, weights, src, dst, csr_src, csr_dst)
+
+
+# ---- a21: fused GRUCellEx -------------------------------------------------------------------------------------
+
+class _GruCellEx(Function):
+    """hy = GRUCellEx(x, h) with input gate and per-row normalised gates (spg_modules.py:226-253), C == 32."""
+
+    @staticmethod
+    def forward(ctx, x, h, w_ig, b_ig, w_ih, w_hh, b_ih, b_hh):
+        _n.require_cuda(x, h)
+        args = [t.contiguous().float() for t in (x, h, w_ig, b_ig, w_ih, w_hh, b_ih, b_hh)]
+        x, h = args[0], args[1]
+        S, C = x.shape
+        hy = torch.empty_like(x)
+        _n.check(_n.hip().wsis_gru_cell_fwd(*[_n.ptr(t) for t in args], _n.ptr(hy), S, C, _n.stream_ptr()),
+                 "gru_cell_fwd")
+        ctx.save_for_backward(*args)
+        return hy
+
+    @staticmethod
+    def backward(ctx, dhy):
+        args = ctx.saved_tensors
+        x, h, w_ig, b_ig, w_ih, w_hh, b_ih, b_hh = args
+        S, C = x.shape
+        lib = _n.hip()
+        dhy = dhy.contiguous().float()
+        dx, dh = torch.empty_like(x), torch.empty_like(h)
+        dwig, dbig = torch.empty_like(w_ig), torch.empty_like(b_ig)
+        dwih, dwhh = torch.empty_like(w_ih), torch.empty_like(w_hh)
+        dbih, dbhh = torch.empty_like(b_ih), torch.empty_like(b_hh)
+        ws_bytes = lib.wsis_gru_cell_workspace_bytes(S)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        _n.check(lib.wsis_gru_cell_bwd(*[_n.ptr(t) for t in args], _n.ptr(dhy), _n.ptr(dx), _n.ptr(dh), _n.ptr(dwig),
+                                       _n.ptr(dbig), _n.ptr(dwih), _n.ptr(dwhh), _n.ptr(dbih), _n.ptr(dbhh), S, C,
+                                       _n.ptr(ws), ws_bytes, _n.stream_ptr()), "gru_cell_bwd")
+        return dx, dh, dwig, dbig, dwih, dwhh, dbih, dbhh
+
+
+def gru_cell_ex(x, h, cell):
+    """fused forward of a graphnet.GRUCellEx module (layernorm + ingate configuration, 32 channels)"""
+    ig = cell._modules["ig"]
+    return _GruCellEx.apply(x, h, ig.weight, ig.bias, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)

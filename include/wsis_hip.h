@@ -243,6 +243,19 @@ int wsis_ecc_message_bwd(const float* d_x, const float* d_w, const float* d_dout
                          const int32_t* d_perm_dst, const int32_t* d_off_dst, const int32_t* d_off_src,
                          float* d_dx, float* d_dw, int64_t S, int64_t E, int32_t C, void* stream);
 
+/* GRUCellEx of the superpoint GNN (modules/model/spg_modules.py:207-253: GRU cell + input gate + per-row
+ * normalisation of the gate pre-activations), C == 32: one kernel forward, one backward + a fixed-order reduce of
+ * the parameter gradients.  Weights in torch.nn.GRUCell layout: Wih/Whh [3C,C] (r,z,n blocks), Wig [C,C]. */
+int64_t wsis_gru_cell_workspace_bytes(int64_t S);
+int wsis_gru_cell_fwd(const float* d_x, const float* d_h, const float* d_Wig, const float* d_big,
+                      const float* d_Wih, const float* d_Whh, const float* d_bih, const float* d_bhh, float* d_hy,
+                      int64_t S, int32_t C, void* stream);
+int wsis_gru_cell_bwd(const float* d_x, const float* d_h, const float* d_Wig, const float* d_big,
+                      const float* d_Wih, const float* d_Whh, const float* d_bih, const float* d_bhh,
+                      const float* d_dhy, float* d_dx, float* d_dh, float* d_dWig, float* d_dbig, float* d_dWih,
+                      float* d_dWhh, float* d_dbih, float* d_dbhh, int64_t S, int32_t C, void* d_ws,
+                      int64_t ws_bytes, void* stream);
+
 /* ---- a17: dense inter-superpoint affinity + label propagation -------------------------------
  * train_scannetv2.py:562-570, modules/datasets/scannetv2_dataset.py:664-721 (fp64, host numpy).
  * A [S,S] fp64 zero-filled then A[u_e, v_e] = aff_e (edge order, later edges win). */

@@ -392,3 +392,27 @@ def test_ecc_message_fwd_bwd(S, deg):
     out.backward(go.to(DEV))
     ref_out.backward(go.double())
     assert close(xg.grad, xr.grad, rtol=1e-3, atol=1e-4) and close(wg.grad, wr.grad, rtol=1e-3, atol=1e-4)
+
+
+# ---------------------------------------------------------------- fused GRUCellEx (a21)
+@pytest.mark.parametrize("S", [1, 7, 300, 1190])
+def test_gru_cell_ex_fwd_bwd(S):
+    import copy
+    import graphnet
+    torch.manual_seed(S)
+    cell = graphnet.GRUCellEx(32, 32, bias=True, layernorm=True, ingate=True)
+    ref = copy.deepcopy(cell).double()
+    cell = cell.to(DEV)
+    g = torch.Generator().manual_seed(S + 1)
+    x, h = torch.randn(S, 32, generator=g), torch.randn(S, 32, generator=g)
+    xg, hg = x.clone().to(DEV).requires_grad_(True), h.clone().to(DEV).requires_grad_(True)
+    hy = cell(xg, hg)
+    xr, hr = x.clone().double().requires_grad_(True), h.clone().double().requires_grad_(True)
+    hyr = ref.forward_reference(xr, hr)
+    assert close(hy, hyr)
+    go = torch.randn(S, 32, generator=g)
+    hy.backward(go.to(DEV))
+    hyr.backward(go.double())
+    assert close(xg.grad, xr.grad, rtol=1e-3, atol=1e-4) and close(hg.grad, hr.grad, rtol=1e-3, atol=1e-4)
+    for (name, p), (_, q) in zip(cell.named_parameters(), ref.named_parameters()):
+        assert close(p.grad, q.grad, rtol=1e-3, atol=1e-4), name
