@@ -525,8 +525,8 @@ __global__ void dw_reduce_kernel(const float* __restrict__ partial, float* __res
 }
 
 int dw_rows_per_chunk(int64_t M_out) {
-  // ~256 row chunks at the large levels: short waves (the loop is latency bound), still only a few MB of slabs
-  int64_t rpc = ceil_div(M_out, 256);
+  // ~64 row chunks at the large levels (more chunks did not shorten the kernel and only grow the slab reduce)
+  int64_t rpc = ceil_div(M_out, 64);
   if (rpc < 256) rpc = 256;
   rpc = (rpc + 63) & ~(int64_t)63;
   return (int)rpc;

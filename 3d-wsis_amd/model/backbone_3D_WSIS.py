@@ -30,11 +30,14 @@ class _Head(nn.Sequential):
 
     def forward(self, x):
         import os
-        if not x.is_cuda or os.environ.get("WSIS_FUSE_BN", "0") == "0":
+        if not x.is_cuda:
             return super().forward(x)
-        x = self[0](x)
-        x = wsis_ops.batch_norm_relu(x, self[1], relu=True)
-        return self[3](x)
+        x = wsis_ops.tall_linear(x, self[0])
+        if os.environ.get("WSIS_FUSE_BN", "0") == "0":
+            x = self[2](self[1](x))
+        else:
+            x = wsis_ops.batch_norm_relu(x, self[1], relu=True)
+        return wsis_ops.tall_linear(x, self[3])
 
 
 class Network(nn.Module):

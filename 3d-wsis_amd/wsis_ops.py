@@ -321,3 +321,36 @@ def gru_cell_ex(x, h, cell):
     """fused forward of a graphnet.GRUCellEx module (layernorm + ingate configuration, 32 channels)"""
     ig = cell._modules["ig"]
     return _GruCellEx.apply(x, h, ig.weight, ig.bias, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)
+
+
+# ---- point-level Linear with a split-K weight gradient ----------------------------------------------------------
+
+class _TallLinear(Function):
+    """y = x @ W^T + b for x [N, Cin] with N ~ 2*10^5 points (backbone_3D_WSIS.py:59-64, 182).  hipBLASLt runs
+    the weight gradient X^T dY (a [Cin x Cout] output reduced over N rows) as ONE workgroup (~0.4 ms); here it
+    goes through the chunked MFMA reduction of the sparse-conv dW kernel (K = 1, dense rows)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        from spconv import ops as sp_ops
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            cout, cin = weight.shape
+            dw = sp_ops._dw(x.contiguous(), None, None, dy, 1, cin, cout).view(cin, cout).t()
+        db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def tall_linear(x, linear):
+    if not x.is_cuda or x.shape[0] < 4096:
+        return linear(x)
+    return _TallLinear.apply(x, linear.weight, linear.bias)
