@@ -211,6 +211,7 @@ def to_device(batch, device):
     out["GIs"][0].cuda()
     S = int(batch["sp_batch_offsets"][-1])
     out["superpoint_csr"] = SegmentCSR(out["superpoint"], S)
+    out["p2v_csr"] = SegmentCSR(out["p2v_map"], int(batch["voxel_locs"].shape[0]))
     out["edge_graph"] = wsis_ops.EdgeGraph(out["edge_u_list"], out["edge_v_list"], S)
     return out
 
@@ -225,7 +226,8 @@ def forward_loss(model, criterion, batch, cfg, epoch=5):
     centre = scatter(coords_float, superpoint, dim=0, reduce="mean", csr=batch.get("superpoint_csr"))
     extra = {"superpoint": superpoint, "GIs": batch["GIs"], "edge_u_list": batch["edge_u_list"],
              "edge_v_list": batch["edge_v_list"], "superpoint_cenetr_xyz": centre,
-             "superpoint_csr": batch.get("superpoint_csr"), "edge_graph": batch.get("edge_graph")}
+             "superpoint_csr": batch.get("superpoint_csr"), "edge_graph": batch.get("edge_graph"),
+             "p2v_csr": batch.get("p2v_csr")}
     feats = batch["feats"]
     if cfg.model.use_coords:
         feats = torch.cat((feats, coords_float), 1)

@@ -118,7 +118,10 @@ class Network(nn.Module):
         output = self.input_conv(input)
         output = self.unet(output)
         output = self.output_layer(output)
-        output_feats = output.features[input_map.long()]            # [N, m] voxel -> point
+        if output.features.is_cuda:                                   # [N, m] voxel -> point
+            output_feats = wsis_ops.gather_rows(output.features, input_map, extra_data.get("p2v_csr"))
+        else:
+            output_feats = output.features[input_map.long()]
 
         ret["semantic_scores"] = self.linear(output_feats)          # [N, nClass]
 

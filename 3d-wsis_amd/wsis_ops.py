@@ -354,3 +354,43 @@ def tall_linear(x, linear):
     if not x.is_cuda or x.shape[0] < 4096:
         return linear(x)
     return _TallLinear.apply(x, linear.weight, linear.bias)
+
+
+# ---- a14: voxel -> point gather with a deterministic backward ---------------------------------------------------
+
+class _GatherRows(Function):
+    """out[p] = src[idx[p]]  (backbone_3D_WSIS.py:179 ``output.features[input_map.long()]``).  Backward is the
+    segmented sum over the points of each voxel (CSR of idx, ascending point order) instead of an atomic
+    index-add: deterministic."""
+
+    @staticmethod
+    def forward(ctx, src, idx, csr):
+        _n.require_cuda(src, idx)
+        src = src.contiguous().float()
+        idx = idx.contiguous()
+        assert idx.dtype in (torch.int32, torch.int64)
+        N, C = idx.numel(), src.shape[1]
+        out = torch.empty((N, C), dtype=torch.float32, device=src.device)
+        _n.check(_n.hip().wsis_gather_rows(_n.ptr(src), _n.ptr(idx), int(idx.dtype == torch.int64), _n.ptr(out), N, C,
+                                           _n.stream_ptr()), "gather_rows")
+        ctx.csr = csr
+        ctx.rows = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        csr = ctx.csr
+        dout = dout.contiguous().float()
+        C = dout.shape[1]
+        dsrc = torch.empty((csr.S, C), dtype=torch.float32, device=dout.device)
+        _n.check(_n.hip().wsis_segment_reduce_fwd(_n.ptr(dout), _n.ptr(csr.perm), _n.ptr(csr.offsets), _n.ptr(dsrc),
+                                                  None, csr.N, csr.S, C, 0, _n.stream_ptr()), "segment_reduce_fwd")
+        assert csr.S == ctx.rows
+        return dsrc, None, None
+
+
+def gather_rows(src, idx, csr=None):
+    """src[idx] with a deterministic backward; ``csr`` = SegmentCSR(idx, src.shape[0]) may be passed for reuse"""
+    if csr is None:
+        csr = SegmentCSR(idx, src.shape[0])
+    return _GatherRows.apply(src, idx, csr)

@@ -416,3 +416,22 @@ def test_gru_cell_ex_fwd_bwd(S):
     assert close(xg.grad, xr.grad, rtol=1e-3, atol=1e-4) and close(hg.grad, hr.grad, rtol=1e-3, atol=1e-4)
     for (name, p), (_, q) in zip(cell.named_parameters(), ref.named_parameters()):
         assert close(p.grad, q.grad, rtol=1e-3, atol=1e-4), name
+
+
+# ---------------------------------------------------------------- voxel -> point gather (a14)
+def test_gather_rows_fwd_bwd_deterministic():
+    g = torch.Generator().manual_seed(3)
+    M, N, C = 700, 5000, 32
+    src = torch.randn(M, C, generator=g)
+    idx = torch.randint(0, M, (N,), generator=g).int()
+    sg = src.clone().to(DEV).requires_grad_(True)
+    out = wsis_ops.gather_rows(sg, idx.to(DEV))
+    assert torch.equal(out.cpu(), src[idx.long()])
+    go = torch.randn(N, C, generator=g)
+    out.backward(go.to(DEV))
+    ref = torch.zeros(M, C, dtype=torch.float64).index_add_(0, idx.long(), go.double())
+    assert close(sg.grad, ref)
+    g1 = sg.grad.clone()
+    sg.grad = None
+    wsis_ops.gather_rows(sg, idx.to(DEV)).backward(go.to(DEV))
+    assert torch.equal(g1, sg.grad)
