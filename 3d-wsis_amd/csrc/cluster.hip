@@ -4,8 +4,14 @@
 // For point p: ascending indices k of same-batch points with |x_p - x_k|^2 < r^2 (strict, p
 // included), at most 1000.  Upstream hands out `start` from a global atomic cursor (order
 // non-deterministic); here start = exclusive prefix sum of the counts -- a valid instance of the
-// upstream contract and run-to-run deterministic.  Count pass + fill pass, candidate points are
-// staged through LDS in tiles so every HBM byte of xyz is read once per workgroup.
+// upstream contract and run-to-run deterministic.
+//
+// Upstream is a brute-force O(N * N_batch) scan.  Here the points are bucketed into a uniform grid with cell size
+// (just above) the radius: radix sort by cell key, a hash of cell -> [start,end) in the sorted order, and each
+// point only visits the 27 cells around it (count pass, exclusive scan, fill pass + per-point ascending sort).
+// Distances are evaluated with exactly the same fp32 expression as the scan, so the neighbour sets are identical.
+// Points with more than 1000 hits (upstream keeps the 1000 smallest indices) are finished by an ascending
+// wave-wide scan over their batch item.
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -23,61 +29,142 @@ constexpr int BQ_CAP = 1000;
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-template <bool FILL>
-__global__ __launch_bounds__(BQ_BLOCK) void ballquery_kernel(
-    const float* __restrict__ xyz, const int32_t* __restrict__ batch_idx, const int32_t* __restrict__ batch_off,
-    int64_t N, float r2, int32_t* __restrict__ counts, const int32_t* __restrict__ start_len,
-    int32_t* __restrict__ idx) {
-  __shared__ float tile[BQ_BLOCK * 3];
-  __shared__ int32_t range[2];
-  const int64_t p = (int64_t)blockIdx.x * BQ_BLOCK + threadIdx.x;
-  const bool live = p < N;
-  float px = 0.f, py = 0.f, pz = 0.f;
-  int32_t lo = 0, hi = 0;
-  if (live) {
-    px = xyz[3 * p];
-    py = xyz[3 * p + 1];
-    pz = xyz[3 * p + 2];
-    const int32_t b = batch_idx[p];
-    lo = batch_off[b];
-    hi = batch_off[b + 1];
+// ---- uniform-grid path ------------------------------------------------------------------------------------
+constexpr int CELL_BITS = 18;                       // per-dimension cell coordinate bits (bias 2^17)
+constexpr int CELL_BIAS = 1 << (CELL_BITS - 1);
+
+__device__ __forceinline__ uint64_t cell_key(int b, int cx, int cy, int cz) {
+  return ((uint64_t)(uint32_t)b << (3 * CELL_BITS)) | ((uint64_t)(uint32_t)(cx + CELL_BIAS) << (2 * CELL_BITS)) |
+         ((uint64_t)(uint32_t)(cy + CELL_BIAS) << CELL_BITS) | (uint64_t)(uint32_t)(cz + CELL_BIAS);
+}
+
+__global__ void bq_keys_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ batch_idx, int64_t N,
+                               float inv_cell, uint64_t* __restrict__ keys, int32_t* __restrict__ iota) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) {
+    const int cx = (int)floorf(xyz[3 * p] * inv_cell), cy = (int)floorf(xyz[3 * p + 1] * inv_cell),
+              cz = (int)floorf(xyz[3 * p + 2] * inv_cell);
+    keys[p] = cell_key(batch_idx[p], cx, cy, cz);
+    iota[p] = (int32_t)p;
   }
-  // candidate range of the whole workgroup = union of its points' batch ranges
-  if (threadIdx.x == 0) {
-    const int64_t first = (int64_t)blockIdx.x * BQ_BLOCK;
-    const int64_t last = min(N, first + BQ_BLOCK) - 1;
-    range[0] = batch_off[batch_idx[first]];
-    range[1] = batch_off[batch_idx[last] + 1];
-  }
-  __syncthreads();
-  const int32_t glo = range[0], ghi = range[1];
-  int32_t cnt = 0;
-  int32_t wpos = 0;
-  if (FILL && live) wpos = start_len[2 * p];
-  for (int32_t t0 = glo; t0 < ghi; t0 += BQ_BLOCK) {
-    const int32_t k = t0 + threadIdx.x;
-    if (k < ghi) {
-      tile[3 * threadIdx.x] = xyz[3 * (int64_t)k];
-      tile[3 * threadIdx.x + 1] = xyz[3 * (int64_t)k + 1];
-      tile[3 * threadIdx.x + 2] = xyz[3 * (int64_t)k + 2];
+}
+
+// cell table: open addressing on the 64-bit cell key; start set by the first sorted point of a cell, end by the last
+__global__ void bq_cells_kernel(const uint64_t* __restrict__ sorted, int64_t N, unsigned long long* __restrict__ hkeys,
+                                int32_t* __restrict__ hstart, int32_t* __restrict__ hend, uint64_t mask) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = sorted[i];
+    const bool first = i == 0 || sorted[i - 1] != key;
+    const bool last = i == N - 1 || sorted[i + 1] != key;
+    if (!first && !last) continue;
+    uint64_t h = mix64(key) & mask;
+    for (;;) {
+      const unsigned long long old = atomicCAS(hkeys + h, ~0ull, (unsigned long long)key);
+      if (old == ~0ull || old == (unsigned long long)key) break;
+      h = (h + 1) & mask;
     }
-    __syncthreads();
-    if (live && cnt < BQ_CAP) {
-      const int32_t a = max(t0, lo), bnd = min(min(t0 + BQ_BLOCK, ghi), hi);
-      for (int32_t kk = a; kk < bnd; ++kk) {
-        const int j = kk - t0;
-        const float dx = px - tile[3 * j], dy = py - tile[3 * j + 1], dz = pz - tile[3 * j + 2];
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        if (d2 < r2) {
-          if (FILL) idx[(int64_t)wpos + cnt] = kk;
-          ++cnt;
-          if (cnt >= BQ_CAP) break;
+    if (first) hstart[h] = (int32_t)i;
+    if (last) hend[h] = (int32_t)i + 1;
+  }
+}
+
+__device__ __forceinline__ bool bq_cell_range(const unsigned long long* __restrict__ hkeys,
+                                              const int32_t* __restrict__ hstart, const int32_t* __restrict__ hend,
+                                              uint64_t mask, uint64_t key, int32_t& s, int32_t& e) {
+  uint64_t h = mix64(key) & mask;
+  for (;;) {
+    const unsigned long long k = hkeys[h];
+    if (k == (unsigned long long)key) {
+      s = hstart[h];
+      e = hend[h];
+      return true;
+    }
+    if (k == ~0ull) return false;
+    h = (h + 1) & mask;
+  }
+}
+
+// FILL = false: counts[p] = true number of hits (uncapped).  FILL = true: writes the hits of points with
+// <= BQ_CAP hits (unsorted, then sorted ascending in place); points above the cap are left to the scan path.
+template <bool FILL>
+__global__ void bq_grid_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ batch_idx, int64_t N,
+                               float r2, float inv_cell, const int32_t* __restrict__ perm,
+                               const unsigned long long* __restrict__ hkeys, const int32_t* __restrict__ hstart,
+                               const int32_t* __restrict__ hend, uint64_t mask, int32_t* __restrict__ counts,
+                               const int32_t* __restrict__ start_len, int32_t* __restrict__ idx) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x) {
+    const float px = xyz[3 * p], py = xyz[3 * p + 1], pz = xyz[3 * p + 2];
+    const int b = batch_idx[p];
+    const int cx = (int)floorf(px * inv_cell), cy = (int)floorf(py * inv_cell), cz = (int)floorf(pz * inv_cell);
+    int32_t cnt = 0;
+    int32_t* dst = nullptr;
+    if (FILL) {
+      if (counts[p] > BQ_CAP) continue;   // handled by the ascending scan kernel
+      dst = idx + start_len[2 * p];
+    }
+    for (int dz = -1; dz <= 1; ++dz)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          int32_t s, e;
+          if (!bq_cell_range(hkeys, hstart, hend, mask, cell_key(b, cx + dx, cy + dy, cz + dz), s, e)) continue;
+          for (int32_t i = s; i < e; ++i) {
+            const int32_t k = perm[i];
+            const float ex = px - xyz[3 * (int64_t)k], ey = py - xyz[3 * (int64_t)k + 1],
+                        ez = pz - xyz[3 * (int64_t)k + 2];
+            const float d2 = ex * ex + ey * ey + ez * ez;
+            if (d2 < r2) {
+              if (FILL) dst[cnt] = k;
+              ++cnt;
+            }
+          }
         }
+    if (!FILL) {
+      counts[p] = cnt;
+    } else {
+      // ascending neighbour order (upstream scans k upward): insertion sort of the short list
+      for (int32_t i = 1; i < cnt; ++i) {
+        const int32_t v = dst[i];
+        int32_t j = i - 1;
+        while (j >= 0 && dst[j] > v) {
+          dst[j + 1] = dst[j];
+          --j;
+        }
+        dst[j + 1] = v;
       }
     }
-    __syncthreads();
   }
-  if (!FILL && live) counts[p] = cnt;
+}
+
+// points with more than BQ_CAP hits: ascending scan over the batch item, first BQ_CAP hits (one wave per point)
+__global__ void bq_overflow_kernel(const float* __restrict__ xyz, const int32_t* __restrict__ batch_idx,
+                                   const int32_t* __restrict__ batch_off, int64_t N, float r2,
+                                   const int32_t* __restrict__ counts, const int32_t* __restrict__ start_len,
+                                   int32_t* __restrict__ idx) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); p < N; p += nw) {
+    if (counts[p] <= BQ_CAP) continue;
+    const float px = xyz[3 * p], py = xyz[3 * p + 1], pz = xyz[3 * p + 2];
+    const int b = batch_idx[p];
+    int32_t* dst = idx + start_len[2 * p];
+    int32_t n = 0;
+    for (int32_t k0 = batch_off[b]; k0 < batch_off[b + 1] && n < BQ_CAP; k0 += 64) {
+      const int32_t k = k0 + lane;
+      bool hit = false;
+      if (k < batch_off[b + 1]) {
+        const float ex = px - xyz[3 * (int64_t)k], ey = py - xyz[3 * (int64_t)k + 1], ez = pz - xyz[3 * (int64_t)k + 2];
+        hit = (ex * ex + ey * ey + ez * ez) < r2;
+      }
+      const unsigned long long m = __ballot(hit);
+      const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+      if (hit && pos < BQ_CAP) dst[pos] = k;
+      n += __popcll(m);
+    }
+  }
+}
+
+__global__ void bq_cap_kernel(int32_t* __restrict__ counts_capped, const int32_t* __restrict__ counts, int64_t N) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < N; p += (int64_t)gridDim.x * blockDim.x)
+    counts_capped[p] = min(counts[p], BQ_CAP);
 }
 
 __global__ void start_len_kernel(const int32_t* __restrict__ counts, const int32_t* __restrict__ starts,
@@ -94,15 +181,59 @@ __global__ void start_len_kernel(const int32_t* __restrict__ counts, const int32
 
 extern "C" {
 
-int64_t wsis_ballquery_workspace_bytes(int64_t N) {
-  if (N < 0) return -1;
-  if (N == 0) return 256;
-  size_t scan_bytes = 0;
+// workspace layout (all 256-byte aligned):
+//   counts_true[N] i32 | counts_cap[N] i32 | starts[N] i32 | perm[N] i32 | iota[N] i32 | keys[N] u64 |
+//   keys_sorted[N] u64 | hkeys[cap] u64 | hstart[cap] i32 | hend[cap] i32 | temp (sort / scan)
+struct BqLayout {
+  size_t counts, capped, starts, perm, iota, keys, keys_sorted, hkeys, hstart, hend, temp, total;
+  int64_t cap;
+};
+
+static BqLayout bq_layout(int64_t N, size_t temp_bytes) {
+  BqLayout L;
+  int64_t cap = 16;
+  while (cap < 2 * N) cap <<= 1;
+  L.cap = cap;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += align256(bytes);
+    return o;
+  };
+  L.counts = take((size_t)N * 4);
+  L.capped = take((size_t)N * 4);
+  L.starts = take((size_t)N * 4);
+  L.perm = take((size_t)N * 4);
+  L.iota = take((size_t)N * 4);
+  L.keys = take((size_t)N * 8);
+  L.keys_sorted = take((size_t)N * 8);
+  L.hkeys = take((size_t)cap * 8);
+  L.hstart = take((size_t)cap * 4);
+  L.hend = take((size_t)cap * 4);
+  L.temp = take(temp_bytes);
+  L.total = off + 256;
+  return L;
+}
+
+static int bq_temp_bytes(int64_t N, size_t* out) {
+  size_t scan_bytes = 0, sort_bytes = 0;
   int32_t* ip = nullptr;
+  uint64_t* kp = nullptr;
   if (rocprim::exclusive_scan(nullptr, scan_bytes, ip, ip, 0, (size_t)N, rocprim::plus<int32_t>(),
                               (hipStream_t)0) != hipSuccess)
     return -1;
-  return (int64_t)(2 * align256((size_t)N * 4) + align256(scan_bytes) + 256);
+  if (rocprim::radix_sort_pairs(nullptr, sort_bytes, kp, kp, ip, ip, (size_t)N, 0, 64, (hipStream_t)0) != hipSuccess)
+    return -1;
+  *out = scan_bytes > sort_bytes ? scan_bytes : sort_bytes;
+  return 0;
+}
+
+int64_t wsis_ballquery_workspace_bytes(int64_t N) {
+  if (N < 0) return -1;
+  if (N == 0) return 256;
+  size_t temp = 0;
+  if (bq_temp_bytes(N, &temp) != 0) return -1;
+  return (int64_t)bq_layout(N, temp).total;
 }
 
 int wsis_ballquery_count(const float* d_xyz, const int32_t* d_batch_idx, const int32_t* d_batch_off,
@@ -113,23 +244,46 @@ int wsis_ballquery_count(const float* d_xyz, const int32_t* d_batch_idx, const i
   WSIS_HIP_CHECK(hipMemsetAsync(d_total, 0, sizeof(int32_t), st));
   if (N == 0) return WSIS_OK;
   WSIS_REQUIRE(d_xyz && d_batch_idx && d_batch_off && d_start_len && d_ws, "null pointer");
+  WSIS_REQUIRE(B < (1 << 10), "ball query supports < 1024 batch items");
+  size_t temp_bytes = 0;
+  WSIS_REQUIRE(bq_temp_bytes(N, &temp_bytes) == 0, "rocprim size query failed");
+  const BqLayout L = bq_layout(N, temp_bytes);
+  WSIS_REQUIRE((int64_t)L.total <= ws_bytes, "workspace too small");
   char* ws = static_cast<char*>(d_ws);
-  const size_t a = align256((size_t)N * 4);
-  WSIS_REQUIRE((int64_t)(2 * a) < ws_bytes, "workspace too small");
-  int32_t* counts = reinterpret_cast<int32_t*>(ws);
-  int32_t* starts = reinterpret_cast<int32_t*>(ws + a);
-  void* temp = ws + 2 * a;
-  size_t temp_bytes = (size_t)ws_bytes - 2 * a;
-  const unsigned grid = (unsigned)ceil_div(N, BQ_BLOCK);
-  hipLaunchKernelGGL(ballquery_kernel<false>, dim3(grid), dim3(BQ_BLOCK), 0, st, d_xyz, d_batch_idx,
-                     d_batch_off, N, radius * radius, counts, (const int32_t*)nullptr, (int32_t*)nullptr);
+  int32_t* counts = reinterpret_cast<int32_t*>(ws + L.counts);
+  int32_t* capped = reinterpret_cast<int32_t*>(ws + L.capped);
+  int32_t* starts = reinterpret_cast<int32_t*>(ws + L.starts);
+  int32_t* perm = reinterpret_cast<int32_t*>(ws + L.perm);
+  int32_t* iota = reinterpret_cast<int32_t*>(ws + L.iota);
+  uint64_t* keys = reinterpret_cast<uint64_t*>(ws + L.keys);
+  uint64_t* keys_sorted = reinterpret_cast<uint64_t*>(ws + L.keys_sorted);
+  unsigned long long* hkeys = reinterpret_cast<unsigned long long*>(ws + L.hkeys);
+  int32_t* hstart = reinterpret_cast<int32_t*>(ws + L.hstart);
+  int32_t* hend = reinterpret_cast<int32_t*>(ws + L.hend);
+  void* temp = ws + L.temp;
+  const float r2 = radius * radius;
+  if (radius <= 0.f) {   // degenerate: no strict-inequality hit at all
+    WSIS_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)N * 4, st));
+  } else {
+    const float inv_cell = 1.0f / (radius * 1.001f);   // cell slightly larger than r: neighbours within +-1 cell
+    const int g = grid_for(N, 256);
+    hipLaunchKernelGGL(bq_keys_kernel, dim3(g), dim3(256), 0, st, d_xyz, d_batch_idx, N, inv_cell, keys, iota);
+    WSIS_LAUNCH_CHECK();
+    size_t tb = temp_bytes;
+    WSIS_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, keys, keys_sorted, iota, perm, (size_t)N, 0, 64, st));
+    WSIS_HIP_CHECK(hipMemsetAsync(hkeys, 0xFF, (size_t)L.cap * 8, st));
+    hipLaunchKernelGGL(bq_cells_kernel, dim3(g), dim3(256), 0, st, keys_sorted, N, hkeys, hstart, hend,
+                       (uint64_t)(L.cap - 1));
+    WSIS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bq_grid_kernel<false>, dim3(g), dim3(256), 0, st, d_xyz, d_batch_idx, N, r2, inv_cell, perm,
+                       hkeys, hstart, hend, (uint64_t)(L.cap - 1), counts, (const int32_t*)nullptr, (int32_t*)nullptr);
+    WSIS_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(bq_cap_kernel, dim3(grid_for(N, 256)), dim3(256), 0, st, capped, counts, N);
   WSIS_LAUNCH_CHECK();
-  size_t need = 0;
-  WSIS_HIP_CHECK(rocprim::exclusive_scan(nullptr, need, counts, starts, 0, (size_t)N, rocprim::plus<int32_t>(), st));
-  WSIS_REQUIRE(need <= temp_bytes, "workspace too small for scan");
-  WSIS_HIP_CHECK(rocprim::exclusive_scan(temp, temp_bytes, counts, starts, 0, (size_t)N,
-                                         rocprim::plus<int32_t>(), st));
-  hipLaunchKernelGGL(start_len_kernel, dim3(grid_for(N, 256)), dim3(256), 0, st, counts, starts, N, d_start_len,
+  size_t tb = temp_bytes;
+  WSIS_HIP_CHECK(rocprim::exclusive_scan(temp, tb, capped, starts, 0, (size_t)N, rocprim::plus<int32_t>(), st));
+  hipLaunchKernelGGL(start_len_kernel, dim3(grid_for(N, 256)), dim3(256), 0, st, capped, starts, N, d_start_len,
                      d_total);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
@@ -139,13 +293,27 @@ int wsis_ballquery_fill(const float* d_xyz, const int32_t* d_batch_idx, const in
                         int64_t N, int32_t B, float radius, const int32_t* d_start_len, int32_t* d_idx,
                         int64_t total, void* d_ws, int64_t ws_bytes, void* stream) {
   WSIS_REQUIRE(N >= 0 && B >= 0 && radius >= 0.f && total >= 0, "bad args");
-  (void)d_ws;
-  (void)ws_bytes;
   if (N == 0 || total == 0) return WSIS_OK;
-  WSIS_REQUIRE(d_xyz && d_batch_idx && d_batch_off && d_start_len && d_idx, "null pointer");
-  const unsigned grid = (unsigned)ceil_div(N, BQ_BLOCK);
-  hipLaunchKernelGGL(ballquery_kernel<true>, dim3(grid), dim3(BQ_BLOCK), 0, as_stream(stream), d_xyz,
-                     d_batch_idx, d_batch_off, N, radius * radius, (int32_t*)nullptr, d_start_len, d_idx);
+  WSIS_REQUIRE(d_xyz && d_batch_idx && d_batch_off && d_start_len && d_idx && d_ws, "null pointer");
+  // the workspace still holds the grid of wsis_ballquery_count (same N, same stream order)
+  size_t temp_bytes = 0;
+  WSIS_REQUIRE(bq_temp_bytes(N, &temp_bytes) == 0, "rocprim size query failed");
+  const BqLayout L = bq_layout(N, temp_bytes);
+  WSIS_REQUIRE((int64_t)L.total <= ws_bytes, "workspace too small");
+  char* ws = static_cast<char*>(d_ws);
+  int32_t* counts = reinterpret_cast<int32_t*>(ws + L.counts);
+  int32_t* perm = reinterpret_cast<int32_t*>(ws + L.perm);
+  unsigned long long* hkeys = reinterpret_cast<unsigned long long*>(ws + L.hkeys);
+  int32_t* hstart = reinterpret_cast<int32_t*>(ws + L.hstart);
+  int32_t* hend = reinterpret_cast<int32_t*>(ws + L.hend);
+  hipStream_t st = as_stream(stream);
+  const float r2 = radius * radius;
+  const float inv_cell = 1.0f / (radius * 1.001f);
+  hipLaunchKernelGGL(bq_grid_kernel<true>, dim3(grid_for(N, 256)), dim3(256), 0, st, d_xyz, d_batch_idx, N, r2,
+                     inv_cell, perm, hkeys, hstart, hend, (uint64_t)(L.cap - 1), counts, d_start_len, d_idx);
+  WSIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bq_overflow_kernel, dim3(grid_for(N * 64, 256)), dim3(256), 0, st, d_xyz, d_batch_idx, d_batch_off,
+                     N, r2, counts, d_start_len, d_idx);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

@@ -278,8 +278,9 @@ int wsis_affinity_colmax(const double* d_T, const int32_t* d_label, int32_t cls,
 /* ---- a19/a20: ballquery_batch_p / bfs_cluster [UPSTREAM PG_OP] ------------------------------
  * For point p: ascending indices k of same-batch points with |x_p-x_k|^2 < r^2 (strict, incl. p),
  * capped at 1000.  Deterministic offsets = exclusive prefix sum of the counts.
- * Pass 1 writes d_start_len int32 [N,2] and d_total int32[1]; pass 2 fills d_idx int32 [total].
- * Uniform-grid acceleration: workspace sized by the query. */
+ * Pass 1 writes d_start_len int32 [N,2] and d_total int32[1]; pass 2 fills d_idx int32 [total] and must get
+ * the SAME workspace back untouched (it holds the uniform grid: points radix-sorted by cell of size ~radius and
+ * a cell hash; each point visits 27 cells instead of its whole batch item).  B < 1024, |coordinate| < 2^17 cells. */
 int64_t wsis_ballquery_workspace_bytes(int64_t N);
 int wsis_ballquery_count(const float* d_xyz, const int32_t* d_batch_idx, const int32_t* d_batch_off,
                          int64_t N, int32_t B, float radius, int32_t* d_start_len, int32_t* d_total,

@@ -435,3 +435,49 @@ def test_gather_rows_fwd_bwd_deterministic():
     sg.grad = None
     wsis_ops.gather_rows(sg, idx.to(DEV)).backward(go.to(DEV))
     assert torch.equal(g1, sg.grad)
+
+
+def test_ballquery_grid_large_properties_and_exactness():
+    """uniform-grid ball query at PointGroup scale: exact against the brute-force oracle on a 20 k subset, and
+    size-independent properties (symmetry, self inclusion, ascending lists, prefix-sum offsets) on 250 k points."""
+    rng = np.random.default_rng(5)
+    B, per = 4, 5000
+    xyz = np.concatenate([np.stack([rng.random(per) * 3, rng.random(per) * 2.5, np.round(rng.random(per) * 3) * 0.4
+                                    + rng.normal(0, 0.004, per)], 1) for _ in range(B)]).astype(np.float32)
+    xyz[:40] = xyz[0]                                   # a dense cluster (many duplicates)
+    bi = np.repeat(np.arange(B), per).astype(np.int32)
+    off = (np.arange(B + 1) * per).astype(np.int32)
+    idx, sl = pointgroup_ops.ballquery_batch_p(torch.from_numpy(xyz).to(DEV), torch.from_numpy(bi).to(DEV),
+                                               torch.from_numpy(off).to(DEV), 0.03, 50)
+    e_idx, e_sl = pg_ops.ballquery_batch_p(xyz, bi, off, 0.03)
+    assert np.array_equal(sl.cpu().numpy(), e_sl) and np.array_equal(idx.cpu().numpy(), e_idx)
+    # large
+    per = 62500
+    N = B * per
+    xyz = np.concatenate([np.stack([rng.random(per) * 5, rng.random(per) * 4, np.round(rng.random(per) * 2) * 1.1
+                                    + rng.normal(0, 0.003, per)], 1) for _ in range(B)]).astype(np.float32)
+    bi = np.repeat(np.arange(B), per).astype(np.int32)
+    off = (np.arange(B + 1) * per).astype(np.int32)
+    idx, sl = pointgroup_ops.ballquery_batch_p(torch.from_numpy(xyz).to(DEV), torch.from_numpy(bi).to(DEV),
+                                               torch.from_numpy(off).to(DEV), 0.03, 50)
+    idx, sl = idx.cpu().numpy().astype(np.int64), sl.cpu().numpy().astype(np.int64)
+    start, cnt = sl[:, 0], sl[:, 1]
+    assert np.array_equal(start, np.concatenate([[0], np.cumsum(cnt)[:-1]])) and idx.size == cnt.sum()
+    owner = np.repeat(np.arange(N), cnt)
+    assert (cnt >= 1).all() and (bi[owner] == bi[idx]).all()
+    d = xyz[owner].astype(np.float32) - xyz[idx].astype(np.float32)
+    d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32) + (d[:, 2] * d[:, 2]).astype(np.float32)
+    assert (d2 < np.float32(0.03) * np.float32(0.03)).all()
+    inner = np.ones(idx.size, dtype=bool)
+    inner[start[cnt > 0]] = False
+    assert (np.diff(idx)[inner[1:]] > 0).all(), "ascending neighbour lists"
+    pairs = set(zip(owner[:200000].tolist(), idx[:200000].tolist()))
+    sample = list(pairs)[:5000]
+    full = set(zip(owner.tolist(), idx.tolist()))
+    assert all((b_, a_) in full for a_, b_ in sample), "symmetric relation"
+    assert all((p, p) in full for p in range(0, N, 997)), "every point finds itself"
+    from scipy.spatial import cKDTree
+    sub = np.arange(0, per, 50)
+    tree = cKDTree(xyz[:per].astype(np.float64))
+    ref_cnt = np.array([len(v) for v in tree.query_ball_point(xyz[sub].astype(np.float64), 0.03)])
+    assert np.abs(ref_cnt - cnt[sub]).max() <= 1
