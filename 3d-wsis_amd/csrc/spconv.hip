@@ -26,13 +26,13 @@ namespace {
 constexpr int TM = 128;       // output rows per workgroup
 constexpr int CK = 32;        // input channels staged per step
 constexpr int A_STRIDE = 36;  // words; 16-B aligned rows, conflict-free ds_read_b128
-constexpr int KG = 32;        // kernel offsets handled per group (bit masks are 32 bit)
+constexpr int KG = 16;        // kernel offsets handled per group (LDS slice 16 x 128 ints = 8 KB)
 
 // ------------------------------------------------------------------------------------------
 // forward / dIn kernel
 // ------------------------------------------------------------------------------------------
 template <int NB, bool VEC4, bool DIAG = false>
-__global__ __launch_bounds__(256, (NB <= 1 ? 4 : (NB <= 3 ? 3 : 2))) void spconv_fwd_kernel(
+__global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2)))) void spconv_fwd_kernel(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ residual,
     float* __restrict__ out, float* __restrict__ partial, int64_t M_in, int64_t M_out, int K, int Cin, int Cout,
@@ -266,24 +266,13 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 4 : (NB <= 3 ? 3 : 2))) void spconv
       if (DIAG) tph[7] += 1;
     };
 
-    Stage s0, s1;
-    bool have1 = false;
+    Stage s0;
     fetch(s0, it_kk, it_ci);
     advance();
-    if (it_valid) {
-      fetch(s1, it_kk, it_ci);
-      advance();
-      have1 = true;
-    }
     for (;;) {
-      bool pf = it_valid;
+      const bool pf = it_valid;
       compute(s0, pf);
-      const bool have0 = pf;
-      if (!have1) break;
-      pf = it_valid;
-      compute(s1, pf);
-      have1 = pf;
-      if (!have0) break;
+      if (!pf) break;
     }
   }
 
