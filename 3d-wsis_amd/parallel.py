@@ -16,7 +16,8 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("WSIS_FORCE_DIST", "0") == "1"    # exercise the collective path with one rank (tests)
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -50,36 +51,23 @@ class GradSync(object):
             size += nbytes
         if cur:
             self.buckets.append(cur)
-        self._flat = [None] * len(self.buckets)
 
     def __call__(self, model=None):
-        if self.world == 1:
+        if self.world == 1 and os.environ.get("WSIS_FORCE_DIST", "0") != "1":
             return
-        handles = []
-        for b, bucket in enumerate(self.buckets):
-            n = sum(p.numel() for p in bucket)
-            flat = self._flat[b]
-            if flat is None or flat.numel() != n or flat.device != bucket[0].device:
-                flat = torch.zeros(n, dtype=bucket[0].dtype, device=bucket[0].device)
-                self._flat[b] = flat
-            off = 0
-            for p in bucket:
-                k = p.numel()
-                if p.grad is None:      # unused parameter on this rank still takes part with zeros
-                    flat[off:off + k].zero_()
-                else:
-                    flat[off:off + k].copy_(p.grad.reshape(-1))
-                off += k
-            handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for b, bucket in enumerate(self.buckets):
-            handles[b].wait()
-            flat = self._flat[b]
-            flat.div_(self.world)
-            off = 0
-            for p in bucket:
-                k = p.numel()
-                if p.grad is None:
-                    p.grad = flat[off:off + k].view_as(p).clone()
-                else:
-                    p.grad.copy_(flat[off:off + k].view_as(p))
-                off += k
+        # flatten every bucket with ONE cat kernel, all-reduce asynchronously, copy back with ONE multi-tensor copy
+        work = []
+        for bucket in self.buckets:
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            handle = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work.append((bucket, grads, flat, handle))
+        for bucket, grads, flat, handle in work:
+            handle.wait()
+            if self.world > 1:
+                flat.div_(self.world)
+            views = [v.view_as(g) for v, g in zip(torch.split(flat, [g.numel() for g in grads]), grads)]
+            torch._foreach_copy_(grads, views)
+            for p, g in zip(bucket, grads):
+                if p.grad is None:      # unused parameter on this rank: it still receives the averaged gradient
+                    p.grad = g

@@ -154,8 +154,9 @@ def main():
     batch_host = harness.collate([scene])
     batch = harness.to_device(batch_host, device)
     model, criterion, optimizer = harness.build_model(cfg, device)
-    grad_sync = parallel.GradSync(model) if world > 1 else None
-    if world > 1:   # identical initial weights on every rank
+    use_dist = dist.is_initialized()
+    grad_sync = parallel.GradSync(model) if use_dist else None
+    if use_dist:   # identical initial weights on every rank
         for p in model.parameters():
             dist.broadcast(p.data, 0)
         for b in model.buffers():
@@ -168,7 +169,7 @@ def main():
         step()
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -178,7 +179,7 @@ def main():
         loss, _ = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -234,7 +235,7 @@ def main():
         }
         out.update(extra)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
