@@ -39,12 +39,6 @@ __global__ void csr_offsets_kernel(const uint32_t* __restrict__ sorted, int64_t 
   }
 }
 
-__global__ void fill_i32_kernel(int32_t* __restrict__ p, int64_t n, int32_t v) {
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x)
-    p[i] = v;
-}
-
 // One wave per segment.  Lanes cover G rows x CP channels per step (CP = channels handled per
 // pass, power of two <= 64); partial results of the G row groups are combined with a fixed
 // butterfly, so the sum order depends only on the segment's (sorted) content.
@@ -70,10 +64,8 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(
           const float v = src[(int64_t)p * C + c];
           if (REDUCE == 2) {
             if (v > acc || arg < 0) {  // first occurrence wins inside a group (ascending p)
-              if (v > acc || arg < 0) {
-                acc = v;
-                arg = p;
-              }
+              acc = v;
+              arg = p;
             }
           } else {
             acc += v;

@@ -6,7 +6,8 @@ Same call signatures as the reference's call sites:
   ballquery_batch_p / bfs_cluster   (exported upstream, named by BASELINE.json north_star)
 
 voxelization_idx / bfs_cluster are host operators (libwsis_host.so, CPU tensors in and out, exactly
-like upstream); voxelization / ballquery_batch_p are HIP kernels (libwsis_hip.so).
+like upstream); voxelization / ballquery_batch_p are HIP kernels (libwsis_hip.so).  Extension: voxelization_idx
+also accepts a CUDA LongTensor and then runs on the device with the same first-occurrence contract.
 """
 import torch
 from torch.autograd import Function
@@ -17,17 +18,39 @@ __all__ = ["voxelization_idx", "voxelization", "ballquery_batch_p", "bfs_cluster
            "Voxelization_Idx", "Voxelization", "BallQueryBatchP", "BFSCluster"]
 
 
+def _voxelization_idx_gpu(coords):
+    lib = _n.hip()
+    dev = coords.device
+    N = coords.size(0)
+    ws_bytes = lib.wsis_voxelize_idx_workspace_bytes(N)
+    if ws_bytes < 0:
+        raise _n.WsisError("voxelize_idx workspace query failed")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    p2v = torch.empty(N, dtype=torch.int32, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    st = _n.stream_ptr()
+    _n.check(lib.wsis_voxelize_idx_map(_n.ptr(coords), N, _n.ptr(p2v), _n.ptr(counts), _n.ptr(ws), ws_bytes, st),
+             "voxelize_idx_map")
+    M, ma = (int(v) for v in counts.tolist())
+    locs = torch.empty((M, 4), dtype=torch.int64, device=dev)
+    v2p = torch.empty((M, ma + 1), dtype=torch.int32, device=dev)
+    _n.check(lib.wsis_voxelize_idx_fill(_n.ptr(coords), N, M, ma, _n.ptr(locs), _n.ptr(v2p), _n.ptr(ws), ws_bytes, st),
+             "voxelize_idx_fill")
+    return locs, p2v, v2p
+
+
 class Voxelization_Idx(Function):
     @staticmethod
     def forward(ctx, coords, batchsize, mode=4):
         """coords: LongTensor [N,4] (batch, x, y, z), CPU, contiguous.
         returns (output_coords Long [M,4], input_map Int [N], output_map Int [M, maxActive+1])"""
         assert coords.dtype == torch.int64 and coords.dim() == 2 and coords.size(1) == 4
-        if coords.is_cuda:
-            raise _n.WsisError("voxelization_idx takes CPU tensors (it runs in DataLoader workers)")
-        assert coords.is_contiguous()
         if mode != 4:
             raise NotImplementedError("only mode=4 (mean) is used by 3D-WSIS (config data.mode: 4)")
+        if coords.is_cuda:
+            # extension (SURVEY 8f-4): device tensors in -> device tensors out, same first-occurrence contract
+            return _voxelization_idx_gpu(coords.contiguous())
+        assert coords.is_contiguous()
         N = coords.size(0)
         lib = _n.host()
         input_map = torch.empty(N, dtype=torch.int32)

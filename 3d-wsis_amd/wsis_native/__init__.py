@@ -54,6 +54,9 @@ _HIP_SIGS = {
     "wsis_device_count": (I32, []),
     "wsis_voxelize_fwd": (I32, [P, P, P, I64, I32, I32, I32, P]),
     "wsis_voxelize_bwd": (I32, [P, P, P, I64, I32, I32, I32, P]),
+    "wsis_voxelize_idx_workspace_bytes": (I64, [I64]),
+    "wsis_voxelize_idx_map": (I32, [P, I64, P, P, P, I64, P]),
+    "wsis_voxelize_idx_fill": (I32, [P, I64, I64, I32, P, P, P, I64, P]),
     "wsis_hash_build": (I32, [P, I64, P, P, P, I64, P]),
     "wsis_rulebook_subm": (I32, [P, I64, P, P, P, P, P, I64, P, P, P]),
     "wsis_rulebook_down_ncand": (I64, [I64, P, P, P]),

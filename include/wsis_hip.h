@@ -91,6 +91,17 @@ int wsis_voxelize_fwd(const float* d_feats, const int32_t* d_v2p, float* d_out, 
 int wsis_voxelize_bwd(const float* d_dout, const int32_t* d_v2p, float* d_dfeats, int64_t M, int32_t C,
                       int32_t stride, int32_t mode, void* stream);
 
+/* ---- GPU voxelization_idx (a1 off the CPU workers) ------------------------------------------------
+ * Same contract as wsis_host_voxelize_idx_* (first-occurrence voxel ids, ascending point lists), bit-exact.
+ * d_coords int64 [N,4] device.  Pass 1 writes d_p2v int32 [N] and d_counts2 int32[2] = {M, max_active}; the caller
+ * reads them back, allocates voxel_locs int64 [M,4] and v2p int32 [M,1+max_active], and calls pass 2 with the SAME
+ * workspace (it holds the points sorted by voxel id). */
+int64_t wsis_voxelize_idx_workspace_bytes(int64_t N);
+int wsis_voxelize_idx_map(const int64_t* d_coords, int64_t N, int32_t* d_p2v, int32_t* d_counts2, void* d_ws,
+                          int64_t ws_bytes, void* stream);
+int wsis_voxelize_idx_fill(const int64_t* d_coords, int64_t N, int64_t M, int32_t max_active,
+                           int64_t* d_voxel_locs, int32_t* d_v2p, void* d_ws, int64_t ws_bytes, void* stream);
+
 /* ---- a5/a6: rulebooks [UPSTREAM spconv getIndicePair]  sparse_unet3d.py:130,261,292 ---------
  * Native rulebook format = gather table nbr int32 [K, M_rows]: nbr[k][r] = row of the OTHER side
  * paired with row r under flat kernel offset k (row-major over the 3 kernel dims), or -1.

@@ -481,3 +481,21 @@ def test_ballquery_grid_large_properties_and_exactness():
     tree = cKDTree(xyz[:per].astype(np.float64))
     ref_cnt = np.array([len(v) for v in tree.query_ball_point(xyz[sub].astype(np.float64), 0.03)])
     assert np.abs(ref_cnt - cnt[sub]).max() <= 1
+
+
+# ---------------------------------------------------------------- GPU voxelization_idx (8f-4)
+@pytest.mark.parametrize("N", [1, 37, 5000, 300000])
+def test_voxelization_idx_gpu_matches_host(N):
+    rng = np.random.default_rng(N)
+    ext = 6 if N < 100 else 70
+    coords = np.concatenate([rng.integers(0, 3, (N, 1)), rng.integers(0, ext, (N, 3))], 1).astype(np.int64)
+    coords[N // 2:, 1] += 2 ** 36                      # large values: the hash may not assume small coordinates
+    h_locs, h_p2v, h_v2p = pointgroup_ops.voxelization_idx(torch.from_numpy(coords), 3, 4)
+    d_locs, d_p2v, d_v2p = pointgroup_ops.voxelization_idx(torch.from_numpy(coords).to(DEV), 3, 4)
+    assert d_locs.is_cuda and d_locs.dtype == torch.int64 and d_p2v.dtype == torch.int32
+    assert torch.equal(d_p2v.cpu(), h_p2v) and torch.equal(d_locs.cpu(), h_locs) and torch.equal(d_v2p.cpu(), h_v2p)
+
+
+def test_voxelization_idx_gpu_empty():
+    locs, p2v, v2p = pointgroup_ops.voxelization_idx(torch.zeros((0, 4), dtype=torch.int64, device=DEV), 1, 4)
+    assert locs.shape == (0, 4) and p2v.shape == (0,) and v2p.shape == (0, 1)
