@@ -86,6 +86,62 @@ __global__ __launch_bounds__(256) void ecc_msg_bwd_kernel(const float* __restric
   }
 }
 
+// backward, C == 32 (the model's width): wave per target node, lane l owns filter row i = l>>1 and the 16 output
+// channels of half l&1 as four float4 -- every filter / filter-gradient matrix moves as one contiguous 4 KB
+// transaction set.  Edge metadata (edge id, source, 1/cnt) of up to 64 incoming edges is fetched by 64 lanes at
+// once and handed out with readlane, so the per-edge loop has no dependent index loads.
+__global__ __launch_bounds__(256) void ecc_msg_bwd32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ dout,
+                                                            const int64_t* __restrict__ src,
+                                                            const int32_t* __restrict__ perm_dst,
+                                                            const int32_t* __restrict__ off_dst,
+                                                            const int32_t* __restrict__ off_src,
+                                                            float* __restrict__ dx, float* __restrict__ dw, int64_t S) {
+  constexpr int C = 32;
+  const int lane = threadIdx.x & 63;
+  const int i = lane >> 1, h = lane & 1;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t d = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); d < S; d += nwaves) {
+    const int beg = off_dst[d], end = off_dst[d + 1];
+    const float xi = x[d * C + i];
+    float acc = 0.0f;
+    for (int base = beg; base < end; base += 64) {
+      const int n = min(64, end - base);
+      int32_t e_l = 0, s_l = 0;
+      float inv_l = 0.0f;
+      if (lane < n) {
+        e_l = perm_dst[base + lane];
+        s_l = (int32_t)src[e_l];
+        const int cnt = off_src[s_l + 1] - off_src[s_l];
+        inv_l = 1.0f / (float)(cnt > 0 ? cnt : 1);
+      }
+      for (int j = 0; j < n; ++j) {
+        const int32_t e = __builtin_amdgcn_readlane(e_l, j);
+        const int32_t sn = __builtin_amdgcn_readlane(s_l, j);
+        const float inv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int32_t, inv_l), j));
+        const float4* dm = reinterpret_cast<const float4*>(dout + (int64_t)sn * C + h * 16);
+        const float4* we = reinterpret_cast<const float4*>(w + (int64_t)e * C * C + i * C + h * 16);
+        float4* dwe = reinterpret_cast<float4*>(dw + (int64_t)e * C * C + i * C + h * 16);
+        float p = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 g = dm[q];
+          const float4 wv = we[q];
+          g.x *= inv; g.y *= inv; g.z *= inv; g.w *= inv;
+          dwe[q] = make_float4(xi * g.x, xi * g.y, xi * g.z, xi * g.w);
+          p += wv.x * g.x;
+          p += wv.y * g.y;
+          p += wv.z * g.z;
+          p += wv.w * g.w;
+        }
+        const float other = __shfl_xor(p, 1, 64);
+        acc += (h == 0) ? (p + other) : (other + p);   // both halves form (low half + high half)
+      }
+    }
+    if (h == 0) dx[d * C + i] = acc;
+  }
+}
+
 int waves_grid(int64_t n) {
   int64_t g = ceil_div(n, 4);
   if (g < 1) g = 1;
@@ -115,8 +171,14 @@ int wsis_ecc_message_bwd(const float* d_x, const float* d_w, const float* d_dout
   if (S == 0) return WSIS_OK;
   WSIS_REQUIRE(d_x && d_dout && d_off_dst && d_off_src && d_dx && (E == 0 || (d_w && d_src && d_perm_dst && d_dw)),
                "null pointer");
-  hipLaunchKernelGGL(ecc_msg_bwd_kernel, dim3(waves_grid(S)), dim3(256), 0, as_stream(stream), d_x, d_w, d_dout,
-                     d_src, d_perm_dst, d_off_dst, d_off_src, d_dx, d_dw, S, C);
+  const bool fast = C == 32 && ((reinterpret_cast<uintptr_t>(d_w) | reinterpret_cast<uintptr_t>(d_dw) |
+                                  reinterpret_cast<uintptr_t>(d_dout)) & 15) == 0;
+  if (fast)
+    hipLaunchKernelGGL(ecc_msg_bwd32_kernel, dim3(waves_grid(S)), dim3(256), 0, as_stream(stream), d_x, d_w, d_dout,
+                       d_src, d_perm_dst, d_off_dst, d_off_src, d_dx, d_dw, S);
+  else
+    hipLaunchKernelGGL(ecc_msg_bwd_kernel, dim3(waves_grid(S)), dim3(256), 0, as_stream(stream), d_x, d_w, d_dout,
+                       d_src, d_perm_dst, d_off_dst, d_off_src, d_dx, d_dw, S, C);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

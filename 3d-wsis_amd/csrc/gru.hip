@@ -234,33 +234,63 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void gru_bwd_kernel(
       dh[row * GC + c] = dhc;
     }
   }
-  // per-wave slab: [Wih 96x32][Whh 96x32][Wig 32x32][bih 96][bhh 96][big 32]
-  float* p = partial + ((int64_t)blockIdx.x * GRU_WAVES + wave) * GRU_P;
+  // per-workgroup slab [Wih 96x32][Whh 96x32][Wig 32x32][bih 96][bhh 96][big 32]: the waves add their
+  // accumulators into one LDS slab in wave order (fixed order -> deterministic), then the slab goes out coalesced
+  __syncthreads();                                   // every wave is done with the weights: reuse their LDS
+  float* slab = reinterpret_cast<float*>(smem);
+  static_assert(sizeof(GruLds) >= GRU_P * sizeof(float), "slab must fit in the weight region");
+  for (int w = 0; w < GRU_WAVES; ++w) {
+    if (wave == w) {
+      const bool first = (w == 0);
 #pragma unroll
-  for (int t = 0; t < 48; ++t) {
-    const int o = hi + 2 * t;
-    p[o * GC + c] = aWih[t];
-    p[G3 * GC + o * GC + c] = aWhh[t];
-  }
+      for (int t = 0; t < 48; ++t) {
+        const int o = hi + 2 * t;
+        float* a = slab + o * GC + c;
+        float* b = slab + G3 * GC + o * GC + c;
+        *a = first ? aWih[t] : *a + aWih[t];
+        *b = first ? aWhh[t] : *b + aWhh[t];
+      }
 #pragma unroll
-  for (int t = 0; t < 16; ++t) p[2 * G3 * GC + (hi + 2 * t) * GC + c] = aWig[t];
-  float* pb = p + 2 * G3 * GC + GC * GC;
-  pb[lane] = abih1;
-  pb[G3 + lane] = abhh1;
-  if (two) {
-    pb[64 + lane] = abih2;
-    pb[G3 + 64 + lane] = abhh2;
-    pb[2 * G3 + lane] = abig;
+      for (int t = 0; t < 16; ++t) {
+        float* a = slab + 2 * G3 * GC + (hi + 2 * t) * GC + c;
+        *a = first ? aWig[t] : *a + aWig[t];
+      }
+      float* pb = slab + 2 * G3 * GC + GC * GC;
+      pb[lane] = first ? abih1 : pb[lane] + abih1;
+      pb[G3 + lane] = first ? abhh1 : pb[G3 + lane] + abhh1;
+      if (two) {
+        pb[64 + lane] = first ? abih2 : pb[64 + lane] + abih2;
+        pb[G3 + 64 + lane] = first ? abhh2 : pb[G3 + 64 + lane] + abhh2;
+        pb[2 * G3 + lane] = first ? abig : pb[2 * G3 + lane] + abig;
+      }
+    }
+    __syncthreads();
   }
+  float* p = partial + (int64_t)blockIdx.x * GRU_P;
+  for (int f = threadIdx.x; f < GRU_P; f += blockDim.x) p[f] = slab[f];
 }
 
-__global__ void gru_reduce_kernel(const float* __restrict__ partial, int nslab, float* __restrict__ dWih,
-                                  float* __restrict__ dWhh, float* __restrict__ dWig, float* __restrict__ dbih,
-                                  float* __restrict__ dbhh, float* __restrict__ dbig) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= GRU_P) return;
+constexpr int RED_OUT = 32;    // outputs per workgroup of the slab reduce
+constexpr int RED_LANES = 8;   // slab lanes per output
+
+__global__ __launch_bounds__(RED_OUT * RED_LANES) void gru_reduce_kernel(
+    const float* __restrict__ partial, int nslab, float* __restrict__ dWih, float* __restrict__ dWhh,
+    float* __restrict__ dWig, float* __restrict__ dbih, float* __restrict__ dbhh, float* __restrict__ dbig) {
+  // 32 outputs x 8 slab lanes per workgroup: lane y sums slabs y, y+8, ... in order, then the 8 partial sums are
+  // added in lane order -- a fixed summation tree, independent of the launch
+  __shared__ float part[RED_LANES][RED_OUT];
+  const int ox = threadIdx.x % RED_OUT, sy = threadIdx.x / RED_OUT;
+  const int i = blockIdx.x * RED_OUT + ox;
   float s = 0.f;
-  for (int k = 0; k < nslab; ++k) s += partial[(int64_t)k * GRU_P + i];
+  if (i < GRU_P) {
+#pragma unroll 4
+    for (int k = sy; k < nslab; k += RED_LANES) s += partial[(int64_t)k * GRU_P + i];
+  }
+  part[sy][ox] = s;
+  __syncthreads();
+  if (sy != 0 || i >= GRU_P) return;
+#pragma unroll
+  for (int y = 1; y < RED_LANES; ++y) s += part[y][ox];
   if (i < G3 * GC)
     dWih[i] = s;
   else if (i < 2 * G3 * GC)
@@ -276,9 +306,9 @@ __global__ void gru_reduce_kernel(const float* __restrict__ partial, int nslab, 
 }
 
 int gru_blocks(int64_t S) {
-  int64_t b = ceil_div(S, GRU_WAVES * 4);   // ~4 rows per wave
+  int64_t b = ceil_div(S, GRU_WAVES * 2);   // ~2 rows per wave
   if (b < 1) b = 1;
-  if (b > 128) b = 128;
+  if (b > 256) b = 256;
   return (int)b;
 }
 
@@ -288,7 +318,7 @@ extern "C" {
 
 int64_t wsis_gru_cell_workspace_bytes(int64_t S) {
   if (S < 0) return -1;
-  return (int64_t)gru_blocks(S) * GRU_WAVES * GRU_P * (int64_t)sizeof(float) + 256;
+  return (int64_t)gru_blocks(S) * GRU_P * (int64_t)sizeof(float) + 256;
 }
 
 int wsis_gru_cell_fwd(const float* d_x, const float* d_h, const float* d_Wig, const float* d_big,
@@ -323,8 +353,8 @@ int wsis_gru_cell_bwd(const float* d_x, const float* d_h, const float* d_Wig, co
   hipLaunchKernelGGL(gru_bwd_kernel, dim3(nb), dim3(64 * GRU_WAVES), lds, st, d_x, d_h, d_Wig, d_big, d_Wih, d_Whh,
                      d_bih, d_bhh, d_dhy, d_dx, d_dh, partial, S);
   WSIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gru_reduce_kernel, dim3((GRU_P + 255) / 256), dim3(256), 0, st, partial, nb * GRU_WAVES, d_dWih,
-                     d_dWhh, d_dWig, d_dbih, d_dbhh, d_dbig);
+  hipLaunchKernelGGL(gru_reduce_kernel, dim3((GRU_P + RED_OUT - 1) / RED_OUT), dim3(RED_OUT * RED_LANES), 0, st, partial,
+                     nb, d_dWih, d_dWhh, d_dWig, d_dbih, d_dbhh, d_dbig);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

@@ -342,12 +342,37 @@ struct ProfScope {
   }
 };
 
-int fwd_ksplit(int64_t M_out, int K, int Cout) {
+// output-channel blocks (of 32) one workgroup owns.  Levels with <= 100 row tiles run one block per workgroup:
+// more workgroups and fewer MFMAs per step on each workgroup's latency chain (measured on the C2 pyramid:
+// 96 ch 55->48 us, 128 ch 44->33 us, 160 ch 41->25 us).  WSIS_FWD_NB_SMALL / WSIS_FWD_SMALL_TILES: tuning knobs.
+int fwd_nb(int64_t M_out, int Cout) {
+  static int nb_small = -1, small_tiles = -1;
+  if (nb_small < 0) {
+    const char* e = getenv("WSIS_FWD_NB_SMALL");
+    nb_small = e ? atoi(e) : 1;
+    e = getenv("WSIS_FWD_SMALL_TILES");
+    small_tiles = e ? atoi(e) : 100;
+  }
   const int nblk = (Cout + 31) / 32;
-  const int NB = nblk <= 5 ? nblk : 4;
+  int NB = nblk <= 5 ? nblk : 4;
+  if (ceil_div(M_out, TM) <= small_tiles && NB > nb_small) {
+    // balanced groups: e.g. 5 blocks with cap 2 -> 3 groups of 2,2,1 ; 4 blocks cap 3 -> 2 groups of 2
+    const int groups = (nblk + nb_small - 1) / nb_small;
+    NB = (nblk + groups - 1) / groups;
+  }
+  return NB;
+}
+
+int fwd_ksplit(int64_t M_out, int K, int Cout) {
+  static int target = -1;   // WSIS_KSPLIT_TARGET: workgroups aimed for when splitting the offsets (tuning knob)
+  if (target < 0) {
+    const char* e = getenv("WSIS_KSPLIT_TARGET");
+    target = e ? atoi(e) : 1024;
+  }
+  const int NB = fwd_nb(M_out, Cout);
   const int64_t wgs = ceil_div(M_out, TM) * ceil_div(Cout, NB * 32);
-  if (wgs >= 512 || K == 1) return 1;
-  int64_t ks = ceil_div(1024, wgs);
+  if (wgs >= target / 2 || K == 1) return 1;
+  int64_t ks = ceil_div(target, wgs);
   if (ks > K) ks = K;
   return (int)ks;
 }
@@ -551,8 +576,7 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
   WSIS_REQUIRE(d_X && d_W && d_out, "null pointer");
   WSIS_REQUIRE(d_nbr || (K == 1 && M_in == M_out), "nbr may be null only for the dense 1x1 case");
   WSIS_REQUIRE(M_out < (int64_t)1 << 31 && M_in < (int64_t)1 << 31, "row count exceeds int32");
-  const int nblk = (Cout + 31) / 32;
-  const int NB = nblk <= 5 ? nblk : 4;
+  const int NB = fwd_nb(M_out, Cout);
   const int ksplit = fwd_ksplit(M_out, K, Cout);
   const int k_per = (K + ksplit - 1) / ksplit;
   const int kz = (K + k_per - 1) / k_per;   // blocks along z that own at least one offset
