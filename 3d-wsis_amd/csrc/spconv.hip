@@ -28,6 +28,19 @@ constexpr int CK = 32;        // input channels staged per step
 constexpr int A_STRIDE = 36;  // words; 16-B aligned rows, conflict-free ds_read_b128
 constexpr int KG = 16;        // kernel offsets handled per group (LDS slice 16 x 128 ints = 8 KB)
 
+// Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8), each with its own 4 MB L2.  With
+// WSIS_XCD_AWARE=1 the work items (tile-major) are dealt so that XCD c owns one contiguous run of tiles, whose
+// overlapping gathers then share that XCD's L2.  Measured on the C2 pyramid it is 5-10 % SLOWER than the plain
+// round-robin (75.6 -> 81.1 us at level 0, 48.9 -> 54.5 us at level 2): the gathers are not L2-miss bound, and
+// contiguous runs lose the statistical load balance of dealing heavy / light tiles over all XCDs.  Default off.
+// Bijection lin -> w for any total (q = total / 8, r = total % 8).
+constexpr int N_XCD = 8;
+__device__ __forceinline__ unsigned xcd_deal(unsigned lin, unsigned total) {
+  const unsigned xcd = lin % N_XCD, idx = lin / N_XCD;
+  const unsigned q = total / N_XCD, r = total % N_XCD;
+  return xcd * q + (xcd < r ? xcd : r) + idx;
+}
+
 // ------------------------------------------------------------------------------------------
 // forward / dIn kernel
 // ------------------------------------------------------------------------------------------
@@ -36,7 +49,7 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ residual,
     float* __restrict__ out, float* __restrict__ partial, int64_t M_in, int64_t M_out, int K, int Cin, int Cout,
-    int k_per, unsigned long long* __restrict__ dbg = nullptr) {
+    int k_per, int xcd_aware, unsigned long long* __restrict__ dbg = nullptr) {
   // DIAG build only: per-phase cycle sums of wave 0 (s_memtime), written to dbg[blockIdx.x*8 + phase]
   unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = 0;
@@ -59,8 +72,17 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2
   const int wave = tid >> 6;
   const int half = lane >> 5;
   const int l31 = lane & 31;
-  const int64_t tile0 = (int64_t)blockIdx.x * TM;
-  const int col0 = blockIdx.y * (NB * 32);
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (xcd_aware) {
+    const unsigned per_tile = gridDim.y * gridDim.z;
+    const unsigned w = xcd_deal(bx + gridDim.x * (by + gridDim.y * bz), gridDim.x * per_tile);
+    bx = w / per_tile;
+    const unsigned rest = w - bx * per_tile;
+    bz = rest / gridDim.y;
+    by = rest - bz * gridDim.y;
+  }
+  const int64_t tile0 = (int64_t)bx * TM;
+  const int col0 = by * (NB * 32);
   const int ncols = min(NB * 32, Cout - col0);
 
   int32_t my_row = -1;
@@ -79,7 +101,7 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2
   // kernel-offset split: blockIdx.z owns offsets [k_begin, k_end); with gridDim.z > 1 the raw sums go to a
   // partial slab that spconv_reduce_kernel adds in a fixed order (small levels have too few tiles to fill
   // 256 CUs otherwise).
-  const int k_begin = blockIdx.z * k_per;
+  const int k_begin = bz * k_per;
   const int k_end = min(K, k_begin + k_per);
 
   // per-thread staging coordinates (constant over the walk)
@@ -278,10 +300,10 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2
 
   if (DIAG && dbg && tid == 0) {
     stamp(6);
-    for (int i = 0; i < 8; ++i) dbg[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + i] = tph[i];
+    for (int i = 0; i < 8; ++i) dbg[((int64_t)bz * gridDim.x + bx) * 8 + i] = tph[i];
   }
   // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*half
-  float* dst = (gridDim.z > 1) ? partial + (int64_t)blockIdx.z * M_out * Cout : out;
+  float* dst = (gridDim.z > 1) ? partial + (int64_t)bz * M_out * Cout : out;
   const bool final_pass = gridDim.z == 1;
 #pragma unroll
   for (int cb = 0; cb < NB; ++cb) {
@@ -589,15 +611,20 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
   const bool vec_ok = (Cin % 4 == 0) && (Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_X) & 15) == 0) &&
                       ((reinterpret_cast<uintptr_t>(d_W) & 15) == 0);
   const dim3 grid((unsigned)ceil_div(M_out, TM), (unsigned)ceil_div(Cout, NB * 32), (unsigned)kz);
+  static int xcd_aware = -1;
+  if (xcd_aware < 0) {
+    const char* e = getenv("WSIS_XCD_AWARE");
+    xcd_aware = e ? atoi(e) : 0;
+  }
   ProfScope prof(0, st);
 #define WSIS_FWD_CASE(n)                                                                          \
   case n:                                                                                         \
     if (vec_ok)                                                                                   \
       hipLaunchKernelGGL((spconv_fwd_kernel<n, true>), grid, dim3(256), 0, st, d_X, d_nbr, d_order, d_W,  \
-                         d_bias, d_residual, d_out, partial, M_in, M_out, K, Cin, Cout, k_per); \
+                         d_bias, d_residual, d_out, partial, M_in, M_out, K, Cin, Cout, k_per, xcd_aware); \
     else                                                                                          \
       hipLaunchKernelGGL((spconv_fwd_kernel<n, false>), grid, dim3(256), 0, st, d_X, d_nbr, d_order, d_W, \
-                         d_bias, d_residual, d_out, partial, M_in, M_out, K, Cin, Cout, k_per); \
+                         d_bias, d_residual, d_out, partial, M_in, M_out, K, Cin, Cout, k_per, xcd_aware); \
     break;
   switch (NB) {
     WSIS_FWD_CASE(1)
@@ -654,7 +681,7 @@ int wsis_debug_spconv_diag(const float* d_X, const int32_t* d_nbr, const int32_t
   case n:                                                                                                   \
     hipLaunchKernelGGL((spconv_fwd_kernel<n, true, true>), grid, dim3(256), 0, st, d_X, d_nbr, d_order, d_W, \
                        (const float*)nullptr, (const float*)nullptr, d_out, d_partial, M_out, M_out, K, Cin, Cout, \
-                       k_per, d_dbg);                                                                       \
+                       k_per, 0, d_dbg);                                                                       \
     break;
   switch (nb) {
     WSIS_DIAG_CASE(1)
