@@ -12,6 +12,7 @@
 // buffer in HBM and no scatter-add atomics (upstream spconv does both); the reduction order is fixed,
 // so results are run-to-run deterministic and independent of the tile order.
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -427,34 +428,62 @@ __global__ void rulebook_pack_kernel(const int32_t* __restrict__ nbr, const int3
 }
 
 // ------------------------------------------------------------------------------------------
-// dW kernel: grid (row chunk, offset k, ci-block).  The MFMA A operand is X^T (lane = input channel, the two
-// k-slots = two tile rows), B is dY -- both are coalesced 128-B row segments loaded straight from global
-// memory, no LDS transposition.
-// A wave scans 64 tile rows at a time (one coalesced table read + ballot), then
-// walks only the ACTIVE rows two at a time (scalar bit scan + v_readlane), so inactive rows cost no vector work.
-template <int NBO>
+// dW kernel: grid (work item, ci-block); a work item is (offset k, row chunk j of n_k).  The MFMA A operand is
+// X^T (lane = input channel, the two k-slots = two tile rows), B is dY -- both are coalesced 128-B row segments
+// loaded straight from global memory, no LDS transposition.
+// A wave scans 64 tile rows at a time (one coalesced table read + ballot, the next block's read already in
+// flight), then walks only the ACTIVE rows two at a time (scalar bit scan + v_readlane), so inactive rows cost no
+// vector work.  Row bases are computed on the scalar unit (the row of a k-slot is wave-uniform) and addressed
+// as 32-bit byte offsets from the tensor base -- the vector unit only selects the half's offset and adds the
+// lane's channel (the first version spent ~40 VALU ops per MFMA on 64-bit address arithmetic and was issue-bound:
+// switching the MFMAs off saved 25 %, making every gather cache-hot saved nothing).
+//
+// Work split: the 27 offsets of a 3x3x3 submanifold table are very unevenly filled (C2 scene, level 0: the
+// centre offset pairs every row, a corner offset 1.5 % of them), so the rows of offset k are cut into n_k chunks
+// with n_k proportional to a static weight of the offset type (centre 4 : face 3 : edge 2 : corner 1); other
+// kernels (2x2x2 strided, 1x1x1) use equal chunks.  Each item writes one [ci_pad][Cout] slab; dw_reduce_kernel
+// adds the slabs of an offset in item order (fixed order -> deterministic).
+constexpr int DW_MAX_K = 128;
+struct DwPlan {
+  int begin[DW_MAX_K + 1];   // items of offset k: [begin[k], begin[k+1])
+};
+
+template <int NBO, bool DIAG = false>
 __global__ __launch_bounds__(256) void spconv_dw_kernel(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ dY, float* __restrict__ partial, int64_t M_in, int64_t M_out, int K, int Cin,
-    int Cout, int rows_per_chunk, int n_cib, int co0) {
+    int Cout, DwPlan plan, int n_cib, int co0, unsigned long long* __restrict__ dbg = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4][NBO][1024]
+  // DIAG build only: per-phase cycle sums (s_memtime) of every wave, dbg[(item*4 + wave)*8 + phase]
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = 0;
+  auto stamp = [&](int ph) {
+    if (DIAG) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tph[ph] += now - tlast;
+      tlast = now;
+    }
+  };
+  if (DIAG) tlast = __builtin_amdgcn_s_memtime();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int half = lane >> 5;
   const int l31 = lane & 31;
-  const int chunk = blockIdx.x;
-  const int k = blockIdx.y;
-  const int cib = blockIdx.z;
+  const int item = blockIdx.x;
+  const int cib = blockIdx.y;
+  int k = 0;
+  while (k + 1 < K && plan.begin[k + 1] <= item) ++k;
+  const int n_k = plan.begin[k + 1] - plan.begin[k];
+  const int j = item - plan.begin[k];
   const int ci = cib * 32 + l31;
   const bool ci_ok = ci < Cin;
 
-  const int64_t row_begin = (int64_t)chunk * rows_per_chunk;
-  const int64_t row_end = min(M_out, row_begin + rows_per_chunk);
-  const int64_t span = row_end - row_begin;
-  const int64_t per_wave = (((span + 3) / 4) + 63) & ~(int64_t)63;
-  const int64_t w_begin = row_begin + wave * per_wave;
-  const int64_t w_end = min(row_end, w_begin + per_wave);
+  // the 64-row blocks of the table are dealt round-robin: block b belongs to chunk b % n_k (every chunk samples
+  // the whole scene, so the chunks of one offset carry the same load whatever the local density), and inside the
+  // workgroup the chunk's blocks go round-robin to the 4 waves
+  const int64_t n_blocks_all = (M_out + 63) >> 6;
+  const int64_t n_blocks = n_blocks_all > j ? (n_blocks_all - j + n_k - 1) / n_k : 0;   // blocks j, j+n_k, ...
 
   f32x16 acc[NBO];
 #pragma unroll
@@ -463,61 +492,95 @@ __global__ __launch_bounds__(256) void spconv_dw_kernel(
     for (int i = 0; i < 16; ++i) acc[cb][i] = 0.0f;
 
   const int32_t* nbk = nbrS ? nbrS + (int64_t)k * M_out : nullptr;
+  // lane parts of the byte offsets (clamped to a valid column; out-of-range lanes are zeroed after the load)
+  const uint32_t a_lane = (uint32_t)(ci_ok ? ci : 0) * 4u;
+  uint32_t b_lane[NBO];
   bool cob_ok[NBO];
 #pragma unroll
-  for (int cb = 0; cb < NBO; ++cb) cob_ok[cb] = (co0 + cb * 32 + l31) < Cout;
+  for (int cb = 0; cb < NBO; ++cb) {
+    const int co = co0 + cb * 32 + l31;
+    cob_ok[cb] = co < Cout;
+    b_lane[cb] = (uint32_t)(cob_ok[cb] ? co : 0) * 4u;
+  }
+  const uint32_t a_pitch = (uint32_t)Cin * 4u, b_pitch = (uint32_t)Cout * 4u;
+  const char* Xb = reinterpret_cast<const char*>(X);
+  const char* Yb = reinterpret_cast<const char*>(dY);
 
-  constexpr int U = (NBO <= 2) ? 8 : 4;   // row pairs in flight per wave
-  for (int64_t tb = w_begin; tb < w_end; tb += 64) {
-    const int64_t t = tb + lane;
-    int32_t yr = 0, nb = -1;
-    if (t < w_end) {
+  constexpr int U = (NBO <= 2) ? 8 : 4;   // MFMAs (row pairs) per group
+  constexpr int QCAP = 2 * U + 64;
+  // Per-wave queue of active rows, as byte offsets (x row, dY row).  A scanned block appends its active rows with
+  // one ballot + mbcnt + LDS write (vector compaction: a scalar ctz/readlane walk cost ~1 us per 16 pairs and was
+  // the largest phase of the first version); whenever 2U rows are queued a full group of U MFMAs runs off the
+  // top of the queue, so sparsely filled offsets do not issue mostly-empty groups.  The queue order depends only
+  // on the table and the plan -> deterministic summation order.
+  __shared__ uint2 queue[4][QCAP];
+  uint2* q = queue[wave];
+  int qn = 0;   // wave-uniform
+
+  auto run_group = [&](int base, int count, auto partial_tag) {
+    constexpr bool PARTIAL = decltype(partial_tag)::value;
+    float a[U];
+    float b[U][NBO];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = 2 * u + half;
+      ok[u] = !PARTIAL || e < count;
+      uint2 off = make_uint2(0u, 0u);
+      if (ok[u]) off = q[base + e];
+      a[u] = *reinterpret_cast<const float*>(Xb + (off.x + a_lane));
+#pragma unroll
+      for (int cb = 0; cb < NBO; ++cb) b[u][cb] = *reinterpret_cast<const float*>(Yb + (off.y + b_lane[cb]));
+    }
+    stamp(3);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (PARTIAL && 2 * u >= count) continue;   // wave-uniform
+      const float av = (ok[u] && ci_ok) ? a[u] : 0.0f;
+#pragma unroll
+      for (int cb = 0; cb < NBO; ++cb) {
+        const float bv = (ok[u] && cob_ok[cb]) ? b[u][cb] : 0.0f;
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[cb], 0, 0, 0);
+      }
+    }
+    stamp(4);
+  };
+
+  // (contiguous row ranges left both the chunks of an offset and the waves of a workgroup unevenly loaded: the
+  // barrier before the cross-wave reduce alone was 28 % of the mean wave time)
+  auto scan = [&](int64_t blk, int32_t& yr, int32_t& nb) {
+    const int64_t t = ((int64_t)j + blk * n_k) * 64 + lane;
+    yr = 0;
+    nb = -1;
+    if (t < M_out) {
       yr = order ? order[t] : (int32_t)t;
       nb = nbk ? nbk[t] : yr;
     }
-    unsigned long long m = __ballot(nb >= 0);
-    while (m) {
-      int32_t g[U], y[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        int32_t g0 = -1, g1 = -1, y0 = 0, y1 = 0;
-        if (m) {
-          const int i0 = __builtin_ctzll(m);
-          m &= m - 1;
-          g0 = __builtin_amdgcn_readlane(nb, i0);
-          y0 = __builtin_amdgcn_readlane(yr, i0);
-          if (m) {
-            const int i1 = __builtin_ctzll(m);
-            m &= m - 1;
-            g1 = __builtin_amdgcn_readlane(nb, i1);
-            y1 = __builtin_amdgcn_readlane(yr, i1);
-          }
-        }
-        g[u] = half ? g1 : g0;
-        y[u] = half ? y1 : y0;
-      }
-      float a[U];
-      float b[U][NBO];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const bool oka = g[u] >= 0 && ci_ok;
-        const float ta = X[oka ? (int64_t)g[u] * Cin + ci : 0];
-        a[u] = oka ? ta : 0.0f;
-#pragma unroll
-        for (int cb = 0; cb < NBO; ++cb) {
-          const bool okb = g[u] >= 0 && cob_ok[cb];
-          const float tb = dY[okb ? (int64_t)y[u] * Cout + co0 + cb * 32 + l31 : 0];
-          b[u][cb] = okb ? tb : 0.0f;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (__ballot(g[u] >= 0) == 0ull) continue;
-#pragma unroll
-        for (int cb = 0; cb < NBO; ++cb)
-          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][cb], acc[cb], 0, 0, 0);
-      }
+  };
+  int32_t yr_n = 0, nb_n = -1;
+  if (wave < n_blocks) scan(wave, yr_n, nb_n);
+  stamp(0);
+  for (int64_t blk = wave; blk < n_blocks; blk += 4) {
+    const int32_t yr = yr_n, nb = nb_n;
+    if (blk + 4 < n_blocks) scan(blk + 4, yr_n, nb_n);   // next block's table entries fly during this block's work
+    const unsigned long long m = __ballot(nb >= 0);
+    stamp(1);
+    if (DIAG) tph[6] += 1;
+    if (m) {
+      const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (nb >= 0) q[pos] = make_uint2((uint32_t)nb * a_pitch, (uint32_t)yr * b_pitch);
+      qn += __builtin_popcountll(m);
     }
+    stamp(2);
+    while (qn >= 2 * U) {
+      if (DIAG) tph[7] += 1;
+      qn -= 2 * U;
+      run_group(qn, 2 * U, std::false_type{});
+    }
+  }
+  if (qn > 0) {
+    if (DIAG) tph[7] += 1;
+    run_group(0, qn, std::true_type{});
   }
 
 #pragma unroll
@@ -528,8 +591,13 @@ __global__ __launch_bounds__(256) void spconv_dw_kernel(
       red[(wave * NBO + cb) * 1024 + row * 32 + l31] = acc[cb][reg];
     }
   __syncthreads();
+  if (DIAG && dbg) {
+    stamp(5);
+    if (lane == 0)
+      for (int i = 0; i < 8; ++i) dbg[(((int64_t)item * gridDim.y + cib) * 4 + wave) * 8 + i] = tph[i];
+  }
   const int ci_pad = n_cib * 32;
-  float* dst = partial + (((int64_t)chunk * K + k) * ci_pad + cib * 32) * (int64_t)Cout;
+  float* dst = partial + ((int64_t)item * ci_pad + cib * 32) * (int64_t)Cout;
   for (int f = tid; f < NBO * 1024; f += 256) {
     const int cb = f >> 10;
     const int row = (f >> 5) & 31;
@@ -543,29 +611,54 @@ __global__ __launch_bounds__(256) void spconv_dw_kernel(
   }
 }
 
-__global__ void dw_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int n_chunks,
-                                 int K, int Cin, int Cout, int ci_pad) {
+__global__ void dw_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, DwPlan plan, int K,
+                                 int Cin, int Cout, int ci_pad) {
   const int64_t total = (int64_t)K * Cin * Cout;
-  const int64_t slab = (int64_t)K * ci_pad * Cout;
+  const int64_t slab = (int64_t)ci_pad * Cout;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
     const int co = (int)(t % Cout);
     const int64_t u = t / Cout;
     const int ci = (int)(u % Cin);
     const int k = (int)(u / Cin);
-    const int64_t off = ((int64_t)k * ci_pad + ci) * Cout + co;
+    const float* src = partial + (int64_t)ci * Cout + co;
     float s = 0.0f;
-    for (int c = 0; c < n_chunks; ++c) s += partial[c * slab + off];
+    const int e = plan.begin[k + 1];
+#pragma unroll 4
+    for (int it = plan.begin[k]; it < e; ++it) s += src[it * slab];
     dW[t] = s;
   }
 }
 
-int dw_rows_per_chunk(int64_t M_out) {
-  // ~64 row chunks at the large levels (more chunks did not shorten the kernel and only grow the slab reduce)
-  int64_t rpc = ceil_div(M_out, 64);
-  if (rpc < 256) rpc = 256;
-  rpc = (rpc + 63) & ~(int64_t)63;
-  return (int)rpc;
+// items per offset: base chunks (~64 at the large levels, >= 256 rows each) scaled by the offset-type weight
+int dw_base_chunks(int64_t M_out) {
+  static int div = -1;   // WSIS_DW_DIV: rows per unit-weight chunk below which a level gets fewer chunks (tuning knob)
+  if (div < 0) {
+    const char* e = getenv("WSIS_DW_DIV");
+    div = e ? atoi(e) : 256;
+    if (div < 64) div = 64;
+  }
+  int64_t c = ceil_div(M_out, div);
+  if (c > 32) c = 32;
+  if (c < 1) c = 1;
+  return (int)c;
+}
+
+void dw_make_plan(int64_t M_out, int K, DwPlan& plan) {
+  const int base = dw_base_chunks(M_out);
+  const int64_t max_chunks = M_out <= 0 ? 1 : ceil_div(M_out, 256);   // >= 64 rows per wave
+  plan.begin[0] = 0;
+  for (int k = 0; k < K; ++k) {
+    int w = 2;   // equal chunks (2 * base ~ 64) for anything but the 3x3x3 table
+    if (K == 27) {
+      const int nz = (k / 9 != 1) + ((k / 3) % 3 != 1) + (k % 3 != 1);   // 0 centre, 1 face, 2 edge, 3 corner
+      w = 4 - nz;
+    }
+    int64_t n = (int64_t)w * base;
+    if (n > max_chunks) n = max_chunks;
+    if (n < 1) n = 1;
+    plan.begin[k + 1] = plan.begin[k] + (int)n;
+  }
 }
 
 }  // namespace
@@ -695,6 +788,31 @@ int wsis_debug_spconv_diag(const float* d_X, const int32_t* d_nbr, const int32_t
   return WSIS_OK;
 }
 
+// diagnostic (not part of the ABI header): dW kernel with phase stamps, dbg[items * n_cib * 4 waves * 8]; returns the
+// number of work items through *n_items.  Cout <= 64.
+int wsis_debug_dw_diag(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY,
+                       float* d_partial, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout,
+                       unsigned long long* d_dbg, int32_t* n_items, void* stream) {
+  WSIS_REQUIRE(K <= DW_MAX_K && Cout <= 64 && n_items, "diag supports Cout <= 64");
+  DwPlan plan;
+  dw_make_plan(M_out, K, plan);
+  *n_items = plan.begin[K];
+  if (!d_dbg) return WSIS_OK;
+  const int n_cib = (int)ceil_div(Cin, 32);
+  const int nbo = (Cout + 31) / 32;
+  const dim3 grid((unsigned)plan.begin[K], (unsigned)n_cib, 1);
+  const size_t lds = (size_t)4 * nbo * 1024 * sizeof(float);
+  hipStream_t st = as_stream(stream);
+  if (nbo == 1)
+    hipLaunchKernelGGL((spconv_dw_kernel<1, true>), grid, dim3(256), lds, st, d_X, d_nbr, d_order, d_dY, d_partial, M_in,
+                       M_out, K, Cin, Cout, plan, n_cib, 0, d_dbg);
+  else
+    hipLaunchKernelGGL((spconv_dw_kernel<2, true>), grid, dim3(256), lds, st, d_X, d_nbr, d_order, d_dY, d_partial, M_in,
+                       M_out, K, Cin, Cout, plan, n_cib, 0, d_dbg);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
 int wsis_weight_transpose(const float* d_W, float* d_WT, int32_t K, int32_t Cin, int32_t Cout,
                           int32_t flip, void* stream) {
   WSIS_REQUIRE(K >= 1 && Cin >= 1 && Cout >= 1 && d_W && d_WT, "bad args");
@@ -707,10 +825,11 @@ int wsis_weight_transpose(const float* d_W, float* d_WT, int32_t K, int32_t Cin,
 
 int64_t wsis_spconv_dw_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout) {
   if (M_out < 0 || K < 1 || Cin < 1 || Cout < 1) return -1;
-  const int rpc = dw_rows_per_chunk(M_out);
-  const int64_t n_chunks = M_out == 0 ? 1 : ceil_div(M_out, rpc);
+  if (K > DW_MAX_K) return -1;
+  DwPlan plan;
+  dw_make_plan(M_out, K, plan);
   const int64_t ci_pad = ceil_div(Cin, 32) * 32;
-  return n_chunks * K * ci_pad * Cout * (int64_t)sizeof(float) + 256;
+  return (int64_t)plan.begin[K] * ci_pad * Cout * (int64_t)sizeof(float) + 256;
 }
 
 int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY,
@@ -724,14 +843,17 @@ int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_orde
   }
   WSIS_REQUIRE(d_X && d_dY && d_ws, "null pointer");
   WSIS_REQUIRE(d_nbr || (K == 1 && M_in == M_out), "nbr may be null only for the dense 1x1 case");
+  WSIS_REQUIRE(K <= DW_MAX_K, "dW supports kernel volumes up to 128 offsets");
+  WSIS_REQUIRE(M_in * Cin * 4 < ((int64_t)1 << 32) && M_out * Cout * 4 < ((int64_t)1 << 32),
+               "dW addresses features as 32-bit byte offsets: a feature matrix must stay below 4 GiB");
   WSIS_REQUIRE(ws_bytes >= wsis_spconv_dw_workspace_bytes(M_out, K, Cin, Cout), "workspace too small");
-  const int rpc = dw_rows_per_chunk(M_out);
-  const int n_chunks = (int)ceil_div(M_out, rpc);
+  DwPlan plan;
+  dw_make_plan(M_out, K, plan);
   const int n_cib = (int)ceil_div(Cin, 32);
   const int ci_pad = n_cib * 32;
   float* partial = static_cast<float*>(d_ws);
   const int nblk = (Cout + 31) / 32;
-  const dim3 grid((unsigned)n_chunks, (unsigned)K, (unsigned)n_cib);
+  const dim3 grid((unsigned)plan.begin[K], (unsigned)n_cib, 1);
   // output-channel blocks are processed in groups of <= 5 per launch (register budget)
   ProfScope prof(1, st);
   for (int cb0 = 0; cb0 < nblk; cb0 += 5) {
@@ -740,10 +862,10 @@ int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_orde
     const size_t lds = (size_t)4 * nbo * 1024 * sizeof(float);
 #define WSIS_DW_CASE(n)                                                                                  \
   case n:                                                                                                \
-    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_dw_kernel<n>,                                 \
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_dw_kernel<n, false>,                          \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
-    hipLaunchKernelGGL(spconv_dw_kernel<n>, grid, dim3(256), lds, st, d_X, d_nbr, d_order, d_dY, partial, \
-                       M_in, M_out, K, Cin, Cout, rpc, n_cib, co0);                                      \
+    hipLaunchKernelGGL((spconv_dw_kernel<n, false>), grid, dim3(256), lds, st, d_X, d_nbr, d_order, d_dY, \
+                       partial, M_in, M_out, K, Cin, Cout, plan, n_cib, co0, nullptr);                   \
     break;
     switch (nbo) {
       WSIS_DW_CASE(1)
@@ -757,8 +879,8 @@ int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_orde
   }
   prof.stop();
   const int64_t total = (int64_t)K * Cin * Cout;
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, partial, d_dW, n_chunks,
-                     K, Cin, Cout, ci_pad);
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, partial, d_dW, plan, K, Cin, Cout,
+                     ci_pad);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }
