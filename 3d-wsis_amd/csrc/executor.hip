@@ -1,0 +1,172 @@
+// Op-list executor (runtime of the sparse UNet hot path): the host side records one forward or backward pass of
+// the UNet as a flat array of wsis_op records -- plain pointers and sizes -- and this file issues all of their
+// kernels from ONE C call on one stream.  The reference runs the same sequence as ~100 (forward) / ~350
+// (backward) separate Python-dispatched autograd nodes (modules/model/sparse_unet3d.py:103-350); issuing them
+// natively removes the per-node interpreter / dispatcher / allocator cost that made the step host-bound.
+// Every op maps 1:1 onto the single-op entry points of this library (same kernels, same summation orders, so the
+// results are bit-identical to calling them one by one); CAT / SPLIT / ADD are the elementwise glue of the UNet
+// (torch.cat of the skip connection, its backward, gradient accumulation at the residual fan-out).
+#include "common.h"
+
+using namespace wsis;
+
+namespace {
+
+constexpr int64_t ALIGN = 256;
+inline int64_t up(int64_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
+
+// out[r] = [a[r] | b[r]]
+__global__ void cat_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                int64_t M, int Ca, int Cb) {
+  const int C = Ca + Cb;
+  const int64_t total = M * C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / C;
+    const int c = (int)(t - r * C);
+    out[t] = c < Ca ? a[r * Ca + c] : b[r * Cb + (c - Ca)];
+  }
+}
+
+__global__ void split_rows_kernel(const float* __restrict__ in, float* __restrict__ a, float* __restrict__ b, int64_t M,
+                                  int Ca, int Cb) {
+  const int C = Ca + Cb;
+  const int64_t total = M * C;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / C;
+    const int c = (int)(t - r * C);
+    const float v = in[t];
+    if (c < Ca)
+      a[r * Ca + c] = v;
+    else
+      b[r * Cb + (c - Ca)] = v;
+  }
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+    dst[t] += src[t];
+}
+
+int64_t op_ws_bytes(const wsis_op& op) {
+  switch (op.kind) {
+    case WSIS_OP_CONV:
+      return up(wsis_spconv_fwd_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout));
+    case WSIS_OP_BN_RELU:
+      return (op.flags & WSIS_OPF_TRAINING) ? up(wsis_bn_workspace_bytes(op.M_in, op.Cin)) : 0;
+    case WSIS_OP_BN_RELU_BWD:
+      return up(wsis_bn_workspace_bytes(op.M_in, op.Cin));
+    case WSIS_OP_CONV_BWD: {
+      const int64_t wt = up((int64_t)op.K * op.Cin * op.Cout * (int64_t)sizeof(float));
+      const int64_t din = op.out[0] ? wsis_spconv_fwd_workspace_bytes(op.M_in, op.K, op.Cout, op.Cin) : 0;
+      const int64_t dw = op.out[1] ? wsis_spconv_dw_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout) : 0;
+      return wt + up(din > dw ? din : dw);
+    }
+    default:
+      return 0;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n) {
+  if (!ops || n < 0) return -1;
+  int64_t need = ALIGN;
+  for (int i = 0; i < n; ++i) {
+    const int64_t b = op_ws_bytes(ops[i]);
+    if (b < 0) return -1;
+    if (b > need) need = b;
+  }
+  return need + ALIGN;
+}
+
+int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(ops && n >= 0, "bad op list");
+  WSIS_REQUIRE(ws_bytes >= wsis_run_ops_workspace_bytes(ops, n) && (d_ws || n == 0), "workspace too small");
+  hipStream_t st = as_stream(stream);
+  char* ws = static_cast<char*>(d_ws);
+  for (int i = 0; i < n; ++i) {
+    const wsis_op& op = ops[i];
+    int rc = WSIS_OK;
+    switch (op.kind) {
+      case WSIS_OP_CONV:
+        rc = wsis_spconv_fwd((const float*)op.in[0], (const int32_t*)op.in[1], (const int32_t*)op.in[2],
+                             (const float*)op.in[3], (const float*)op.in[4], (const float*)op.in[5],
+                             (float*)op.out[0], op.M_in, op.M_out, op.K, op.Cin, op.Cout, ws, ws_bytes, stream);
+        break;
+      case WSIS_OP_BN_RELU: {
+        const float* mean = (const float*)op.out[1];
+        const float* var = (const float*)op.out[2];
+        if (op.flags & WSIS_OPF_TRAINING) {
+          const bool upd = (op.flags & WSIS_OPF_UPDATE_RUNNING) != 0;
+          rc = wsis_bn_stats((const float*)op.in[0], op.M_in, op.Cin, (float*)op.out[1], (float*)op.out[2],
+                             upd ? (float*)op.in[3] : nullptr, upd ? (float*)op.in[4] : nullptr, op.momentum, ws,
+                             ws_bytes, stream);
+          if (rc != WSIS_OK) break;
+        } else {
+          mean = (const float*)op.in[3];
+          var = (const float*)op.in[4];
+        }
+        rc = wsis_bn_apply((const float*)op.in[0], mean, var, (const float*)op.in[1], (const float*)op.in[2], op.eps,
+                           (op.flags & WSIS_OPF_RELU) ? 1 : 0, (float*)op.out[0], op.M_in, op.Cin, stream);
+        break;
+      }
+      case WSIS_OP_CAT:
+        if (op.M_in > 0) {
+          hipLaunchKernelGGL(cat_rows_kernel, dim3(grid_for(op.M_in * (op.Cin + op.Cout), 256)), dim3(256), 0, st,
+                             (const float*)op.in[0], (const float*)op.in[1], (float*)op.out[0], op.M_in, op.Cin,
+                             op.Cout);
+          WSIS_LAUNCH_CHECK();
+        }
+        break;
+      case WSIS_OP_SPLIT:
+        if (op.M_in > 0) {
+          hipLaunchKernelGGL(split_rows_kernel, dim3(grid_for(op.M_in * (op.Cin + op.Cout), 256)), dim3(256), 0, st,
+                             (const float*)op.in[0], (float*)op.out[0], (float*)op.out[1], op.M_in, op.Cin, op.Cout);
+          WSIS_LAUNCH_CHECK();
+        }
+        break;
+      case WSIS_OP_ADD:
+        if (op.M_in * op.Cin > 0) {
+          hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(op.M_in * op.Cin, 256)), dim3(256), 0, st,
+                             (float*)op.out[0], (const float*)op.in[0], op.M_in * op.Cin);
+          WSIS_LAUNCH_CHECK();
+        }
+        break;
+      case WSIS_OP_CONV_BWD: {
+        // in: X, W, dY, nbr_f, order_f, nbr_b, order_b ; out: dX (optional), dW (optional)
+        const int64_t wt_bytes = up((int64_t)op.K * op.Cin * op.Cout * (int64_t)sizeof(float));
+        float* WT = reinterpret_cast<float*>(ws);
+        char* rest = ws + wt_bytes;
+        const int64_t rest_bytes = ws_bytes - wt_bytes;
+        if (op.out[0]) {
+          rc = wsis_weight_transpose((const float*)op.in[1], WT, op.K, op.Cin, op.Cout,
+                                     (op.flags & WSIS_OPF_FLIP) ? 1 : 0, stream);
+          if (rc != WSIS_OK) break;
+          rc = wsis_spconv_fwd((const float*)op.in[2], (const int32_t*)op.in[5], (const int32_t*)op.in[6], WT, nullptr,
+                               nullptr, (float*)op.out[0], op.M_out, op.M_in, op.K, op.Cout, op.Cin, rest, rest_bytes,
+                               stream);
+          if (rc != WSIS_OK) break;
+        }
+        if (op.out[1])
+          rc = wsis_spconv_dw((const float*)op.in[0], (const int32_t*)op.in[3], (const int32_t*)op.in[4],
+                              (const float*)op.in[2], (float*)op.out[1], op.M_in, op.M_out, op.K, op.Cin, op.Cout, rest,
+                              rest_bytes, stream);
+        break;
+      }
+      case WSIS_OP_BN_RELU_BWD:
+        rc = wsis_bn_bwd((const float*)op.in[0], (const float*)op.in[1], (const float*)op.in[2], (const float*)op.in[3],
+                         (const float*)op.in[4], (const float*)op.in[5], op.eps, (op.flags & WSIS_OPF_RELU) ? 1 : 0,
+                         (op.flags & WSIS_OPF_TRAINING) ? 1 : 0, (float*)op.out[0], (float*)op.out[1], (float*)op.out[2],
+                         op.M_in, op.Cin, ws, ws_bytes, stream);
+        break;
+      default:
+        return fail(WSIS_ERR_ARG, "wsis_run_ops: unknown op kind");
+    }
+    if (rc != WSIS_OK) return rc;
+  }
+  return WSIS_OK;
+}
+
+}  // extern "C"

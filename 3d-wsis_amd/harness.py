@@ -234,6 +234,9 @@ def forward_loss(model, criterion, batch, cfg, epoch=5):
     voxel_feats = pointgroup_ops.voxelization(feats, batch["v2p_map"], cfg.mode)
     input_ = spconv.SparseConvTensor(voxel_feats, batch["voxel_coords_int"], batch["spatial_shape"], cfg.batch_size)
     input_._ready_event = batch.get("coords_ready_event")
+    rulebooks = batch.get("rulebooks")        # built ahead by a spconv.ops.RulebookPrefetcher (loader stage)
+    if rulebooks is not None:
+        rulebooks.attach(input_)
     ret = model(input_, batch["p2v_map"], extra)
     loss_inp = {
         "point_labels": (batch["semantic_labels"], batch["instance_labels"]),
@@ -262,6 +265,17 @@ def train_step(model, criterion, optimizer, batch, cfg, epoch=5, grad_sync=None)
         torch._foreach_clamp_max_(grads, 1.0)
     optimizer.step()
     return loss.detach(), ret
+
+
+def make_prefetcher(model):
+    """rulebook prefetcher for ``model``'s UNet pyramid (one batch in flight)"""
+    import spconv
+    return spconv.ops.RulebookPrefetcher(model.blocks)
+
+
+def prefetch_rulebooks(prefetcher, batch):
+    """start building the rulebooks of device batch ``batch`` in the background (loader stage)"""
+    prefetcher.submit(batch["voxel_coords_int"], batch["spatial_shape"], batch.get("coords_ready_event"))
 
 
 def build_model(cfg, device, seed=123):

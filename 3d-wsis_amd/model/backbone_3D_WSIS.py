@@ -112,16 +112,23 @@ class Network(nn.Module):
             getattr(self, name).eval()
 
         import os
-        if input.features.is_cuda and os.environ.get("WSIS_PREBUILD", "1") != "0":
-            # all 5 + 4 rulebooks up front: their host syncs happen before the first conv is queued
-            spconv.ops.prebuild_unet_rulebooks(input, self.blocks)
-        output = self.input_conv(input)
-        output = self.unet(output)
-        output = self.output_layer(output)
-        if output.features.is_cuda:                                   # [N, m] voxel -> point
-            output_feats = wsis_ops.gather_rows(output.features, input_map, extra_data.get("p2v_csr"))
+        if input.features.is_cuda and os.environ.get("WSIS_NATIVE_UNET", "1") != "0":
+            # input_conv -> unet -> output_layer recorded as an op list and issued by one native call per pass
+            # (model/unet_native.py); WSIS_NATIVE_UNET=0 walks the modules instead (same kernels, same results)
+            import unet_native
+            voxel_feats = unet_native.run_unet(self, input)
         else:
-            output_feats = output.features[input_map.long()]
+            if input.features.is_cuda and os.environ.get("WSIS_PREBUILD", "1") != "0":
+                # all 5 + 4 rulebooks up front: their host syncs happen before the first conv is queued
+                spconv.ops.prebuild_unet_rulebooks(input, self.blocks)
+            output = self.input_conv(input)
+            output = self.unet(output)
+            output = self.output_layer(output)
+            voxel_feats = output.features
+        if voxel_feats.is_cuda:                                       # [N, m] voxel -> point
+            output_feats = wsis_ops.gather_rows(voxel_feats, input_map, extra_data.get("p2v_csr"))
+        else:
+            output_feats = voxel_feats[input_map.long()]
 
         ret["semantic_scores"] = self.linear(output_feats)          # [N, nClass]
 

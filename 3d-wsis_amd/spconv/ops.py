@@ -385,6 +385,34 @@ def _rulebook_tensors(rb):
     return [t for t in out if t is not None]
 
 
+def _build_pyramid(tensor, n_levels, subm_key, down_key, first_id):
+    """the rulebook chain itself (current stream); returns the tensors it allocated"""
+    built = []
+    indices, shape = tensor.indices, [int(s) for s in tensor.spatial_shape]
+    hash_tab = tensor._hash
+    for lvl in range(n_levels):
+        kid = first_id + lvl
+        key = subm_key.format(kid)
+        if key not in tensor.indice_dict:
+            if hash_tab is None:
+                hash_tab = build_hash(indices, shape)
+                if lvl == 0:
+                    tensor._hash = hash_tab
+                    built += [hash_tab[0], hash_tab[1]]
+            rb = build_subm_rulebook(indices, shape, [3, 3, 3], [1, 1, 1], hash_tab)
+            tensor.indice_dict[key] = rb
+            built += _rulebook_tensors(rb)
+        if lvl + 1 < n_levels:
+            dkey = down_key.format(kid)
+            rb = tensor.indice_dict.get(dkey)
+            if rb is None:
+                rb = build_down_rulebook(indices, shape, [2, 2, 2], [2, 2, 2], [0, 0, 0])
+                tensor.indice_dict[dkey] = rb
+                built += _rulebook_tensors(rb)
+            indices, shape, hash_tab = rb.out_indices, rb.out_shape, rb.out_hash
+    return built
+
+
 def prebuild_unet_rulebooks(tensor, n_levels, subm_key="subm{}", down_key="spconv{}", first_id=1, side_stream=None):
     """Builds every rulebook of a UBlock pyramid (SubM k3 p1 per level, k2 s2 between levels) up front and
     stores them in ``tensor.indice_dict`` under the keys the modules will look up.
@@ -394,44 +422,99 @@ def prebuild_unet_rulebooks(tensor, n_levels, subm_key="subm{}", down_key="spcon
     queued (the previous step's backward / optimizer), so the pipeline is never drained; the main stream joins
     the side stream before the first convolution.  ``tensor.indices`` must be complete before the call
     (``tensor._ready_event``, if set, is waited for on the side stream)."""
+    keys = [subm_key.format(first_id + l) for l in range(n_levels)] + \
+           [down_key.format(first_id + l) for l in range(n_levels - 1)]
+    if all(k in tensor.indice_dict for k in keys):
+        return                   # e.g. attached from a RulebookPrefetcher
     if side_stream is None:
         side_stream = os.environ.get("WSIS_RULEBOOK_STREAM", "1") != "0"
     dev = tensor.indices.device
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev) if side_stream else None
     ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
-    built = []
     if side is not None:
         ev = getattr(tensor, "_ready_event", None)
         if ev is not None:
             side.wait_event(ev)
     with ctx:
-        indices, shape = tensor.indices, [int(s) for s in tensor.spatial_shape]
-        hash_tab = tensor._hash
-        for lvl in range(n_levels):
-            kid = first_id + lvl
-            key = subm_key.format(kid)
-            if key not in tensor.indice_dict:
-                if hash_tab is None:
-                    hash_tab = build_hash(indices, shape)
-                    if lvl == 0:
-                        tensor._hash = hash_tab
-                        built += [hash_tab[0], hash_tab[1]]
-                rb = build_subm_rulebook(indices, shape, [3, 3, 3], [1, 1, 1], hash_tab)
-                tensor.indice_dict[key] = rb
-                built += _rulebook_tensors(rb)
-            if lvl + 1 < n_levels:
-                dkey = down_key.format(kid)
-                rb = tensor.indice_dict.get(dkey)
-                if rb is None:
-                    rb = build_down_rulebook(indices, shape, [2, 2, 2], [2, 2, 2], [0, 0, 0])
-                    tensor.indice_dict[dkey] = rb
-                    built += _rulebook_tensors(rb)
-                indices, shape, hash_tab = rb.out_indices, rb.out_shape, rb.out_hash
+        built = _build_pyramid(tensor, n_levels, subm_key, down_key, first_id)
     if side is not None:
         main.wait_stream(side)
         for t in built:          # allocated on the side stream, consumed on the main stream
             t.record_stream(main)
+
+
+class RulebookSet(object):
+    """Rulebooks of one batch built ahead of its forward pass (see RulebookPrefetcher): the indice_dict / hash a
+    SparseConvTensor of the same coordinates adopts, plus the event that orders them before their consumers."""
+
+    def __init__(self, indices, spatial_shape):
+        self.indices = indices
+        self.spatial_shape = spatial_shape
+        self.indice_dict = {}
+        self._hash = None
+        self.done = None       # recorded on the building stream after the last rulebook kernel
+        self.tensors = []
+
+    def attach(self, tensor):
+        """hand the rulebooks to ``tensor`` (same indices); the current stream waits for the build"""
+        main = torch.cuda.current_stream(tensor.indices.device)
+        if self.done is not None:
+            main.wait_event(self.done)
+        for t in self.tensors:   # allocated on the building stream, consumed on this one
+            t.record_stream(main)
+        tensor.indice_dict.update(self.indice_dict)
+        tensor._hash = self._hash
+
+
+class RulebookPrefetcher(object):
+    """Builds the rulebook pyramid of the NEXT batch on a side stream from a background thread while the current
+    step is still being issued -- the data-loader stage of the sparse-conv path.  The per-level host syncs of the
+    chain (output row counts of the strided levels) then block only the helper thread (torch releases the GIL
+    while it waits), neither the issuing thread nor the main stream.
+
+        pre = RulebookPrefetcher(n_levels)
+        pre.submit(coords_int32, spatial_shape, ready_event)      # batch i+1
+        ... train_step(batch i) ...
+        rulebooks = pre.result()                                  # RulebookSet for batch i+1
+    """
+
+    def __init__(self, n_levels, subm_key="subm{}", down_key="spconv{}", first_id=1):
+        self.args = (n_levels, subm_key, down_key, first_id)
+        self._thread = None
+        self._out = None
+        self._err = None
+
+    def _work(self, rs, ready_event, device):
+        try:
+            torch.cuda.set_device(device)
+            side = _side_stream(device)
+            if ready_event is not None:
+                side.wait_event(ready_event)
+            with torch.cuda.stream(side):
+                rs.tensors = _build_pyramid(rs, *self.args)
+                rs.done = torch.cuda.Event()
+                rs.done.record(side)
+            self._out = rs
+        except BaseException as e:   # surfaced by result()
+            self._err = e
+
+    def submit(self, indices, spatial_shape, ready_event=None):
+        import threading
+        assert self._thread is None, "one batch in flight at a time"
+        _check_indices(indices)
+        rs = RulebookSet(indices, spatial_shape)
+        self._out = self._err = None
+        self._thread = threading.Thread(target=self._work, args=(rs, ready_event, indices.device), daemon=True)
+        self._thread.start()
+
+    def result(self):
+        assert self._thread is not None, "nothing submitted"
+        self._thread.join()
+        self._thread = None
+        if self._err is not None:
+            raise self._err
+        return self._out
 
 
 class _NullCtx(object):

@@ -49,12 +49,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prefetch", action="store_true",
+                    help="build the next step's rulebooks from a helper thread (measured slower: GIL contention)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra event-instrumented steps for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=8)
     ap.add_argument("--cpu-timeout", type=int, default=150)
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-stages", action="store_true",
+                    help="skip the side measurements (copy/triad bandwidth, optimizer step, clustering stage)")
     ap.add_argument("--scene-seed", type=int, default=1)
     ap.add_argument("--small", action="store_true", help="debug: a small room instead of the C2 scene")
     return ap.parse_args()
@@ -93,6 +97,63 @@ def cpu_worker(args):
     dt = (time.time() - t0) / iters
     print(json.dumps({"dt": dt, "warm": warm, "iters": iters, "voxels": int(batch_host["voxel_locs"].shape[0]),
                       "threads": threads}), flush=True)
+
+
+def _gpu_ms(fn, iters):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def side_measurements(harness, optimizer, device, args):
+    """SURVEY 8(d) companions of the headline number, each outside the timed region:
+    measured device copy / triad bandwidth (next to the nominal 8 TB/s), the optimizer step on its own, and the
+    PointGroup-style clustering stage (ballquery_batch_p on the GPU + bfs_cluster on the host) on a C3 batch."""
+    import pointgroup_ops
+    out = {}
+    n = 1 << 28                                     # 1 GiB fp32 per array
+    x = torch.empty(n, dtype=torch.float32, device=device).fill_(1.0)
+    y = torch.empty_like(x).fill_(2.0)
+    z = torch.empty_like(x)
+    ms = _gpu_ms(lambda: z.copy_(x), 10)
+    out["measured_copy_GBs"] = round(2 * n * 4 / (ms * 1e-3) / 1e9, 1)
+    ms = _gpu_ms(lambda: torch.add(x, y, alpha=3.0, out=z), 10)
+    out["measured_triad_GBs"] = round(3 * n * 4 / (ms * 1e-3) / 1e9, 1)
+    del x, y, z
+    out["optimizer_step_ms"] = round(_gpu_ms(optimizer.step, 5), 3)      # fused AdamW over the 11.1 M parameters
+
+    # C3: 4 scenes, non floor/wall points, r = 0.03 m, threshold 50 (SURVEY 8d / Appendix A.2)
+    scenes = [harness.make_scene(s, room=(3.2, 2.6, 2.2), n_box=4) for s in (1, 2, 3, 4)]
+    b = harness.collate(scenes)
+    sem = b["superpoint"] % 20       # stand-in for the predicted class: constant per superpoint, 20 classes
+    keep = torch.nonzero(sem > 1).flatten()
+    coords = b["locs_float"][keep].contiguous().to(device)
+    batch_idx = b["locs"][keep, 0].int().contiguous()
+    offs = torch.zeros(len(scenes) + 1, dtype=torch.int32)
+    offs[1:] = torch.cumsum(torch.bincount(batch_idx.long(), minlength=len(scenes)), 0).int()
+    bi_d, off_d = batch_idx.to(device), offs.to(device)
+    sem_keep = sem[keep].int().contiguous()
+    res = {}
+
+    def bq():
+        res["idx"], res["start_len"] = pointgroup_ops.ballquery_batch_p(coords, bi_d, off_d, 0.03, 50)
+
+    ms_bq = _gpu_ms(bq, 5)
+    idx_c, sl_c = res["idx"].cpu(), res["start_len"].cpu()
+    t0 = time.perf_counter()
+    cl_idx, cl_off = pointgroup_ops.bfs_cluster(sem_keep, idx_c, sl_c, 50)
+    ms_bfs = (time.perf_counter() - t0) * 1e3
+    out["cluster_stage"] = {"workload": "C3: 4 synthetic scenes, non floor/wall points, r=0.03 m, threshold 50",
+                            "points": int(coords.shape[0]), "neighbour_pairs": int(idx_c.numel()),
+                            "clusters": int(cl_off.numel() - 1), "ballquery_ms": round(ms_bq, 3),
+                            "bfs_cluster_host_ms": round(ms_bfs, 3)}
+    return out
 
 
 def cpu_baseline(full_voxels, args):
@@ -162,8 +223,21 @@ def main():
         for b in model.buffers():
             dist.broadcast(b.data, 0)
 
+    # default: the rulebooks are built inline at the top of every forward pass (side stream).  --prefetch moves the
+    # build of the NEXT step's rulebooks (same synthetic scene, rebuilt every step, inside the timed region) to a
+    # helper thread; on one MI355X that was slower (17.1 -> 18.0 ms/step: the helper contends for the GIL).
+    pre = harness.make_prefetcher(model) if args.prefetch else None
+    if pre is not None:
+        harness.prefetch_rulebooks(pre, batch)
+        batch["rulebooks"] = pre.result()
+
     def step():
-        return harness.train_step(model, criterion, optimizer, batch, cfg, grad_sync=grad_sync)
+        if pre is not None:
+            harness.prefetch_rulebooks(pre, batch)
+        out = harness.train_step(model, criterion, optimizer, batch, cfg, grad_sync=grad_sync)
+        if pre is not None:
+            batch["rulebooks"] = pre.result()
+        return out
 
     for _ in range(args.warmup):
         step()
@@ -213,6 +287,9 @@ def main():
                                   "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)}
         if k and d:
             extra["conv_ms_per_step"] = round((k["ms"] + d["ms"]) / args.profile_steps, 3)
+
+    if rank == 0 and world == 1 and not args.no_stages:
+        extra.update(side_measurements(harness, optimizer, device, args))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -299,6 +299,36 @@ int wsis_ballquery_count(const float* d_xyz, const int32_t* d_batch_idx, const i
 int wsis_ballquery_fill(const float* d_xyz, const int32_t* d_batch_idx, const int32_t* d_batch_off,
                         int64_t N, int32_t B, float radius, const int32_t* d_start_len, int32_t* d_idx,
                         int64_t total, void* d_ws, int64_t ws_bytes, void* stream);
+
+/* ---- op-list executor: one C call issues a recorded forward or backward pass of the sparse UNet ------------
+ * Replaces the Python-dispatched module walk of sparse_unet3d.py:103-350 (ResidualBlock.forward / UBlock.forward
+ * and their autograd backward): the host records the pass as wsis_op records (plain device pointers + sizes) and
+ * wsis_run_ops launches every kernel on `stream`.  Each op is exactly one of the single-op entry points above
+ * (same kernels and summation orders -> bit-identical to calling them one by one):
+ *   CONV         in: X, nbr, order, W, bias, residual          out: Y                      (wsis_spconv_fwd)
+ *   BN_RELU      in: x, gamma, beta, running_mean, running_var out: y, mean, var           (wsis_bn_stats+apply)
+ *   CAT          in: a [M,Cin], b [M,Cout]                     out: [M,Cin+Cout]           (torch.cat dim 1)
+ *   SPLIT        in: [M,Cin+Cout]                              out: a [M,Cin], b [M,Cout]  (its backward)
+ *   ADD          in: src [M_in*Cin]                            out: dst += src             (gradient fan-in)
+ *   CONV_BWD     in: X, W, dY, nbr_f, order_f, nbr_b, order_b  out: dX (may be NULL), dW (may be NULL)
+ *                M_in = rows of X / dX, M_out = rows of dY     (weight_transpose + wsis_spconv_fwd + wsis_spconv_dw)
+ *   BN_RELU_BWD  in: x, dy, mean, var, gamma, beta             out: dx, dgamma, dbeta      (wsis_bn_bwd)
+ * BN ops use M_in rows and Cin channels.  d_ws from wsis_run_ops_workspace_bytes (max over the ops). */
+enum {
+  WSIS_OP_CONV = 1, WSIS_OP_BN_RELU = 2, WSIS_OP_CAT = 3, WSIS_OP_SPLIT = 4, WSIS_OP_ADD = 5, WSIS_OP_CONV_BWD = 6,
+  WSIS_OP_BN_RELU_BWD = 7
+};
+enum { WSIS_OPF_RELU = 1, WSIS_OPF_TRAINING = 2, WSIS_OPF_UPDATE_RUNNING = 4, WSIS_OPF_FLIP = 8 };
+typedef struct wsis_op {
+  int32_t kind, flags;
+  int64_t M_in, M_out;
+  int32_t K, Cin, Cout, reserved;
+  float eps, momentum;
+  const void* in[8];
+  void* out[4];
+} wsis_op;
+int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n);
+int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* stream);
 #ifdef __cplusplus
 }
 #endif

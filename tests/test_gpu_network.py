@@ -96,3 +96,37 @@ def test_eval_mode_and_state_dict_roundtrip():
     assert sd["unet.blocks_tail.block0.i_branch.0.weight"].shape == (1, 1, 1, 64, 32)
     assert sd["unet.conv.2.weight"].shape == (2, 2, 2, 32, 64) and sd["unet.deconv.2.weight"].shape == (2, 2, 2, 64, 32)
     assert sd["ecc.0._cell.weight_ih"].shape == (96, 32) and sd["ecc.0._fnet.7.weight"].shape == (1024, 64)
+
+
+def _one_pass(monkeypatch, native, batch_host, cfg):
+    monkeypatch.setenv("WSIS_NATIVE_UNET", "1" if native else "0")
+    model, crit, opt = harness.build_model(cfg, "cuda")
+    batch = harness.to_device(batch_host, "cuda")
+    loss, ret = harness.forward_loss(model, crit, batch, cfg)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    stats = {n: v.clone() for n, v in model.state_dict().items() if "running_" in n or "num_batches" in n}
+    return float(loss), grads, stats, ret["semantic_scores"].detach().clone()
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_native_unet_executor_is_bit_identical_to_the_module_walk(monkeypatch, train):
+    """WSIS_NATIVE_UNET=1 (one wsis_run_ops call per pass, model/unet_native.py) and =0 (spconv modules walked by
+    torch) launch the same kernels in the same order: loss, every gradient and every BN buffer must be EQUAL."""
+    cfg = harness.default_cfg()
+    batch_host = harness.collate([harness.make_scene(21, room=(1.8, 1.4, 1.1), n_box=2)])
+    if not train:
+        orig = harness.build_model
+
+        def build_eval(*a, **k):
+            m, c, o = orig(*a, **k)
+            m.eval()
+            return m, c, o
+        monkeypatch.setattr(harness, "build_model", build_eval)
+    l0, g0, s0, y0 = _one_pass(monkeypatch, False, batch_host, cfg)
+    l1, g1, s1, y1 = _one_pass(monkeypatch, True, batch_host, cfg)
+    assert l0 == l1 and torch.equal(y0, y1)
+    assert set(g0) == set(g1) and len(g0) > 150
+    assert [n for n in g0 if not torch.equal(g0[n], g1[n])] == []
+    assert [n for n in s0 if not torch.equal(s0[n], s1[n])] == []

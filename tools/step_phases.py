@@ -16,6 +16,11 @@ orig_unet=model.unet.forward
 def unet_fwd(x):
     mark('unet_start'); y=orig_unet(x); mark('unet_end'); return y
 model.unet.forward=unet_fwd
+import unet_native                      # default path: the whole UNet is one native call per pass
+orig_run=unet_native.run_unet
+def run_unet(net, t):
+    mark('unet_start'); y=orig_run(net, t); mark('unet_end'); return y
+unet_native.run_unet=run_unet
 orig_ecc=model.ecc.forward
 def ecc_fwd(x):
     mark('ecc_start'); y=orig_ecc(x); mark('ecc_end'); return y
