@@ -275,8 +275,9 @@ __global__ __launch_bounds__(64) void bn_bwd_final_kernel(const float* __restric
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                     const float* __restrict__ mean, const float* __restrict__ var,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta, float eps,
-                                    int relu, int training, float* __restrict__ dx, int64_t M, int C) {
+                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                    const float* __restrict__ addend, float eps, int relu, int training,
+                                    float* __restrict__ dx, int64_t M, int C) {
   const int64_t total = M * C;
   const float inv_m = 1.0f / (float)M;
   const bool vec = (C & 3) == 0;
@@ -284,9 +285,29 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
   const int64_t totalw = total / W;
   const unsigned Cw = (unsigned)(C / W);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < totalw; t += stride) {
-    const int c0 = (int)(t % Cw) * W;
-    float xv[4], dv[4], ov[4];
+  int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  // per-channel coefficients stay in registers while the thread's channel group does not change (it never does
+  // when the grid stride is a multiple of the channel groups; the launcher rounds the grid to make it so)
+  const bool fixed_c = (stride % Cw) == 0;
+  float mu[4], rstd[4], gm[4], bt[4], k1[4], k2[4];
+  auto coef = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e < W) {
+        const int c = c0 + e;
+        mu[e] = mean[c];
+        rstd[e] = rsqrtf(var[c] + eps);
+        gm[e] = gamma ? gamma[c] : 1.0f;
+        bt[e] = beta ? beta[c] : 0.0f;
+        k1[e] = training ? dbeta[c] * inv_m : 0.0f;
+        k2[e] = training ? dgamma[c] * inv_m : 0.0f;
+      }
+    }
+  };
+  if (t < totalw) coef((int)(t % Cw) * W);
+  for (; t < totalw; t += stride) {
+    if (!fixed_c) coef((int)(t % Cw) * W);
+    float xv[4], dv[4], av[4] = {0.f, 0.f, 0.f, 0.f}, ov[4];
     if (vec) {
       const f4 tx = ld4(x + t * 4, true), td = ld4(dy + t * 4, true);
 #pragma unroll
@@ -294,28 +315,165 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
         xv[e] = tx.v[e];
         dv[e] = td.v[e];
       }
+      if (addend) {
+        const f4 ta = ld4(addend + t * 4, true);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[e] = ta.v[e];
+      }
     } else {
       xv[0] = x[t];
       dv[0] = dy[t];
+      if (addend) av[0] = addend[t];
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (e < W) {
-        const int c = c0 + e;
-        const float rstd = rsqrtf(var[c] + eps);
-        const float g = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
-        const float xh = (xv[e] - mean[c]) * rstd;
+        const float xh = (xv[e] - mu[e]) * rstd[e];
         float dz = dv[e];
-        if (relu && xh * g + bt <= 0.0f) dz = 0.0f;
+        if (relu && xh * gm[e] + bt[e] <= 0.0f) dz = 0.0f;
         float r = dz;
-        if (training) r = dz - dbeta[c] * inv_m - xh * dgamma[c] * inv_m;
-        ov[e] = g * rstd * r;
+        if (training) r = dz - k1[e] - xh * k2[e];
+        ov[e] = gm[e] * rstd[e] * r;
+        if (addend) ov[e] += av[e];
       }
     }
     if (vec)
       reinterpret_cast<float4*>(dx)[t] = make_float4(ov[0], ov[1], ov[2], ov[3]);
     else
       dx[t] = ov[0];
+  }
+}
+
+// ---- small inputs (M <= BN_SMALL_ROWS): the whole reduction in ONE launch, one workgroup per channel group of 4.
+// Two launches (partial + final) of a few microseconds each are pure latency at the deep UNet levels.
+// Threads stride over the rows, then a fixed LDS tree (fp64) -> deterministic.
+constexpr int BN_SMALL_ROWS = 8192;
+
+__device__ __forceinline__ void block_sum2_f64(double (&a)[4], double (&b)[4], double* sh) {
+  // sh: [256][8] doubles
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sh[tid * 8 + e] = a[e];
+    sh[tid * 8 + 4 + e] = b[e];
+  }
+  __syncthreads();
+  for (int s = BN_THREADS / 2; s >= 1; s >>= 1) {
+    if (tid < s) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sh[tid * 8 + e] += sh[(tid + s) * 8 + e];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    a[e] = sh[e];
+    b[e] = sh[4 + e];
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_small_kernel(const float* __restrict__ x, int64_t M, int C,
+                                                                    float* __restrict__ mean, float* __restrict__ var,
+                                                                    float* __restrict__ running_mean,
+                                                                    float* __restrict__ running_var, float momentum) {
+  __shared__ double sh[BN_THREADS * 8];
+  const int c0 = blockIdx.x * 4;
+  const bool vec = (C & 3) == 0;
+  float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int64_t r = threadIdx.x; r < M; r += BN_THREADS) {
+    float v[4];
+    if (vec) {
+      const f4 t = ld4(x + r * C + c0, true);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = t.v[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (c0 + e < C) ? x[r * C + c0 + e] : 0.0f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sa[e] += v[e];
+      sb[e] += v[e] * v[e];
+    }
+  }
+  double a[4], b[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    a[e] = sa[e];
+    b[e] = sb[e];
+  }
+  block_sum2_f64(a, b, sh);
+  if (threadIdx.x < 4 && c0 + (int)threadIdx.x < C) {
+    const int e = threadIdx.x, c = c0 + e;
+    const double n = (double)M;
+    const double mu = a[e] / n;
+    double v = b[e] / n - mu * mu;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)mu;
+    var[c] = (float)v;
+    if (running_mean) {
+      const double unb = n > 1 ? v * n / (n - 1) : v;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_small_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+    int relu, int64_t M, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double sh[BN_THREADS * 8];
+  const int c0 = blockIdx.x * 4;
+  const bool vec = (C & 3) == 0;
+  float mu[4], rstd[4], gm[4], bt[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int cc = min(c0 + e, C - 1);
+    mu[e] = mean[cc];
+    rstd[e] = rsqrtf(var[cc] + eps);
+    gm[e] = gamma ? gamma[cc] : 1.0f;
+    bt[e] = beta ? beta[cc] : 0.0f;
+  }
+  float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int64_t r = threadIdx.x; r < M; r += BN_THREADS) {
+    float xv[4], dv[4];
+    if (vec) {
+      const f4 tx = ld4(x + r * C + c0, true), td = ld4(dy + r * C + c0, true);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xv[e] = tx.v[e];
+        dv[e] = td.v[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = c0 + e < C;
+        xv[e] = ok ? x[r * C + c0 + e] : 0.0f;
+        dv[e] = ok ? dy[r * C + c0 + e] : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xv[e] - mu[e]) * rstd[e];
+      float dz = dv[e];
+      if (relu && xh * gm[e] + bt[e] <= 0.0f) dz = 0.0f;
+      sa[e] += dz;
+      sb[e] += dz * xh;
+    }
+  }
+  double a[4], b[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    a[e] = sa[e];
+    b[e] = sb[e];
+  }
+  block_sum2_f64(a, b, sh);
+  if (threadIdx.x < 4 && c0 + (int)threadIdx.x < C) {
+    dbeta[c0 + threadIdx.x] = (float)a[threadIdx.x];
+    dgamma[c0 + threadIdx.x] = (float)b[threadIdx.x];
   }
 }
 
@@ -341,6 +499,12 @@ int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* 
   hipStream_t st = as_stream(stream);
   const int Cp = (C + 3) / 4 * 4;
   WSIS_REQUIRE(Cp / 4 <= BN_THREADS, "C > 1024 is not supported");
+  if (M <= BN_SMALL_ROWS) {
+    hipLaunchKernelGGL(bn_stats_small_kernel, dim3(Cp / 4), dim3(BN_THREADS), 0, st, d_x, M, C, d_mean, d_var,
+                       d_running_mean, d_running_var, momentum);
+    WSIS_LAUNCH_CHECK();
+    return WSIS_OK;
+  }
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk), dim3(BN_THREADS), 0, st, d_x, M, C, Cp, partial);
   WSIS_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, st, partial, nblk, C, Cp, M, d_mean,
@@ -363,8 +527,8 @@ int wsis_bn_apply(const float* d_x, const float* d_mean, const float* d_var, con
 
 int wsis_bn_bwd(const float* d_x, const float* d_dy, const float* d_mean, const float* d_var,
                 const float* d_gamma, const float* d_beta, float eps, int32_t relu, int32_t training,
-                float* d_dx, float* d_dgamma, float* d_dbeta, int64_t M, int32_t C, void* d_ws, int64_t ws_bytes,
-                void* stream) {
+                float* d_dx, float* d_dgamma, float* d_dbeta, const float* d_addend, int64_t M, int32_t C, void* d_ws,
+                int64_t ws_bytes, void* stream) {
   WSIS_REQUIRE(M >= 1 && C >= 1 && d_x && d_dy && d_mean && d_var && d_dgamma && d_dbeta && d_ws, "bad args");
   WSIS_REQUIRE(ws_bytes >= wsis_bn_workspace_bytes(M, C), "workspace too small");
   const int nblk = bn_nblk(M);
@@ -372,15 +536,25 @@ int wsis_bn_bwd(const float* d_x, const float* d_dy, const float* d_mean, const 
   hipStream_t st = as_stream(stream);
   const int Cp = (C + 3) / 4 * 4;
   WSIS_REQUIRE(Cp / 4 <= BN_THREADS, "C > 1024 is not supported");
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(BN_THREADS), 0, st, d_x, d_dy, d_mean, d_var, d_gamma,
-                     d_beta, eps, relu, M, C, Cp, partial);
-  WSIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, st, partial, nblk, C, Cp, d_dgamma,
-                     d_dbeta);
-  WSIS_LAUNCH_CHECK();
+  if (M <= BN_SMALL_ROWS) {
+    hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(Cp / 4), dim3(BN_THREADS), 0, st, d_x, d_dy, d_mean, d_var, d_gamma,
+                       d_beta, eps, relu, M, C, d_dgamma, d_dbeta);
+    WSIS_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk), dim3(BN_THREADS), 0, st, d_x, d_dy, d_mean, d_var, d_gamma,
+                       d_beta, eps, relu, M, C, Cp, partial);
+    WSIS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, st, partial, nblk, C, Cp, d_dgamma, d_dbeta);
+    WSIS_LAUNCH_CHECK();
+  }
   if (d_dx) {
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((C & 3) == 0 ? (M * C) >> 2 : M * C, 256)), dim3(256), 0, st, d_x, d_dy, d_mean, d_var,
-                       d_gamma, d_beta, d_dgamma, d_dbeta, eps, relu, training, d_dx, M, C);
+    // grid rounded to a multiple of the channel groups: a thread then keeps one channel group for its whole walk
+    const int64_t work = (C & 3) == 0 ? (M * C) >> 2 : M * C;
+    const int cw = (C & 3) == 0 ? C >> 2 : C;
+    int grid = grid_for(work, 256);
+    if (grid > cw) grid -= grid % cw;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, d_x, d_dy, d_mean, d_var, d_gamma, d_beta,
+                       d_dgamma, d_dbeta, d_addend, eps, relu, training, d_dx, M, C);
     WSIS_LAUNCH_CHECK();
   }
   return WSIS_OK;

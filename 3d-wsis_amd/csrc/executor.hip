@@ -159,7 +159,7 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
         rc = wsis_bn_bwd((const float*)op.in[0], (const float*)op.in[1], (const float*)op.in[2], (const float*)op.in[3],
                          (const float*)op.in[4], (const float*)op.in[5], op.eps, (op.flags & WSIS_OPF_RELU) ? 1 : 0,
                          (op.flags & WSIS_OPF_TRAINING) ? 1 : 0, (float*)op.out[0], (float*)op.out[1], (float*)op.out[2],
-                         op.M_in, op.Cin, ws, ws_bytes, stream);
+                         (const float*)op.in[6], op.M_in, op.Cin, ws, ws_bytes, stream);
         break;
       default:
         return fail(WSIS_ERR_ARG, "wsis_run_ops: unknown op kind");

@@ -129,12 +129,14 @@ class UNetProgram(object):
                inp=(x, _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var)),
                out=(y, mean if training else 0, var if training else 0))
 
-        def bwd(recb, dy):
+        def bwd(recb, dy, addend=0):
+            # ``addend``: gradient arriving at x over a second path (residual skip / UNet skip connection), added
+            # in the same pass instead of a separate accumulation kernel
             dx = recb.alloc(M * C)
             dg = self._grad_handle(recb, bn.weight) if bn.weight is not None else recb.alloc(C)
             db = self._grad_handle(recb, bn.bias) if bn.bias is not None else recb.alloc(C)
             recb.op(OP_BN_RELU_BWD, flags, M, M, 0, C, C, bn.eps, 0.0,
-                    inp=(x, dy, mean, var, _ptr(bn.weight), _ptr(bn.bias)), out=(dx, dg, db))
+                    inp=(x, dy, mean, var, _ptr(bn.weight), _ptr(bn.bias), addend), out=(dx, dg, db))
             return dx
         return y, bwd
 
@@ -150,16 +152,13 @@ class UNetProgram(object):
         else:
             res, b_i = self._conv(rec, x, first, None, M, M)          # 1x1 projection of the skip path
         out, b_c2 = self._conv(rec, a2, conv2, table, M, M, residual=res)
-        Cin = conv1.in_channels
 
         def bwd(recb, d_out):
             d_a2 = b_c2(recb, d_out)
             d_z1 = b_bn2(recb, d_a2)
             d_a1 = b_c1(recb, d_z1)
-            d_x = b_bn1(recb, d_a1)
             d_skip = d_out if b_i is None else b_i(recb, d_out)
-            recb.op(OP_ADD, 0, M, M, 0, Cin, Cin, inp=(d_skip,), out=(d_x,))
-            return d_x
+            return b_bn1(recb, d_a1, addend=d_skip)
         return out, bwd
 
     def _ublock(self, rec, x, ub, lvl):
@@ -201,8 +200,7 @@ class UNetProgram(object):
             d_u = b_bn2(recb, d_a2)
             d_d = b_u(recb, d_u)
             d_a = b_down(recb, d_d)
-            d_x = b_bn(recb, d_a)
-            recb.op(OP_ADD, 0, M, M, 0, C0, C0, inp=(d_id,), out=(d_x,))
+            d_x = b_bn(recb, d_a, addend=d_id)
             for b in reversed(bwds):
                 d_x = b(recb, d_x)
             return d_x

@@ -78,7 +78,7 @@ _HIP_SIGS = {
     "wsis_bn_workspace_bytes": (I64, [I64, I32]),
     "wsis_bn_stats": (I32, [P, I64, I32, P, P, P, P, F32, P, I64, P]),
     "wsis_bn_apply": (I32, [P, P, P, P, P, F32, I32, P, I64, I32, P]),
-    "wsis_bn_bwd": (I32, [P, P, P, P, P, P, F32, I32, I32, P, P, P, I64, I32, P, I64, P]),
+    "wsis_bn_bwd": (I32, [P, P, P, P, P, P, F32, I32, I32, P, P, P, P, I64, I32, P, I64, P]),
     "wsis_segment_csr_workspace_bytes": (I64, [I64, I64]),
     "wsis_segment_csr": (I32, [P, I64, I64, P, P, P, I64, P]),
     "wsis_segment_reduce_fwd": (I32, [P, P, P, P, P, I64, I64, I32, I32, P]),

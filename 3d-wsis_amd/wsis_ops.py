@@ -199,7 +199,7 @@ class _BatchNormReLU(Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         _n.check(lib.wsis_bn_bwd(_n.ptr(x), _n.ptr(dy), _n.ptr(mean), _n.ptr(var), _n.ptr(weight), _n.ptr(bias), eps,
-                                 relu, batch_stats, _n.ptr(dx), _n.ptr(dgamma), _n.ptr(dbeta), M, C, _n.ptr(ws),
+                                 relu, batch_stats, _n.ptr(dx), _n.ptr(dgamma), _n.ptr(dbeta), None, M, C, _n.ptr(ws),
                                  ws_bytes, _n.stream_ptr()), "bn_bwd")
         gw = dgamma if (weight is not None and ctx.needs_input_grad[1]) else None
         gb = dbeta if (bias is not None and ctx.needs_input_grad[2]) else None

@@ -199,11 +199,13 @@ int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* 
 int wsis_bn_apply(const float* d_x, const float* d_mean, const float* d_var, const float* d_gamma,
                   const float* d_beta, float eps, int32_t relu, float* d_y, int64_t M, int32_t C, void* stream);
 /* backward of the fused BN(+ReLU): dgamma = sum dz*xhat, dbeta = sum dz (dz = dy masked by the ReLU),
- * dx = gamma*rstd*(dz - dbeta/M - xhat*dgamma/M) when training, gamma*rstd*dz otherwise; d_dx may be NULL. */
+ * dx = gamma*rstd*(dz - dbeta/M - xhat*dgamma/M) when training, gamma*rstd*dz otherwise; d_dx may be NULL.
+ * d_addend (optional, [M,C]) is added to dx in the same pass: the gradient arriving over the residual skip
+ * connection of sparse_unet3d.py:164-172, which autograd would otherwise add with one more kernel. */
 int wsis_bn_bwd(const float* d_x, const float* d_dy, const float* d_mean, const float* d_var,
                 const float* d_gamma, const float* d_beta, float eps, int32_t relu, int32_t training,
-                float* d_dx, float* d_dgamma, float* d_dbeta, int64_t M, int32_t C, void* d_ws, int64_t ws_bytes,
-                void* stream);
+                float* d_dx, float* d_dgamma, float* d_dbeta, const float* d_addend, int64_t M, int32_t C, void* d_ws,
+                int64_t ws_bytes, void* stream);
 
 /* ---- a14/a15: row gather and torch_scatter.scatter  backbone_3D_WSIS.py:179,188,225,232,244 --
  * CSR of a (possibly unsorted) index vector: d_perm int32 [N] = stable argsort(index),
@@ -312,7 +314,7 @@ int wsis_ballquery_fill(const float* d_xyz, const int32_t* d_batch_idx, const in
  *   ADD          in: src [M_in*Cin]                            out: dst += src             (gradient fan-in)
  *   CONV_BWD     in: X, W, dY, nbr_f, order_f, nbr_b, order_b  out: dX (may be NULL), dW (may be NULL)
  *                M_in = rows of X / dX, M_out = rows of dY     (weight_transpose + wsis_spconv_fwd + wsis_spconv_dw)
- *   BN_RELU_BWD  in: x, dy, mean, var, gamma, beta             out: dx, dgamma, dbeta      (wsis_bn_bwd)
+ *   BN_RELU_BWD  in: x, dy, mean, var, gamma, beta, addend     out: dx, dgamma, dbeta      (wsis_bn_bwd)
  * BN ops use M_in rows and Cin channels.  d_ws from wsis_run_ops_workspace_bytes (max over the ops). */
 enum {
   WSIS_OP_CONV = 1, WSIS_OP_BN_RELU = 2, WSIS_OP_CAT = 3, WSIS_OP_SPLIT = 4, WSIS_OP_ADD = 5, WSIS_OP_CONV_BWD = 6,
