@@ -6,6 +6,8 @@
 // Every op maps 1:1 onto the single-op entry points of this library (same kernels, same summation orders, so the
 // results are bit-identical to calling them one by one); CAT / SPLIT / ADD are the elementwise glue of the UNet
 // (torch.cat of the skip connection, its backward, gradient accumulation at the residual fan-out).
+#include <vector>
+
 #include "common.h"
 
 using namespace wsis;
@@ -47,6 +49,43 @@ __global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restr
     dst[t] += src[t];
 }
 
+// every dIn convolution of a backward pass needs W[k]^T (flipped for submanifold tables): all of them are produced
+// by ONE launch up front instead of one small launch per layer
+constexpr int WT_MAX = 64;
+struct WtBatch {
+  const float* src[WT_MAX];
+  float* dst[WT_MAX];
+  int K[WT_MAX], Cin[WT_MAX], Cout[WT_MAX], flip[WT_MAX];
+  int64_t start[WT_MAX + 1];
+  int n;
+};
+
+__global__ void weight_transpose_batch_kernel(WtBatch b) {
+  const int64_t total = b.start[b.n];
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int lo = 0, hi = b.n - 1;           // largest i with start[i] <= t
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (b.start[mid] <= t)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    const int64_t u = t - b.start[lo];  // index into WT [K, Cout, Cin]
+    const int Cin = b.Cin[lo], Cout = b.Cout[lo], K = b.K[lo];
+    const int ci = (int)(u % Cin);
+    const int64_t v = u / Cin;
+    const int co = (int)(v % Cout);
+    const int kt = (int)(v / Cout);
+    const int ks = b.flip[lo] ? (K - 1 - kt) : kt;
+    b.dst[lo][u] = b.src[lo][((int64_t)ks * Cin + ci) * Cout + co];
+  }
+}
+
+inline int64_t wt_bytes_of(const wsis_op& op) {
+  return up((int64_t)op.K * op.Cin * op.Cout * (int64_t)sizeof(float));
+}
+
 int64_t op_ws_bytes(const wsis_op& op) {
   switch (op.kind) {
     case WSIS_OP_CONV:
@@ -55,11 +94,10 @@ int64_t op_ws_bytes(const wsis_op& op) {
       return (op.flags & WSIS_OPF_TRAINING) ? up(wsis_bn_workspace_bytes(op.M_in, op.Cin)) : 0;
     case WSIS_OP_BN_RELU_BWD:
       return up(wsis_bn_workspace_bytes(op.M_in, op.Cin));
-    case WSIS_OP_CONV_BWD: {
-      const int64_t wt = up((int64_t)op.K * op.Cin * op.Cout * (int64_t)sizeof(float));
+    case WSIS_OP_CONV_BWD: {   // the transposed weights live in the shared WT region, not here
       const int64_t din = op.out[0] ? wsis_spconv_fwd_workspace_bytes(op.M_in, op.K, op.Cout, op.Cin) : 0;
       const int64_t dw = op.out[1] ? wsis_spconv_dw_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout) : 0;
-      return wt + up(din > dw ? din : dw);
+      return up(din > dw ? din : dw);
     }
     default:
       return 0;
@@ -72,13 +110,14 @@ extern "C" {
 
 int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n) {
   if (!ops || n < 0) return -1;
-  int64_t need = ALIGN;
+  int64_t need = ALIGN, wt = 0;
   for (int i = 0; i < n; ++i) {
     const int64_t b = op_ws_bytes(ops[i]);
     if (b < 0) return -1;
     if (b > need) need = b;
+    if (ops[i].kind == WSIS_OP_CONV_BWD && ops[i].out[0]) wt += wt_bytes_of(ops[i]);
   }
-  return need + ALIGN;
+  return wt + need + ALIGN;
 }
 
 int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* stream) {
@@ -86,6 +125,45 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
   WSIS_REQUIRE(ws_bytes >= wsis_run_ops_workspace_bytes(ops, n) && (d_ws || n == 0), "workspace too small");
   hipStream_t st = as_stream(stream);
   char* ws = static_cast<char*>(d_ws);
+  // ---- all transposed weights of the pass, WT_MAX layers per launch; wt_off[i] = offset of op i's W^T
+  std::vector<int64_t> wt_off(n, -1);
+  int64_t wt_total = 0;
+  {
+    WtBatch b;
+    b.n = 0;
+    b.start[0] = 0;
+    auto flush = [&]() -> int {
+      if (b.n == 0) return WSIS_OK;
+      hipLaunchKernelGGL(weight_transpose_batch_kernel, dim3(grid_for(b.start[b.n], 256)), dim3(256), 0, st, b);
+      WSIS_LAUNCH_CHECK();
+      b.n = 0;
+      return WSIS_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+      const wsis_op& op = ops[i];
+      if (op.kind != WSIS_OP_CONV_BWD || !op.out[0]) continue;
+      WSIS_REQUIRE(op.in[1], "CONV_BWD without weights");
+      wt_off[i] = wt_total;
+      b.src[b.n] = (const float*)op.in[1];
+      b.dst[b.n] = reinterpret_cast<float*>(ws + wt_total);
+      b.K[b.n] = op.K;
+      b.Cin[b.n] = op.Cin;
+      b.Cout[b.n] = op.Cout;
+      b.flip[b.n] = (op.flags & WSIS_OPF_FLIP) ? 1 : 0;
+      b.start[b.n + 1] = b.start[b.n] + (int64_t)op.K * op.Cin * op.Cout;
+      ++b.n;
+      wt_total += wt_bytes_of(op);
+      if (b.n == WT_MAX) {
+        const int rc = flush();
+        if (rc != WSIS_OK) return rc;
+      }
+    }
+    const int rc = flush();
+    if (rc != WSIS_OK) return rc;
+  }
+  ws += wt_total;
+  ws_bytes -= wt_total;
+  char* const wt_base = static_cast<char*>(d_ws);
   for (int i = 0; i < n; ++i) {
     const wsis_op& op = ops[i];
     int rc = WSIS_OK;
@@ -136,14 +214,10 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
         break;
       case WSIS_OP_CONV_BWD: {
         // in: X, W, dY, nbr_f, order_f, nbr_b, order_b ; out: dX (optional), dW (optional)
-        const int64_t wt_bytes = up((int64_t)op.K * op.Cin * op.Cout * (int64_t)sizeof(float));
-        float* WT = reinterpret_cast<float*>(ws);
-        char* rest = ws + wt_bytes;
-        const int64_t rest_bytes = ws_bytes - wt_bytes;
+        char* rest = ws;
+        const int64_t rest_bytes = ws_bytes;
         if (op.out[0]) {
-          rc = wsis_weight_transpose((const float*)op.in[1], WT, op.K, op.Cin, op.Cout,
-                                     (op.flags & WSIS_OPF_FLIP) ? 1 : 0, stream);
-          if (rc != WSIS_OK) break;
+          const float* WT = reinterpret_cast<const float*>(wt_base + wt_off[i]);
           rc = wsis_spconv_fwd((const float*)op.in[2], (const int32_t*)op.in[5], (const int32_t*)op.in[6], WT, nullptr,
                                nullptr, (float*)op.out[0], op.M_out, op.M_in, op.K, op.Cout, op.Cin, rest, rest_bytes,
                                stream);
