@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <cmath>
 #include <vector>
 
 #include "../../include/wsis_hip.h"
@@ -179,6 +180,51 @@ int wsis_host_bfs_cluster_fill(const int32_t* h_point_cluster, const int32_t* h_
     h_cluster_idxs[2 * r] = c;
     h_cluster_idxs[2 * r + 1] = (int32_t)p;
   }
+  return WSIS_OK;
+}
+
+// Superpoint-graph BFS of the test-time instance grouping (test_scannetv2.py:312-340, called from :372-381):
+// seeds ascending over the superpoints of a valid class; a neighbour joins the seed's group iff it has the
+// seed's class, is unvisited and its predicted instance centre lies closer than 0.25 * ins_size[seed] to the
+// CURRENT superpoint's centre (fp32 norm, fp32 threshold, as numpy evaluates it).
+// h_adj_off int32 [S+1] / h_adj int32 [nnz]: neighbours of every superpoint (igraph neighbors(mode='all')).
+// Output: h_group int32 [S] = group id in seed order or -1; *n_groups.
+int wsis_host_graph_bfs(const int32_t* h_label, const uint8_t* h_class_valid, int32_t n_class,
+                        const float* h_centre, const float* h_ins_size, const int32_t* h_adj_off,
+                        const int32_t* h_adj, int64_t S, int32_t* h_group, int64_t* n_groups) {
+  if (S < 0 || n_class < 1 || !n_groups || (S > 0 && (!h_label || !h_class_valid || !h_centre || !h_ins_size ||
+                                                      !h_adj_off || !h_group)))
+    return fail(WSIS_ERR_ARG, "graph_bfs: bad args");
+  for (int64_t s = 0; s < S; ++s) h_group[s] = -1;
+  std::vector<int32_t> queue;
+  int64_t ng = 0;
+  for (int64_t seed = 0; seed < S; ++seed) {
+    const int32_t lab = h_label[seed];
+    if (lab < 0 || lab >= n_class) return fail(WSIS_ERR_ARG, "graph_bfs: class label out of range");
+    if (!h_class_valid[lab] || h_group[seed] >= 0) continue;
+    const float thr = 0.25f * h_ins_size[seed];
+    queue.clear();
+    queue.push_back((int32_t)seed);
+    h_group[seed] = (int32_t)ng;
+    for (size_t head = 0; head < queue.size(); ++head) {
+      const int32_t cur = queue[head];
+      const float* cc = h_centre + 3 * (int64_t)cur;
+      for (int32_t e = h_adj_off[cur]; e < h_adj_off[cur + 1]; ++e) {
+        const int32_t nb = h_adj[e];
+        if (nb < 0 || nb >= S) return fail(WSIS_ERR_ARG, "graph_bfs: neighbour id out of range");
+        if (h_label[nb] != lab || h_group[nb] >= 0) continue;
+        const float* cn = h_centre + 3 * (int64_t)nb;
+        const float dx = cc[0] - cn[0], dy = cc[1] - cn[1], dz = cc[2] - cn[2];
+        const float d = std::sqrt((dx * dx + dy * dy) + dz * dz);
+        if (d < thr) {
+          h_group[nb] = (int32_t)ng;
+          queue.push_back(nb);
+        }
+      }
+    }
+    ++ng;
+  }
+  *n_groups = ng;
   return WSIS_OK;
 }
 

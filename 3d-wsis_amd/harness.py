@@ -129,6 +129,19 @@ def make_scene(seed, room=(4.6, 3.6, 2.2), n_box=8, dup=0.3, voxel=0.02, sp_cell
                 sp_size=inst_size[sp_inst].astype(np.float32), n_inst=n_inst, S=S)
 
 
+def synthetic_predictions(scene, seed=0, noise=0.02):
+    """plausible superpoint-level network outputs for a ``make_scene`` scene (inputs of the test-time grouping,
+    test_scannetv2.py:244-260): a class per instance, ground-truth offsets / log-occupancy / size plus noise.
+    -> (sp_semantic_pred int64 [S], offsets f32 [S,3], occupancy f32 [S,1], ins_size f32 [S,1])"""
+    rng = np.random.default_rng(seed)
+    S = scene["S"]
+    sem = (np.round(scene["sp_size"] * 1000).astype(np.int64) % 20)          # constant per instance, 20 classes
+    offsets = (scene["sp_offset"] + rng.normal(0, noise, (S, 3))).astype(np.float32)
+    occupancy = (np.log(scene["sp_voxnum"]) + rng.normal(0, 0.1, S)).astype(np.float32).reshape(S, 1)
+    size = (scene["sp_size"] * (1 + rng.normal(0, 0.05, S))).astype(np.float32).reshape(S, 1)
+    return sem, offsets, occupancy, size
+
+
 # -------------------------------------------------------------------------------------------------------------
 def collate(scenes, mode=4):
     """Batch dict with the schema of scannetv2_dataset.py:460-474; host tensors."""

@@ -46,6 +46,7 @@ _HOST_SIGS = {
     "wsis_host_voxelize_idx_fill": (I32, [P, I64, P, I64, I32, P, P]),
     "wsis_host_bfs_cluster_count": (I32, [P, P, P, I64, I32, P, P, P, P]),
     "wsis_host_bfs_cluster_fill": (I32, [P, P, I64, I64, I64, P, P]),
+    "wsis_host_graph_bfs": (I32, [P, P, I32, P, P, P, P, I64, P, P]),
 }
 
 _HIP_SIGS = {

@@ -151,6 +151,18 @@ def side_measurements(harness, optimizer, device, args):
     t0 = time.perf_counter()
     cl_idx, cl_off = pointgroup_ops.bfs_cluster(sem_keep, idx_c, sl_c, 50)
     ms_bfs = (time.perf_counter() - t0) * 1e3
+    # test-time grouping on the superpoint graph (test_scannetv2.py:281-455) on the C2 scene, synthetic predictions
+    import inference
+    sc = harness.make_scene(args.scene_seed)
+    sem, off, occ, size = harness.synthetic_predictions(sc, args.scene_seed)
+    graph = (sc["edges"][:, 0], sc["edges"][:, 1])
+    xyz = sc["xyz"].astype("float32")
+    inference.clustering_in_graph("c2", xyz, sc["superpoint"], graph, sem, off, occ, size)      # warm-up
+    t0 = time.perf_counter()
+    conf, _, _ = inference.clustering_in_graph("c2", xyz, sc["superpoint"], graph, sem, off, occ, size)
+    out["graph_cluster_stage"] = {"workload": "clustering_in_graph on the C2 scene (host arrays in, host masks out)",
+                                  "points": int(len(xyz)), "superpoints": int(sc["S"]), "instances": int(len(conf)),
+                                  "ms": round((time.perf_counter() - t0) * 1e3, 2)}
     out["cluster_stage"] = {"workload": "C3: 4 synthetic scenes, non floor/wall points, r=0.03 m, threshold 50",
                             "points": int(coords.shape[0]), "neighbour_pairs": int(idx_c.numel()),
                             "clusters": int(cl_off.numel() - 1), "ballquery_ms": round(ms_bq, 3),

@@ -73,6 +73,15 @@ int wsis_host_bfs_cluster_fill(const int32_t* h_point_cluster, const int32_t* h_
                                int64_t n_clusters, int64_t n_points, int32_t* h_cluster_idxs,
                                int32_t* h_cluster_offsets);
 
+/* Superpoint-graph BFS of the test-time grouping, test_scannetv2.py:312-340 (`BFS`) driven by the seed loop of
+ * :372-381.  Seeds ascending over superpoints whose class is valid and that are unvisited; a
+ * neighbour joins iff same class as the seed, unvisited, and ||centre[cur] - centre[nb]||_2 < 0.25*ins_size[seed]
+ * (fp32).  h_adj_off int32 [S+1], h_adj int32 [nnz] = igraph `neighbors(mode='all')` lists; h_class_valid
+ * uint8 [n_class].  h_group int32 [S] = group id in seed order or -1. */
+int wsis_host_graph_bfs(const int32_t* h_label, const uint8_t* h_class_valid, int32_t n_class,
+                        const float* h_centre, const float* h_ins_size, const int32_t* h_adj_off,
+                        const int32_t* h_adj, int64_t S, int32_t* h_group, int64_t* n_groups);
+
 /* ------------------------------------------------------------------------------------------ */
 /* libwsis_hip.so : device operators                                                          */
 /* ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,79 @@
+"""Generates tests/golden/cluster_golden.npz by running the REFERENCE's own ``clustering_in_graph``
+(/root/reference/test_scannetv2.py:281-455) in this container on a seeded synthetic scene.
+
+The reference module cannot be imported as a whole (plyfile / igraph / spconv binaries are absent), so the function's
+source is read from the reference checkout AT GENERATION TIME, compiled and executed with the names it uses
+(np, torch, collections, sqrt, pointgroup_ops = this repo's host voxelization_idx); nothing of it is stored here.
+The igraph graph is replaced by an object with the one method the function calls, ``neighbors(vertex=, mode=)``.
+
+    python tests/golden/make_cluster_golden.py
+"""
+import ast
+import collections
+import importlib
+import io
+import os
+import sys
+from contextlib import redirect_stdout
+from math import sqrt
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+importlib.import_module("3d-wsis_amd")
+import harness                      # noqa: E402
+import pointgroup_ops               # noqa: E402
+from oracle import cluster_ref      # noqa: E402
+
+REF = "/root/reference/test_scannetv2.py"
+
+
+class Graph(object):
+    def __init__(self, lists):
+        self.lists = lists
+
+    def neighbors(self, vertex, mode="all"):
+        assert mode == "all"
+        return [int(v) for v in self.lists[int(vertex)]]
+
+
+def reference_function():
+    src = open(REF).read()
+    tree = ast.parse(src)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "clustering_in_graph"][0]
+    code = compile(ast.Module(body=[fn], type_ignores=[]), REF, "exec")
+    ns = {"np": np, "torch": torch, "collections": collections, "sqrt": sqrt, "pointgroup_ops": pointgroup_ops}
+    exec(code, ns)
+    return ns["clustering_in_graph"]
+
+
+def main():
+    fn = reference_function()
+    out = {}
+    for tag, seed, room, n_box in (("a", 7, (1.5, 1.3, 1.1), 4), ("b", 11, (1.6, 1.2, 1.2), 5)):
+        sc = harness.make_scene(seed, room=room, n_box=n_box)
+        sem, off, occ, size = harness.synthetic_predictions(sc, seed)
+        flip = np.random.default_rng(seed + 100).random(sc["S"]) < 0.06     # mis-classified superpoints -> fragments
+        sem = np.where(flip, (sem + 3) % 20, sem)
+        lists = cluster_ref.neighbour_lists(sc["edges"], sc["S"])
+        xyz = sc["xyz"].astype(np.float32)
+        with redirect_stdout(io.StringIO()):
+            conf, label_id, masks = fn("synthetic", xyz, sc["superpoint"], Graph(lists), sem, off, occ, size)
+        inst = np.full(len(xyz), -1, dtype=np.int32)       # masks are disjoint: store them as one id per point
+        for i, m in enumerate(masks):
+            assert (inst[m.astype(bool)] == -1).all()
+            inst[m.astype(bool)] = i
+        out.update({f"{tag}_xyz": xyz, f"{tag}_superpoint": sc["superpoint"].astype(np.int32),
+                    f"{tag}_edges": sc["edges"].astype(np.int32), f"{tag}_sem": sem.astype(np.int32),
+                    f"{tag}_off": off, f"{tag}_occ": occ, f"{tag}_size": size, f"{tag}_conf": conf,
+                    f"{tag}_label_id": label_id, f"{tag}_inst": inst})
+        print(tag, "points", len(xyz), "superpoints", sc["S"], "instances", len(conf), "labels", sorted(set(label_id)))
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cluster_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

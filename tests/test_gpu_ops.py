@@ -499,3 +499,62 @@ def test_voxelization_idx_gpu_matches_host(N):
 def test_voxelization_idx_gpu_empty():
     locs, p2v, v2p = pointgroup_ops.voxelization_idx(torch.zeros((0, 4), dtype=torch.int64, device=DEV), 1, 4)
     assert locs.shape == (0, 4) and p2v.shape == (0,) and v2p.shape == (0, 1)
+
+
+# ---- test-time grouping on the superpoint graph (test_scannetv2.py:281-455) ----------------------
+
+def _cluster_case(tag):
+    import os
+    from oracle import cluster_ref
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cluster_golden.npz"))
+    S = len(g[f"{tag}_sem"])
+    return g, S, cluster_ref
+
+
+class _Graph(object):          # the one igraph method the reference calls
+    def __init__(self, lists):
+        self.lists = lists
+
+    def neighbors(self, vertex, mode="all"):
+        return [int(v) for v in self.lists[int(vertex)]]
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("graph_kind", ["igraph_like", "edge_arrays"])
+def test_clustering_in_graph_matches_reference_outputs(tag, graph_kind):
+    """product (GPU segmented stages + host BFS) against the outputs of the reference's own function"""
+    import inference
+    g, S, cluster_ref = _cluster_case(tag)
+    lists = cluster_ref.neighbour_lists(g[f"{tag}_edges"], S)
+    graph = _Graph(lists) if graph_kind == "igraph_like" else (g[f"{tag}_edges"][:, 0], g[f"{tag}_edges"][:, 1])
+    conf, label_id, masks = inference.clustering_in_graph("golden", g[f"{tag}_xyz"], g[f"{tag}_superpoint"], graph,
+                                                          g[f"{tag}_sem"], g[f"{tag}_off"], g[f"{tag}_occ"],
+                                                          g[f"{tag}_size"])
+    assert masks.shape == (len(g[f"{tag}_conf"]), len(g[f"{tag}_xyz"])) and masks.dtype == np.int64
+    inst = np.full(masks.shape[1], -1, dtype=np.int64)
+    for i, m in enumerate(masks):
+        assert (inst[m.astype(bool)] == -1).all(), "instance masks are disjoint"
+        inst[m.astype(bool)] = i
+    assert np.array_equal(label_id, g[f"{tag}_label_id"])
+    assert np.array_equal(inst, g[f"{tag}_inst"]), "bit-exact instance membership"
+    assert np.allclose(conf, g[f"{tag}_conf"], rtol=1e-5, atol=0)     # fp32 means, member order differs
+
+
+def test_clustering_in_graph_matches_oracle_on_a_fresh_scene_and_handles_no_instances():
+    import harness
+    import inference
+    from oracle import cluster_ref
+    sc = harness.make_scene(23, room=(1.7, 1.2, 1.3), n_box=5)
+    sem, off, occ, size = harness.synthetic_predictions(sc, 23, noise=0.03)
+    sem = np.where(np.random.default_rng(5).random(sc["S"]) < 0.1, (sem + 7) % 20, sem)
+    lists = cluster_ref.neighbour_lists(sc["edges"], sc["S"])
+    xyz = sc["xyz"].astype(np.float32)
+    e_conf, e_lab, e_masks = cluster_ref.clustering_in_graph(xyz, sc["superpoint"], lists, sem, off, occ, size)
+    conf, lab, masks = inference.clustering_in_graph("s", xyz, sc["superpoint"], _Graph(lists), sem, off, occ, size)
+    assert np.array_equal(lab, e_lab) and np.array_equal(masks, e_masks) and np.allclose(conf, e_conf, rtol=1e-5)
+    # only wall / floor predictions: no instance at all
+    conf, lab, masks = inference.clustering_in_graph("s", xyz, sc["superpoint"], _Graph(lists),
+                                                     np.zeros(sc["S"], np.int64), off, occ, size)
+    assert len(conf) == 0 and len(lab) == 0 and len(masks) == 0
+    with pytest.raises(Exception):
+        inference.clustering_in_graph("s", xyz, sc["superpoint"], _Graph(lists), sem, off, occ, size, device="cpu")
