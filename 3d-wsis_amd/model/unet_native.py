@@ -31,19 +31,21 @@ assert OP_DTYPE.itemsize == 144          # sizeof(wsis_op)
 
 _REL = 1 << 62                            # tag: byte offset into the FORWARD arena, resolved at launch
 _GREL = 1 << 61                           # tag: byte offset into the BACKWARD arena
+_PREL = 1 << 60                           # tag: byte offset into the flat PARAMETER-GRADIENT buffer
 
 
 class _Recorder(object):
     """op list + bump allocator of one pass (``tag`` marks the arena its allocations live in)"""
 
-    def __init__(self, tag):
+    def __init__(self, tag, align=256):
         self.rows = []
         self.bytes = 0
         self.tag = tag
+        self.align = align
 
     def alloc(self, n_floats):
         off = self.bytes
-        self.bytes += (int(n_floats) * 4 + 255) // 256 * 256
+        self.bytes += (int(n_floats) * 4 + self.align - 1) // self.align * self.align
         return self.tag | off
 
     def op(self, kind, flags=0, M_in=0, M_out=0, K=0, Cin=0, Cout=0, eps=0.0, momentum=0.0, inp=(), out=()):
@@ -88,7 +90,7 @@ class UNetProgram(object):
     def __init__(self, net):
         self.net = net
         self.params = [p for m in (net.input_conv, net.unet, net.output_layer) for p in m.parameters()]
-        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self.flat_grad, self.flat_params = None, []
 
     # ---- forward recording: every helper returns (out_handle, backward_closure) -----------------------------
     def _conv(self, rec, x, conv, table, M_in, M_out, residual=0):
@@ -208,9 +210,10 @@ class UNetProgram(object):
 
     # ---- bookkeeping ----------------------------------------------------------------------------------------
     def _grad_handle(self, recb, p):
+        # parameter gradients live densely in their own flat buffer (one all-reduce for data parallelism)
         h = self._grad.get(id(p))
         if h is None:
-            h = recb.alloc(p.numel())
+            h = self._palloc.alloc(p.numel())
             self._grad[id(p)] = h
         return h
 
@@ -283,17 +286,25 @@ class UNetFunction(Function):
         d_out = d_out if (d_out.dtype == torch.float32 and d_out.is_contiguous()) else d_out.contiguous().float()
         recb = _Recorder(_GREL)
         prog._grad = {}
+        prog._palloc = _Recorder(_PREL, align=16)
         need_dx = ctx.needs_input_grad[0]
         dx_h = ctx.record_backward(recb, d_out.data_ptr(), need_dx)
         garena, gbase = _arena(recb.bytes, d_out.device)
-        _run(_n.hip(), recb.finish({_REL: ctx.base, _GREL: gbase}), d_out.device)
-        grads = []
+        pflat = torch.zeros(prog._palloc.bytes // 4 + 64, dtype=torch.float32, device=d_out.device)
+        pbase = (pflat.data_ptr() + 255) // 256 * 256
+        _run(_n.hip(), recb.finish({_REL: ctx.base, _GREL: gbase, _PREL: pbase}), d_out.device)
+        first = (pbase - pflat.data_ptr()) // 4
+        grads, covered = [], []
         for i, p in enumerate(prog.params):
             h = prog._grad.get(id(p))
             if h is None or not ctx.needs_input_grad[2 + i]:
                 grads.append(None)
             else:
-                grads.append(_view(garena, gbase, _GREL, h, tuple(p.shape)))
+                off = first + (h ^ _PREL) // 4
+                grads.append(pflat[off:off + p.numel()].view(p.shape))
+                covered.append(p)
+        # data-parallel hook: the gradients of ``flat_params`` are views of ``flat_grad`` (parallel.GradSync)
+        prog.flat_grad, prog.flat_params = pflat, covered
         dx = _view(garena, gbase, _GREL, dx_h, tuple(ctx.x.shape)) if need_dx else None
         return (dx, None) + tuple(grads)
 

@@ -52,12 +52,35 @@ class GradSync(object):
         if cur:
             self.buckets.append(cur)
 
+    @staticmethod
+    def _flat_source(model):
+        """(flat gradient buffer, ids of the parameters whose .grad are views of it) -- the native UNet pass
+        (model/unet_native.py) writes its 10.96 M parameter gradients densely into one buffer, which is then
+        all-reduced in place: no flatten / copy-back for 98 % of the gradient bytes"""
+        prog = getattr(model, "_native_prog", None) if model is not None else None
+        flat = getattr(prog, "flat_grad", None)
+        if flat is None:
+            return None, set()
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+        ok = [p for p in prog.flat_params if p.grad is not None and lo <= p.grad.data_ptr() < hi]
+        if len(ok) != len(prog.flat_params):      # some gradient was replaced / accumulated elsewhere: fall back
+            return None, set()
+        return flat, {id(p) for p in ok}
+
     def __call__(self, model=None):
         if self.world == 1 and os.environ.get("WSIS_FORCE_DIST", "0") != "1":
             return
-        # flatten every bucket with ONE cat kernel, all-reduce asynchronously, copy back with ONE multi-tensor copy
         work = []
+        flat_src, covered = self._flat_source(model)
+        self.last_flat_params = len(covered)        # diagnostics / tests: parameters synchronised without a copy
+        flat_handle = None
+        if flat_src is not None:
+            flat_handle = dist.all_reduce(flat_src, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        # flatten every bucket with ONE cat kernel, all-reduce asynchronously, copy back with ONE multi-tensor copy
         for bucket in self.buckets:
+            bucket = [p for p in bucket if id(p) not in covered]
+            if not bucket:
+                continue
             grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in bucket]
             flat = torch.cat([g.reshape(-1) for g in grads])
             handle = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -71,3 +94,7 @@ class GradSync(object):
             for p, g in zip(bucket, grads):
                 if p.grad is None:      # unused parameter on this rank: it still receives the averaged gradient
                     p.grad = g
+        if flat_handle is not None:
+            flat_handle.wait()
+            if self.world > 1:
+                flat_src.div_(self.world)

@@ -215,6 +215,8 @@ def main():
     import parallel
     from spconv import ops as sp_ops
 
+    if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+        os.environ["NCCL_DEBUG"] = "WARN"          # no version banner on stdout next to the JSON line
     rank, local_rank, world = parallel.init_distributed()
     assert world == max(args.gpus, 1) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
@@ -231,6 +233,8 @@ def main():
     model, criterion, optimizer = harness.build_model(cfg, device)
     use_dist = dist.is_initialized()
     grad_sync = parallel.GradSync(model) if use_dist else None
+    if os.environ.get("WSIS_BENCH_NOSYNC", "0") == "1":   # diagnostics only: process group up, no gradient exchange
+        grad_sync = None
     if use_dist:   # identical initial weights on every rank
         for p in model.parameters():
             dist.broadcast(p.data, 0)
@@ -329,6 +333,11 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         out.update(extra)
+        # the JSON line must be the LAST thing on stdout: RCCL prints its version banner through C stdio, which is
+        # fully buffered on a pipe and would otherwise be flushed after this line at process exit
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
