@@ -6,6 +6,10 @@
 // Every op maps 1:1 onto the single-op entry points of this library (same kernels, same summation orders, so the
 // results are bit-identical to calling them one by one); CAT / SPLIT / ADD are the elementwise glue of the UNet
 // (torch.cat of the skip connection, its backward, gradient accumulation at the residual fan-out).
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -82,6 +86,50 @@ __global__ void weight_transpose_batch_kernel(WtBatch b) {
   }
 }
 
+// ---- weight-gradient side stream: dW of a layer is a leaf of the backward graph (nothing downstream reads it
+// before the optimizer), while dIn feeds the next layer.  All dW launches of a pass go to one library-owned side
+// stream (fork: an event after the producer of dY; join: one event at the end of the pass), so they overlap the
+// dIn / BatchNorm-backward chain -- at the deep levels neither kernel fills 256 CUs on its own.  dW has its own
+// workspace region.  WSIS_DW_STREAM=0 keeps everything on the caller's stream.
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t join = nullptr;
+  std::vector<hipEvent_t> fork;
+  size_t next = 0;
+};
+
+SideStream* side_stream_for(hipStream_t main) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, SideStream> pool;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  SideStream& s = pool[std::make_pair(dev, main)];
+  if (!s.stream) {
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &s;
+}
+
+hipEvent_t next_fork_event(SideStream* s) {
+  if (s->next == s->fork.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    s->fork.push_back(e);
+  }
+  return s->fork[s->next++];
+}
+
+bool dw_stream_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("WSIS_DW_STREAM");
+    on = e ? atoi(e) : 1;
+  }
+  return on != 0;
+}
+
 inline int64_t wt_bytes_of(const wsis_op& op) {
   return up((int64_t)op.K * op.Cin * op.Cout * (int64_t)sizeof(float));
 }
@@ -94,11 +142,8 @@ int64_t op_ws_bytes(const wsis_op& op) {
       return (op.flags & WSIS_OPF_TRAINING) ? up(wsis_bn_workspace_bytes(op.M_in, op.Cin)) : 0;
     case WSIS_OP_BN_RELU_BWD:
       return up(wsis_bn_workspace_bytes(op.M_in, op.Cin));
-    case WSIS_OP_CONV_BWD: {   // the transposed weights live in the shared WT region, not here
-      const int64_t din = op.out[0] ? wsis_spconv_fwd_workspace_bytes(op.M_in, op.K, op.Cout, op.Cin) : 0;
-      const int64_t dw = op.out[1] ? wsis_spconv_dw_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout) : 0;
-      return up(din > dw ? din : dw);
-    }
+    case WSIS_OP_CONV_BWD:     // the transposed weights and the dW slabs live in their own regions, not here
+      return op.out[0] ? up(wsis_spconv_fwd_workspace_bytes(op.M_in, op.K, op.Cout, op.Cin)) : 0;
     default:
       return 0;
   }
@@ -110,14 +155,18 @@ extern "C" {
 
 int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n) {
   if (!ops || n < 0) return -1;
-  int64_t need = ALIGN, wt = 0;
+  int64_t need = ALIGN, wt = 0, dw = 0;
   for (int i = 0; i < n; ++i) {
     const int64_t b = op_ws_bytes(ops[i]);
     if (b < 0) return -1;
     if (b > need) need = b;
     if (ops[i].kind == WSIS_OP_CONV_BWD && ops[i].out[0]) wt += wt_bytes_of(ops[i]);
+    if (ops[i].kind == WSIS_OP_CONV_BWD && ops[i].out[1]) {
+      const int64_t d = up(wsis_spconv_dw_workspace_bytes(ops[i].M_out, ops[i].K, ops[i].Cin, ops[i].Cout));
+      if (d > dw) dw = d;
+    }
   }
-  return wt + need + ALIGN;
+  return wt + dw + need + ALIGN;
 }
 
 int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* stream) {
@@ -164,6 +213,19 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
   ws += wt_total;
   ws_bytes -= wt_total;
   char* const wt_base = static_cast<char*>(d_ws);
+  // dW region (shared by the dW launches, which are ordered among themselves on one stream)
+  int64_t dw_bytes = 0;
+  for (int i = 0; i < n; ++i)
+    if (ops[i].kind == WSIS_OP_CONV_BWD && ops[i].out[1]) {
+      const int64_t d = up(wsis_spconv_dw_workspace_bytes(ops[i].M_out, ops[i].K, ops[i].Cin, ops[i].Cout));
+      if (d > dw_bytes) dw_bytes = d;
+    }
+  char* const dw_ws = ws;
+  ws += dw_bytes;
+  ws_bytes -= dw_bytes;
+  SideStream* side = (dw_bytes > 0 && dw_stream_enabled()) ? side_stream_for(st) : nullptr;
+  if (side) side->next = 0;
+  bool forked = false;
   for (int i = 0; i < n; ++i) {
     const wsis_op& op = ops[i];
     int rc = WSIS_OK;
@@ -223,10 +285,20 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
                                stream);
           if (rc != WSIS_OK) break;
         }
-        if (op.out[1])
+        if (op.out[1]) {
+          void* dw_stream = stream;
+          if (side) {   // dY is complete once everything enqueued so far on the caller's stream has run
+            hipEvent_t e = next_fork_event(side);
+            WSIS_REQUIRE(e, "event creation failed");
+            WSIS_HIP_CHECK(hipEventRecord(e, st));
+            WSIS_HIP_CHECK(hipStreamWaitEvent(side->stream, e, 0));
+            dw_stream = side->stream;
+            forked = true;
+          }
           rc = wsis_spconv_dw((const float*)op.in[0], (const int32_t*)op.in[3], (const int32_t*)op.in[4],
-                              (const float*)op.in[2], (float*)op.out[1], op.M_in, op.M_out, op.K, op.Cin, op.Cout, rest,
-                              rest_bytes, stream);
+                              (const float*)op.in[2], (float*)op.out[1], op.M_in, op.M_out, op.K, op.Cin, op.Cout, dw_ws,
+                              dw_bytes, dw_stream);
+        }
         break;
       }
       case WSIS_OP_BN_RELU_BWD:
@@ -239,6 +311,10 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
         return fail(WSIS_ERR_ARG, "wsis_run_ops: unknown op kind");
     }
     if (rc != WSIS_OK) return rc;
+  }
+  if (forked) {   // join: whatever follows on the caller's stream (optimizer, gradient all-reduce) sees every dW
+    WSIS_HIP_CHECK(hipEventRecord(side->join, side->stream));
+    WSIS_HIP_CHECK(hipStreamWaitEvent(st, side->join, 0));
   }
   return WSIS_OK;
 }
