@@ -121,13 +121,9 @@ hipEvent_t next_fork_event(SideStream* s) {
   return s->fork[s->next++];
 }
 
-bool dw_stream_enabled() {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("WSIS_DW_STREAM");
-    on = e ? atoi(e) : 1;
-  }
-  return on != 0;
+bool dw_stream_enabled() {   // read per pass: bench.py switches it off for its event-instrumented roofline steps
+  const char* e = getenv("WSIS_DW_STREAM");
+  return e ? atoi(e) != 0 : true;
 }
 
 inline int64_t wt_bytes_of(const wsis_op& op) {
