@@ -2,7 +2,16 @@
 signature, ``loss_inp`` keys and returned ``(loss, loss_out)`` as the reference's
 modules/model/losses_3D_WSIS.py:13-253; pinned against the imported reference by tests/golden/loss_golden.npz.
 
-Pure torch; ``device`` follows the inputs instead of the reference's hard-coded 'cuda' attribute (:33)."""
+Pure torch; ``device`` follows the inputs instead of the reference's hard-coded 'cuda' attribute (:33).
+
+Two evaluations of the same formulas: the reference's shape (boolean-mask indexing, ``torch.unique`` -- every one of
+them a device->host sync, 12+ per step) and the default MASKED one, which keeps every intermediate at its full,
+host-known shape (rows that the reference drops get weight 0; per-instance means come from a dense same-instance
+matrix instead of ``unique``), so the host never waits for the GPU inside the loss and can keep issuing the backward
+pass while the forward is still running.  ``WSIS_LOSS_INDEXED=1`` selects the reference-shaped evaluation; both are
+checked against the golden vectors."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -43,11 +52,17 @@ class MultiTaskLoss(nn.Module):
         loss_out = {}
         semantic_labels, instance_labels = loss_inp["point_labels"]
         semantic_scores = loss_inp["semantic_scores"]
+        indexed = os.environ.get("WSIS_LOSS_INDEXED", "0") == "1"
         semantic_loss = self.semantic_criterion(semantic_scores, semantic_labels)
         if self.semantic_dice:
             keep = semantic_labels != self.ignore_label
-            semantic_scores = F.softmax(semantic_scores[keep], dim=-1)
-            one_hot = F.one_hot(semantic_labels[keep], num_classes=self.semantic_class_num)
+            if indexed:
+                semantic_scores = F.softmax(semantic_scores[keep], dim=-1)
+                one_hot = F.one_hot(semantic_labels[keep], num_classes=self.semantic_class_num)
+            else:       # dropped rows -> zero rows: every column sum of the dice terms is unchanged
+                w = keep.unsqueeze(1).to(semantic_scores.dtype)
+                semantic_scores = F.softmax(semantic_scores, dim=-1) * w
+                one_hot = F.one_hot(semantic_labels.clamp(min=0), num_classes=self.semantic_class_num) * w
             semantic_loss = semantic_loss + dice_loss_multi_classes(semantic_scores, one_hot).mean()
         loss_out["semantic_loss"] = (semantic_loss, semantic_scores.sum())
 
@@ -78,17 +93,24 @@ class MultiTaskLoss(nn.Module):
             for i in range(1, len(offs)):
                 b, e = offs[i - 1], offs[i]
                 valid = sp_valid[b:e]
-                d_loss, _, _, _ = self.discriminative_loss(feats[b:e][valid], sp_ins_labels[b:e][valid])
+                if indexed:
+                    d_loss, _, _, _ = self.discriminative_loss(feats[b:e][valid], sp_ins_labels[b:e][valid])
+                else:
+                    d_loss = self.discriminative_loss_masked(feats[b:e], sp_ins_labels[b:e], valid)
                 d_losses.append(d_loss.view(-1))
             sp_d_loss = torch.mean(torch.cat(d_losses))
             loss_out["superpoint_discriminative_loss"] = (sp_d_loss, feats.shape[0])
 
             if self.supervise_instance_size:
                 pred_occ, gt_occ = loss_inp["sp_occupancy"]
-                occupancy_loss = self.occupany_L1loss(pred_occ[sp_valid], gt_occ[sp_valid])
-                loss_out["occupancy_loss"] = (occupancy_loss, n_valid)
                 pred_size, gt_size = loss_inp["sp_instance_size"]
-                instance_size_loss = self.instance_size_L1loss(pred_size[sp_valid], gt_size[sp_valid])
+                if indexed:
+                    occupancy_loss = self.occupany_L1loss(pred_occ[sp_valid], gt_occ[sp_valid])
+                    instance_size_loss = self.instance_size_L1loss(pred_size[sp_valid], gt_size[sp_valid])
+                else:
+                    occupancy_loss = _masked_l1(pred_occ, gt_occ, sp_valid)
+                    instance_size_loss = _masked_l1(pred_size, gt_size, sp_valid)
+                loss_out["occupancy_loss"] = (occupancy_loss, n_valid)
                 loss_out["instance_size_loss"] = (instance_size_loss, n_valid)
 
         loss = 0.0
@@ -135,6 +157,36 @@ class MultiTaskLoss(nn.Module):
         l_dist = self.param_dist * l_dist
         l_reg = self.param_reg * l_reg
         return l_var + l_dist + l_reg, l_var, l_dist, l_reg
+
+    def discriminative_loss_masked(self, prediction, label, valid):
+        """the same pull / push / reg terms (losses_3D_WSIS.py:157-230) without ``unique`` / mask indexing: rows with
+        ``valid`` False get weight 0; same[i,j] = both valid and the same instance; count_i = size of i's
+        instance; an instance-level sum over c becomes a row-level sum weighted by 1/count_i."""
+        pred = torch.reshape(prediction, [-1, self.discriminative_feature_dim])
+        v = valid.to(pred.dtype)
+        same = ((label.unsqueeze(0) == label.unsqueeze(1)) & valid.unsqueeze(0) & valid.unsqueeze(1)).to(pred.dtype)
+        count = same.sum(1).clamp(min=1.0)                       # [S] (1 for invalid rows: their weight is 0 anyway)
+        w = v / count                                            # sums to 1 over each instance
+        n = torch.round(w.sum())                                 # number of instances (0-dim tensor, no sync)
+        mu = (same @ pred) / count.unsqueeze(1)                  # [S,D]: the mean of the row's instance
+        dist = torch.norm(pred - mu, p=2, dim=1)
+        dist = torch.square(torch.clamp(dist - self.delta_v, min=0.))
+        l_var = torch.sum(dist * w) / n
+        d = 2. * self.delta_d - torch.cdist(mu, mu, p=1)         # row pair (i,j) stands for instance pair (c_i,c_j)
+        other = (1.0 - same) * v.unsqueeze(0) * v.unsqueeze(1)   # valid rows of DIFFERENT instances
+        pair_w = other * w.unsqueeze(0) * w.unsqueeze(1)         # every ordered instance pair weighs 1 in total
+        l_dist = torch.sum(torch.square(torch.clamp(d, min=0.)) * pair_w) / torch.clamp(n * (n - 1), min=1.0)
+        l_reg = torch.sum(torch.norm(mu, p=2, dim=1) * w)
+        return self.param_var * l_var + self.param_dist * l_dist + self.param_reg * l_reg
+
+
+def _masked_l1(pred, target, row_valid):
+    """nn.L1Loss()(pred[row_valid], target[row_valid]) without the boolean indexing"""
+    w = row_valid.to(pred.dtype)
+    while w.dim() < pred.dim():
+        w = w.unsqueeze(-1)
+    per_row = pred[0].numel() if pred.dim() > 1 else 1
+    return torch.sum(torch.abs(pred - target) * w) / (row_valid.sum() * per_row)
 
 
 def dice_loss_multi_classes(input, target, epsilon=1e-5, weight=None):
