@@ -1,22 +1,24 @@
 """Native execution of the sparse UNet (input_conv -> UBlock -> output_layer) through the op-list executor.
 
-The module tree of ``Network`` (same parameters, same state-dict) is walked ONCE per pass on the host to record the
-forward pass as ``wsis_op`` records (include/wsis_hip.h: device pointers + sizes) into a numpy array; one C call
-(``wsis_run_ops``) then issues every kernel.  The backward pass is recorded the same way from the closures the
-forward walk leaves behind (a hand-written tape for the four op kinds of the UNet) and runs as a second C call.
+The module tree of ``Network`` (same parameters, same state-dict) is walked ONCE per (model, mode) to record the
+forward pass and -- from the closures the forward walk leaves behind, a hand-written tape for the four op kinds of
+the UNet -- the backward pass as SYMBOLIC ``wsis_op`` templates (include/wsis_hip.h: device pointers + sizes): row
+counts are level indices, activations are arena allocation ids, gather tables are slots.  Per step the templates are
+instantiated with a handful of vectorised numpy assignments (row counts of the scene's pyramid, table pointers,
+arena bases) and ONE C call per pass (``wsis_run_ops``) issues every kernel.
 Numerically this is the same kernel sequence the per-module path (spconv.SubMConv3d / BatchNorm / ...) launches,
 so both paths agree bit for bit; what disappears is ~450 Python-dispatched autograd nodes per step
 (sparse_unet3d.py:103-350 walked by torch in the reference).
 
 Activations live in one arena per pass (bump allocation, nothing is freed before the backward: 288 GB of HBM make
-rematerialisation pointless at these sizes), parameter gradients in one flat buffer whose views become ``p.grad``.
+rematerialisation pointless at these sizes), parameter gradients densely in one flat buffer whose views become
+``p.grad`` (and which ``parallel.GradSync`` all-reduces in place).
 """
 import numpy as np
 import torch
 from torch import nn
 from torch.autograd import Function
 
-import spconv
 import wsis_native as _n
 import wsis_ops
 from spconv import ops as sp_ops
@@ -29,47 +31,94 @@ OP_DTYPE = np.dtype([("kind", "<i4"), ("flags", "<i4"), ("M_in", "<i8"), ("M_out
                      ("inp", "<u8", (8,)), ("out", "<u8", (4,))])
 assert OP_DTYPE.itemsize == 144          # sizeof(wsis_op)
 
-_REL = 1 << 62                            # tag: byte offset into the FORWARD arena, resolved at launch
-_GREL = 1 << 61                           # tag: byte offset into the BACKWARD arena
-_PREL = 1 << 60                           # tag: byte offset into the flat PARAMETER-GRADIENT buffer
+# symbolic pointer = tag | id; plain device pointers (parameters, BN buffers) carry no tag
+_FWD = 1 << 62      # allocation id in the FORWARD arena
+_BWD = 1 << 61      # allocation id in the BACKWARD arena
+_PAR = 1 << 60      # allocation id in the flat PARAMETER-GRADIENT buffer
+_TBL = 1 << 59      # gather-table slot: level*6 + {0 subm.nbr, 1 subm.order, 2 down.nbr, 3 down.order, 4 up.nbr, 5 up.order}
+_EXT = 1 << 58      # external tensor: 0 = input features, 1 = gradient of the output
+_TAGS = (_FWD, _BWD, _PAR, _TBL, _EXT)
+_ID_MASK = (1 << 58) - 1
+
+
+def _lvl(level):
+    """symbolic row count of a pyramid level (negative code, resolved per scene)"""
+    return -(level + 1)
 
 
 class _Recorder(object):
-    """op list + bump allocator of one pass (``tag`` marks the arena its allocations live in)"""
+    """symbolic op list + allocation table of one arena"""
 
     def __init__(self, tag, align=256):
+        self.tag, self.align = tag, align
         self.rows = []
-        self.bytes = 0
-        self.tag = tag
-        self.align = align
+        self.alloc_level, self.alloc_mult = [], []
 
-    def alloc(self, n_floats):
-        off = self.bytes
-        self.bytes += (int(n_floats) * 4 + self.align - 1) // self.align * self.align
-        return self.tag | off
+    def alloc(self, level, mult):
+        """``mult`` floats per row of pyramid level ``level`` (level < 0: ``mult`` floats in total)"""
+        self.alloc_level.append(level)
+        self.alloc_mult.append(int(mult))
+        return self.tag | (len(self.alloc_level) - 1)
 
     def op(self, kind, flags=0, M_in=0, M_out=0, K=0, Cin=0, Cout=0, eps=0.0, momentum=0.0, inp=(), out=()):
         self.rows.append((kind, flags, M_in, M_out, K, Cin, Cout, eps, momentum, inp, out))
 
-    def finish(self, bases):
-        """-> wsis_op array with the tagged pointers resolved; ``bases`` = {tag: arena base address}"""
-        n = len(self.rows)
-        arr = np.zeros(n, dtype=OP_DTYPE)
-        inp = np.zeros((n, 8), dtype=np.uint64)
-        out = np.zeros((n, 4), dtype=np.uint64)
-        for i, r in enumerate(self.rows):
-            arr[i] = (r[0], r[1], r[2], r[3], r[4], r[5], r[6], 0, r[7], r[8], 0, 0)
+
+class _Arena(object):
+    """allocation table -> per-scene byte offsets"""
+
+    def __init__(self, rec):
+        self.level = np.asarray(rec.alloc_level, dtype=np.int64)
+        self.mult = np.asarray(rec.alloc_mult, dtype=np.int64)
+        self.align = rec.align
+
+    def layout(self, Mvec):
+        if len(self.level) == 0:
+            return np.zeros(0, dtype=np.int64), 0
+        rows = np.where(self.level >= 0, Mvec[np.maximum(self.level, 0)], 1)
+        size = (rows * self.mult * 4 + self.align - 1) // self.align * self.align
+        end = np.cumsum(size)
+        return end - size, int(end[-1])
+
+
+class _Template(object):
+    """op records with every static field filled in; row counts and tagged pointers are patched per scene"""
+
+    def __init__(self, rec):
+        n = len(rec.rows)
+        self.arr = np.zeros(n, dtype=OP_DTYPE)
+        ptr = np.zeros((n, 12), dtype=np.uint64)          # inp[0..7] | out[0..3]
+        m_in = np.zeros(n, dtype=np.int64)
+        m_out = np.zeros(n, dtype=np.int64)
+        for i, r in enumerate(rec.rows):
+            self.arr[i] = (r[0], r[1], 0, 0, r[4], r[5], r[6], 0, r[7], r[8], 0, 0)
+            m_in[i], m_out[i] = r[2], r[3]
             if r[9]:
-                inp[i, :len(r[9])] = r[9]
+                ptr[i, :len(r[9])] = r[9]
             if r[10]:
-                out[i, :len(r[10])] = r[10]
-        for a in (inp, out):
-            for tag, base in bases.items():
-                t = np.uint64(tag)
-                m = (a & t) != 0
-                a[m] = (a[m] ^ t) + np.uint64(base)
-        arr["inp"] = inp
-        arr["out"] = out
+                ptr[i, 8:8 + len(r[10])] = r[10]
+        self.m_in_lit, self.m_out_lit = np.maximum(m_in, 0), np.maximum(m_out, 0)
+        self.m_in_lvl, self.m_out_lvl = np.maximum(-m_in - 1, 0), np.maximum(-m_out - 1, 0)
+        self.m_in_sym, self.m_out_sym = m_in < 0, m_out < 0
+        flat = ptr.reshape(-1)
+        self.static = flat.copy()
+        self.patch = {}
+        for tag in _TAGS:
+            pos = np.nonzero((flat & np.uint64(tag)) != 0)[0]
+            self.patch[tag] = (pos, (flat[pos] & np.uint64(_ID_MASK)).astype(np.int64))
+            self.static[pos] = 0
+
+    def instantiate(self, Mvec, luts):
+        arr = self.arr.copy()
+        arr["M_in"] = np.where(self.m_in_sym, Mvec[self.m_in_lvl], self.m_in_lit)
+        arr["M_out"] = np.where(self.m_out_sym, Mvec[self.m_out_lvl], self.m_out_lit)
+        flat = self.static.copy()
+        for tag, (pos, idx) in self.patch.items():
+            if len(pos):
+                flat[pos] = luts[tag][idx]
+        ptr = flat.reshape(-1, 12)
+        arr["inp"] = ptr[:, :8]
+        arr["out"] = ptr[:, 8:]
         return arr
 
 
@@ -78,10 +127,27 @@ def _ptr(t):
 
 
 class _Table(object):
-    """gather tables of one conv: forward (rows = outputs) and dIn (rows = inputs) + flip flag"""
+    """gather tables of one conv as slots: forward (rows = outputs) and dIn (rows = inputs) + flip flag"""
 
-    def __init__(self, nbr_f, order_f, nbr_b, order_b, flip):
+    def __init__(self, nbr_f=0, order_f=0, nbr_b=0, order_b=0, flip=0):
         self.nbr_f, self.order_f, self.nbr_b, self.order_b, self.flip = nbr_f, order_f, nbr_b, order_b, flip
+
+
+def _subm(l):
+    return _Table(_TBL | (l * 6), _TBL | (l * 6 + 1), _TBL | (l * 6), _TBL | (l * 6 + 1), 1)
+
+
+def _down(l):
+    return _Table(_TBL | (l * 6 + 2), _TBL | (l * 6 + 3), _TBL | (l * 6 + 4), _TBL | (l * 6 + 5), 0)
+
+
+def _up(l):
+    return _Table(_TBL | (l * 6 + 4), _TBL | (l * 6 + 5), _TBL | (l * 6 + 2), _TBL | (l * 6 + 3), 0)
+
+
+class _Compiled(object):
+    """forward + backward templates of one (model, mode)"""
+    pass
 
 
 class UNetProgram(object):
@@ -90,70 +156,72 @@ class UNetProgram(object):
     def __init__(self, net):
         self.net = net
         self.params = [p for m in (net.input_conv, net.unet, net.output_layer) for p in m.parameters()]
+        self.bns = [m for mod in (net.unet, net.output_layer) for m in mod.modules() if isinstance(m, nn.BatchNorm1d)]
         self.flat_grad, self.flat_params = None, []
+        self._cache = {}
 
-    # ---- forward recording: every helper returns (out_handle, backward_closure) -----------------------------
-    def _conv(self, rec, x, conv, table, M_in, M_out, residual=0):
+    # ---- symbolic recording: every helper returns (out_handle, backward_closure) -----------------------------
+    def _conv(self, rec, x, conv, table, lvl_in, lvl_out, residual=0):
         K = int(np.prod(conv.kernel_size))
         Cin, Cout = conv.in_channels, conv.out_channels
         W = conv.weight
         assert conv.bias is None, "the UNet convolutions carry no bias (sparse_unet3d.py)"
-        y = rec.alloc(M_out * Cout)
-        t = table if table is not None else _Table(None, None, None, None, 0)
-        rec.op(OP_CONV, 0, M_in, M_out, K, Cin, Cout, inp=(x, _ptr(t.nbr_f), _ptr(t.order_f), W.data_ptr(), 0, residual),
-               out=(y,))
-        self._account("spconv_fwd_kernel", t.nbr_f, M_out, Cin, Cout)
+        y = rec.alloc(lvl_out, Cout)
+        t = table if table is not None else _Table()
+        rec.op(OP_CONV, 0, _lvl(lvl_in), _lvl(lvl_out), K, Cin, Cout,
+               inp=(x, t.nbr_f, t.order_f, W.data_ptr(), 0, residual), out=(y,))
+        self._acc_f.append(("spconv_fwd_kernel", t.nbr_f, lvl_out, Cin, Cout))
 
         def bwd(recb, dy, need_dx=True):
-            dx = recb.alloc(M_in * Cin) if need_dx else 0
-            dW = self._grad_handle(recb, W)
-            recb.op(OP_CONV_BWD, F_FLIP if t.flip else 0, M_in, M_out, K, Cin, Cout,
-                    inp=(x, W.data_ptr(), dy, _ptr(t.nbr_f), _ptr(t.order_f), _ptr(t.nbr_b), _ptr(t.order_b)),
-                    out=(dx, dW))
+            dx = recb.alloc(lvl_in, Cin) if need_dx else 0
+            dW = self._grad_handle(W)
+            recb.op(OP_CONV_BWD, F_FLIP if t.flip else 0, _lvl(lvl_in), _lvl(lvl_out), K, Cin, Cout,
+                    inp=(x, W.data_ptr(), dy, t.nbr_f, t.order_f, t.nbr_b, t.order_b), out=(dx, dW))
             if need_dx:
-                self._account("spconv_fwd_kernel", t.nbr_b, M_in, Cout, Cin)
-            self._account("spconv_dw_kernel", t.nbr_f, M_out, Cin, Cout)
+                self._acc_b.append(("spconv_fwd_kernel", t.nbr_b, lvl_in, Cout, Cin))
+            self._acc_b.append(("spconv_dw_kernel", t.nbr_f, lvl_out, Cin, Cout))
             return dx
         return y, bwd
 
-    def _bn_relu(self, rec, x, bn, M, relu=True):
+    def _bn_relu(self, rec, x, bn, lvl, relu=True):
         C = bn.num_features
         training = bn.training or not bn.track_running_stats
         update = bn.training and bn.track_running_stats
         flags = (F_RELU if relu else 0) | (F_TRAINING if training else 0) | (F_UPDATE if update else 0)
         if update and bn.num_batches_tracked is not None:
             assert bn.momentum is not None, "cumulative-average BatchNorm is not used by 3D-WSIS"
-            wsis_ops._defer_batch_count(bn)
-        y = rec.alloc(M * C)
-        mean = rec.alloc(C) if training else bn.running_mean.data_ptr()
-        var = rec.alloc(C) if training else bn.running_var.data_ptr()
-        rec.op(OP_BN_RELU, flags, M, M, 0, C, C, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+            self._count.append(bn)
+        y = rec.alloc(lvl, C)
+        mean = rec.alloc(-1, C) if training else bn.running_mean.data_ptr()
+        var = rec.alloc(-1, C) if training else bn.running_var.data_ptr()
+        rec.op(OP_BN_RELU, flags, _lvl(lvl), _lvl(lvl), 0, C, C, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
                inp=(x, _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var)),
                out=(y, mean if training else 0, var if training else 0))
 
         def bwd(recb, dy, addend=0):
             # ``addend``: gradient arriving at x over a second path (residual skip / UNet skip connection), added
             # in the same pass instead of a separate accumulation kernel
-            dx = recb.alloc(M * C)
-            dg = self._grad_handle(recb, bn.weight) if bn.weight is not None else recb.alloc(C)
-            db = self._grad_handle(recb, bn.bias) if bn.bias is not None else recb.alloc(C)
-            recb.op(OP_BN_RELU_BWD, flags, M, M, 0, C, C, bn.eps, 0.0,
+            dx = recb.alloc(lvl, C)
+            dg = self._grad_handle(bn.weight) if bn.weight is not None else recb.alloc(-1, C)
+            db = self._grad_handle(bn.bias) if bn.bias is not None else recb.alloc(-1, C)
+            recb.op(OP_BN_RELU_BWD, flags, _lvl(lvl), _lvl(lvl), 0, C, C, bn.eps, 0.0,
                     inp=(x, dy, mean, var, _ptr(bn.weight), _ptr(bn.bias), addend), out=(dx, dg, db))
             return dx
         return y, bwd
 
-    def _residual_block(self, rec, x, blk, table, M):
+    def _residual_block(self, rec, x, blk, lvl):
         seq = blk.conv_branch
         bn1, conv1, bn2, conv2 = seq[0], seq[2], seq[3], seq[5]
-        a1, b_bn1 = self._bn_relu(rec, x, bn1, M)
-        z1, b_c1 = self._conv(rec, a1, conv1, table, M, M)
-        a2, b_bn2 = self._bn_relu(rec, z1, bn2, M)
+        table = _subm(lvl)
+        a1, b_bn1 = self._bn_relu(rec, x, bn1, lvl)
+        z1, b_c1 = self._conv(rec, a1, conv1, table, lvl, lvl)
+        a2, b_bn2 = self._bn_relu(rec, z1, bn2, lvl)
         first = blk.i_branch[0]
         if isinstance(first, nn.Identity):
             res, b_i = x, None
         else:
-            res, b_i = self._conv(rec, x, first, None, M, M)          # 1x1 projection of the skip path
-        out, b_c2 = self._conv(rec, a2, conv2, table, M, M, residual=res)
+            res, b_i = self._conv(rec, x, first, None, lvl, lvl)          # 1x1 projection of the skip path
+        out, b_c2 = self._conv(rec, a2, conv2, table, lvl, lvl, residual=res)
 
         def bwd(recb, d_out):
             d_a2 = b_c2(recb, d_out)
@@ -164,11 +232,9 @@ class UNetProgram(object):
         return out, bwd
 
     def _ublock(self, rec, x, ub, lvl):
-        M = self.M[lvl]
-        subm = self.subm[lvl]
         bwds = []
         for blk in ub.blocks:
-            x, b = self._residual_block(rec, x, blk, subm, M)
+            x, b = self._residual_block(rec, x, blk, lvl)
             bwds.append(b)
         if len(ub.nPlanes) == 1:
             def bwd_leaf(recb, d):
@@ -176,28 +242,27 @@ class UNetProgram(object):
                     d = b(recb, d)
                 return d
             return x, bwd_leaf
-        C0, C1 = ub.nPlanes[0], ub.nPlanes[1]
-        M1 = self.M[lvl + 1]
+        C0 = ub.nPlanes[0]
         identity = x
-        a, b_bn = self._bn_relu(rec, x, ub.conv[0], M)
-        d, b_down = self._conv(rec, a, ub.conv[2], self.down[lvl], M, M1)
+        a, b_bn = self._bn_relu(rec, x, ub.conv[0], lvl)
+        d, b_down = self._conv(rec, a, ub.conv[2], _down(lvl), lvl, lvl + 1)
         u, b_u = self._ublock(rec, d, ub.u, lvl + 1)
-        a2, b_bn2 = self._bn_relu(rec, u, ub.deconv[0], M1)
-        up, b_up = self._conv(rec, a2, ub.deconv[2], self.up[lvl], M1, M)
-        cat = rec.alloc(M * 2 * C0)
-        rec.op(OP_CAT, 0, M, M, 0, C0, C0, inp=(identity, up), out=(cat,))
+        a2, b_bn2 = self._bn_relu(rec, u, ub.deconv[0], lvl + 1)
+        up, b_up = self._conv(rec, a2, ub.deconv[2], _up(lvl), lvl + 1, lvl)
+        cat = rec.alloc(lvl, 2 * C0)
+        rec.op(OP_CAT, 0, _lvl(lvl), _lvl(lvl), 0, C0, C0, inp=(identity, up), out=(cat,))
         x = cat
         tails = []
         for blk in ub.blocks_tail:
-            x, b = self._residual_block(rec, x, blk, subm, M)
+            x, b = self._residual_block(rec, x, blk, lvl)
             tails.append(b)
 
         def bwd(recb, dcur):
             for b in reversed(tails):
                 dcur = b(recb, dcur)
-            d_id = recb.alloc(M * C0)
-            d_up = recb.alloc(M * C0)
-            recb.op(OP_SPLIT, 0, M, M, 0, C0, C0, inp=(dcur,), out=(d_id, d_up))
+            d_id = recb.alloc(lvl, C0)
+            d_up = recb.alloc(lvl, C0)
+            recb.op(OP_SPLIT, 0, _lvl(lvl), _lvl(lvl), 0, C0, C0, inp=(dcur,), out=(d_id, d_up))
             d_a2 = b_up(recb, d_up)
             d_u = b_bn2(recb, d_a2)
             d_d = b_u(recb, d_u)
@@ -208,59 +273,85 @@ class UNetProgram(object):
             return d_x
         return x, bwd
 
-    # ---- bookkeeping ----------------------------------------------------------------------------------------
-    def _grad_handle(self, recb, p):
+    def _grad_handle(self, p):
         # parameter gradients live densely in their own flat buffer (one all-reduce for data parallelism)
         h = self._grad.get(id(p))
         if h is None:
-            h = self._palloc.alloc(p.numel())
+            h = self._prec.alloc(-1, p.numel())
             self._grad[id(p)] = h
         return h
 
-    def _account(self, name, nbr, M_out, Cin, Cout):
-        prof = sp_ops.PROFILER
-        if prof is not None:
-            P = prof.pairs(nbr, M_out)
-            prof.end(name, None, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout)
+    # ---- compile (once per mode) / bind (per scene) ------------------------------------------------------------
+    def _mode_key(self, need_dx):
+        return (need_dx, tuple(bn.training for bn in self.bns), tuple(p.data_ptr() for p in self.params),
+                tuple(bn.running_mean.data_ptr() if bn.running_mean is not None else 0 for bn in self.bns))
+
+    def compiled(self, need_dx):
+        key = self._mode_key(need_dx)
+        c = self._cache.get(key)
+        if c is not None:
+            return c
+        if len(self._cache) > 8:
+            self._cache.clear()
+        net = self.net
+        c = _Compiled()
+        rec, recb = _Recorder(_FWD), _Recorder(_BWD)
+        self._prec, self._grad = _Recorder(_PAR, align=16), {}
+        self._acc_f, self._acc_b, self._count = [], [], []
+        y, b_in = self._conv(rec, _EXT | 0, net.input_conv[0], _subm(0), 0, 0)
+        y, b_u = self._ublock(rec, y, net.unet, 0)
+        out, b_out = self._bn_relu(rec, y, net.output_layer[0], 0)
+        d = b_out(recb, _EXT | 1)
+        d = b_u(recb, d)
+        dx = b_in(recb, d, need_dx)
+        c.fwd, c.bwd = _Template(rec), _Template(recb)
+        c.fwd_arena, c.bwd_arena, c.par_arena = _Arena(rec), _Arena(recb), _Arena(self._prec)
+        c.out_id, c.dx_id = out & _ID_MASK, (dx & _ID_MASK) if need_dx else -1
+        c.grad_ids = [(self._grad[id(p)] & _ID_MASK) if id(p) in self._grad else -1 for p in self.params]
+        c.acc_f, c.acc_b, c.count = self._acc_f, self._acc_b, self._count
+        c.out_channels = net.output_layer[0].num_features
+        self._cache[key] = c
+        return c
 
     def bind(self, tensor):
-        """rulebooks of the pyramid of ``tensor`` (built if missing) -> per-level tables and row counts"""
+        """rulebooks of the pyramid of ``tensor`` (built if missing) -> row counts and the table-pointer LUT"""
         net = self.net
         sp_ops.prebuild_unet_rulebooks(tensor, net.blocks)
-        self.M, self.subm, self.down, self.up = [], [], [], []
-        for lvl in range(net.blocks):
+        L = net.blocks
+        self.Mvec = np.zeros(L, dtype=np.int64)
+        self.table_lut = np.zeros(L * 6, dtype=np.uint64)
+        self.table_tensors = [None] * (L * 6)
+        for lvl in range(L):
             rb = tensor.indice_dict["subm%d" % (lvl + 1)]
-            self.M.append(int(rb.in_indices.shape[0]))
-            self.subm.append(_Table(rb.nbr_p, rb.order, rb.nbr_p, rb.order, 1))
-            if lvl + 1 < net.blocks:
+            self.Mvec[lvl] = rb.in_indices.shape[0]
+            ts = [rb.nbr_p, rb.order, None, None, None, None]
+            if lvl + 1 < L:
                 rd = tensor.indice_dict["spconv%d" % (lvl + 1)]
-                self.down.append(_Table(rd.nbr_p, rd.order, rd.nbr_up_p, rd.order_up, 0))
-                self.up.append(_Table(rd.nbr_up_p, rd.order_up, rd.nbr_p, rd.order, 0))
+                ts[2:] = [rd.nbr_p, rd.order, rd.nbr_up_p, rd.order_up]
+            for j, t in enumerate(ts):
+                self.table_lut[lvl * 6 + j] = _ptr(t)
+                self.table_tensors[lvl * 6 + j] = t
         self.keep = [tensor.indice_dict]     # the tables must outlive the backward pass
 
-    def record_forward(self, x_ptr, Cin0):
-        net = self.net
-        rec = _Recorder(_REL)
-        M0 = self.M[0]
-        y, b_in = self._conv(rec, x_ptr, net.input_conv[0], self.subm[0], M0, M0)
-        y, b_u = self._ublock(rec, y, net.unet, 0)
-        out, b_out = self._bn_relu(rec, y, net.output_layer[0], M0)
-
-        def backward(recb, d_out, need_dx):
-            d = b_out(recb, d_out)
-            d = b_u(recb, d)
-            return b_in(recb, d, need_dx)
-        return rec, out, backward
+    def account(self, entries, Mvec, tensors):
+        prof = sp_ops.PROFILER
+        if prof is None:
+            return
+        for name, nbr, lvl, Cin, Cout in entries:
+            t = tensors[nbr & _ID_MASK] if nbr else None
+            P = prof.pairs(t, int(Mvec[lvl]))
+            prof.end(name, None, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout)
 
 
-def _arena(nbytes, device):
-    t = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+def _arena_tensor(nbytes, device, zero=False):
+    make = torch.zeros if zero else torch.empty
+    t = make(nbytes + 256, dtype=torch.uint8, device=device)
     return t, (t.data_ptr() + 255) // 256 * 256
 
 
-def _view(arena, base, tag, handle, shape):
+def _view(arena, base, offset, shape):
     numel = int(np.prod(shape))
-    off = (handle ^ tag) + base - arena.data_ptr()
+    off = base + int(offset) - arena.data_ptr()
     return arena[off:off + numel * 4].view(torch.float32).view(shape)
 
 
@@ -272,40 +363,52 @@ class UNetFunction(Function):
     def forward(ctx, x, prog, *params):
         _n.require_cuda(x)
         x = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.contiguous().float()
-        rec, out_h, backward = prog.record_forward(x.data_ptr(), x.shape[1])
-        arena, base = _arena(rec.bytes, x.device)
-        _run(_n.hip(), rec.finish({_REL: base}), x.device)
-        out = _view(arena, base, _REL, out_h, (prog.M[0], prog.net.output_layer[0].num_features))
-        ctx.prog, ctx.record_backward, ctx.arena, ctx.base, ctx.x = prog, backward, arena, base, x
-        ctx.keep = prog.keep
+        need_dx = bool(x.requires_grad)
+        c = prog.compiled(need_dx)
+        for bn in c.count:
+            wsis_ops._defer_batch_count(bn)
+        Mvec, table_lut, tensors = prog.Mvec, prog.table_lut, prog.table_tensors
+        offs, total = c.fwd_arena.layout(Mvec)
+        arena, base = _arena_tensor(total, x.device)
+        fwd_lut = offs.astype(np.uint64) + np.uint64(base)
+        none = fwd_lut[:0]
+        luts = {_FWD: fwd_lut, _TBL: table_lut, _EXT: np.array([x.data_ptr(), 0], dtype=np.uint64), _BWD: none,
+                _PAR: none}
+        _run(_n.hip(), c.fwd.instantiate(Mvec, luts), x.device)
+        prog.account(c.acc_f, Mvec, tensors)
+        out = _view(arena, base, offs[c.out_id], (int(Mvec[0]), c.out_channels))
+        ctx.prog, ctx.c, ctx.arena, ctx.fwd_lut, ctx.x = prog, c, arena, fwd_lut, x
+        ctx.Mvec, ctx.table_lut, ctx.tensors, ctx.keep = Mvec, table_lut, tensors, prog.keep
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        prog = ctx.prog
+        prog, c, Mvec = ctx.prog, ctx.c, ctx.Mvec
         d_out = d_out if (d_out.dtype == torch.float32 and d_out.is_contiguous()) else d_out.contiguous().float()
-        recb = _Recorder(_GREL)
-        prog._grad = {}
-        prog._palloc = _Recorder(_PREL, align=16)
-        need_dx = ctx.needs_input_grad[0]
-        dx_h = ctx.record_backward(recb, d_out.data_ptr(), need_dx)
-        garena, gbase = _arena(recb.bytes, d_out.device)
-        pflat = torch.zeros(prog._palloc.bytes // 4 + 64, dtype=torch.float32, device=d_out.device)
-        pbase = (pflat.data_ptr() + 255) // 256 * 256
-        _run(_n.hip(), recb.finish({_REL: ctx.base, _GREL: gbase, _PREL: pbase}), d_out.device)
-        first = (pbase - pflat.data_ptr()) // 4
+        dev = d_out.device
+        boffs, btotal = c.bwd_arena.layout(Mvec)
+        poffs, ptotal = c.par_arena.layout(Mvec)
+        garena, gbase = _arena_tensor(btotal, dev)
+        parena, pbase = _arena_tensor(ptotal, dev, zero=True)     # alignment gaps are part of the all-reduced buffer
+        luts = {_FWD: ctx.fwd_lut, _BWD: boffs.astype(np.uint64) + np.uint64(gbase),
+                _PAR: poffs.astype(np.uint64) + np.uint64(pbase), _TBL: ctx.table_lut,
+                _EXT: np.array([ctx.x.data_ptr(), d_out.data_ptr()], dtype=np.uint64)}
+        _run(_n.hip(), c.bwd.instantiate(Mvec, luts), dev)
+        prog.account(c.acc_b, Mvec, ctx.tensors)
+        pflat = parena.view(torch.float32)
+        first = (pbase - parena.data_ptr()) // 4
         grads, covered = [], []
         for i, p in enumerate(prog.params):
-            h = prog._grad.get(id(p))
-            if h is None or not ctx.needs_input_grad[2 + i]:
+            gid = c.grad_ids[i]
+            if gid < 0 or not ctx.needs_input_grad[2 + i]:
                 grads.append(None)
             else:
-                off = first + (h ^ _PREL) // 4
+                off = first + int(poffs[gid]) // 4
                 grads.append(pflat[off:off + p.numel()].view(p.shape))
                 covered.append(p)
         # data-parallel hook: the gradients of ``flat_params`` are views of ``flat_grad`` (parallel.GradSync)
         prog.flat_grad, prog.flat_params = pflat, covered
-        dx = _view(garena, gbase, _GREL, dx_h, tuple(ctx.x.shape)) if need_dx else None
+        dx = _view(garena, gbase, boffs[c.dx_id], tuple(ctx.x.shape)) if c.dx_id >= 0 else None
         return (dx, None) + tuple(grads)
 
 
