@@ -28,5 +28,6 @@ for lvl in range(5):
     tot=d[:,:7].sum(1)
     print(f"L{lvl} M={M} C={C} tiles={nt} kz={kz} WGs={nt*kz}: mean cycles/WG {tot.mean():.0f} ({tot.mean()/2400:.1f} us @2.4GHz) steps/WG {d[:,7].mean():.1f}")
     print("    "+"  ".join(f"{n}:{d[:,i].mean():.0f}" for i,n in enumerate(names[:7])))
+    print(f"    WG time p50 {np.percentile(tot,50):.0f} p90 {np.percentile(tot,90):.0f} max {tot.max():.0f} cycles; steps p50 {np.percentile(d[:,7],50):.0f} p90 {np.percentile(d[:,7],90):.0f} max {d[:,7].max():.0f}; cycles/step of the slowest 10%: {(tot[tot>=np.percentile(tot,90)]/np.maximum(d[tot>=np.percentile(tot,90),7],1)).mean():.0f}")
     if lvl<4:
         rd=ops.build_down_rulebook(idx, shape,[2]*3,[2]*3,[0]*3); idx, shape = rd.out_indices, rd.out_shape
