@@ -158,6 +158,8 @@ class UNetProgram(object):
         self.params = [p for m in (net.input_conv, net.unet, net.output_layer) for p in m.parameters()]
         self.bns = [m for mod in (net.unet, net.output_layer) for m in mod.modules() if isinstance(m, nn.BatchNorm1d)]
         self.flat_grad, self.flat_params = None, []
+        self.flat_tail = None        # spare floats behind the gradients (parallel.GradSync packs the other
+        self.tail_floats = 0         # parameters' gradients there: ONE collective per step)
         self._cache = {}
 
     # ---- symbolic recording: every helper returns (out_handle, backward_closure) -----------------------------
@@ -389,7 +391,8 @@ class UNetFunction(Function):
         boffs, btotal = c.bwd_arena.layout(Mvec)
         poffs, ptotal = c.par_arena.layout(Mvec)
         garena, gbase = _arena_tensor(btotal, dev)
-        parena, pbase = _arena_tensor(ptotal, dev, zero=True)     # alignment gaps are part of the all-reduced buffer
+        tail = int(prog.tail_floats) * 4
+        parena, pbase = _arena_tensor(ptotal + tail, dev, zero=True)   # alignment gaps are all-reduced too
         luts = {_FWD: ctx.fwd_lut, _BWD: boffs.astype(np.uint64) + np.uint64(gbase),
                 _PAR: poffs.astype(np.uint64) + np.uint64(pbase), _TBL: ctx.table_lut,
                 _EXT: np.array([ctx.x.data_ptr(), d_out.data_ptr()], dtype=np.uint64)}
@@ -408,6 +411,8 @@ class UNetFunction(Function):
                 covered.append(p)
         # data-parallel hook: the gradients of ``flat_params`` are views of ``flat_grad`` (parallel.GradSync)
         prog.flat_grad, prog.flat_params = pflat, covered
+        t0 = first + (ptotal + 3) // 4
+        prog.flat_tail = pflat[t0:t0 + prog.tail_floats] if prog.tail_floats else None
         dx = _view(garena, gbase, boffs[c.dx_id], tuple(ctx.x.shape)) if c.dx_id >= 0 else None
         return (dx, None) + tuple(grads)
 

@@ -67,6 +67,14 @@ class GradSync(object):
             return None, set()
         return flat, {id(p) for p in ok}
 
+    def _reserve_tail(self, model):
+        """ask the native UNet pass for spare room behind its gradients: the remaining parameters' gradients are
+        packed there, so a step needs ONE collective"""
+        prog = getattr(model, "_native_prog", None) if model is not None else None
+        if prog is not None and prog.tail_floats == 0 and os.environ.get("WSIS_SYNC_TAIL", "1") != "0":
+            covered = {id(p) for p in prog.params}
+            prog.tail_floats = sum(p.numel() for b in self.buckets for p in b if id(p) not in covered)
+
     def __call__(self, model=None):
         if self.world == 1 and os.environ.get("WSIS_FORCE_DIST", "0") != "1":
             return
@@ -74,7 +82,17 @@ class GradSync(object):
         flat_src, covered = self._flat_source(model)
         self.last_flat_params = len(covered)        # diagnostics / tests: parameters synchronised without a copy
         flat_handle = None
+        self._reserve_tail(model)
+        tail_job = None
         if flat_src is not None:
+            prog = model._native_prog
+            rest = [p for b in self.buckets for p in b if id(p) not in covered]
+            n_rest = sum(p.numel() for p in rest)
+            if prog.flat_tail is not None and prog.flat_tail.numel() == n_rest and n_rest > 0:
+                grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in rest]
+                torch.cat([g.reshape(-1) for g in grads], out=prog.flat_tail)
+                tail_job = (rest, grads, prog.flat_tail)
+                covered = covered | {id(p) for p in rest}
             flat_handle = dist.all_reduce(flat_src, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         # flatten every bucket with ONE cat kernel, all-reduce asynchronously, copy back with ONE multi-tensor copy
         for bucket in self.buckets:
@@ -98,3 +116,10 @@ class GradSync(object):
             flat_handle.wait()
             if self.world > 1:
                 flat_src.div_(self.world)
+            if tail_job is not None:
+                rest, grads, tail = tail_job
+                views = [v.view_as(g) for v, g in zip(torch.split(tail, [g.numel() for g in grads]), grads)]
+                torch._foreach_copy_(grads, views)
+                for p, g in zip(rest, grads):
+                    if p.grad is None:
+                        p.grad = g

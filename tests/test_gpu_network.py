@@ -183,5 +183,18 @@ def test_gradsync_allreduces_the_flat_unet_gradient_buffer_in_place():
         for n, p in model.named_parameters():
             if p.grad is not None:     # sum over one rank, divided by the pretended world of 2
                 assert torch.allclose(p.grad, before[n] / 2, rtol=0, atol=0), n
+        # second step: the native pass now leaves room behind its gradients and the remaining parameters'
+        # gradients travel in the same (single) collective
+        assert model._native_prog.tail_floats > 0
+        opt.zero_grad(set_to_none=True)
+        loss, _ = harness.forward_loss(model, crit, batch, cfg)
+        loss.backward()
+        before = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        assert model._native_prog.flat_tail is not None
+        gs(model)
+        torch.cuda.synchronize()
+        for n, p in model.named_parameters():
+            if p.grad is not None:
+                assert torch.allclose(p.grad, before[n] / 2, rtol=0, atol=0), n
     finally:
         dist.destroy_process_group()
