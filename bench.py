@@ -73,6 +73,7 @@ def parse():
     return ap.parse_args()
 
 
+MFMA_FP32_PEAK_TFLOPS = 157.3      # dense fp32 matrix peak (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU x 256 CUs x 2.4 GHz)
 CPU_SAMPLE_ROOM = (2.3, 1.8, 2.2)   # quarter-area room of the C2 scene: the bounded cpu_baseline sample
 CPU_SAMPLE_BOXES = 2
 
@@ -158,6 +159,9 @@ def side_measurements(harness, optimizer, device, args):
     t0 = time.perf_counter()
     cl_idx, cl_off = pointgroup_ops.bfs_cluster(sem_keep, idx_c, sl_c, 50)
     ms_bfs = (time.perf_counter() - t0) * 1e3
+    # BASELINE configs C3 / C4 as side numbers (same process, after the timed region)
+    out.update(other_configs(harness, device, args))
+
     # test-time grouping on the superpoint graph (test_scannetv2.py:281-455) on the C2 scene, synthetic predictions
     import inference
     sc = harness.make_scene(args.scene_seed)
@@ -174,6 +178,37 @@ def side_measurements(harness, optimizer, device, args):
                             "points": int(coords.shape[0]), "neighbour_pairs": int(idx_c.numel()),
                             "clusters": int(cl_off.numel() - 1), "ballquery_ms": round(ms_bq, 3),
                             "bfs_cluster_host_ms": round(ms_bfs, 3)}
+    return out
+
+
+def other_configs(harness, device, args):
+    """C3: training step on a batch of 4 scenes (full loss); C4: eval-mode forward of a ~1 M-point room."""
+    out = {}
+    cfg = harness.default_cfg()
+    cfg.batch_size = 4
+    scenes = [harness.make_scene(s, room=(3.2, 2.6, 2.2), n_box=4) for s in (1, 2, 3, 4)]
+    b = harness.to_device(harness.collate(scenes), device)
+    model, crit, opt = harness.build_model(cfg, device)
+    for _ in range(3):
+        harness.train_step(model, crit, opt, b, cfg)
+    ms = _gpu_ms(lambda: harness.train_step(model, crit, opt, b, cfg), 5)
+    out["c3_batch4_train"] = {"workload": "C3: 4 scenes per step, fwd+bwd+AdamW, full loss",
+                              "active_voxels": int(b["voxel_locs"].shape[0]), "ms_per_step": round(ms, 3),
+                              "scenes_per_s": round(4e3 / ms, 2)}
+    del b
+    cfg.batch_size = 1
+    big = harness.to_device(harness.collate([harness.make_scene(5, room=(13.0, 10.0, 3.0), n_box=36)]), device)
+    model.eval()
+
+    def infer():
+        with torch.no_grad():
+            harness.forward_loss(model, crit, big, cfg)
+
+    infer()
+    ms = _gpu_ms(infer, 3)
+    out["c4_inference"] = {"workload": "C4: eval-mode forward (+loss) of one ~1 M-point room",
+                           "points": int(big["locs"].shape[0]), "active_voxels": int(big["voxel_locs"].shape[0]),
+                           "ms": round(ms, 3)}
     return out
 
 
@@ -317,6 +352,7 @@ def main():
                     "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 2),
                     "alg_bytes_per_step": k["bytes"] // args.profile_steps,
                     "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2),
+                    "mfma_frac_fp32": round(k["flops"] / (k["ms"] * 1e-3) / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4),
                     "measured": "HIP events around every launch in %d extra steps with the dW side stream off "
                                 "(kernel alone on the GPU); rocprofv3 of WSIS_DW_STREAM=0 agrees, see profiles/"
                                 % args.profile_steps}
