@@ -124,6 +124,9 @@ def hip():
     """libwsis_hip.so (device operators)."""
     global _hip
     if _hip is None:
+        # torch first: it ships its own libamdhip64; loaded afterwards, libwsis_hip.so resolves against that copy.
+        # The other order leaves two HIP runtimes in the process (this library then sees zero devices).
+        import torch  # noqa: F401
         _hip = _bind(_load("libwsis_hip.so"), _HIP_SIGS)
     return _hip
 
