@@ -21,36 +21,47 @@ namespace {
 constexpr int64_t ALIGN = 256;
 inline int64_t up(int64_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
 
-// out[r] = [a[r] | b[r]]
+// out[r] = [a[r] | b[r]]  (float4 granules when both widths are multiples of 4)
+template <int W>
 __global__ void cat_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                                 int64_t M, int Ca, int Cb) {
-  const int C = Ca + Cb;
-  const int64_t total = M * C;
+  const int Ca_w = Ca / W, C_w = (Ca + Cb) / W;
+  const int64_t total = M * C_w;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = t / C;
-    const int c = (int)(t - r * C);
-    out[t] = c < Ca ? a[r * Ca + c] : b[r * Cb + (c - Ca)];
+    const int64_t r = t / C_w;
+    const int c = (int)(t - r * C_w);
+    const float* src = c < Ca_w ? a + (r * Ca_w + c) * W : b + (r * (C_w - Ca_w) + (c - Ca_w)) * W;
+    if (W == 4)
+      reinterpret_cast<float4*>(out)[t] = *reinterpret_cast<const float4*>(src);
+    else
+      out[t] = *src;
   }
 }
 
+template <int W>
 __global__ void split_rows_kernel(const float* __restrict__ in, float* __restrict__ a, float* __restrict__ b, int64_t M,
                                   int Ca, int Cb) {
-  const int C = Ca + Cb;
-  const int64_t total = M * C;
+  const int Ca_w = Ca / W, C_w = (Ca + Cb) / W;
+  const int64_t total = M * C_w;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = t / C;
-    const int c = (int)(t - r * C);
-    const float v = in[t];
-    if (c < Ca)
-      a[r * Ca + c] = v;
+    const int64_t r = t / C_w;
+    const int c = (int)(t - r * C_w);
+    float* dst = c < Ca_w ? a + (r * Ca_w + c) * W : b + (r * (C_w - Ca_w) + (c - Ca_w)) * W;
+    if (W == 4)
+      *reinterpret_cast<float4*>(dst) = reinterpret_cast<const float4*>(in)[t];
     else
-      b[r * Cb + (c - Ca)] = v;
+      *dst = in[t];
   }
 }
 
 __global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
     dst[t] += src[t];
+}
+
+inline bool vec4_ok(const wsis_op& op, const void* p0, const void* p1, const void* p2) {
+  return (op.Cin % 4 == 0) && (op.Cout % 4 == 0) &&
+         ((reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
 }
 
 // every dIn convolution of a backward pass needs W[k]^T (flipped for submanifold tables): all of them are produced
@@ -250,16 +261,26 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
       }
       case WSIS_OP_CAT:
         if (op.M_in > 0) {
-          hipLaunchKernelGGL(cat_rows_kernel, dim3(grid_for(op.M_in * (op.Cin + op.Cout), 256)), dim3(256), 0, st,
-                             (const float*)op.in[0], (const float*)op.in[1], (float*)op.out[0], op.M_in, op.Cin,
-                             op.Cout);
+          if (vec4_ok(op, op.in[0], op.in[1], op.out[0]))
+            hipLaunchKernelGGL(cat_rows_kernel<4>, dim3(grid_for(op.M_in * (op.Cin + op.Cout) / 4, 256)), dim3(256), 0,
+                               st, (const float*)op.in[0], (const float*)op.in[1], (float*)op.out[0], op.M_in, op.Cin,
+                               op.Cout);
+          else
+            hipLaunchKernelGGL(cat_rows_kernel<1>, dim3(grid_for(op.M_in * (op.Cin + op.Cout), 256)), dim3(256), 0, st,
+                               (const float*)op.in[0], (const float*)op.in[1], (float*)op.out[0], op.M_in, op.Cin,
+                               op.Cout);
           WSIS_LAUNCH_CHECK();
         }
         break;
       case WSIS_OP_SPLIT:
         if (op.M_in > 0) {
-          hipLaunchKernelGGL(split_rows_kernel, dim3(grid_for(op.M_in * (op.Cin + op.Cout), 256)), dim3(256), 0, st,
-                             (const float*)op.in[0], (float*)op.out[0], (float*)op.out[1], op.M_in, op.Cin, op.Cout);
+          if (vec4_ok(op, op.in[0], op.out[0], op.out[1]))
+            hipLaunchKernelGGL(split_rows_kernel<4>, dim3(grid_for(op.M_in * (op.Cin + op.Cout) / 4, 256)), dim3(256),
+                               0, st, (const float*)op.in[0], (float*)op.out[0], (float*)op.out[1], op.M_in, op.Cin,
+                               op.Cout);
+          else
+            hipLaunchKernelGGL(split_rows_kernel<1>, dim3(grid_for(op.M_in * (op.Cin + op.Cout), 256)), dim3(256), 0, st,
+                               (const float*)op.in[0], (float*)op.out[0], (float*)op.out[1], op.M_in, op.Cin, op.Cout);
           WSIS_LAUNCH_CHECK();
         }
         break;
