@@ -48,6 +48,11 @@ def adjacency_csr(graph, S):
     return off, dst.astype(np.int32)
 
 
+# test_s3dis.py:297-541: 13 classes, ceiling / floor / wall (0, 1, 2) are stuff, growth radius 0.8 * size
+S3DIS_LABEL_IDX = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+S3DIS_VALID_LABELS = S3DIS_LABEL_IDX[3:]
+
+
 def graph_bfs(label, class_valid, centre, ins_size, adj_off, adj):
     """wsis_host_graph_bfs -> (group int32 [S], n_groups)"""
     import ctypes
@@ -69,7 +74,12 @@ def graph_bfs(label, class_valid, centre, ins_size, adj_off, adj):
 
 def clustering_in_graph(scene_name, xyz_origin, superpoint, graph, sp_semnatic_pred, pred_sp_offset_vectors,
                         pred_sp_occupancy, pred_sp_ins_size, device="cuda", semantic_ind2label=SEMANTIC_IND2LABEL,
-                        valid_labels=INSTANCE_VALID_LABELS):
+                        valid_labels=INSTANCE_VALID_LABELS, radius_factor=0.25, stuff_classes=()):
+    """``radius_factor``: 0.25 (ScanNet, test_scannetv2.py:331) / 0.8 (S3DIS, test_s3dis.py:349).
+    ``stuff_classes``: predicted classes reported as ONE instance each (confidence 1) when they cover more than 100
+    points -- ceiling and floor of test_s3dis.py:524-531, appended after the grouped instances.  The reference's
+    S3DIS walls additionally go through open3d's RANSAC ``segment_plane`` (utils/planeSegment.py), which is not part
+    of this path."""
     assert len(xyz_origin) == len(superpoint)
     N, S = len(xyz_origin), len(sp_semnatic_pred)
     dev = torch.device(device)
@@ -92,19 +102,22 @@ def clustering_in_graph(scene_name, xyz_origin, superpoint, graph, sp_semnatic_p
 
     class_valid = np.isin(semantic_ind2label, valid_labels)
     adj_off, adj = adjacency_csr(graph, S)
-    group, n_groups = graph_bfs(label, class_valid, inst_centre, size[:, 0], adj_off, adj)
-    if n_groups == 0:
+    # the operator compares against 0.25 * size[seed]: other radii go in through the size argument
+    seed_size = size[:, 0] if radius_factor == 0.25 else (size[:, 0] * np.float32(radius_factor / 0.25))
+    group, n_groups = graph_bfs(label, class_valid, inst_centre, seed_size, adj_off, adj)
+    if n_groups == 0 and not stuff_classes:
         return np.array([]), np.array([]), np.array([])
 
     # points -> group id; voxels per group with ONE voxelization_idx over (group, trunc(xyz * 50))
     group_d = torch.from_numpy(group).to(dev)
     pg = group_d[sp]                                               # [N] group of every point, -1 = ungrouped
-    sel = torch.nonzero(pg >= 0).flatten()
-    vox = (xyz[sel] * 50).long()                                   # float32 product, truncation: as :381-383
-    coords = torch.cat([pg[sel].long().unsqueeze(1), vox], 1).contiguous()
-    voxel_locs, _, _ = pointgroup_ops.voxelization_idx(coords, n_groups, 4)
-    group_voxels = torch.bincount(voxel_locs[:, 0], minlength=n_groups).cpu().numpy()
-    group_n = torch.bincount(pg[sel].long(), minlength=n_groups).cpu().numpy()
+    if n_groups > 0:
+        sel = torch.nonzero(pg >= 0).flatten()
+        vox = (xyz[sel] * 50).long()                               # float32 product, truncation: as :381-383
+        coords = torch.cat([pg[sel].long().unsqueeze(1), vox], 1).contiguous()
+        voxel_locs, _, _ = pointgroup_ops.voxelization_idx(coords, n_groups, 4)
+        group_voxels = torch.bincount(voxel_locs[:, 0], minlength=n_groups).cpu().numpy()
+        group_n = torch.bincount(pg[sel].long(), minlength=n_groups).cpu().numpy()
 
     members = [np.nonzero(group == g)[0] for g in range(n_groups)]     # ascending superpoint ids
     seed_label = np.array([label[m[0]] for m in members])
@@ -151,14 +164,24 @@ def clustering_in_graph(scene_name, xyz_origin, superpoint, graph, sp_semnatic_p
 
     # ---- results (:441-455) -------------------------------------------------------------------------------
     conf, label_id = [], []
-    inst_of_group = np.full(n_groups, -1, dtype=np.int64)
+    inst_of_group = np.full(max(n_groups, 1), -1, dtype=np.int64)
     for i, prim in enumerate(primaries):
         conf.append(min(prim["group_n"] / occupancy_of(prim["members"]), 1))
         label_id.append(semantic_ind2label[prim["classLabel"]])
         inst_of_group[prim["groups"]] = i
-    if not primaries:
+    mask_rows = []
+    if primaries:
+        inst_d = torch.from_numpy(inst_of_group).to(dev)
+        pi = torch.where(pg >= 0, inst_d[pg.clamp(min=0).long()], torch.full_like(pg, -1, dtype=torch.int64))
+        mask_rows.append((pi.unsqueeze(0) == torch.arange(len(primaries), device=dev).unsqueeze(1)).to(torch.int64))
+    if stuff_classes:                                                  # test_s3dis.py:524-531
+        point_label = torch.from_numpy(label).to(dev)[sp]
+        for c in stuff_classes:
+            m = point_label == int(c)
+            if int(m.sum()) > 100:
+                conf.append(1)
+                label_id.append(semantic_ind2label[int(c)])
+                mask_rows.append(m.to(torch.int64).unsqueeze(0))
+    if not mask_rows:
         return np.array([]), np.array([]), np.array([])
-    inst_d = torch.from_numpy(inst_of_group).to(dev)
-    pi = torch.where(pg >= 0, inst_d[pg.clamp(min=0).long()], torch.full_like(pg, -1, dtype=torch.int64))
-    masks = (pi.unsqueeze(0) == torch.arange(len(primaries), device=dev).unsqueeze(1)).to(torch.int64)
-    return np.array(conf), np.array(label_id), masks.cpu().numpy()
+    return np.array(conf), np.array(label_id), torch.cat(mask_rows, 0).cpu().numpy()

@@ -28,23 +28,28 @@ import pointgroup_ops               # noqa: E402
 from oracle import cluster_ref      # noqa: E402
 
 REF = "/root/reference/test_scannetv2.py"
+REF_S3DIS = "/root/reference/test_s3dis.py"
 
 
 class Graph(object):
     def __init__(self, lists):
         self.lists = lists
+        self.vs = [{"v": i} for i in range(len(lists))]      # test_s3dis.py walks graph.vs for the stuff classes
 
     def neighbors(self, vertex, mode="all"):
         assert mode == "all"
         return [int(v) for v in self.lists[int(vertex)]]
 
 
-def reference_function():
-    src = open(REF).read()
+def reference_function(path=REF):
+    src = open(path).read()
     tree = ast.parse(src)
     fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "clustering_in_graph"][0]
-    code = compile(ast.Module(body=[fn], type_ignores=[]), REF, "exec")
-    ns = {"np": np, "torch": torch, "collections": collections, "sqrt": sqrt, "pointgroup_ops": pointgroup_ops}
+    code = compile(ast.Module(body=[fn], type_ignores=[]), path, "exec")
+    # get_room_walls (S3DIS only) is open3d's RANSAC plane segmentation: absent here and outside the path; the
+    # golden vectors cover everything the function returns except those wall instances
+    ns = {"np": np, "torch": torch, "collections": collections, "sqrt": sqrt, "pointgroup_ops": pointgroup_ops,
+          "get_room_walls": lambda xyz, mask, max_num=4: []}
     exec(code, ns)
     return ns["clustering_in_graph"]
 
@@ -70,6 +75,22 @@ def main():
                     f"{tag}_off": off, f"{tag}_occ": occ, f"{tag}_size": size, f"{tag}_conf": conf,
                     f"{tag}_label_id": label_id, f"{tag}_inst": inst})
         print(tag, "points", len(xyz), "superpoints", sc["S"], "instances", len(conf), "labels", sorted(set(label_id)))
+    # S3DIS variant (test_s3dis.py:297-541): 13 classes, growth radius 0.8 * size, ceiling / floor as stuff
+    fn3 = reference_function(REF_S3DIS)
+    sc = harness.make_scene(13, room=(1.6, 1.3, 1.1), n_box=4)
+    sem, off, occ, size = harness.synthetic_predictions(sc, 13)
+    sem = sem % 13
+    sem[::9] = 0                                   # some ceiling / floor / wall predictions (stuff classes)
+    sem[4::13] = 1
+    sem[7::17] = 2
+    lists = cluster_ref.neighbour_lists(sc["edges"], sc["S"])
+    xyz = sc["xyz"].astype(np.float32)
+    with redirect_stdout(io.StringIO()):
+        conf, label_id, masks = fn3("synthetic", xyz, sc["superpoint"], Graph(lists), sem, off, occ, size)
+    out.update({"s_xyz": xyz, "s_superpoint": sc["superpoint"].astype(np.int32), "s_edges": sc["edges"].astype(np.int32),
+                "s_sem": sem.astype(np.int32), "s_off": off, "s_occ": occ, "s_size": size, "s_conf": conf,
+                "s_label_id": label_id, "s_masks": np.packbits(masks.astype(bool), axis=1)})
+    print("s3dis points", len(xyz), "superpoints", sc["S"], "instances", len(conf), "labels", list(label_id))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cluster_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -558,3 +558,19 @@ def test_clustering_in_graph_matches_oracle_on_a_fresh_scene_and_handles_no_inst
     assert len(conf) == 0 and len(lab) == 0 and len(masks) == 0
     with pytest.raises(Exception):
         inference.clustering_in_graph("s", xyz, sc["superpoint"], _Graph(lists), sem, off, occ, size, device="cpu")
+
+
+def test_clustering_in_graph_s3dis_variant_matches_reference_outputs():
+    """test_s3dis.py:297-541 (13 classes, growth radius 0.8 * size, ceiling / floor reported as stuff instances)
+    against the outputs of that function (its RANSAC wall split stubbed out when the vectors were made)"""
+    import inference
+    g, S, cluster_ref = _cluster_case("s")
+    lists = cluster_ref.neighbour_lists(g["s_edges"], S)
+    conf, label_id, masks = inference.clustering_in_graph(
+        "golden", g["s_xyz"], g["s_superpoint"], _Graph(lists), g["s_sem"], g["s_off"], g["s_occ"], g["s_size"],
+        semantic_ind2label=inference.S3DIS_LABEL_IDX, valid_labels=inference.S3DIS_VALID_LABELS, radius_factor=0.8,
+        stuff_classes=(0, 1))
+    want = np.unpackbits(g["s_masks"], axis=1)[:, :masks.shape[1]].astype(np.int64)
+    assert np.array_equal(label_id, g["s_label_id"]) and 1 in label_id and 2 in label_id
+    assert np.array_equal(masks, want)
+    assert np.allclose(conf, g["s_conf"], rtol=1e-5, atol=0)
