@@ -185,3 +185,28 @@ def clustering_in_graph(scene_name, xyz_origin, superpoint, graph, sp_semnatic_p
     if not mask_rows:
         return np.array([]), np.array([]), np.array([])
     return np.array(conf), np.array(label_id), torch.cat(mask_rows, 0).cpu().numpy()
+
+
+def superpoint_majority_label(point_pred, superpoint, n_class, device="cuda"):
+    """Middle-level semantic prediction of test_scannetv2.py:216-224: every point gets the most frequent point-level
+    class of its superpoint (``scipy.stats.mode`` semantics: the SMALLEST class among ties).  The reference loops over
+    the superpoints with one ``np.where`` each (O(S*N)); here it is one [S, n_class] histogram (index_add) + argmax
+    + gather on the device.  Returns (per-point labels int64 [N], per-superpoint labels int64 [S])."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise _n.WsisError("superpoint_majority_label runs on the MI355X (there is no CPU fallback)")
+    pred = torch.as_tensor(point_pred).to(dev).long()
+    sp = torch.as_tensor(superpoint).to(dev).long()
+    S = int(sp.max().item()) + 1 if sp.numel() else 0
+    hist = torch.zeros(S * n_class, dtype=torch.int32, device=dev)
+    hist.index_add_(0, sp * n_class + pred, torch.ones_like(pred, dtype=torch.int32))
+    hist = hist.view(S, n_class)
+    # argmax with ties -> smallest class: torch.argmax may return any maximal index, so compare against the row max
+    first = (hist == hist.max(1, keepdim=True)[0]).to(torch.int32).argmax(1) if S else hist.new_zeros(0).long()
+    return first[sp], first
+
+
+def broadcast_superpoint_label(sp_label, superpoint, device="cuda"):
+    """test_scannetv2.py:236-240: point_level_pred[superpoint == spID] = sp_label[spID] for every spID, as one gather"""
+    dev = torch.device(device)
+    return torch.as_tensor(sp_label).to(dev)[torch.as_tensor(superpoint).to(dev).long()]

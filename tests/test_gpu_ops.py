@@ -574,3 +574,22 @@ def test_clustering_in_graph_s3dis_variant_matches_reference_outputs():
     assert np.array_equal(label_id, g["s_label_id"]) and 1 in label_id and 2 in label_id
     assert np.array_equal(masks, want)
     assert np.allclose(conf, g["s_conf"], rtol=1e-5, atol=0)
+
+
+def test_superpoint_majority_label_matches_scipy_mode_loop():
+    """test_scannetv2.py:216-224 restated with its own loop (np.where + scipy.stats.mode per superpoint)"""
+    import inference
+    from scipy import stats
+    rng = np.random.default_rng(3)
+    S, N, C = 300, 20000, 20
+    sp = rng.integers(0, S, N)
+    sp[:S] = np.arange(S)                                  # every superpoint occurs
+    pred = rng.integers(0, C, N)
+    pred[sp < 40] = (sp[sp < 40] % 3) * 2                  # exact ties inside small superpoints are likely as well
+    want = np.zeros(N, dtype=np.int64)
+    for s in np.unique(sp):
+        m = np.where(sp == s)[0]
+        want[m] = np.atleast_1d(stats.mode(pred[m], keepdims=True)[0])[0]
+    got, per_sp = inference.superpoint_majority_label(pred, sp, C)
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(inference.broadcast_superpoint_label(per_sp, sp).cpu().numpy(), want)
