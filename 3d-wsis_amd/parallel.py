@@ -18,12 +18,12 @@ def init_distributed(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force = os.environ.get("WSIS_FORCE_DIST", "0") == "1"    # exercise the collective path with one rank (tests)
     if (world > 1 or force) and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:   # WSIS_DIST_BACKEND=gloo: control-flow tests of N ranks on one GPU (RCCL refuses that)
+            backend = os.environ.get("WSIS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 

@@ -262,8 +262,9 @@ def main():
     rank, local_rank, world = parallel.init_distributed()
     assert world == max(args.gpus, 1) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()     # > 1 rank per GPU only in gloo control-flow tests
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
 
     cfg = harness.default_cfg()
     if args.small:
@@ -327,21 +328,26 @@ def main():
     # ---- roofline of the dominant kernel: event-instrumented extra steps (same inputs, same process) ----
     roof = None
     extra = {}
-    if rank == 0 and args.profile_steps > 0:
+    summ = {}
+    if args.profile_steps > 0:
         # per-kernel durations are only a property of the kernel when it runs alone: the instrumented steps keep the
         # weight-gradient launches on the main stream (in the timed region they overlap the dIn launches of
-        # spconv_fwd_kernel on a side stream, which stretches both -- good for the step, meaningless per kernel)
+        # spconv_fwd_kernel on a side stream, which stretches both -- good for the step, meaningless per kernel).
+        # EVERY rank runs these steps (they contain the gradient collective); only rank 0 instruments them.
         prev = os.environ.get("WSIS_DW_STREAM")
         os.environ["WSIS_DW_STREAM"] = "0"
-        sp_ops.PROFILER = sp_ops.KernelProfiler()
+        if rank == 0:
+            sp_ops.PROFILER = sp_ops.KernelProfiler()
         for _ in range(args.profile_steps):
             step()
-        summ = sp_ops.PROFILER.summary()
-        sp_ops.PROFILER = None
+        if rank == 0:
+            summ = sp_ops.PROFILER.summary()
+            sp_ops.PROFILER = None
         if prev is None:
             del os.environ["WSIS_DW_STREAM"]
         else:
             os.environ["WSIS_DW_STREAM"] = prev
+    if rank == 0 and summ:
         k = summ.get("spconv_fwd_kernel")
         if k and k["ms"] > 0:
             gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
