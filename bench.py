@@ -257,8 +257,8 @@ def main():
     import parallel
     from spconv import ops as sp_ops
 
-    if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
-        os.environ["NCCL_DEBUG"] = "WARN"          # no version banner on stdout next to the JSON line
+    if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION", "WARN"):
+        os.environ["NCCL_DEBUG"] = "NONE"          # nothing from RCCL on stdout next to the JSON line
     rank, local_rank, world = parallel.init_distributed()
     assert world == max(args.gpus, 1) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
@@ -378,6 +378,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(int(batch_host["voxel_locs"].shape[0]), args)
 
+    # the JSON line must be the LAST thing on stdout: anything a library printed through C stdio (fully buffered on
+    # a pipe) is flushed now, by every rank, before rank 0 prints
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if use_dist:
+        dist.barrier()
     if rank == 0:
         M = int(batch_host["voxel_locs"].shape[0])
         out = {
@@ -394,11 +401,6 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         out.update(extra)
-        # the JSON line must be the LAST thing on stdout: RCCL prints its version banner through C stdio, which is
-        # fully buffered on a pipe and would otherwise be flushed after this line at process exit
-        import ctypes
-        sys.stdout.flush()
-        ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
