@@ -1,0 +1,30 @@
+"""One level of the C2 pyramid, forward conv only, for PMC passes of the dominant kernel:
+   cd /tmp && export TMPDIR=/tmp
+   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv \
+             -d <out> -- python3 tools/conv_pmc.py 0
+   python tools/conv_pmc.py --parse <out>      # per-launch means of every counter for spconv_fwd_kernel"""
+import importlib, sys, os, glob, csv
+if len(sys.argv) > 2 and sys.argv[1] == "--parse":
+    acc = {}
+    for f in glob.glob(os.path.join(sys.argv[2], "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "spconv_fwd_kernel" in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, v in sorted(acc.items()):
+        print(f"{k:32s} launches {len(v):4d}  mean {sum(v)/len(v):16.1f}")
+    sys.exit(0)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); importlib.import_module("3d-wsis_amd")
+import torch, harness
+from spconv import ops
+level = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+dev = 'cuda:0'
+b = harness.collate([harness.make_scene(1)])
+idx = b['voxel_locs'].int().to(dev).contiguous(); shape = [int(s) for s in b['spatial_shape']]
+for l in range(level):
+    rd = ops.build_down_rulebook(idx, shape, [2]*3, [2]*3, [0]*3); idx, shape = rd.out_indices, rd.out_shape
+rb = ops.build_subm_rulebook(idx, shape, [3]*3, [1]*3)
+C = 32 * (level + 1); M = idx.shape[0]
+X = torch.randn(M, C, device=dev); W = torch.randn(27, C, C, device=dev) * 0.05
+for _ in range(10):
+    ops._conv(X, rb.nbr_p, rb.order, W, None, None, M)
+torch.cuda.synchronize()
