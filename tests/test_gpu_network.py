@@ -198,3 +198,30 @@ def test_gradsync_allreduces_the_flat_unet_gradient_buffer_in_place():
                 assert torch.allclose(p.grad, before[n] / 2, rtol=0, atol=0), n
     finally:
         dist.destroy_process_group()
+
+
+def test_native_unet_input_gradient_matches_module_walk():
+    """need_dx path of the executor (features that require grad): dX of input_conv equal to the module walk's"""
+    import numpy as np
+    import spconv
+    import unet_native
+    cfg = harness.default_cfg()
+    batch = harness.to_device(harness.collate([harness.make_scene(33, room=(1.4, 1.2, 1.0), n_box=2)]), "cuda")
+    model, _, _ = harness.build_model(cfg, "cuda")
+    idx, shape = batch["voxel_coords_int"], batch["spatial_shape"]
+    M = idx.shape[0]
+    x0 = torch.randn(M, model.input_channel, device="cuda")
+    outs = []
+    for native in (False, True):
+        x = x0.clone().requires_grad_(True)
+        t = spconv.SparseConvTensor(x, idx, shape, 1)
+        if native:
+            y = unet_native.run_unet(model, t)
+        else:
+            spconv.ops.prebuild_unet_rulebooks(t, model.blocks)
+            y = model.output_layer(model.unet(model.input_conv(t))).features
+        model.zero_grad(set_to_none=True)
+        (y * torch.linspace(-1, 1, y.numel(), device="cuda").view_as(y)).sum().backward()
+        outs.append((y.detach().clone(), x.grad.clone(), model.input_conv[0].weight.grad.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
