@@ -21,6 +21,8 @@ using namespace wsis;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -45,7 +47,12 @@ __device__ __forceinline__ unsigned xcd_deal(unsigned lin, unsigned total) {
 // ------------------------------------------------------------------------------------------
 // forward / dIn kernel
 // ------------------------------------------------------------------------------------------
-template <int NB, bool VEC4, bool DIAG = false>
+// MATH 0: v_mfma_f32_32x32x2_f32, exact fp32 (a k-ordered fma chain).
+// MATH 1: every fp32 operand split into two bf16 terms (hi = bf16(x), lo = bf16(x - hi)) when it is staged to LDS and
+//         the product evaluated as lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+//         6 MFMAs of 32 cycles per (32 rows x 32 ch x 32 cols) step instead of 16 of 64 cycles; the dropped lo*lo
+//         term and the 16-bit operand mantissa bound the error at ~2^-16 per product (NOT bit-identical to fp32).
+template <int NB, bool VEC4, bool DIAG = false, int MATH = 0>
 __global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2)))) void spconv_fwd_kernel(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ residual,
@@ -62,8 +69,14 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2
     }
   };
   if (DIAG) tlast = __builtin_amdgcn_s_memtime();
+  // fp32 mode: As [TM][A_STRIDE] floats, Bs [CK][NB*32] floats.
+  // bf16 mode: a row of A (tile row) / of B (output column) is 2 terms x 32 channels of bf16 = 128 B + 16 B pad
+  //            (the same 144-B pitch as A_STRIDE words, so the ds_read_b128 fragment reads stay conflict-free).
+  constexpr int ROWB = A_STRIDE * 4;                                   // 144 bytes
+  constexpr int BS_BYTES = MATH == 0 ? CK * NB * 32 * 4 : NB * 32 * ROWB;
   __shared__ __attribute__((aligned(16))) float As[TM * A_STRIDE];
-  __shared__ __attribute__((aligned(16))) float Bs[CK * NB * 32];
+  __shared__ __attribute__((aligned(16))) unsigned char BsRaw[BS_BYTES];
+  float* const Bs = reinterpret_cast<float*>(BsRaw);
   __shared__ int32_t nbT[KG * TM];   // [offset in group][tile row] -> input row or -1
   __shared__ int32_t rowId[TM];
   __shared__ uint32_t grpMask[4];    // per 32-row slice: bit k set iff some row of the slice uses offset k
@@ -255,13 +268,42 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2
     };
     auto compute = [&](Stage& st, bool prefetch_more) {
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      if (MATH == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4*>(&As[a_row[j] * A_STRIDE + a_c4[j]]) = ((st.ok_bits >> j) & 1u) ? st.ra[j] : zero4;
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(&As[a_row[j] * A_STRIDE + a_c4[j]]) = ((st.ok_bits >> j) & 1u) ? st.ra[j] : zero4;
 #pragma unroll
-      for (int j = 0; j < NB; ++j)
-        *reinterpret_cast<f32x4*>(&Bs[b_kr[j] * (NB * 32) + b_c4[j]]) =
-            ((st.ok_bits >> (8 + j)) & 1u) ? st.rb[j] : zero4;
+        for (int j = 0; j < NB; ++j)
+          *reinterpret_cast<f32x4*>(&Bs[b_kr[j] * (NB * 32) + b_c4[j]]) =
+              ((st.ok_bits >> (8 + j)) & 1u) ? st.rb[j] : zero4;
+      } else {
+        unsigned char* const A8 = reinterpret_cast<unsigned char*>(As);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 v = ((st.ok_bits >> j) & 1u) ? st.ra[j] : zero4;
+          bf16x4 hi, lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            hi[e] = (__bf16)v[e];
+            lo[e] = (__bf16)(v[e] - (float)hi[e]);
+          }
+          unsigned char* dst = A8 + a_row[j] * ROWB + a_c4[j] * 2;
+          *reinterpret_cast<bf16x4*>(dst) = hi;
+          *reinterpret_cast<bf16x4*>(dst + 64) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {   // W[k = b_kr][4 columns] -> transposed: column rows, channel k inside
+          const f32x4 v = ((st.ok_bits >> (8 + j)) & 1u) ? st.rb[j] : zero4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const __bf16 hi = (__bf16)v[e];
+            const __bf16 lo = (__bf16)(v[e] - (float)hi);
+            unsigned char* dst = BsRaw + (b_c4[j] + e) * ROWB + b_kr[j] * 2;
+            *reinterpret_cast<__bf16*>(dst) = hi;
+            *reinterpret_cast<__bf16*>(dst + 64) = lo;
+          }
+        }
+      }
       const int cur_kk = st.kk;
       const int cin_here = st.cin_here;
       stamp(1);   // wait for the stage's loads + LDS write
@@ -273,27 +315,53 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2
       }
       stamp(3);   // issue prefetch
       if ((my_mask >> cur_kk) & 1u) {
-        // MFMA k index (step s, half h) <-> staged channel h*16 + s, so a lane reads 16 contiguous
-        // floats of its A row with four ds_read_b128.
-        const float* arow = &As[(wave * 32 + l31) * A_STRIDE + half * 16];
-        float a[16];
+        if (MATH == 0) {
+          // MFMA k index (step s, half h) <-> staged channel h*16 + s, so a lane reads 16 contiguous
+          // floats of its A row with four ds_read_b128.
+          const float* arow = &As[(wave * 32 + l31) * A_STRIDE + half * 16];
+          float a[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(arow + 4 * q);
-          a[4 * q + 0] = t[0];
-          a[4 * q + 1] = t[1];
-          a[4 * q + 2] = t[2];
-          a[4 * q + 3] = t[3];
-        }
-        const int nsteps = min(16, cin_here);  // channels >= cin_here are zero in A and B
-        const float* bcol = &Bs[(half * 16) * (NB * 32) + l31];
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(arow + 4 * q);
+            a[4 * q + 0] = t[0];
+            a[4 * q + 1] = t[1];
+            a[4 * q + 2] = t[2];
+            a[4 * q + 3] = t[3];
+          }
+          const int nsteps = min(16, cin_here);  // channels >= cin_here are zero in A and B
+          const float* bcol = &Bs[(half * 16) * (NB * 32) + l31];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-          if (s < nsteps) {
+          for (int s = 0; s < 16; ++s) {
+            if (s < nsteps) {
 #pragma unroll
-            for (int cb = 0; cb < NB; ++cb) {
-              const float b = bcol[s * (NB * 32) + cb * 32];
-              acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b, acc[cb], 0, 0, 0);
+              for (int cb = 0; cb < NB; ++cb) {
+                const float b = bcol[s * (NB * 32) + cb * 32];
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b, acc[cb], 0, 0, 0);
+              }
+            }
+          }
+        } else {
+          // MFMA j covers channels j*16 .. j*16+15; lane (row / column l31, half) supplies the 8 channels
+          // j*16 + half*8 .. +7 of its row -- one ds_read_b128 per term.  Channels >= cin_here are zero in A and B.
+          const unsigned char* arow = reinterpret_cast<const unsigned char*>(As) + (wave * 32 + l31) * ROWB + half * 16;
+          bf16x8 a_hi[2], a_lo[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            a_hi[j] = *reinterpret_cast<const bf16x8*>(arow + j * 32);
+            a_lo[j] = *reinterpret_cast<const bf16x8*>(arow + 64 + j * 32);
+          }
+#pragma unroll
+          for (int cb = 0; cb < NB; ++cb) {
+            const unsigned char* brow = BsRaw + (cb * 32 + l31) * ROWB + half * 16;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              if (j * 16 < cin_here) {
+                const bf16x8 b_hi = *reinterpret_cast<const bf16x8*>(brow + j * 32);
+                const bf16x8 b_lo = *reinterpret_cast<const bf16x8*>(brow + 64 + j * 32);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[j], b_hi, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[j], b_lo, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[j], b_hi, acc[cb], 0, 0, 0);
+              }
             }
           }
         }
@@ -724,10 +792,16 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
     const char* e = getenv("WSIS_XCD_AWARE");
     xcd_aware = e ? atoi(e) : 0;
   }
+  // WSIS_CONV_MATH (read per call, so a process can switch): 0 = exact fp32 MFMA (default), 1 = split-bf16 products
+  const char* math_env = getenv("WSIS_CONV_MATH");
+  const int conv_math = math_env ? atoi(math_env) : 0;
   ProfScope prof(0, st);
 #define WSIS_FWD_CASE(n)                                                                          \
   case n:                                                                                         \
-    if (vec_ok)                                                                                   \
+    if (vec_ok && conv_math == 1)                                                                 \
+      hipLaunchKernelGGL((spconv_fwd_kernel<n, true, false, 1>), grid, dim3(256), 0, st, d_X, d_nbr, d_order, d_W, \
+                         d_bias, d_residual, d_out, partial, M_in, M_out, K, Cin, Cout, k_per, xcd_aware); \
+    else if (vec_ok)                                                                              \
       hipLaunchKernelGGL((spconv_fwd_kernel<n, true>), grid, dim3(256), 0, st, d_X, d_nbr, d_order, d_W,  \
                          d_bias, d_residual, d_out, partial, M_in, M_out, K, Cin, Cout, k_per, xcd_aware); \
     else                                                                                          \
