@@ -73,11 +73,13 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2
   // bf16 mode: a row of A (tile row) / of B (output column) is 2 terms x 32 channels of bf16 = 128 B + 16 B pad
   //            (the same 144-B pitch as A_STRIDE words, so the ds_read_b128 fragment reads stay conflict-free).
   constexpr int ROWB = A_STRIDE * 4;                                   // 144 bytes
-  constexpr int BS_BYTES = MATH == 0 ? CK * NB * 32 * 4 : NB * 32 * ROWB;
+  constexpr int ROWB3 = 3 * 64 + 16;                                   // MATH 2: three terms per column row
+  constexpr int KGL = MATH == 2 ? 8 : KG;                              // offsets per table group
+  constexpr int BS_BYTES = MATH == 0 ? CK * NB * 32 * 4 : (MATH == 1 ? NB * 32 * ROWB : NB * 32 * ROWB3);
   __shared__ __attribute__((aligned(16))) float As[TM * A_STRIDE];
   __shared__ __attribute__((aligned(16))) unsigned char BsRaw[BS_BYTES];
   float* const Bs = reinterpret_cast<float*>(BsRaw);
-  __shared__ int32_t nbT[KG * TM];   // [offset in group][tile row] -> input row or -1
+  __shared__ int32_t nbT[KGL * TM];   // [offset in group][tile row] -> input row or -1
   __shared__ int32_t rowId[TM];
   __shared__ uint32_t grpMask[4];    // per 32-row slice: bit k set iff some row of the slice uses offset k
 
@@ -134,17 +136,17 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2
     b_c4[j] = (f - b_kr[j] * (NB * 8)) * 4;
   }
 
-  for (int kg0 = k_begin; kg0 < k_end; kg0 += KG) {
-    const int kcount = min(KG, k_end - kg0);
+  for (int kg0 = k_begin; kg0 < k_end; kg0 += KGL) {
+    const int kcount = min(KGL, k_end - kg0);
     __syncthreads();  // previous group's nbT / grpMask readers are done (also publishes rowId)
     // ---- tile slice of the packed gather table: nbrS[k][tile0 + t], coalesced 512-B pieces.  All loads are
     //      issued before any of them is consumed: one memory latency for the whole slice.
     if (tid < TM) {
       // loads in batches of 8 offsets (independent, one latency per batch); batches beyond kcount are skipped,
       // which matters when the offsets are split over blockIdx.z (kcount is 1..6 there)
-      int32_t v[KG];
+      int32_t v[KGL];
 #pragma unroll
-      for (int g8 = 0; g8 < KG; g8 += 8) {
+      for (int g8 = 0; g8 < KGL; g8 += 8) {
         if (g8 < kcount) {
 #pragma unroll
           for (int kk = g8; kk < g8 + 8; ++kk) {
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2
       }
       uint32_t bits_lo = 0u, bits_hi = 0u;
 #pragma unroll
-      for (int g8 = 0; g8 < KG; g8 += 8) {
+      for (int g8 = 0; g8 < KGL; g8 += 8) {
         if (g8 < kcount) {
 #pragma unroll
           for (int kk = g8; kk < g8 + 8; ++kk) {
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2
       // lasts as long as its slowest tile): their waves get a higher priority in the SIMD's MFMA / VALU arbitration
       // against the light workgroups sharing the SIMD (level 0: 75.5 -> 70.7 us, 64->32 layer 134.8 -> 124.5 us;
       // thresholds 12/8/4 and 10/6/3 measure the same, priority by REMAINING offsets per step measured worse).
-      const int act = __builtin_popcount(tile_mask);
+      const int act = __builtin_popcount(tile_mask) * (KG / KGL);
       if (act >= 14)
         __builtin_amdgcn_s_setprio(3);
       else if (act >= 10)
@@ -268,14 +270,32 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2
     };
     auto compute = [&](Stage& st, bool prefetch_more) {
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-      if (MATH == 0) {
+      if (MATH == 0 || MATH == 2) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           *reinterpret_cast<f32x4*>(&As[a_row[j] * A_STRIDE + a_c4[j]]) = ((st.ok_bits >> j) & 1u) ? st.ra[j] : zero4;
+      }
+      if (MATH == 0) {
 #pragma unroll
         for (int j = 0; j < NB; ++j)
           *reinterpret_cast<f32x4*>(&Bs[b_kr[j] * (NB * 32) + b_c4[j]]) =
               ((st.ok_bits >> (8 + j)) & 1u) ? st.rb[j] : zero4;
+      } else if (MATH == 2) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {   // W[k = b_kr][4 columns] -> column rows of three 32-channel bf16 terms
+          const f32x4 v = ((st.ok_bits >> (8 + j)) & 1u) ? st.rb[j] : zero4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const __bf16 t1 = (__bf16)v[e];
+            const float r1 = v[e] - (float)t1;
+            const __bf16 t2 = (__bf16)r1;
+            const __bf16 t3 = (__bf16)(r1 - (float)t2);
+            unsigned char* dst = BsRaw + (b_c4[j] + e) * ROWB3 + b_kr[j] * 2;
+            *reinterpret_cast<__bf16*>(dst) = t1;
+            *reinterpret_cast<__bf16*>(dst + 64) = t2;
+            *reinterpret_cast<__bf16*>(dst + 128) = t3;
+          }
+        }
       } else {
         unsigned char* const A8 = reinterpret_cast<unsigned char*>(As);
 #pragma unroll
@@ -337,6 +357,44 @@ __global__ __launch_bounds__(256, (NB <= 1 ? 5 : (NB <= 2 ? 4 : (NB <= 3 ? 3 : 2
               for (int cb = 0; cb < NB; ++cb) {
                 const float b = bcol[s * (NB * 32) + cb * 32];
                 acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b, acc[cb], 0, 0, 0);
+              }
+            }
+          }
+        } else if (MATH == 2) {
+          // the lane's 16 fp32 values (channels half*16 .. +15 of its row); MFMA j takes its channels half*16 + j*8
+          // .. +7 as the lane's 8 k-slots, B rows are laid out the same way
+          const float* arow = &As[(wave * 32 + l31) * A_STRIDE + half * 16];
+          bf16x8 a1[2], a2[2], a3[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(arow + 8 * j);
+            const f32x4 u1 = *reinterpret_cast<const f32x4*>(arow + 8 * j + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float x = e < 4 ? u0[e] : u1[e - 4];
+              const __bf16 t1 = (__bf16)x;
+              const float r1 = x - (float)t1;
+              const __bf16 t2 = (__bf16)r1;
+              a1[j][e] = t1;
+              a2[j][e] = t2;
+              a3[j][e] = (__bf16)(r1 - (float)t2);
+            }
+          }
+#pragma unroll
+          for (int cb = 0; cb < NB; ++cb) {
+            const unsigned char* brow = BsRaw + (cb * 32 + l31) * ROWB3 + half * 32;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              if (j * 8 < cin_here) {      // channels of both halves beyond cin_here are zero
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(brow + j * 16);
+                const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(brow + 64 + j * 16);
+                const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(brow + 128 + j * 16);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[j], b3, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[j], b1, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[j], b2, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[j], b1, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[j], b2, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[j], b1, acc[cb], 0, 0, 0);
               }
             }
           }
@@ -800,6 +858,9 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
   case n:                                                                                         \
     if (vec_ok && conv_math == 1)                                                                 \
       hipLaunchKernelGGL((spconv_fwd_kernel<n, true, false, 1>), grid, dim3(256), 0, st, d_X, d_nbr, d_order, d_W, \
+                         d_bias, d_residual, d_out, partial, M_in, M_out, K, Cin, Cout, k_per, xcd_aware); \
+    else if (vec_ok && conv_math == 2)                                                            \
+      hipLaunchKernelGGL((spconv_fwd_kernel<n, true, false, 2>), grid, dim3(256), 0, st, d_X, d_nbr, d_order, d_W, \
                          d_bias, d_residual, d_out, partial, M_in, M_out, K, Cin, Cout, k_per, xcd_aware); \
     else if (vec_ok)                                                                              \
       hipLaunchKernelGGL((spconv_fwd_kernel<n, true>), grid, dim3(256), 0, st, d_X, d_nbr, d_order, d_W,  \

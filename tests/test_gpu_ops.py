@@ -593,3 +593,34 @@ def test_superpoint_majority_label_matches_scipy_mode_loop():
     got, per_sp = inference.superpoint_majority_label(pred, sp, C)
     assert np.array_equal(got.cpu().numpy(), want)
     assert np.array_equal(inference.broadcast_superpoint_label(per_sp, sp).cpu().numpy(), want)
+
+
+# ---- arithmetic modes of spconv_fwd_kernel (WSIS_CONV_MATH) ---------------------------------------------------
+
+@pytest.mark.parametrize("mode,tol", [("0", 1e-6), ("2", 1e-6), ("1", 2e-5)])
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 96), (160, 160), (24, 40)])
+def test_conv_math_modes_against_fp64(monkeypatch, mode, tol, cin, cout):
+    """0: exact fp32 MFMA (default).  2: three bf16 terms per operand, six products (fp32-equivalent: the tolerance
+    is the SAME 1e-6 relative L2 as for mode 0).  1: two terms, three products (stated tolerance 2e-5 relative L2).
+    Reference: fp64 gather-GEMM-scatter through the same table."""
+    import harness
+    from spconv import ops
+    monkeypatch.setenv("WSIS_CONV_MATH", mode)
+    b = harness.collate([harness.make_scene(41, room=(1.6, 1.3, 1.0), n_box=2)])
+    idx = b["voxel_locs"].int().to(DEV).contiguous()
+    shape = [int(s) for s in b["spatial_shape"]]
+    rb = ops.build_subm_rulebook(idx, shape, [3] * 3, [1] * 3)
+    M = idx.shape[0]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    X = torch.randn(M, cin, generator=g).to(DEV)
+    W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(DEV)
+    res = torch.randn(M, cout, generator=g).to(DEV)
+    out = ops._conv(X, rb.nbr_p, rb.order, W, None, res, M)
+    assert torch.equal(out, ops._conv(X, rb.nbr_p, rb.order, W, None, res, M)), "deterministic in every mode"
+    ref = res.double().clone()
+    for k in range(27):
+        nb = rb.nbr[k].long()
+        v = nb >= 0
+        ref[v] += X[nb[v]].double() @ W[k].double()
+    rel = float((out.double() - ref).norm() / ref.norm())
+    assert rel < tol, (mode, rel)
