@@ -115,6 +115,18 @@ def _conv_case(kind, cin, cout, shape, density, seed, bias=False, surface=False)
         mod = spconv.SparseConv3d(cin, cout, 2, stride=2, bias=bias, indice_key="k").to(DEV)
         out_idx, _, pairs = ref.down_pairs(idx, shape, 2, 2, 0)
         M_out, x_rows = out_idx.shape[0], M
+    elif kind == "subm5":           # 125 offsets: several table groups, uniform dW chunk plan
+        mod = spconv.SubMConv3d(cin, cout, 5, padding=2, bias=bias, indice_key="k5").to(DEV)
+        pairs = ref.subm_pairs(idx, shape, 5, 2)
+        M_out, x_rows = M, M
+    elif kind == "subm133":         # anisotropic 1x3x3 kernel (9 offsets)
+        mod = spconv.SubMConv3d(cin, cout, (1, 3, 3), padding=(0, 1, 1), bias=bias, indice_key="k133").to(DEV)
+        pairs = ref.subm_pairs(idx, shape, (1, 3, 3), (0, 1, 1))
+        M_out, x_rows = M, M
+    elif kind == "down3":           # overlapping strided conv k3 s2 p1 (27 offsets, several parents per voxel)
+        mod = spconv.SparseConv3d(cin, cout, 3, stride=2, padding=1, bias=bias, indice_key="k3s2").to(DEV)
+        out_idx, _, pairs = ref.down_pairs(idx, shape, 3, 2, 1)
+        M_out, x_rows = out_idx.shape[0], M
     else:
         raise ValueError(kind)
     x = torch.randn(x_rows, cin, generator=g)
@@ -147,6 +159,13 @@ def test_subm_conv_bias_and_surface_tiles():
 @pytest.mark.parametrize("cin,cout", [(32, 64), (128, 160), (64, 96)])
 def test_down_conv(cin, cout):
     _conv_case("down", cin, cout, (13, 12, 11), 0.3, 23)
+
+
+@pytest.mark.parametrize("kind,cin,cout", [("subm5", 16, 32), ("subm5", 40, 24), ("subm133", 32, 32),
+                                           ("down3", 32, 48)])
+def test_other_kernel_volumes(kind, cin, cout):
+    """kernel volumes the reference's UNet does not use but the operator surface accepts (upstream spconv does)"""
+    _conv_case(kind, cin, cout, (14, 12, 10), 0.3, 27)
 
 
 @pytest.mark.parametrize("cin,cout", [(64, 32), (256, 128), (192, 96)])
