@@ -507,8 +507,15 @@ int wsis_tile_order(const int32_t* d_indices, const uint32_t* d_mask, int64_t M,
     WSIS_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, need2, tkeys, tkeys_out, tids, tsorted, (size_t)n_tiles, 0, 6, st));
     WSIS_REQUIRE(need2 <= temp_bytes, "workspace too small for the tile sort");
     WSIS_HIP_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, tkeys, tkeys_out, tids, tsorted, (size_t)n_tiles, 0, 6, st));
+    // Snake period = distance, in tiles, between the consecutive workgroups of one CU.  One workgroup per tile
+    // (n_tiles >= n_cu, no offset split): n_cu.  Fewer tiles than CUs: the launch splits the offsets over blockIdx.z
+    // with workgroup id = tile + n_tiles * z, so CU c holds tiles c, c + n_cu mod n_tiles, ... of successive slices.
+    const int n_cu = sched_band();
+    const int64_t grid_tiles = (M + SCHED_TM - 1) / SCHED_TM;
+    int band = grid_tiles >= n_cu ? n_cu : (int)(n_cu % grid_tiles);
+    if (band == 0) band = (int)grid_tiles;
     hipLaunchKernelGGL(tile_permute_kernel, dim3(grid_for(M, 256)), dim3(256), 0, st, ord0, tsorted, M, n_tiles,
-                       sched_band(), d_order);
+                       band, d_order);
     WSIS_LAUNCH_CHECK();
   }
   return WSIS_OK;
