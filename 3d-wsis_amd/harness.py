@@ -265,11 +265,16 @@ def forward_loss(model, criterion, batch, cfg, epoch=5):
     return loss, ret
 
 
-def train_step(model, criterion, optimizer, batch, cfg, epoch=5, grad_sync=None):
-    """one iteration of train_scannetv2.py:143-252 (forward, loss, backward, ECC grad clamp, AdamW step)."""
+def train_step(model, criterion, optimizer, batch, cfg, epoch=5, grad_sync=None, pipeline=None):
+    """one iteration of train_scannetv2.py:143-252 (forward, loss, backward, ECC grad clamp, AdamW step).
+    ``pipeline``: a started spconv.ops.RulebookPipeline of the NEXT batch, advanced between the phases."""
     loss, ret = forward_loss(model, criterion, batch, cfg, epoch)
+    if pipeline is not None:
+        pipeline.pump()
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
+    if pipeline is not None:
+        pipeline.pump()
     if grad_sync is not None:
         grad_sync(model)
     grads = [p.grad for p in model.ecc.parameters() if p.grad is not None]
@@ -277,7 +282,19 @@ def train_step(model, criterion, optimizer, batch, cfg, epoch=5, grad_sync=None)
         torch._foreach_clamp_min_(grads, -1.0)
         torch._foreach_clamp_max_(grads, 1.0)
     optimizer.step()
+    if pipeline is not None:
+        pipeline.pump()
     return loss.detach(), ret
+
+
+def make_pipeline(model):
+    """rulebook pipeline for ``model``'s UNet pyramid (next batch built while the current step runs)"""
+    import spconv
+    return spconv.ops.RulebookPipeline(model.blocks)
+
+
+def start_rulebooks(pipeline, batch):
+    pipeline.start(batch["voxel_coords_int"], batch["spatial_shape"], batch.get("coords_ready_event"))
 
 
 def make_prefetcher(model):

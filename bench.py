@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pipeline", action="store_true",
+                    help="build the next step's rulebooks in slices between the phases of the current step "
+                         "(spconv.ops.RulebookPipeline; measured neutral: 69.0 / 69.3 vs 68.9 / 69.1 scenes/s)")
     ap.add_argument("--prefetch", action="store_true",
                     help="build the next step's rulebooks from a helper thread (measured slower: GIL contention)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra event-instrumented steps for the roofline")
@@ -326,13 +329,23 @@ def main():
     if pre is not None:
         harness.prefetch_rulebooks(pre, batch)
         batch["rulebooks"] = pre.result()
+    # --pipeline: the rulebooks of the NEXT step's scene (the same synthetic scene, rebuilt every step, inside the
+    # timed region) are built in slices between the phases of the current step (spconv.ops.RulebookPipeline)
+    pipe = harness.make_pipeline(model) if (pre is None and args.pipeline) else None
+    if pipe is not None:
+        harness.start_rulebooks(pipe, batch)
+        batch["rulebooks"] = pipe.finish()
 
     def step():
         if pre is not None:
             harness.prefetch_rulebooks(pre, batch)
-        out = harness.train_step(model, criterion, optimizer, batch, cfg, grad_sync=grad_sync)
+        if pipe is not None:
+            harness.start_rulebooks(pipe, batch)
+        out = harness.train_step(model, criterion, optimizer, batch, cfg, grad_sync=grad_sync, pipeline=pipe)
         if pre is not None:
             batch["rulebooks"] = pre.result()
+        if pipe is not None:
+            batch["rulebooks"] = pipe.finish()
         return out
 
     # initialisation (not part of the W warm-up steps): the first passes load code objects lazily (hipBLASLt /

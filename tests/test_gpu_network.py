@@ -225,3 +225,39 @@ def test_native_unet_input_gradient_matches_module_walk():
         outs.append((y.detach().clone(), x.grad.clone(), model.input_conv[0].weight.grad.clone()))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_rulebook_pipeline_slices_give_the_inline_pyramid_and_the_same_step():
+    """spconv.ops.RulebookPipeline (chain advanced between the phases of a step, no helper thread): same tables as
+    the inline build, and a training step fed by it produces the same loss as the inline step"""
+    import spconv
+    from spconv import ops
+    cfg = harness.default_cfg()
+    batch = harness.to_device(harness.collate([harness.make_scene(34, room=(1.6, 1.3, 1.0), n_box=2)]), "cuda")
+    idx, shape = batch["voxel_coords_int"], batch["spatial_shape"]
+    pipe = ops.RulebookPipeline(5)
+    pipe.start(idx, shape, batch.get("coords_ready_event"))
+    pipe.pump()
+    rs = pipe.finish()
+    ref = spconv.SparseConvTensor(torch.zeros(idx.shape[0], 1, device="cuda"), idx, shape, 1)
+    ops.prebuild_unet_rulebooks(ref, 5)
+    torch.cuda.synchronize()
+    for k, rb in ref.indice_dict.items():
+        for name in ("nbr_p", "nbr_up_p", "order", "order_up", "out_indices"):
+            a, b = getattr(rb, name, None), getattr(rs.indice_dict[k], name, None)
+            assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), (k, name)
+    losses = []
+    for use_pipe in (False, True):
+        model, crit, opt = harness.build_model(cfg, "cuda")
+        b = dict(batch)
+        p = harness.make_pipeline(model) if use_pipe else None
+        if p is not None:
+            harness.start_rulebooks(p, b)
+            b["rulebooks"] = p.finish()
+            harness.start_rulebooks(p, b)
+        loss, _ = harness.train_step(model, crit, opt, b, cfg, pipeline=p)
+        if p is not None:
+            b["rulebooks"] = p.finish()
+        loss2, _ = harness.train_step(model, crit, opt, b, cfg)
+        losses.append((float(loss), float(loss2)))
+    assert losses[0] == losses[1]
