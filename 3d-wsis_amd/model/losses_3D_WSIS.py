@@ -172,7 +172,10 @@ class MultiTaskLoss(nn.Module):
         dist = torch.norm(pred - mu, p=2, dim=1)
         dist = torch.square(torch.clamp(dist - self.delta_v, min=0.))
         l_var = torch.sum(dist * w) / n
-        d = 2. * self.delta_d - torch.cdist(mu, mu, p=1)         # row pair (i,j) stands for instance pair (c_i,c_j)
+        # L1 distance of every row pair (row pair (i,j) stands for instance pair (c_i,c_j)).  Broadcast form:
+        # torch.cdist(p=1) took 0.85 ms forward + 0.52 ms backward for 1190 rows (one thread per pair, 7-term loop)
+        l1 = (mu.unsqueeze(0) - mu.unsqueeze(1)).abs().sum(-1)
+        d = 2. * self.delta_d - l1
         other = (1.0 - same) * v.unsqueeze(0) * v.unsqueeze(1)   # valid rows of DIFFERENT instances
         pair_w = other * w.unsqueeze(0) * w.unsqueeze(1)         # every ordered instance pair weighs 1 in total
         l_dist = torch.sum(torch.square(torch.clamp(d, min=0.)) * pair_w) / torch.clamp(n * (n - 1), min=1.0)
