@@ -1,0 +1,294 @@
+"""Host side of the input contract: the reference's per-scene preparation and batch assembly for the hot path.
+
+Mirrors ``modules/datasets/scannetv2_dataset.py`` -- ``__getitem__`` (:96-190), ``data_aug_with_graph`` (:194-209),
+``elastic`` (:225-250), ``crop`` (:252-273), ``get_instance_info`` (:275-309), ``get_cropped_inst_label`` (:311-330)
+and ``collate_fn`` (:343-474, schema in SURVEY App. C) -- on plain numpy arrays.  Pure host code, safe in DataLoader
+workers (``pointgroup_ops.voxelization_idx`` runs in ``libwsis_host.so``).
+
+Two deliberate differences:
+
+* randomness comes from an explicit ``numpy.random.RandomState`` (the reference uses numpy's global state; with
+  ``RandomState(seed)`` the draws equal the reference's after ``np.random.seed(seed)``), and the colour jitter from
+  a ``torch.Generator``;
+* the superpoint graph is a :class:`PlainGraph` (arrays) instead of an ``igraph.Graph``: igraph is not in the
+  image, so the ``*_spg.dat`` pickles cannot be opened here.  ``PlainGraph.from_igraph`` is the converter a
+  maintainer runs where igraph exists.
+"""
+import math
+
+import numpy as np
+import torch
+
+VERTEX_ATTRS = ("v", "semantic_label", "instance_label", "superpoint_offset_vector", "instance_voxel_num",
+                "instance_size")
+
+
+class PlainGraph(object):
+    """Superpoint graph as arrays: per-vertex attributes (``prepare_data_inst_ScanNetV2.py:268-271``) and a directed
+    edge list with 13 edge features ``f`` and the ``is1ins`` flag."""
+
+    def __init__(self, vs, edges, f=None, is1ins=None):
+        self.vs = {k: np.asarray(a) for k, a in vs.items()}
+        self.edges = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+        n_e = self.edges.shape[0]
+        self.f = np.zeros((n_e, 13), np.float32) if f is None else np.asarray(f, dtype=np.float32).reshape(n_e, -1)
+        self.is1ins = np.zeros(n_e, np.int64) if is1ins is None else np.asarray(is1ins, dtype=np.int64)
+
+    @property
+    def vcount(self):
+        return len(next(iter(self.vs.values())))
+
+    def copy(self):
+        return PlainGraph({k: a.copy() for k, a in self.vs.items()}, self.edges.copy(), self.f.copy(),
+                          self.is1ins.copy())
+
+    def subgraph(self, subset):
+        """Induced subgraph on the ascending vertex list ``subset`` (``superpoint_graph.subgraph(subset)``, :169):
+        kept vertices are renumbered 0..len-1 in that order, edges with both ends kept stay in their order."""
+        subset = np.asarray(subset, dtype=np.int64)
+        new_id = np.full(self.vcount, -1, np.int64)
+        new_id[subset] = np.arange(len(subset))
+        e = new_id[self.edges] if len(self.edges) else self.edges
+        keep = (e >= 0).all(1) if len(e) else np.zeros(0, bool)
+        return PlainGraph({k: a[subset] for k, a in self.vs.items()}, e[keep], self.f[keep], self.is1ins[keep])
+
+    @staticmethod
+    def from_igraph(g):
+        """Converter for a machine that has igraph (not this image): ``igraph.Graph.Read_Pickle(..._spg.dat)``."""
+        vs = {k: np.asarray(g.vs[k]) for k in g.vs.attributes()}
+        edges = np.asarray([e.tuple for e in g.es], dtype=np.int64).reshape(-1, 2)
+        f = np.asarray(g.es["f"], dtype=np.float32) if "f" in g.es.attributes() else None
+        one = np.asarray(g.es["is1ins"]) if "is1ins" in g.es.attributes() else None
+        return PlainGraph(vs, edges, f, one)
+
+    def save(self, path):
+        np.savez_compressed(path, edges=self.edges, f=self.f, is1ins=self.is1ins,
+                            **{"vs_" + k: a for k, a in self.vs.items()})
+
+    @staticmethod
+    def load(path):
+        z = np.load(path)
+        return PlainGraph({k[3:]: z[k] for k in z.files if k.startswith("vs_")}, z["edges"], z["f"], z["is1ins"])
+
+
+def load_scene_file(path):
+    """The reference's per-scene ``.pth``: ``(coords, colors, sem, inst, superpoint, scene_name)``
+    (``prepare_data_inst_ScanNetV2.py:166``, read at ``scannetv2_dataset.py:62,72``)."""
+    t = torch.load(path, weights_only=False)
+    if not (isinstance(t, (tuple, list)) and len(t) == 6):
+        raise ValueError(f"{path}: expected the 6-tuple (coords, colors, sem, inst, superpoint, scene)")
+    coords, colors, sem, inst, superpoint, scene = t
+    return (np.asarray(coords), np.asarray(colors), np.asarray(sem), np.asarray(inst), np.asarray(superpoint),
+            str(scene))
+
+
+class ScenePrep(object):
+    """Per-scene transform of ``ScanNetV2Inst_spg.__getitem__``.
+
+    ``full_scale`` [128, 512], ``scale`` 50, ``max_npoint`` 250000 are the values of
+    ``config/ScanNet_v2_3D_WSIS.yaml`` (read at ``scannetv2_dataset.py:36-38``)."""
+
+    def __init__(self, full_scale=(128, 512), scale=50, max_npoint=250000, aug=True, test_mode=False, seed=None):
+        self.full_scale = [int(full_scale[0]), int(full_scale[1])]
+        self.scale = scale
+        self.max_npoint = max_npoint
+        self.aug_flag = aug
+        self.test_mode = test_mode
+        self.rng = np.random.RandomState(seed)
+        self.gen = torch.Generator()
+        if seed is not None:
+            self.gen.manual_seed(int(seed))
+
+    # -- :211-222 / :194-209 -------------------------------------------------------------------------------------
+    def aug_matrix(self, jitter=False, flip=False, rot=False):
+        m = np.eye(3)
+        if jitter:
+            m += self.rng.randn(3, 3) * 0.1
+        if flip:
+            m[0][0] *= self.rng.randint(0, 2) * 2 - 1
+        if rot:
+            theta = self.rng.rand() * 2 * math.pi
+            m = np.matmul(m, [[math.cos(theta), math.sin(theta), 0], [-math.sin(theta), math.cos(theta), 0],
+                              [0, 0, 1]])
+        return m
+
+    def data_aug(self, xyz, jitter=False, flip=False, rot=False):
+        return np.matmul(xyz, self.aug_matrix(jitter, flip, rot))
+
+    def data_aug_with_graph(self, xyz, graph, jitter=False, flip=False, rot=False):
+        """The same matrix also rotates every superpoint's offset vector (the reference loops over ``graph.vs``)."""
+        m = self.aug_matrix(jitter, flip, rot)
+        graph.vs["superpoint_offset_vector"] = np.matmul(graph.vs["superpoint_offset_vector"], m)
+        return np.matmul(xyz, m)
+
+    # -- :225-250 ------------------------------------------------------------------------------------------------
+    def elastic(self, xyz, gran, mag):
+        import scipy.interpolate
+        import scipy.ndimage
+        bb = np.abs(xyz).max(0).astype(np.int32) // gran + 3
+        noise = [self.rng.randn(bb[0], bb[1], bb[2]).astype("float32") for _ in range(3)]
+        for _ in range(2):
+            for axis in range(3):
+                shape = [1, 1, 1]
+                shape[axis] = 3
+                blur = np.ones(shape, "float32") / 3
+                noise = [scipy.ndimage.convolve(n, blur, mode="constant", cval=0) for n in noise]
+        ax = [np.linspace(-(b - 1) * gran, (b - 1) * gran, b) for b in bb]
+        interp = [scipy.interpolate.RegularGridInterpolator(ax, n, bounds_error=0, fill_value=0) for n in noise]
+        return xyz + np.hstack([i(xyz)[:, None] for i in interp]) * mag
+
+    # -- :252-273 ------------------------------------------------------------------------------------------------
+    def crop(self, xyz):
+        xyz_offset = xyz.copy()
+        valid = xyz_offset.min(1) >= 0
+        if valid.sum() != xyz.shape[0]:
+            raise ValueError("crop expects coordinates already shifted to be non-negative (:151-152)")
+        full_scale = np.array([self.full_scale[1]] * 3)
+        room_range = xyz.max(0) - xyz.min(0)
+        while valid.sum() > self.max_npoint:
+            offset = np.clip(full_scale - room_range + 0.001, None, 0) * self.rng.rand(3)
+            xyz_offset = xyz + offset
+            valid = (xyz_offset.min(1) >= 0) * ((xyz_offset < full_scale).sum(1) == 3)
+            full_scale[:2] -= 32
+        return xyz_offset, valid
+
+    # -- :311-330 ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def get_cropped_inst_label(instance_label, valid_idxs):
+        """Re-compacts the ids after a crop exactly as the reference does: walking j upward, an empty id j takes over
+        the points of the current largest id."""
+        instance_label = instance_label[valid_idxs]
+        if instance_label.size == 0:
+            return instance_label
+        j = 0
+        while j < instance_label.max():
+            if not (instance_label == j).any():
+                instance_label[instance_label == instance_label.max()] = j
+            j += 1
+        return instance_label
+
+    # -- :275-309 ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def get_instance_info(xyz, instance_label):
+        info = np.ones((xyz.shape[0], 9), dtype=np.float32) * -100.0
+        pointnum = []
+        n_inst = int(instance_label.max()) + 1 if instance_label.size else 0
+        for i in range(n_inst):
+            idx = np.where(instance_label == i)[0]
+            pointnum.append(idx.size)
+            if idx.size == 0:      # the reference would take min() of an empty array here; ids are compact, see above
+                continue
+            p = xyz[idx]
+            info[idx, 0:3] = p.mean(0)
+            info[idx, 3:6] = p.min(0)
+            info[idx, 6:9] = p.max(0)
+        return n_inst, {"instance_info": info, "instance_pointnum": pointnum}
+
+    # -- :96-190 -------------------------------------------------------------------------------------------------
+    def __call__(self, scene_tuple, graph):
+        """(coords, colors, sem, inst, superpoint, scene), PlainGraph -> the 12-tuple ``__getitem__`` returns."""
+        xyz_origin, rgb, semantic_label, instance_label, superpoint, scene = scene_tuple
+        graph = graph.copy()
+        flag = bool(self.aug_flag)
+        xyz_middle = self.data_aug_with_graph(np.asarray(xyz_origin), graph, flag, flag, flag)
+        xyz = xyz_middle * self.scale
+        xyz_offset = xyz.min(0)
+        xyz = xyz - xyz_offset
+        valid = np.ones(len(xyz_middle), dtype=bool)
+        if not self.test_mode:
+            xyz, valid = self.crop(xyz)
+        xyz_middle = xyz_middle[valid]
+        xyz = xyz[valid]
+        rgb = np.asarray(rgb)[valid]
+        semantic_label = np.asarray(semantic_label)[valid]
+        instance_label = self.get_cropped_inst_label(np.asarray(instance_label).copy(), valid)
+        superpoint = np.asarray(superpoint)[valid]
+        subset, new_superpoint = np.unique(superpoint, return_inverse=True)
+        sub = graph.subgraph(subset)
+        inst_num, infos = self.get_instance_info(xyz_middle, instance_label.astype(np.int32))
+        feat = torch.from_numpy(np.ascontiguousarray(rgb))
+        if self.aug_flag:
+            feat = feat + torch.randn(3, generator=self.gen) * 0.1
+        return (scene, torch.from_numpy(xyz).long(), torch.from_numpy(xyz_offset).long(),
+                torch.from_numpy(xyz_middle), feat, torch.from_numpy(semantic_label),
+                torch.from_numpy(instance_label), torch.from_numpy(new_superpoint.reshape(-1)), sub, inst_num,
+                torch.from_numpy(infos["instance_info"]), infos["instance_pointnum"])
+
+
+def collate_fn(batch, full_scale_min=128, mode=4):
+    """``collate_fn`` (:343-474): list of ``ScenePrep`` 12-tuples -> batch dict."""
+    import pointgroup_ops
+    from graphnet import GraphConvInfo
+    locs, loc_offsets, locs_float, feats, sems, inss, sps = [], [], [], [], [], [], []
+    infos, pointnum, scene_list = [], [], []
+    sp_sem, sp_ins, sp_off, sp_vox, sp_size = [], [], [], [], []
+    edge_sorted, feat_sorted, edges_ext, is1ins = [], [], [], []
+    batch_offsets, sp_batch_offsets = [0], [0]
+    sp_bias, total_inst = 0, 0
+    for i, data in enumerate(batch):
+        scene, loc, loc_offset, loc_float, feat, sem, ins, superpoint, graph, inst_num, inst_info, inst_pointnum = data
+        scene_list.append(scene)
+        superpoint = superpoint + sp_bias
+        this_bias = sp_bias
+        sp_bias = int(superpoint.max()) + 1
+        sp_batch_offsets.append(sp_bias)
+        ins = ins.clone()
+        ins[ins != -100] += total_inst
+        total_inst += inst_num
+        batch_offsets.append(batch_offsets[-1] + loc.shape[0])
+        locs.append(torch.cat([torch.full((loc.shape[0], 1), i, dtype=torch.int64), loc], 1))
+        loc_offsets.append(loc_offset)
+        locs_float.append(loc_float)
+        feats.append(feat)
+        sems.append(sem)
+        inss.append(ins)
+        sps.append(superpoint)
+        sp_sem.append(torch.as_tensor(graph.vs["semantic_label"]))
+        sp_ins.append(torch.as_tensor(graph.vs["instance_label"]))
+        sp_off.append(torch.as_tensor(graph.vs["superpoint_offset_vector"]))
+        sp_vox.append(torch.as_tensor(graph.vs["instance_voxel_num"]))
+        sp_size.append(torch.as_tensor(graph.vs["instance_size"]))
+        infos.append(inst_info)
+        pointnum.extend(inst_pointnum)
+        E = graph.edges
+        order = np.argsort(E[:, 1], kind="stable")                 # ecc/GraphConvInfo.py:54-70 (sorted by target)
+        edge_sorted.append(torch.from_numpy(E[order] + this_bias))
+        feat_sorted.append(torch.from_numpy(graph.f[order]))
+        edges_ext.append(torch.from_numpy(E + this_bias))          # original order (:455-457)
+        is1ins.append(torch.from_numpy(graph.is1ins))
+    locs = torch.cat(locs, 0)
+    superpoint = torch.cat(sps, 0).long()
+    if len(np.unique(superpoint.numpy())) != int(superpoint.max()) + 1:
+        raise ValueError("superpoint ids are not dense after batching (:422)")
+    spatial_shape = np.clip((locs.max(0)[0][1:] + 1).numpy(), full_scale_min, None)
+    voxel_locs, p2v_map, v2p_map = pointgroup_ops.voxelization_idx(locs, len(batch), mode)
+    GIs = [GraphConvInfo(torch.cat(edge_sorted, 0).t().contiguous(), torch.cat(feat_sorted, 0).float(), sp_bias)]
+    edges = torch.cat(edges_ext, 0)
+    return {
+        "locs": locs, "locs_offset": torch.stack(loc_offsets), "voxel_locs": voxel_locs, "p2v_map": p2v_map,
+        "v2p_map": v2p_map, "locs_float": torch.cat(locs_float, 0).to(torch.float32),
+        "feats": torch.cat(feats, 0).to(torch.float32), "semantic_labels": torch.cat(sems, 0).long(),
+        "instance_labels": torch.cat(inss, 0).long(), "instance_info": torch.cat(infos, 0).to(torch.float32),
+        "instance_pointnum": torch.tensor(pointnum, dtype=torch.int),
+        "offsets": torch.tensor(batch_offsets, dtype=torch.int), "spatial_shape": spatial_shape,
+        "superpoint": superpoint, "GIs": GIs, "sp_batch_offsets": torch.tensor(sp_batch_offsets, dtype=torch.int),
+        "edge_u_list": edges[:, 0].contiguous().long(), "edge_v_list": edges[:, 1].contiguous().long(),
+        "is1ins_labels": torch.cat(is1ins, 0),
+        "superpoint_semantic_labels": torch.cat(sp_sem, 0).long(),
+        "superpoint_instance_labels": torch.cat(sp_ins, 0).long(),
+        "superpoint_offset_vector": torch.cat(sp_off, 0).to(torch.float32),
+        "superpoint_instance_voxel_num": torch.log(torch.cat(sp_vox, 0).to(torch.float32)),
+        "superpoint_instance_size": torch.cat(sp_size, 0).to(torch.float32),
+        "scene_list": scene_list,
+    }
+
+
+def synthetic_scene_to_reference_format(sc):
+    """A ``harness.make_scene`` scene as the reference's on-disk pair: the 6-tuple and the superpoint graph."""
+    tup = (sc["xyz"].astype(np.float32), sc["rgb"].astype(np.float32), sc["sem_label"].astype(np.float64),
+           sc["ins_label"].astype(np.float64), sc["superpoint"].astype(np.int64), "synthetic")
+    g = PlainGraph({"v": np.arange(sc["S"]), "semantic_label": sc["sp_sem"], "instance_label": sc["sp_ins"],
+                    "superpoint_offset_vector": sc["sp_offset"].astype(np.float64),
+                    "instance_voxel_num": sc["sp_voxnum"], "instance_size": sc["sp_size"]},
+                   sc["edges"], sc["edge_feats"])
+    return tup, g

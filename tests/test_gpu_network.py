@@ -261,3 +261,31 @@ def test_rulebook_pipeline_slices_give_the_inline_pyramid_and_the_same_step():
         loss2, _ = harness.train_step(model, crit, opt, b, cfg)
         losses.append((float(loss), float(loss2)))
     assert losses[0] == losses[1]
+
+
+def test_augmented_cropped_batch_from_the_reference_pipeline_matches_oracle():
+    """The reference's host pipeline (datasets.ScenePrep: jitter/flip/rotation, crop, id re-compaction, graph
+    restriction; datasets.collate_fn) feeds the HIP path; forward tensors and the loss against the CPU oracle."""
+    import datasets
+    cfg = harness.default_cfg()
+    cfg.batch_size = 2
+    scenes = [harness.make_scene(5 + i, room=(1.0, 0.9, 0.8), n_box=2) for i in range(2)]
+    prep = datasets.ScenePrep(max_npoint=11000, aug=True, seed=4)
+    batch_host = datasets.collate_fn([prep(*datasets.synthetic_scene_to_reference_format(sc)) for sc in scenes])
+    assert int(batch_host["offsets"][-1]) < sum(len(sc["xyz"]) for sc in scenes)          # the crop removed points
+    # stage-3 targets the synthetic graph carries raw; -inf/NaN-free after the crop
+    assert torch.isfinite(batch_host["superpoint_instance_voxel_num"]).all()
+    model, crit, opt = harness.build_model(cfg, "cuda")
+    ref = network_ref.RefNetwork()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=True)
+    batch = harness.to_device(batch_host, "cuda")
+    model.train(); ref.train()
+    loss, ret = harness.forward_loss(model, crit, batch, cfg)
+    loss.backward()
+    r_loss, r_ret = network_ref.forward_loss_cpu(ref, crit, batch_host)
+    for k in ("semantic_scores", "sp_semantic_scores", "pred_sp_offset_vectors", "edge_affinity",
+              "sp_discriminative_feats"):
+        assert ret[k].shape == r_ret[k].shape, k
+        assert _rel(ret[k], r_ret[k]) < 2e-3, (k, _rel(ret[k], r_ret[k]))
+    assert abs(float(loss) - float(r_loss)) < 2e-3 * abs(float(r_loss))
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
