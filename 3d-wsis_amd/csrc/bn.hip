@@ -11,7 +11,14 @@ using namespace wsis;
 
 namespace {
 
-constexpr int BN_ROWS = 256;   // rows reduced by one workgroup
+constexpr int BN_ROWS_PER_THREAD = 8;   // rows one thread accumulates: all 8 (x, dy) loads are in flight at once
+// rows reduced by one workgroup: 256 threads = G channel groups x R row lanes, 8 rows per lane.  (A fixed 256 rows
+// made a thread of the wide levels walk 26-32 rows four at a time: 7-8 memory latencies per launch.)
+__host__ __device__ inline int bn_rows_per_wg(int Cp) {
+  const int G = Cp >> 2;
+  const int R = 256 / G > 1 ? 256 / G : 1;
+  return R * BN_ROWS_PER_THREAD;
+}
 constexpr int BN_THREADS = 256;
 
 struct f4 {
@@ -38,15 +45,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_partial_kernel(const floa
   const int G = Cp >> 2;                       // channel groups
   const int R = max(BN_THREADS / G, 1);        // row lanes
   const bool vec = (C & 3) == 0;
-  const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS;
-  const int64_t r1 = min(M, r0 + BN_ROWS);
+  const int64_t r0 = (int64_t)blockIdx.x * bn_rows_per_wg(Cp);
+  const int64_t r1 = min(M, r0 + bn_rows_per_wg(Cp));
   for (int g0 = 0; g0 < G; g0 += BN_THREADS) {  // G <= 256 in practice: one trip
     const int g = g0 + (threadIdx.x % min(G, BN_THREADS));
     const int rl = threadIdx.x / min(G, BN_THREADS);
     float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
     if (g < G && rl < R) {
       const int c = g * 4;
-#pragma unroll 4
+#pragma unroll 8
       for (int64_t r = r0 + rl; r < r1; r += R) {
         float v[4];
         if (vec) {
@@ -104,6 +111,7 @@ __global__ __launch_bounds__(64) void bn_stats_final_kernel(const float* __restr
                                                             float* __restrict__ running_var, float momentum) {
   const int c = blockIdx.x;
   double s = 0.0, q = 0.0;
+#pragma unroll 8
   for (int b = threadIdx.x; b < nblk; b += 64) {
     s += partial[(int64_t)b * 2 * Cp + c];
     q += partial[(int64_t)b * 2 * Cp + Cp + c];
@@ -186,8 +194,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(
   const int gw = min(G, BN_THREADS);
   const int R = max(BN_THREADS / G, 1);
   const bool vec = (C & 3) == 0;
-  const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS;
-  const int64_t r1 = min(M, r0 + BN_ROWS);
+  const int64_t r0 = (int64_t)blockIdx.x * bn_rows_per_wg(Cp);
+  const int64_t r1 = min(M, r0 + bn_rows_per_wg(Cp));
   for (int g0 = 0; g0 < G; g0 += BN_THREADS) {
     const int g = g0 + (threadIdx.x % gw);
     const int rl = threadIdx.x / gw;
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(
         gm[e] = gamma ? gamma[cc] : 1.0f;
         bt[e] = beta ? beta[cc] : 0.0f;
       }
-#pragma unroll 4
+#pragma unroll 8
       for (int64_t r = r0 + rl; r < r1; r += R) {
         float xv[4], dv[4];
         if (vec) {
@@ -260,6 +268,7 @@ __global__ __launch_bounds__(64) void bn_bwd_final_kernel(const float* __restric
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int c = blockIdx.x;
   double a = 0.0, b = 0.0;
+#pragma unroll 8
   for (int k = threadIdx.x; k < nblk; k += 64) {
     a += partial[(int64_t)k * 2 * Cp + c];
     b += partial[(int64_t)k * 2 * Cp + Cp + c];
@@ -344,44 +353,62 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
   }
 }
 
-// ---- small inputs (M <= BN_SMALL_ROWS): the whole reduction in ONE launch, one workgroup per channel group of 4.
-// Two launches (partial + final) of a few microseconds each are pure latency at the deep UNet levels.
-// Threads stride over the rows, then a fixed LDS tree (fp64) -> deterministic.
-constexpr int BN_SMALL_ROWS = 8192;
+// ---- small inputs (M <= bn_small_rows): the whole reduction in ONE launch, one workgroup per channel group of 4.
+// Two launches (partial + final) of a few microseconds each are pure latency at the deep UNet levels (<= 4096 rows;
+// above that the 16-byte-per-row slices of one workgroup per channel group stall on cache-line throughput).
+// 1024 threads stride over the rows (<= 8 rows each, every load in flight at once: the kernel is one memory latency
+// long, not M/256 of them), then a fixed reduction in fp64: xor-shuffle inside each wave, 16 wave results through
+// LDS, summed in wave order -> deterministic.
+int64_t bn_small_rows() {  // WSIS_BN_SMALL_ROWS: rows up to which the one-launch reduction is used
+  static const int64_t v = [] {
+    const char* e = getenv("WSIS_BN_SMALL_ROWS");
+    return e ? (int64_t)atoll(e) : (int64_t)4096;
+  }();
+  return v;
+}
+constexpr int BN_SMALL_THREADS = 1024;
 
 __device__ __forceinline__ void block_sum2_f64(double (&a)[4], double (&b)[4], double* sh) {
-  // sh: [256][8] doubles
-  const int tid = threadIdx.x;
+  // sh: [BN_SMALL_THREADS / 64][8] doubles
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    sh[tid * 8 + e] = a[e];
-    sh[tid * 8 + 4 + e] = b[e];
+  for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] += __shfl_xor(a[e], off, 64);
+      b[e] += __shfl_xor(b[e], off, 64);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sh[wave * 8 + e] = a[e];
+      sh[wave * 8 + 4 + e] = b[e];
+    }
   }
   __syncthreads();
-  for (int s = BN_THREADS / 2; s >= 1; s >>= 1) {
-    if (tid < s) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sh[tid * 8 + e] += sh[(tid + s) * 8 + e];
-    }
-    __syncthreads();
-  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    a[e] = sh[e];
-    b[e] = sh[4 + e];
+    double sa = 0.0, sb = 0.0;
+    for (int w = 0; w < BN_SMALL_THREADS / 64; ++w) {
+      sa += sh[w * 8 + e];
+      sb += sh[w * 8 + 4 + e];
+    }
+    a[e] = sa;
+    b[e] = sb;
   }
 }
 
-__global__ __launch_bounds__(BN_THREADS) void bn_stats_small_kernel(const float* __restrict__ x, int64_t M, int C,
+__global__ __launch_bounds__(BN_SMALL_THREADS) void bn_stats_small_kernel(const float* __restrict__ x, int64_t M, int C,
                                                                     float* __restrict__ mean, float* __restrict__ var,
                                                                     float* __restrict__ running_mean,
                                                                     float* __restrict__ running_var, float momentum) {
-  __shared__ double sh[BN_THREADS * 8];
+  __shared__ double sh[BN_SMALL_THREADS / 64 * 8];
   const int c0 = blockIdx.x * 4;
   const bool vec = (C & 3) == 0;
   float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int64_t r = threadIdx.x; r < M; r += BN_THREADS) {
+#pragma unroll 8
+  for (int64_t r = threadIdx.x; r < M; r += BN_SMALL_THREADS) {
     float v[4];
     if (vec) {
       const f4 t = ld4(x + r * C + c0, true);
@@ -420,11 +447,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_small_kernel(const float*
   }
 }
 
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_small_kernel(
+__global__ __launch_bounds__(BN_SMALL_THREADS) void bn_bwd_small_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
     int relu, int64_t M, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double sh[BN_THREADS * 8];
+  __shared__ double sh[BN_SMALL_THREADS / 64 * 8];
   const int c0 = blockIdx.x * 4;
   const bool vec = (C & 3) == 0;
   float mu[4], rstd[4], gm[4], bt[4];
@@ -437,8 +464,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_small_kernel(
     bt[e] = beta ? beta[cc] : 0.0f;
   }
   float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int64_t r = threadIdx.x; r < M; r += BN_THREADS) {
+#pragma unroll 8
+  for (int64_t r = threadIdx.x; r < M; r += BN_SMALL_THREADS) {
     float xv[4], dv[4];
     if (vec) {
       const f4 tx = ld4(x + r * C + c0, true), td = ld4(dy + r * C + c0, true);
@@ -477,7 +504,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_small_kernel(
   }
 }
 
-int bn_nblk(int64_t M) { return (int)ceil_div(M > 0 ? M : 1, BN_ROWS); }
+int bn_nblk(int64_t M, int Cp) { return (int)ceil_div(M > 0 ? M : 1, (int64_t)bn_rows_per_wg(Cp)); }
 
 }  // namespace
 
@@ -486,7 +513,7 @@ extern "C" {
 int64_t wsis_bn_workspace_bytes(int64_t M, int32_t C) {
   if (M < 0 || C < 1) return -1;
   const int64_t Cp = (C + 3) / 4 * 4;
-  return (int64_t)bn_nblk(M) * 2 * Cp * (int64_t)sizeof(float) + 256;
+  return (int64_t)bn_nblk(M, (int)Cp) * 2 * Cp * (int64_t)sizeof(float) + 256;
 }
 
 int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* d_var, float* d_running_mean,
@@ -494,13 +521,13 @@ int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* 
   WSIS_REQUIRE(M >= 1 && C >= 1 && d_x && d_mean && d_var && d_ws, "bad args");
   WSIS_REQUIRE(ws_bytes >= wsis_bn_workspace_bytes(M, C), "workspace too small");
   WSIS_REQUIRE((d_running_mean == nullptr) == (d_running_var == nullptr), "running stats come in pairs");
-  const int nblk = bn_nblk(M);
+  const int Cp = (C + 3) / 4 * 4;
+  const int nblk = bn_nblk(M, Cp);
   float* partial = static_cast<float*>(d_ws);
   hipStream_t st = as_stream(stream);
-  const int Cp = (C + 3) / 4 * 4;
   WSIS_REQUIRE(Cp / 4 <= BN_THREADS, "C > 1024 is not supported");
-  if (M <= BN_SMALL_ROWS) {
-    hipLaunchKernelGGL(bn_stats_small_kernel, dim3(Cp / 4), dim3(BN_THREADS), 0, st, d_x, M, C, d_mean, d_var,
+  if (M <= bn_small_rows()) {
+    hipLaunchKernelGGL(bn_stats_small_kernel, dim3(Cp / 4), dim3(BN_SMALL_THREADS), 0, st, d_x, M, C, d_mean, d_var,
                        d_running_mean, d_running_var, momentum);
     WSIS_LAUNCH_CHECK();
     return WSIS_OK;
@@ -531,13 +558,13 @@ int wsis_bn_bwd(const float* d_x, const float* d_dy, const float* d_mean, const 
                 int64_t ws_bytes, void* stream) {
   WSIS_REQUIRE(M >= 1 && C >= 1 && d_x && d_dy && d_mean && d_var && d_dgamma && d_dbeta && d_ws, "bad args");
   WSIS_REQUIRE(ws_bytes >= wsis_bn_workspace_bytes(M, C), "workspace too small");
-  const int nblk = bn_nblk(M);
+  const int Cp = (C + 3) / 4 * 4;
+  const int nblk = bn_nblk(M, Cp);
   float* partial = static_cast<float*>(d_ws);
   hipStream_t st = as_stream(stream);
-  const int Cp = (C + 3) / 4 * 4;
   WSIS_REQUIRE(Cp / 4 <= BN_THREADS, "C > 1024 is not supported");
-  if (M <= BN_SMALL_ROWS) {
-    hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(Cp / 4), dim3(BN_THREADS), 0, st, d_x, d_dy, d_mean, d_var, d_gamma,
+  if (M <= bn_small_rows()) {
+    hipLaunchKernelGGL(bn_bwd_small_kernel, dim3(Cp / 4), dim3(BN_SMALL_THREADS), 0, st, d_x, d_dy, d_mean, d_var, d_gamma,
                        d_beta, eps, relu, M, C, d_dgamma, d_dbeta);
     WSIS_LAUNCH_CHECK();
   } else {

@@ -9,7 +9,7 @@ def timeit(f,n=50):
     s.record()
     for _ in range(n): f()
     e.record(); torch.cuda.synchronize(); return s.elapsed_time(e)/n*1e3
-for M,C in [(153685,32),(153685,64),(26819,64),(26819,128),(5300,96),(1520,128),(400,160)]:
+for M,C in [(153685,32),(153685,64),(26819,64),(26819,128),(6500,96),(1600,128),(400,160),(1190,64)]:
     x=torch.randn(M,C,device=dev); dy=torch.randn(M,C,device=dev); y=torch.empty_like(x); dx=torch.empty_like(x)
     g=torch.rand(C,device=dev)+0.5; b=torch.randn(C,device=dev); mean=torch.empty(C,device=dev); var=torch.empty(C,device=dev)
     dg=torch.empty(C,device=dev); db=torch.empty(C,device=dev)
