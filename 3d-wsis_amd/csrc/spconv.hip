@@ -479,6 +479,30 @@ __global__ void spconv_reduce_kernel(const float* __restrict__ partial, const fl
   }
 }
 
+// the same sum, four channels per thread (Cout % 4 == 0, 16-byte aligned buffers): same order of additions per element
+__global__ void spconv_reduce4_kernel(const float4* __restrict__ partial, const float4* __restrict__ bias,
+                                      const float4* __restrict__ residual, float4* __restrict__ out, int64_t total4,
+                                      int cout4, int ksplit) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total4;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll 4
+    for (int z = 0; z < ksplit; ++z) {
+      const float4 v = partial[(int64_t)z * total4 + t];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) {
+      const float4 v = bias[t % cout4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (residual) {
+      const float4 v = residual[t];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    out[t] = s;
+  }
+}
+
 // ---- live kernel timing for bench.py's roofline: HIP events recorded on the launch stream directly around
 // the dominant kernels (not around the host wrapper), enabled by wsis_prof_enable().
 struct ProfRec {
@@ -771,6 +795,29 @@ __global__ void dw_reduce_kernel(const float* __restrict__ partial, float* __res
   }
 }
 
+// four output channels per thread (Cout % 4 == 0, aligned dW): the slab walk issues eight 16-byte loads at a time
+__global__ void dw_reduce4_kernel(const float4* __restrict__ partial, float4* __restrict__ dW, DwPlan plan, int K,
+                                  int Cin, int cout4, int ci_pad) {
+  const int64_t total4 = (int64_t)K * Cin * cout4;
+  const int64_t slab4 = (int64_t)ci_pad * cout4;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total4;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(t % cout4);
+    const int64_t u = t / cout4;
+    const int ci = (int)(u % Cin);
+    const int k = (int)(u / Cin);
+    const float4* src = partial + (int64_t)ci * cout4 + co;
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int e = plan.begin[k + 1];
+#pragma unroll 8
+    for (int it = plan.begin[k]; it < e; ++it) {
+      const float4 v = src[it * slab4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    dW[t] = s;
+  }
+}
+
 // items per offset: base chunks (~64 at the large levels, >= 256 rows each) scaled by the offset-type weight
 int dw_base_chunks(int64_t M_out) {
   static int div = -1;   // WSIS_DW_DIV: rows per unit-weight chunk below which a level gets fewer chunks (tuning knob)
@@ -882,8 +929,18 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
   prof.stop();
   WSIS_LAUNCH_CHECK();
   if (kz > 1) {
-    hipLaunchKernelGGL(spconv_reduce_kernel, dim3(grid_for(M_out * Cout, 256)), dim3(256), 0, st, partial, d_bias,
-                       d_residual, d_out, M_out, Cout, kz);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(d_bias) |
+                         reinterpret_cast<uintptr_t>(d_residual) | reinterpret_cast<uintptr_t>(d_out);
+    if ((Cout & 3) == 0 && (al & 15) == 0) {
+      const int64_t total4 = M_out * Cout / 4;
+      hipLaunchKernelGGL(spconv_reduce4_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, st,
+                         reinterpret_cast<const float4*>(partial), reinterpret_cast<const float4*>(d_bias),
+                         reinterpret_cast<const float4*>(d_residual), reinterpret_cast<float4*>(d_out), total4,
+                         Cout / 4, kz);
+    } else {
+      hipLaunchKernelGGL(spconv_reduce_kernel, dim3(grid_for(M_out * Cout, 256)), dim3(256), 0, st, partial, d_bias,
+                         d_residual, d_out, M_out, Cout, kz);
+    }
     WSIS_LAUNCH_CHECK();
   }
   return WSIS_OK;
@@ -1029,8 +1086,14 @@ int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_orde
   }
   prof.stop();
   const int64_t total = (int64_t)K * Cin * Cout;
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, partial, d_dW, plan, K, Cin, Cout,
-                     ci_pad);
+  if ((Cout & 3) == 0 && ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(d_dW)) & 15) == 0) {
+    hipLaunchKernelGGL(dw_reduce4_kernel, dim3(grid_for(total / 4, 256)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(d_dW), plan, K, Cin, Cout / 4,
+                       ci_pad);
+  } else {
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, partial, d_dW, plan, K, Cin,
+                       Cout, ci_pad);
+  }
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }
