@@ -83,6 +83,60 @@ __global__ void subm_kernel(const int32_t* __restrict__ indices, int64_t M, Geo 
   }
 }
 
+// 3x3x3 / pad 1 (every SubMConv3d of the UNet): the same lookups, nine at a time.  The generic kernel walks its 27
+// probes one after the other (runtime loop bounds, a dependent key -> value load pair each: 27 x 2 memory latencies
+// per thread); here the nine first-probe key loads of a plane are issued together, then the value loads of the hits,
+// and only a collision falls back to the probing loop.
+__global__ void subm3_kernel(const int32_t* __restrict__ indices, int64_t M, Geo g,
+                             const int64_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                             uint64_t mask, int32_t* __restrict__ nbr, uint32_t* __restrict__ omask) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < M;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(indices)[r];
+    uint32_t bits = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int x = c.y - 1 + a;
+      const bool xin = x >= 0 && x < g.shape_in[0];
+      int64_t key[9], k0[9];
+      uint32_t h[9];
+      bool ok[9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const int y = c.z - 1 + j / 3, z = c.w - 1 + j % 3;
+        ok[j] = xin && y >= 0 && y < g.shape_in[1] && z >= 0 && z < g.shape_in[2] && !(a == 1 && j == 4);
+        key[j] = lin_key(c.x, x, y, z, g.shape_in);
+        h[j] = (uint32_t)(mix64((uint64_t)key[j]) & mask);
+      }
+#pragma unroll
+      for (int j = 0; j < 9; ++j) k0[j] = ok[j] ? keys[h[j]] : kEmptyKey;
+      int32_t v[9];
+#pragma unroll
+      for (int j = 0; j < 9; ++j) v[j] = (ok[j] && k0[j] == key[j]) ? vals[h[j]] : -1;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        if (ok[j] && k0[j] != key[j] && k0[j] != kEmptyKey) {      // first slot taken by another key: keep probing
+          uint64_t hh = (h[j] + 1) & mask;
+          for (;;) {
+            const int64_t k = keys[hh];
+            if (k == key[j]) {
+              v[j] = vals[hh];
+              break;
+            }
+            if (k == kEmptyKey) break;
+            hh = (hh + 1) & mask;
+          }
+        }
+        if (a == 1 && j == 4) v[j] = (int32_t)r;                  // centre: the row itself
+        const int kf = a * 9 + j;
+        nbr[(int64_t)kf * M + r] = v[j];
+        if (v[j] >= 0) bits |= (1u << kf);
+      }
+    }
+    if (omask) omask[r] = bits;
+  }
+}
+
 // candidate output keys of every active input; invalid candidates get key == invalid
 __global__ void down_cand_kernel(const int32_t* __restrict__ indices, int64_t M, Geo g, int fast,
                                  int64_t invalid, int64_t* __restrict__ cand) {
@@ -301,6 +355,40 @@ int bits_for(int64_t max_value) {
   return b;
 }
 
+// several 32-bit pattern fills in ONE launch (the tables and masks of a level were five hipMemsetAsync launches)
+constexpr int FILL_MAX = 6;
+struct FillBatch {
+  uint32_t* p[FILL_MAX];
+  uint64_t words[FILL_MAX];
+  uint32_t v[FILL_MAX];
+  int n = 0;
+  void add(void* ptr, uint64_t bytes, uint32_t pattern) {
+    if (bytes == 0) return;
+    p[n] = static_cast<uint32_t*>(ptr);
+    words[n] = bytes / 4;
+    v[n] = pattern;
+    ++n;
+  }
+};
+
+__global__ void multi_fill_kernel(FillBatch b) {
+  const int s = blockIdx.y;
+  uint32_t* __restrict__ p = b.p[s];
+  const uint64_t n = b.words[s];
+  const uint32_t v = b.v[s];
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+int run_fills(const FillBatch& b, hipStream_t st) {
+  if (b.n == 0) return WSIS_OK;
+  uint64_t mx = 0;
+  for (int i = 0; i < b.n; ++i) mx = b.words[i] > mx ? b.words[i] : mx;
+  hipLaunchKernelGGL(multi_fill_kernel, dim3(grid_for((int64_t)((mx + 3) / 4), 256), b.n), dim3(256), 0, st, b);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -312,8 +400,13 @@ int wsis_hash_build(const int32_t* d_indices, int64_t M, const int32_t* h_shape3
   Geo g;
   WSIS_REQUIRE(fill_geo(g, h_shape3, nullptr, nullptr, nullptr, nullptr) == 0, "bad geometry");
   hipStream_t st = as_stream(stream);
-  WSIS_HIP_CHECK(hipMemsetAsync(d_keys, 0xFF, sizeof(int64_t) * (size_t)cap, st));
-  WSIS_HIP_CHECK(hipMemsetAsync(d_vals, 0x7F, sizeof(int32_t) * (size_t)cap, st));
+  {
+    FillBatch fb;
+    fb.add(d_keys, sizeof(int64_t) * (uint64_t)cap, 0xFFFFFFFFu);
+    fb.add(d_vals, sizeof(int32_t) * (uint64_t)cap, 0x7F7F7F7Fu);
+    const int rc = run_fills(fb, st);
+    if (rc != WSIS_OK) return rc;
+  }
   if (M == 0) return WSIS_OK;
   WSIS_REQUIRE(d_indices, "null indices");
   hipLaunchKernelGGL(hash_insert_kernel, dim3(grid_for(M, 256)), dim3(256), 0, st, d_indices, M, g,
@@ -331,8 +424,14 @@ int wsis_rulebook_subm(const int32_t* d_indices, int64_t M, const int32_t* h_sha
   WSIS_REQUIRE(d_indices && d_keys && d_vals && d_nbr && is_pow2(cap), "null pointer / bad cap");
   Geo g;
   WSIS_REQUIRE(fill_geo(g, h_shape3, h_shape3, h_ksize3, nullptr, h_pad3) == 0, "bad geometry");
-  hipLaunchKernelGGL(subm_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), d_indices, M,
-                     g, d_keys, d_vals, (uint64_t)(cap - 1), d_nbr, d_mask);
+  const bool k3 = g.k[0] == 3 && g.k[1] == 3 && g.k[2] == 3 && g.p[0] == 1 && g.p[1] == 1 && g.p[2] == 1 &&
+                  cap <= ((int64_t)1 << 32);
+  if (k3)
+    hipLaunchKernelGGL(subm3_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), d_indices, M, g, d_keys,
+                       d_vals, (uint64_t)(cap - 1), d_nbr, d_mask);
+  else
+    hipLaunchKernelGGL(subm_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), d_indices, M,
+                       g, d_keys, d_vals, (uint64_t)(cap - 1), d_nbr, d_mask);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }
@@ -421,27 +520,33 @@ int wsis_rulebook_down_fill(const int32_t* d_indices_in, int64_t M_in, const int
   WSIS_REQUIRE(fill_geo(g, h_in_shape3, h_out_shape3, h_ksize3, h_stride3, h_pad3) == 0, "bad geometry");
   const int K = g.k[0] * g.k[1] * g.k[2];
   hipStream_t st = as_stream(stream);
-  WSIS_HIP_CHECK(hipMemsetAsync(d_keys, 0xFF, sizeof(int64_t) * (size_t)cap, st));
-  WSIS_HIP_CHECK(hipMemsetAsync(d_vals, 0x7F, sizeof(int32_t) * (size_t)cap, st));
+  if (M_out > 0) WSIS_REQUIRE(d_out_keys && d_indices_out && d_nbr_down, "null pointer");
+  if (M_in > 0) WSIS_REQUIRE(d_indices_in && d_nbr_up, "null pointer");
+  {
+    FillBatch fb;
+    fb.add(d_keys, sizeof(int64_t) * (uint64_t)cap, 0xFFFFFFFFu);
+    fb.add(d_vals, sizeof(int32_t) * (uint64_t)cap, 0x7F7F7F7Fu);
+    if (M_out > 0) {
+      fb.add(d_nbr_down, sizeof(int32_t) * (uint64_t)(K * M_out), 0xFFFFFFFFu);
+      if (d_mask_down) fb.add(d_mask_down, sizeof(uint32_t) * (uint64_t)M_out, 0u);
+    }
+    if (M_in > 0) {
+      fb.add(d_nbr_up, sizeof(int32_t) * (uint64_t)(K * M_in), 0xFFFFFFFFu);
+      if (M_out == 0 && d_mask_up) fb.add(d_mask_up, sizeof(uint32_t) * (uint64_t)M_in, 0u);
+    }
+    const int rc = run_fills(fb, st);
+    if (rc != WSIS_OK) return rc;
+  }
   if (M_out > 0) {
-    WSIS_REQUIRE(d_out_keys && d_indices_out && d_nbr_down, "null pointer");
-    WSIS_HIP_CHECK(hipMemsetAsync(d_nbr_down, 0xFF, sizeof(int32_t) * (size_t)(K * M_out), st));
-    if (d_mask_down) WSIS_HIP_CHECK(hipMemsetAsync(d_mask_down, 0, sizeof(uint32_t) * (size_t)M_out, st));
     hipLaunchKernelGGL(down_decode_kernel, dim3(grid_for(M_out, 256)), dim3(256), 0, st, d_out_keys, M_out,
                        g, d_indices_out, d_keys, d_vals, (uint64_t)(cap - 1));
     WSIS_LAUNCH_CHECK();
   }
-  if (M_in > 0) {
-    WSIS_REQUIRE(d_indices_in && d_nbr_up, "null pointer");
-    WSIS_HIP_CHECK(hipMemsetAsync(d_nbr_up, 0xFF, sizeof(int32_t) * (size_t)(K * M_in), st));
-    if (M_out > 0) {
-      hipLaunchKernelGGL(down_fill_kernel, dim3(grid_for(M_in, 256)), dim3(256), 0, st, d_indices_in, M_in,
-                         M_out, g, d_keys, d_vals, (uint64_t)(cap - 1), d_nbr_down, d_nbr_up, d_mask_down,
-                         d_mask_up);
-      WSIS_LAUNCH_CHECK();
-    } else if (d_mask_up) {
-      WSIS_HIP_CHECK(hipMemsetAsync(d_mask_up, 0, sizeof(uint32_t) * (size_t)M_in, st));
-    }
+  if (M_in > 0 && M_out > 0) {
+    hipLaunchKernelGGL(down_fill_kernel, dim3(grid_for(M_in, 256)), dim3(256), 0, st, d_indices_in, M_in,
+                       M_out, g, d_keys, d_vals, (uint64_t)(cap - 1), d_nbr_down, d_nbr_up, d_mask_down,
+                       d_mask_up);
+    WSIS_LAUNCH_CHECK();
   }
   return WSIS_OK;
 }
