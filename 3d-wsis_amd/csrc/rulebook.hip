@@ -315,6 +315,83 @@ __global__ void tile_permute_kernel(const int32_t* __restrict__ order_in, const 
   }
 }
 
+// ---- batched form: the tile orders of ALL gather tables of a pyramid from one sort.  Each table's keys carry the
+// table number in their top 4 bits, so one stable sort of the concatenated keys leaves every table's order in its own
+// contiguous segment (13 tables of the C2 pyramid: 13 x ~9 merge-sort launches of a few microseconds each -> ~11).
+constexpr int TOB_MAX = 16;
+struct TileBatch {
+  const int32_t* indices[TOB_MAX];
+  const uint32_t* mask[TOB_MAX];
+  int64_t base[TOB_MAX + 1];      // first element of each table in the concatenated arrays
+  int64_t tile_base[TOB_MAX + 1]; // first scheduled tile of each table (tables that are not scheduled: empty range)
+  int band[TOB_MAX];
+  int n;
+  int bs;
+};
+
+__device__ __forceinline__ int batch_table_of(const int64_t* base, int n, int64_t e) {
+  int t = 0;
+#pragma unroll 1
+  while (t + 1 < n && base[t + 1] <= e) ++t;
+  return t;
+}
+
+__global__ void tile_key_batch_kernel(TileBatch b, uint64_t* __restrict__ keys, int32_t* __restrict__ iota) {
+  const int64_t total = b.base[b.n];
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int t = batch_table_of(b.base, b.n, e);
+    const int64_t r = e - b.base[t];
+    const int4 c = reinterpret_cast<const int4*>(b.indices[t])[r];
+    const uint32_t mort = spread3((uint32_t)c.y >> b.bs) | (spread3((uint32_t)c.z >> b.bs) << 1) |
+                          (spread3((uint32_t)c.w >> b.bs) << 2);
+    keys[e] = ((uint64_t)t << 60) | ((uint64_t)((uint32_t)c.x & 0xfu) << 56) | ((uint64_t)(mort & 0xffffffu) << 32) |
+              (uint64_t)(b.mask[t] ? b.mask[t][r] : 0u);
+    iota[e] = (int32_t)r;
+  }
+}
+
+__global__ __launch_bounds__(64) void tile_weight_batch_kernel(TileBatch b, const int32_t* __restrict__ order,
+                                                               uint32_t* __restrict__ keys,
+                                                               int32_t* __restrict__ ids) {
+  const int64_t g = blockIdx.x;
+  if (g >= b.tile_base[b.n]) return;
+  const int t = batch_table_of(b.tile_base, b.n, g);
+  const int64_t tile = g - b.tile_base[t];
+  const int32_t* ord = order + b.base[t];
+  const uint32_t* mask = b.mask[t];
+  const int lane = threadIdx.x;
+  uint32_t m = mask[ord[tile * SCHED_TM + lane]] | mask[ord[tile * SCHED_TM + 64 + lane]];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m |= __shfl_xor(m, off, 64);
+  if (lane == 0) {
+    keys[g] = ((uint32_t)t << 6) | (32u - (uint32_t)__popc(m));   // table-major, then descending weight
+    ids[g] = (int32_t)tile;
+  }
+}
+
+__global__ void tile_permute_batch_kernel(TileBatch b, const int32_t* __restrict__ order_in,
+                                          const int32_t* __restrict__ sorted_tiles,
+                                          int32_t* __restrict__ order_out) {
+  const int64_t total = b.base[b.n];
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int t = batch_table_of(b.base, b.n, e);
+    const int64_t n_tiles = b.tile_base[t + 1] - b.tile_base[t];
+    const int64_t p = e - b.base[t];
+    const int64_t slot = p / SCHED_TM;
+    if (slot >= n_tiles) continue;      // table not scheduled / partial tile at the end: order_out already holds it
+    const int band = b.band[t];
+    const int64_t bb = slot / band, c = slot - bb * band;
+    int64_t rank = slot;
+    if (bb & 1) {
+      const int64_t width = min((int64_t)band, n_tiles - bb * band);
+      rank = bb * band + (width - 1 - c);
+    }
+    order_out[e] = order_in[b.base[t] + (int64_t)sorted_tiles[b.tile_base[t] + rank] * SCHED_TM + (p - slot * SCHED_TM)];
+  }
+}
+
 int sched_band() {
   static int cus = 0;
   if (cus == 0) {
@@ -621,6 +698,94 @@ int wsis_tile_order(const int32_t* d_indices, const uint32_t* d_mask, int64_t M,
     if (band == 0) band = (int)grid_tiles;
     hipLaunchKernelGGL(tile_permute_kernel, dim3(grid_for(M, 256)), dim3(256), 0, st, ord0, tsorted, M, n_tiles,
                        band, d_order);
+    WSIS_LAUNCH_CHECK();
+  }
+  return WSIS_OK;
+}
+
+int64_t wsis_tile_order_batch_workspace_bytes(int64_t N) {
+  if (N < 0) return -1;
+  if (N == 0) return 256;
+  size_t sort_bytes = 0;
+  uint64_t* kp = nullptr;
+  int32_t* vp = nullptr;
+  if (rocprim::radix_sort_pairs(nullptr, sort_bytes, kp, kp, vp, vp, (size_t)N, 0, 64, (hipStream_t)0) !=
+      hipSuccess)
+    return -1;
+  // layout: [keys N*8][keys_out N*8][iota N*4][temp]; the tile schedule reuses keys / keys_out after the sort
+  return (int64_t)(2 * align256((size_t)N * 8) + align256((size_t)N * 4) + align256(sort_bytes) + 256);
+}
+
+int wsis_tile_order_batch(int32_t n, const void* const* h_indices, const void* const* h_mask, const int64_t* h_M,
+                          int32_t block_shift, int32_t batch_size, int32_t* d_order_all, void* d_ws,
+                          int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(n >= 0 && n <= TOB_MAX && block_shift >= 0 && block_shift < 16, "bad args (at most 16 tables)");
+  WSIS_REQUIRE(batch_size >= 1 && batch_size <= 16, "the batched tile order packs the batch index into 4 bits");
+  if (n == 0) return WSIS_OK;
+  WSIS_REQUIRE(h_indices && h_mask && h_M, "null pointer");
+  TileBatch b;
+  b.n = n;
+  b.bs = block_shift;
+  b.base[0] = 0;
+  for (int t = 0; t < n; ++t) {
+    WSIS_REQUIRE(h_M[t] >= 0 && (h_M[t] == 0 || h_indices[t]), "bad table");
+    b.indices[t] = static_cast<const int32_t*>(h_indices[t]);
+    b.mask[t] = static_cast<const uint32_t*>(h_mask[t]);
+    b.base[t + 1] = b.base[t] + h_M[t];
+  }
+  const int64_t N = b.base[n];
+  if (N == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_order_all && d_ws, "null pointer");
+  hipStream_t st = as_stream(stream);
+  char* ws = static_cast<char*>(d_ws);
+  const size_t a8 = align256((size_t)N * 8), a4 = align256((size_t)N * 4);
+  WSIS_REQUIRE((int64_t)(2 * a8 + a4) < ws_bytes, "workspace too small");
+  uint64_t* keys = reinterpret_cast<uint64_t*>(ws);
+  uint64_t* keys_out = reinterpret_cast<uint64_t*>(ws + a8);
+  int32_t* iota = reinterpret_cast<int32_t*>(ws + 2 * a8);
+  void* temp = ws + 2 * a8 + a4;
+  size_t temp_bytes = (size_t)ws_bytes - (2 * a8 + a4);
+  static int sched = -1, sched_min = 150;
+  if (sched < 0) {
+    const char* e = getenv("WSIS_TILE_SCHED");
+    sched = e ? atoi(e) : 1;
+    e = getenv("WSIS_TILE_SCHED_MIN");
+    if (e) sched_min = atoi(e);
+  }
+  const int n_cu = sched_band();
+  b.tile_base[0] = 0;
+  for (int t = 0; t < n; ++t) {
+    const int64_t n_tiles = h_M[t] / SCHED_TM;
+    const bool on = sched && b.mask[t] && n_tiles >= sched_min;
+    b.tile_base[t + 1] = b.tile_base[t] + (on ? n_tiles : 0);
+    const int64_t grid_tiles = (h_M[t] + SCHED_TM - 1) / SCHED_TM;
+    int band = grid_tiles >= n_cu ? n_cu : (grid_tiles > 0 ? (int)(n_cu % grid_tiles) : 1);
+    if (band == 0) band = (int)grid_tiles;
+    b.band[t] = band > 0 ? band : 1;
+  }
+  hipLaunchKernelGGL(tile_key_batch_kernel, dim3(grid_for(N, 256)), dim3(256), 0, st, b, keys, iota);
+  WSIS_LAUNCH_CHECK();
+  size_t need = 0;
+  WSIS_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, need, keys, keys_out, iota, d_order_all, (size_t)N, 0, 64, st));
+  WSIS_REQUIRE(need <= temp_bytes, "workspace too small for sort");
+  WSIS_HIP_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_out, iota, d_order_all, (size_t)N, 0, 64, st));
+  const int64_t T = b.tile_base[n];
+  if (T > 0) {
+    int32_t* ord0 = reinterpret_cast<int32_t*>(keys);                       // N ints
+    uint32_t* tkeys = reinterpret_cast<uint32_t*>(keys_out);                // T each, 4 arrays
+    uint32_t* tkeys_out = tkeys + T;
+    int32_t* tids = reinterpret_cast<int32_t*>(tkeys_out + T);
+    int32_t* tsorted = tids + T;
+    WSIS_REQUIRE((size_t)T * 16 <= a8, "workspace too small for the tile schedule");
+    WSIS_HIP_CHECK(hipMemcpyAsync(ord0, d_order_all, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(tile_weight_batch_kernel, dim3((unsigned)T), dim3(64), 0, st, b, ord0, tkeys, tids);
+    WSIS_LAUNCH_CHECK();
+    size_t need2 = 0;
+    WSIS_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, need2, tkeys, tkeys_out, tids, tsorted, (size_t)T, 0, 10, st));
+    WSIS_REQUIRE(need2 <= temp_bytes, "workspace too small for the tile sort");
+    WSIS_HIP_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, tkeys, tkeys_out, tids, tsorted, (size_t)T, 0, 10, st));
+    hipLaunchKernelGGL(tile_permute_batch_kernel, dim3(grid_for(N, 256)), dim3(256), 0, st, b, ord0, tsorted,
+                       d_order_all);
     WSIS_LAUNCH_CHECK();
   }
   return WSIS_OK;

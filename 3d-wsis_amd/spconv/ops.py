@@ -82,6 +82,49 @@ def _tile_order(indices, mask):
     return order
 
 
+def _tile_batch_enabled(batch_size):
+    """one sort for all tables of a pyramid (WSIS_TILE_BATCH=0: one sort per table)"""
+    return (os.environ.get("WSIS_TILE_BATCH", "1") != "0" and _use_mask_order() and _tile_block_shift() >= 0
+            and 1 <= int(batch_size) <= 16)
+
+
+def finish_tile_orders(deferred, batch_size):
+    """``deferred``: [(rulebook, "order" | "order_up", indices, mask)] collected while the tables of a pyramid were
+    built without their tile orders.  One ``wsis_tile_order_batch`` call (a single sort with the table number in the
+    top key bits) produces all of them -- the same orders ``_tile_order`` gives table by table -- then every rulebook
+    is packed."""
+    import ctypes
+    lib = _n.hip()
+    todo = [d for d in deferred if d[2].shape[0] > 0]
+    rbs = []
+    for d in deferred:
+        if not any(d[0] is r for r in rbs):
+            rbs.append(d[0])
+    for i in range(0, len(todo), 16):
+        part = todo[i:i + 16]
+        n = len(part)
+        Ms = [int(d[2].shape[0]) for d in part]
+        N = sum(Ms)
+        dev = part[0][2].device
+        ws_bytes = lib.wsis_tile_order_batch_workspace_bytes(N)
+        if ws_bytes < 0:
+            raise _n.WsisError("tile_order_batch workspace query failed")
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        order_all = torch.empty(N, dtype=torch.int32, device=dev)
+        h_ind = (ctypes.c_void_p * n)(*[d[2].data_ptr() for d in part])
+        h_mask = (ctypes.c_void_p * n)(*[d[3].data_ptr() for d in part])
+        h_M = (ctypes.c_int64 * n)(*Ms)
+        _n.check(lib.wsis_tile_order_batch(n, h_ind, h_mask, h_M, _tile_block_shift(), int(batch_size),
+                                           _n.ptr(order_all), _n.ptr(ws), ws_bytes, _n.stream_ptr()),
+                 "tile_order_batch")
+        off = 0
+        for d, M in zip(part, Ms):
+            setattr(d[0], d[1], order_all[off:off + M])
+            off += M
+    for rb in rbs:
+        rb.pack()
+
+
 def _mask_order(mask):
     M = mask.shape[0]
     lib = _n.hip()
@@ -144,8 +187,9 @@ class Rulebook(object):
         return pairs, num
 
 
-def build_subm_rulebook(indices, spatial_shape, ksize, padding, hash_tab=None):
-    """SubMConv3d rulebook (a5): out rows == in rows, nbr[k][o] = i with coord_i = coord_o - pad + kappa."""
+def build_subm_rulebook(indices, spatial_shape, ksize, padding, hash_tab=None, deferred=None):
+    """SubMConv3d rulebook (a5): out rows == in rows, nbr[k][o] = i with coord_i = coord_o - pad + kappa.
+    With ``deferred`` (a list) the tile order and the packed table are left to ``finish_tile_orders``."""
     _n.require_cuda(indices)
     _check_indices(indices)
     M = indices.shape[0]
@@ -160,10 +204,13 @@ def build_subm_rulebook(indices, spatial_shape, ksize, padding, hash_tab=None):
     _n.check(_n.hip().wsis_rulebook_subm(_n.ptr(indices), M, _n.i32x3(spatial_shape), _n.i32x3(ksize),
                                          _n.i32x3(padding), _n.ptr(keys), _n.ptr(vals), cap, _n.ptr(rb.nbr),
                                          _n.ptr(mask), _n.stream_ptr()), "rulebook_subm")
+    rb.out_hash = hash_tab
+    if deferred is not None and mask is not None and _use_mask_order():
+        deferred.append((rb, "order", indices, mask))
+        return rb
     if mask is not None and _use_mask_order() and M > 0:
         rb.order = _tile_order(indices, mask)
     rb.pack()
-    rb.out_hash = hash_tab
     return rb
 
 
@@ -177,7 +224,7 @@ def build_down_rulebook(indices, spatial_shape, ksize, stride, padding):
         return done.value
 
 
-def _down_rulebook_gen(indices, spatial_shape, ksize, stride, padding):
+def _down_rulebook_gen(indices, spatial_shape, ksize, stride, padding, deferred=None):
     """generator form: yields once, right before the host reads the output row count (the one sync of the level),
     so that a caller can do other work while the candidate / sort / unique kernels run (RulebookPipeline)"""
     _n.require_cuda(indices)
@@ -217,13 +264,17 @@ def _down_rulebook_gen(indices, spatial_shape, ksize, stride, padding):
                                          _n.ptr(out_indices), _n.ptr(keys), _n.ptr(vals), cap, _n.ptr(rb.nbr),
                                          _n.ptr(rb.nbr_up), _n.ptr(mask_down), _n.ptr(mask_up), st),
              "rulebook_down_fill")
+    rb.out_hash = (keys, vals, cap)
+    if deferred is not None and use_mask and _use_mask_order():
+        deferred.append((rb, "order", out_indices, mask_down))
+        deferred.append((rb, "order_up", indices, mask_up))
+        return rb
     if use_mask and _use_mask_order():
         if M_out > 0:
             rb.order = _tile_order(out_indices, mask_down)
         if M_in > 0:
             rb.order_up = _tile_order(indices, mask_up)
     rb.pack()
-    rb.out_hash = (keys, vals, cap)
     return rb
 
 
@@ -412,6 +463,9 @@ def _build_pyramid_gen(tensor, n_levels, subm_key, down_key, first_id):
     built = []
     indices, shape = tensor.indices, [int(s) for s in tensor.spatial_shape]
     hash_tab = tensor._hash
+    batch_size = int(getattr(tensor, "batch_size", 0) or 0)
+    deferred = [] if _tile_batch_enabled(batch_size) else None
+    new_rbs = []
     for lvl in range(n_levels):
         kid = first_id + lvl
         key = subm_key.format(kid)
@@ -421,17 +475,21 @@ def _build_pyramid_gen(tensor, n_levels, subm_key, down_key, first_id):
                 if lvl == 0:
                     tensor._hash = hash_tab
                     built += [hash_tab[0], hash_tab[1]]
-            rb = build_subm_rulebook(indices, shape, [3, 3, 3], [1, 1, 1], hash_tab)
+            rb = build_subm_rulebook(indices, shape, [3, 3, 3], [1, 1, 1], hash_tab, deferred=deferred)
             tensor.indice_dict[key] = rb
-            built += _rulebook_tensors(rb)
+            new_rbs.append(rb)
         if lvl + 1 < n_levels:
             dkey = down_key.format(kid)
             rb = tensor.indice_dict.get(dkey)
             if rb is None:
-                rb = yield from _down_rulebook_gen(indices, shape, [2, 2, 2], [2, 2, 2], [0, 0, 0])
+                rb = yield from _down_rulebook_gen(indices, shape, [2, 2, 2], [2, 2, 2], [0, 0, 0], deferred=deferred)
                 tensor.indice_dict[dkey] = rb
-                built += _rulebook_tensors(rb)
+                new_rbs.append(rb)
             indices, shape, hash_tab = rb.out_indices, rb.out_shape, rb.out_hash
+    if deferred:
+        finish_tile_orders(deferred, batch_size)
+    for rb in new_rbs:
+        built += _rulebook_tensors(rb)
     return built
 
 

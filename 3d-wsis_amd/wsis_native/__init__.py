@@ -68,6 +68,8 @@ _HIP_SIGS = {
     "wsis_mask_order": (I32, [P, I64, P, P, I64, P]),
     "wsis_tile_order_workspace_bytes": (I64, [I64]),
     "wsis_tile_order": (I32, [P, P, I64, I32, P, P, I64, P]),
+    "wsis_tile_order_batch_workspace_bytes": (I64, [I64]),
+    "wsis_tile_order_batch": (I32, [I32, P, P, P, I32, I32, P, P, I64, P]),
     "wsis_spconv_fwd_workspace_bytes": (I64, [I64, I32, I32, I32]),
     "wsis_spconv_fwd": (I32, [P, P, P, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
     "wsis_weight_transpose": (I32, [P, P, I32, I32, I32, I32, P]),

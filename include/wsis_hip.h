@@ -156,6 +156,15 @@ int wsis_tile_order(const int32_t* d_indices, const uint32_t* d_mask, int64_t M,
                     int32_t* d_order, void* d_ws, int64_t ws_bytes, void* stream);
 int wsis_mask_order(const uint32_t* d_mask, int64_t M, int32_t* d_order, void* d_ws, int64_t ws_bytes,
                     void* stream);
+/* The tile orders of up to 16 gather tables (every table of a UNet pyramid) from ONE sort: h_indices[t] /
+ * h_mask[t] are host arrays of device pointers (int32 [M_t,4] / uint32 [M_t] or NULL), h_M the row counts.
+ * d_order_all int32 [sum M_t]: table t's order (row numbers local to the table, identical to what
+ * wsis_tile_order returns for it) at offset sum_{u<t} M_u.  The batch index of every row must be < 16
+ * (batch_size, checked on the host side); N = sum M_t for the workspace query. */
+int64_t wsis_tile_order_batch_workspace_bytes(int64_t N);
+int wsis_tile_order_batch(int32_t n, const void* const* h_indices, const void* const* h_mask, const int64_t* h_M,
+                          int32_t block_shift, int32_t batch_size, int32_t* d_order_all, void* d_ws,
+                          int64_t ws_bytes, void* stream);
 
 /* Packed gather table for the convolution kernels: nbr_packed[k][t] = nbr[k][order[t]] (columns in tile
  * order, so a 128-row tile reads K coalesced 512-byte pieces).  With d_order == NULL the kernels take the

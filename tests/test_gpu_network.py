@@ -289,3 +289,38 @@ def test_augmented_cropped_batch_from_the_reference_pipeline_matches_oracle():
         assert _rel(ret[k], r_ret[k]) < 2e-3, (k, _rel(ret[k], r_ret[k]))
     assert abs(float(loss) - float(r_loss)) < 2e-3 * abs(float(r_loss))
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("n_scenes", [1, 3])
+def test_batched_tile_order_equals_the_per_table_orders(monkeypatch, n_scenes):
+    """wsis_tile_order_batch (all 13 tables of the pyramid from one sort, table number in the top key bits, batched
+    tile scheduling) against wsis_tile_order called table by table: identical orders and packed tables."""
+    import spconv
+    from spconv import ops
+    scenes = [harness.make_scene(40 + i, room=(1.8, 1.5, 1.1), n_box=2) for i in range(n_scenes)]
+    batch = harness.to_device(harness.collate(scenes), "cuda")
+    idx, shape = batch["voxel_coords_int"], batch["spatial_shape"]
+    assert idx.shape[0] // 128 >= 150                      # level 0 is large enough for the tile scheduling
+
+    def build(flag, batch_size):
+        monkeypatch.setenv("WSIS_TILE_BATCH", flag)
+        t = spconv.SparseConvTensor(torch.zeros(idx.shape[0], 1, device="cuda"), idx, shape, batch_size)
+        ops.prebuild_unet_rulebooks(t, 5)
+        torch.cuda.synchronize()
+        return t
+
+    one, per = build("1", n_scenes), build("0", n_scenes)
+    far = build("1", 17)                                   # batch_size > 16: the batched form steps aside
+    assert len(one.indice_dict) == 9
+    for other in (per, far):
+        for k, rb in one.indice_dict.items():
+            for name in ("order", "order_up", "nbr_p", "nbr_up_p"):
+                a, b = getattr(rb, name, None), getattr(other.indice_dict[k], name, None)
+                assert (a is None) == (b is None), (k, name)
+                if a is not None:
+                    assert torch.equal(a, b), (k, name)
+    # every order is a permutation of its rows
+    for k, rb in one.indice_dict.items():
+        for o in (rb.order, rb.order_up):
+            if o is not None:
+                assert torch.equal(torch.sort(o.long())[0], torch.arange(o.numel(), device="cuda"))
