@@ -592,6 +592,31 @@ __global__ void rulebook_pack_kernel(const int32_t* __restrict__ nbr, const int3
   }
 }
 
+// the same for up to 16 tables in one launch (all tables of a pyramid)
+constexpr int PACK_MAX = 16;
+struct PackBatch {
+  const int32_t* nbr[PACK_MAX];
+  const int32_t* order[PACK_MAX];
+  int32_t* out[PACK_MAX];
+  int64_t M[PACK_MAX];
+  int64_t base[PACK_MAX + 1];   // first element (K*M entries per table) in the concatenated index space
+  int n;
+};
+
+__global__ void rulebook_pack_batch_kernel(PackBatch b) {
+  const int64_t total = b.base[b.n];
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int t = 0;
+#pragma unroll 1
+    while (t + 1 < b.n && b.base[t + 1] <= e) ++t;
+    const int64_t u = e - b.base[t], M = b.M[t];
+    const int64_t k = u / M;
+    const int64_t c = u - k * M;
+    b.out[t][u] = b.nbr[t][k * M + b.order[t][c]];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // dW kernel: grid (work item, ci-block); a work item is (offset k, row chunk j of n_k).  The MFMA A operand is
 // X^T (lane = input channel, the two k-slots = two tile rows), B is dY -- both are coalesced 128-B row segments
@@ -860,6 +885,31 @@ int wsis_rulebook_pack(const int32_t* d_nbr, const int32_t* d_order, int32_t* d_
   WSIS_REQUIRE(d_nbr && d_order && d_nbr_packed, "null pointer");
   hipLaunchKernelGGL(rulebook_pack_kernel, dim3(grid_for(M * K, 256)), dim3(256), 0, as_stream(stream), d_nbr,
                      d_order, d_nbr_packed, M, K);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_rulebook_pack_batch(int32_t n, const void* const* h_nbr, const void* const* h_order,
+                             void* const* h_nbr_packed, const int64_t* h_M, const int32_t* h_K, void* stream) {
+  WSIS_REQUIRE(n >= 0 && n <= PACK_MAX, "at most 16 tables per call");
+  if (n == 0) return WSIS_OK;
+  WSIS_REQUIRE(h_nbr && h_order && h_nbr_packed && h_M && h_K, "null pointer");
+  PackBatch b;
+  b.n = 0;
+  b.base[0] = 0;
+  for (int t = 0; t < n; ++t) {
+    WSIS_REQUIRE(h_M[t] >= 0 && h_K[t] >= 1, "bad sizes");
+    if (h_M[t] == 0) continue;
+    WSIS_REQUIRE(h_nbr[t] && h_order[t] && h_nbr_packed[t], "null table pointer");
+    b.nbr[b.n] = static_cast<const int32_t*>(h_nbr[t]);
+    b.order[b.n] = static_cast<const int32_t*>(h_order[t]);
+    b.out[b.n] = static_cast<int32_t*>(h_nbr_packed[t]);
+    b.M[b.n] = h_M[t];
+    b.base[b.n + 1] = b.base[b.n] + h_M[t] * h_K[t];
+    ++b.n;
+  }
+  if (b.n == 0) return WSIS_OK;
+  hipLaunchKernelGGL(rulebook_pack_batch_kernel, dim3(grid_for(b.base[b.n], 256)), dim3(256), 0, as_stream(stream), b);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

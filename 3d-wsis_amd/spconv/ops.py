@@ -121,8 +121,27 @@ def finish_tile_orders(deferred, batch_size):
         for d, M in zip(part, Ms):
             setattr(d[0], d[1], order_all[off:off + M])
             off += M
+    # packed tables (columns in tile order) of every rulebook, 16 tables per launch
+    jobs = []
     for rb in rbs:
-        rb.pack()
+        for nbr, order, name in ((rb.nbr, rb.order, "nbr_p"), (rb.nbr_up, rb.order_up, "nbr_up_p")):
+            if nbr is None:
+                continue
+            if order is None or nbr.shape[1] == 0:
+                setattr(rb, name, nbr)
+                continue
+            out = torch.empty_like(nbr)
+            setattr(rb, name, out)
+            jobs.append((nbr, order, out))
+    for i in range(0, len(jobs), 16):
+        part = jobs[i:i + 16]
+        n = len(part)
+        _n.check(lib.wsis_rulebook_pack_batch(
+            n, (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in part]),
+            (ctypes.c_void_p * n)(*[j[1].data_ptr() for j in part]),
+            (ctypes.c_void_p * n)(*[j[2].data_ptr() for j in part]),
+            (ctypes.c_int64 * n)(*[int(j[0].shape[1]) for j in part]),
+            (ctypes.c_int32 * n)(*[int(j[0].shape[0]) for j in part]), _n.stream_ptr()), "rulebook_pack_batch")
 
 
 def _mask_order(mask):

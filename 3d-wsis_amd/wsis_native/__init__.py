@@ -76,6 +76,7 @@ _HIP_SIGS = {
     "wsis_spconv_dw_workspace_bytes": (I64, [I64, I32, I32, I32]),
     "wsis_spconv_dw": (I32, [P, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
     "wsis_rulebook_pack": (I32, [P, P, P, I64, I32, P]),
+    "wsis_rulebook_pack_batch": (I32, [I32, P, P, P, P, P, P]),
     "wsis_prof_enable": (I32, [I32]),
     "wsis_prof_summary": (I32, [I32, P, P]),
     "wsis_bn_workspace_bytes": (I64, [I64, I32]),

@@ -171,6 +171,9 @@ int wsis_tile_order_batch(int32_t n, const void* const* h_indices, const void* c
  * unpacked table as is. */
 int wsis_rulebook_pack(const int32_t* d_nbr, const int32_t* d_order, int32_t* d_nbr_packed, int64_t M,
                        int32_t K, void* stream);
+/* the same for up to 16 tables in one launch: host arrays of device pointers / sizes, one entry per table */
+int wsis_rulebook_pack_batch(int32_t n, const void* const* h_nbr, const void* const* h_order,
+                             void* const* h_nbr_packed, const int64_t* h_M, const int32_t* h_K, void* stream);
 
 /* ---- a7-a11: sparse convolution [UPSTREAM spconv indiceConv / indiceConvBackward] -----------
  * out[r,:] = sum_k X[nbr[k][r],:] @ W[k]  (rows with nbr<0 contribute nothing), fp32.
