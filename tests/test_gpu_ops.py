@@ -643,3 +643,65 @@ def test_conv_math_modes_against_fp64(monkeypatch, mode, tol, cin, cout):
         ref[v] += X[nb[v]].double() @ W[k].double()
     rel = float((out.double() - ref).norm() / ref.norm())
     assert rel < tol, (mode, rel)
+
+
+@pytest.mark.gpu
+def test_batched_order_and_pack_edge_cases():
+    """wsis_tile_order_batch / wsis_rulebook_pack_batch: no tables, an empty table among others, a table without a
+    mask, more than 16 tables (rejected), a batch index range that does not fit the key (rejected)."""
+    import ctypes
+    import wsis_native as _n
+    lib = _n.hip()
+    dev = "cuda"
+    st = _n.stream_ptr()
+    assert lib.wsis_tile_order_batch(0, None, None, None, 4, 1, None, None, 0, st) == 0
+    g = torch.Generator().manual_seed(5)
+    tabs = []
+    for M in (700, 0, 300):
+        c = torch.cat([torch.randint(0, 3, (M, 1), generator=g), torch.randint(0, 60, (M, 3), generator=g)], 1).int().to(dev)
+        m = torch.randint(0, 1 << 27, (M,), generator=g, dtype=torch.int32).to(dev)
+        tabs.append((c, m))
+    tabs[2] = (tabs[2][0], None)                        # pure spatial order for the last table
+    n = len(tabs)
+    Ms = [int(c.shape[0]) for c, _ in tabs]
+    N = sum(Ms)
+    ws_bytes = lib.wsis_tile_order_batch_workspace_bytes(N)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    order_all = torch.full((N,), -7, dtype=torch.int32, device=dev)
+    h_ind = (ctypes.c_void_p * n)(*[c.data_ptr() if c.shape[0] else None for c, _ in tabs])
+    h_mask = (ctypes.c_void_p * n)(*[(m.data_ptr() if m is not None and m.shape[0] else None) for _, m in tabs])
+    h_M = (ctypes.c_int64 * n)(*Ms)
+    _n.check(lib.wsis_tile_order_batch(n, h_ind, h_mask, h_M, 4, 3, order_all.data_ptr(), ws.data_ptr(), ws_bytes, st),
+             "tile_order_batch")
+    off = 0
+    for (c, m), M in zip(tabs, Ms):
+        if M == 0:
+            continue
+        want = torch.empty(M, dtype=torch.int32, device=dev)
+        wsb = lib.wsis_tile_order_workspace_bytes(M)
+        w1 = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _n.check(lib.wsis_tile_order(c.data_ptr(), None if m is None else m.data_ptr(), M, 4, want.data_ptr(),
+                                     w1.data_ptr(), wsb, st), "tile_order")
+        assert torch.equal(order_all[off:off + M], want)
+        off += M
+    # 17 tables / batch size 17: refused with an error status, nothing launched
+    h17 = (ctypes.c_void_p * 17)(*[tabs[0][0].data_ptr()] * 17)
+    m17 = (ctypes.c_void_p * 17)(*[None] * 17)
+    M17 = (ctypes.c_int64 * 17)(*[4] * 17)
+    assert lib.wsis_tile_order_batch(17, h17, m17, M17, 4, 1, order_all.data_ptr(), ws.data_ptr(), ws_bytes, st) != 0
+    assert lib.wsis_tile_order_batch(n, h_ind, h_mask, h_M, 4, 17, order_all.data_ptr(), ws.data_ptr(), ws_bytes, st) != 0
+    assert b"4 bits" in lib.wsis_last_error()
+    # pack: one empty table among two real ones == the single-table entry point
+    K = 8
+    nbrs = [torch.randint(-1, 50, (K, M), generator=g, dtype=torch.int32).to(dev) for M in (700, 0, 300)]
+    orders = [torch.randperm(M, generator=g).int().to(dev) for M in (700, 0, 300)]
+    outs = [torch.full_like(x, -9) for x in nbrs]
+    _n.check(lib.wsis_rulebook_pack_batch(
+        3, (ctypes.c_void_p * 3)(*[x.data_ptr() if x.numel() else None for x in nbrs]),
+        (ctypes.c_void_p * 3)(*[x.data_ptr() if x.numel() else None for x in orders]),
+        (ctypes.c_void_p * 3)(*[x.data_ptr() if x.numel() else None for x in outs]),
+        (ctypes.c_int64 * 3)(700, 0, 300), (ctypes.c_int32 * 3)(K, K, K), st), "pack_batch")
+    for x, o, got in zip(nbrs, orders, outs):
+        if x.numel():
+            assert torch.equal(got, x[:, o.long()])
+    assert lib.wsis_rulebook_pack_batch(17, None, None, None, None, None, st) != 0
