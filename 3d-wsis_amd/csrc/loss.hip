@@ -1,0 +1,219 @@
+// Point-level semantic loss of MultiTaskLoss (losses_3D_WSIS.py:52-67 of the reference: CrossEntropyLoss with
+// ignore_index + dice_loss_multi_classes on the softmax of the kept rows) as two passes over the [N, C] scores:
+//   loss = sum_valid(-log_softmax(x)[y]) / n_valid + mean_c(1 - (2 A_c + eps) / (B_c + K_c + 1e-4 + eps))
+//   A_c = sum_valid p_c [y = c],  B_c = sum_valid p_c^2,  K_c = #valid rows of class c,  eps = 1e-5.
+// The torch evaluation is ~40 launches over [N, 20] tensors (log_softmax, nll_loss with a one-workgroup reduction,
+// softmax, a 32-MB int64 one_hot, two maskings, three column sums, and their backward nodes): ~0.7 ms per step.
+// Forward: one thread per row keeps the per-class sums in registers (static indices), a workgroup reduces them with
+// wave shuffles + a 4-entry LDS stage, one partial row per workgroup; a single-workgroup final kernel sums the partials
+// in fp64 in a fixed order and evaluates the loss -> deterministic.  Backward: one pass, analytic gradient.
+#include "common.h"
+
+namespace wsis {
+namespace {
+
+constexpr int SL_CMAX = 32;                  // classes held in registers
+constexpr int SL_THREADS = 256;
+constexpr int SL_VALS = 3 * SL_CMAX + 2;     // A[32] B[32] K[32] ce n
+constexpr int SL_MAX_BLOCKS = 512;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(SL_THREADS) void sem_loss_fwd_kernel(const float* __restrict__ x,
+                                                                  const int64_t* __restrict__ y, int64_t N, int C,
+                                                                  int64_t ignore, float* __restrict__ partial) {
+  __shared__ float sh[SL_THREADS / 64][SL_VALS];
+  float A[SL_CMAX], B[SL_CMAX], K[SL_CMAX];
+#pragma unroll
+  for (int c = 0; c < SL_CMAX; ++c) A[c] = B[c] = K[c] = 0.0f;
+  float ce = 0.0f, n = 0.0f;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t lab = y[r];
+    if (lab == ignore) continue;
+    const float* row = x + r * C;
+    float v[SL_CMAX];
+    float m = -INFINITY, xl = 0.0f;
+#pragma unroll
+    for (int c = 0; c < SL_CMAX; ++c) {
+      v[c] = c < C ? row[c] : -INFINITY;
+      m = fmaxf(m, v[c]);
+      if ((int64_t)c == lab && c < C) xl = v[c];
+    }
+    float Z = 0.0f;
+#pragma unroll
+    for (int c = 0; c < SL_CMAX; ++c) {
+      v[c] = c < C ? expf(v[c] - m) : 0.0f;
+      Z += v[c];
+    }
+    const float inv = 1.0f / Z, logZ = logf(Z);
+#pragma unroll
+    for (int c = 0; c < SL_CMAX; ++c) {
+      const float p = v[c] * inv;
+      const bool hit = (int64_t)c == lab;
+      B[c] += p * p;
+      A[c] += hit ? p : 0.0f;
+      K[c] += hit ? 1.0f : 0.0f;
+    }
+    ce += (m + logZ) - xl;      // -log_softmax(x)[y]
+    n += 1.0f;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < SL_CMAX; ++c) {
+    const float a = wave_sum(A[c]), b = wave_sum(B[c]), k = wave_sum(K[c]);
+    if (lane == 0) {
+      sh[wave][c] = a;
+      sh[wave][SL_CMAX + c] = b;
+      sh[wave][2 * SL_CMAX + c] = k;
+    }
+  }
+  {
+    const float a = wave_sum(ce), b = wave_sum(n);
+    if (lane == 0) {
+      sh[wave][3 * SL_CMAX] = a;
+      sh[wave][3 * SL_CMAX + 1] = b;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < SL_VALS) {
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < SL_THREADS / 64; ++w) s += sh[w][threadIdx.x];
+    partial[(int64_t)blockIdx.x * SL_VALS + threadIdx.x] = s;
+  }
+}
+
+// out[0] = loss, out[1] = n_valid; saved[0..C) = Num_c, saved[C..2C) = Den_c, saved[2C] = n_valid
+__global__ __launch_bounds__(1024) void sem_loss_final_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                              float* __restrict__ out, float* __restrict__ saved) {
+  __shared__ double sums[128];
+  const int v = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  double s = 0.0;
+  if (v < SL_VALS)
+    for (int b = sub; b < nblk; b += 8) s += (double)partial[(int64_t)b * SL_VALS + v];
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (sub == 0 && v < 128) sums[v] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double eps = 1e-5;
+    const double n = sums[3 * SL_CMAX + 1];
+    double dice_sum = 0.0;
+    for (int c = 0; c < C; ++c) {
+      const double num = 2.0 * sums[c] + eps;
+      const double den = sums[SL_CMAX + c] + sums[2 * SL_CMAX + c] + 1e-4 + eps;
+      saved[c] = (float)num;
+      saved[C + c] = (float)den;
+      dice_sum += 1.0 - num / den;
+    }
+    saved[2 * C] = (float)n;
+    out[0] = (float)(sums[3 * SL_CMAX] / n + dice_sum / (double)C);   // n == 0 -> nan, as the reference's CE
+    out[1] = (float)n;
+  }
+}
+
+__global__ __launch_bounds__(SL_THREADS) void sem_loss_bwd_kernel(const float* __restrict__ x,
+                                                                  const int64_t* __restrict__ y, int64_t N, int C,
+                                                                  int64_t ignore, const float* __restrict__ saved,
+                                                                  const float* __restrict__ gout,
+                                                                  float* __restrict__ dx) {
+  __shared__ float s_num[SL_CMAX], s_den[SL_CMAX];
+  if (threadIdx.x < SL_CMAX) {
+    s_num[threadIdx.x] = threadIdx.x < C ? saved[threadIdx.x] : 0.0f;
+    s_den[threadIdx.x] = threadIdx.x < C ? saved[C + threadIdx.x] : 1.0f;
+  }
+  __syncthreads();
+  const float g = gout[0];
+  const float inv_n = 1.0f / saved[2 * C];
+  const float inv_c = 1.0f / (float)C;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t lab = y[r];
+    float* out = dx + r * C;
+    if (lab == ignore) {
+      for (int c = 0; c < C; ++c) out[c] = 0.0f;
+      continue;
+    }
+    const float* row = x + r * C;
+    float v[SL_CMAX];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < SL_CMAX; ++c) {
+      v[c] = c < C ? row[c] : -INFINITY;
+      m = fmaxf(m, v[c]);
+    }
+    float Z = 0.0f;
+#pragma unroll
+    for (int c = 0; c < SL_CMAX; ++c) {
+      v[c] = c < C ? expf(v[c] - m) : 0.0f;
+      Z += v[c];
+    }
+    const float inv = 1.0f / Z;
+    // dL/dp_c = (1/C) (2 p_c Num_c / Den_c^2 - 2 [y = c] / Den_c);  dx_j = p_j (gp_j - sum_c gp_c p_c) + (p_j - [y=j]) / n
+    float gp[SL_CMAX];
+    float dot = 0.0f;
+#pragma unroll
+    for (int c = 0; c < SL_CMAX; ++c) {
+      const float p = v[c] * inv;
+      v[c] = p;
+      const float den = s_den[c];
+      gp[c] = c < C ? inv_c * (2.0f * p * s_num[c] / (den * den) - (((int64_t)c == lab) ? 2.0f / den : 0.0f)) : 0.0f;
+      dot += gp[c] * p;
+    }
+#pragma unroll
+    for (int c = 0; c < SL_CMAX; ++c)
+      if (c < C) out[c] = g * (v[c] * (gp[c] - dot) + (v[c] - (((int64_t)c == lab) ? 1.0f : 0.0f)) * inv_n);
+  }
+}
+
+int sl_blocks(int64_t N) {
+  int64_t b = ceil_div(N > 0 ? N : 1, SL_THREADS);
+  if (b > SL_MAX_BLOCKS) b = SL_MAX_BLOCKS;
+  return (int)b;
+}
+
+}  // namespace
+}  // namespace wsis
+
+using namespace wsis;
+
+extern "C" {
+
+int64_t wsis_semantic_loss_workspace_bytes(int64_t N) {
+  if (N < 0) return -1;
+  return (int64_t)sl_blocks(N) * SL_VALS * (int64_t)sizeof(float) + 256;
+}
+
+int wsis_semantic_loss_fwd(const float* d_scores, const int64_t* d_labels, int64_t N, int32_t C, int64_t ignore_label,
+                           float* d_out2, float* d_saved, void* d_ws, int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(N >= 0 && C >= 1 && C <= SL_CMAX, "1 <= classes <= 32");
+  WSIS_REQUIRE(d_out2 && d_saved && d_ws, "null pointer");
+  WSIS_REQUIRE(N == 0 || (d_scores && d_labels), "null input");
+  WSIS_REQUIRE(ws_bytes >= wsis_semantic_loss_workspace_bytes(N), "workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int nblk = sl_blocks(N);
+  float* partial = static_cast<float*>(d_ws);
+  hipLaunchKernelGGL(sem_loss_fwd_kernel, dim3(nblk), dim3(SL_THREADS), 0, st, d_scores, d_labels, N, (int)C,
+                     ignore_label, partial);
+  WSIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sem_loss_final_kernel, dim3(1), dim3(1024), 0, st, partial, nblk, (int)C, d_out2, d_saved);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_semantic_loss_bwd(const float* d_scores, const int64_t* d_labels, int64_t N, int32_t C, int64_t ignore_label,
+                           const float* d_saved, const float* d_grad_loss, float* d_dscores, void* stream) {
+  WSIS_REQUIRE(N >= 0 && C >= 1 && C <= SL_CMAX, "1 <= classes <= 32");
+  if (N == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_scores && d_labels && d_saved && d_grad_loss && d_dscores, "null pointer");
+  hipLaunchKernelGGL(sem_loss_bwd_kernel, dim3(grid_for(N, SL_THREADS)), dim3(SL_THREADS), 0, as_stream(stream),
+                     d_scores, d_labels, N, (int)C, ignore_label, d_saved, d_grad_loss, d_dscores);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+}  // extern "C"

@@ -53,8 +53,15 @@ class MultiTaskLoss(nn.Module):
         semantic_labels, instance_labels = loss_inp["point_labels"]
         semantic_scores = loss_inp["semantic_scores"]
         indexed = os.environ.get("WSIS_LOSS_INDEXED", "0") == "1"
-        semantic_loss = self.semantic_criterion(semantic_scores, semantic_labels)
-        if self.semantic_dice:
+        fused = (not indexed and self.semantic_dice and semantic_scores.is_cuda and semantic_scores.shape[1] <= 32
+                 and os.environ.get("WSIS_FUSE_SEM_LOSS", "1") != "0")
+        if fused:       # CE + dice in two passes over [N, C] (csrc/loss.hip) instead of ~40 torch launches
+            import wsis_ops
+            semantic_loss, n_kept = wsis_ops.semantic_point_loss(semantic_scores, semantic_labels, self.ignore_label)
+            loss_out["semantic_loss"] = (semantic_loss, n_kept)
+        else:
+            semantic_loss = self.semantic_criterion(semantic_scores, semantic_labels)
+        if self.semantic_dice and not fused:
             keep = semantic_labels != self.ignore_label
             if indexed:
                 semantic_scores = F.softmax(semantic_scores[keep], dim=-1)
@@ -64,7 +71,8 @@ class MultiTaskLoss(nn.Module):
                 semantic_scores = F.softmax(semantic_scores, dim=-1) * w
                 one_hot = F.one_hot(semantic_labels.clamp(min=0), num_classes=self.semantic_class_num) * w
             semantic_loss = semantic_loss + dice_loss_multi_classes(semantic_scores, one_hot).mean()
-        loss_out["semantic_loss"] = (semantic_loss, semantic_scores.sum())
+        if not fused:
+            loss_out["semantic_loss"] = (semantic_loss, semantic_scores.sum())
 
         joint = epoch > self.joint_training_epoch
         if joint:

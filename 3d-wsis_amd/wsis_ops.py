@@ -394,3 +394,43 @@ def gather_rows(src, idx, csr=None):
     if csr is None:
         csr = SegmentCSR(idx, src.shape[0])
     return _GatherRows.apply(src, idx, csr)
+
+
+class _SemanticPointLoss(Function):
+    """CrossEntropy(ignore_index) + mean per-class dice of the point-level scores in two passes over [N, C]
+    (``csrc/loss.hip``; reference ``losses_3D_WSIS.py:52-67``).  Returns (loss, number of kept rows)."""
+
+    @staticmethod
+    def forward(ctx, scores, labels, ignore_label):
+        _n.require_cuda(scores, labels)
+        lib = _n.hip()
+        scores = scores.contiguous().float()
+        labels = labels.contiguous().long()
+        N, C = scores.shape
+        out = torch.empty(2, dtype=torch.float32, device=scores.device)
+        saved = torch.empty(2 * C + 1, dtype=torch.float32, device=scores.device)
+        ws_bytes = lib.wsis_semantic_loss_workspace_bytes(N)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=scores.device)
+        _n.check(lib.wsis_semantic_loss_fwd(_n.ptr(scores), _n.ptr(labels), N, C, int(ignore_label), _n.ptr(out),
+                                            _n.ptr(saved), _n.ptr(ws), ws_bytes, _n.stream_ptr()),
+                 "semantic_loss_fwd")
+        ctx.save_for_backward(scores, labels, saved)
+        ctx.ignore_label = int(ignore_label)
+        loss, n_valid = out[0], out[1]
+        ctx.mark_non_differentiable(n_valid)
+        return loss, n_valid
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_n):
+        scores, labels, saved = ctx.saved_tensors
+        N, C = scores.shape
+        d = torch.empty_like(scores)
+        g = g_loss.contiguous().float()
+        _n.check(_n.hip().wsis_semantic_loss_bwd(_n.ptr(scores), _n.ptr(labels), N, C, ctx.ignore_label,
+                                                 _n.ptr(saved), _n.ptr(g), _n.ptr(d), _n.stream_ptr()),
+                 "semantic_loss_bwd")
+        return d, None, None
+
+
+def semantic_point_loss(scores, labels, ignore_label=-100):
+    return _SemanticPointLoss.apply(scores, labels, ignore_label)

@@ -323,6 +323,17 @@ int wsis_ballquery_fill(const float* d_xyz, const int32_t* d_batch_idx, const in
                         int64_t N, int32_t B, float radius, const int32_t* d_start_len, int32_t* d_idx,
                         int64_t total, void* d_ws, int64_t ws_bytes, void* stream);
 
+/* ---- a18 (point-level part): semantic loss of MultiTaskLoss.forward (losses_3D_WSIS.py:52-67 of the reference):
+ * CrossEntropyLoss(ignore_index) + mean_c(1 - dice_c) with dice_c = (2 sum p_c y_c + 1e-5) / (sum p_c^2 + sum y_c
+ * + 1e-4 + 1e-5) over the rows whose label != ignore_label, p = softmax(scores).  d_scores fp32 [N,C] (C <= 32),
+ * d_labels int64 [N].  fwd: d_out2[0] = loss, d_out2[1] = number of kept rows; d_saved fp32 [2C+1] feeds bwd.
+ * bwd: d_dscores [N,C] = *d_grad_loss * dloss/dscores (zero rows for ignored labels).  Deterministic. */
+int64_t wsis_semantic_loss_workspace_bytes(int64_t N);
+int wsis_semantic_loss_fwd(const float* d_scores, const int64_t* d_labels, int64_t N, int32_t C, int64_t ignore_label,
+                           float* d_out2, float* d_saved, void* d_ws, int64_t ws_bytes, void* stream);
+int wsis_semantic_loss_bwd(const float* d_scores, const int64_t* d_labels, int64_t N, int32_t C, int64_t ignore_label,
+                           const float* d_saved, const float* d_grad_loss, float* d_dscores, void* stream);
+
 /* ---- op-list executor: one C call issues a recorded forward or backward pass of the sparse UNet ------------
  * Replaces the Python-dispatched module walk of sparse_unet3d.py:103-350 (ResidualBlock.forward / UBlock.forward
  * and their autograd backward): the host records the pass as wsis_op records (plain device pointers + sizes) and

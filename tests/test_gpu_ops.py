@@ -705,3 +705,39 @@ def test_batched_order_and_pack_edge_cases():
         if x.numel():
             assert torch.equal(got, x[:, o.long()])
     assert lib.wsis_rulebook_pack_batch(17, None, None, None, None, None, st) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,frac_ignored", [(5000, 20, 0.7), (257, 13, 0.0), (1, 20, 0.0), (40000, 32, 0.95)])
+def test_fused_semantic_loss_matches_torch_formulation(N, C, frac_ignored):
+    """wsis_semantic_loss_fwd/bwd (CE with ignore_index + per-class dice, csrc/loss.hip) against the torch
+    evaluation of the reference's formulas (losses_3D_WSIS.py:52-67, dice :233-253) in fp64; tolerance: 2e-6
+    relative on the loss, 1e-5 of the largest gradient entry on d(scores)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(N + C)
+    x = (torch.randn(N, C, generator=g) * 3).cuda().requires_grad_(True)
+    y = torch.randint(0, C, (N,), generator=g)
+    y[torch.rand(N, generator=g) < frac_ignored] = -100
+    if (y == -100).all():
+        y[0] = 1
+    y = y.cuda()
+    loss, n_kept = wsis_ops.semantic_point_loss(x, y, -100)
+    (loss * 1.7).backward()
+    xd = x.detach().double().requires_grad_(True)
+    keep = y != -100
+    ce = F.cross_entropy(xd, y, ignore_index=-100)
+    p = F.softmax(xd[keep], -1)
+    oh = F.one_hot(y[keep], C).double()
+    dice = (2 * (p * oh).sum(0) + 1e-5) / ((p * p).sum(0) + (oh * oh).sum(0) + 1e-4 + 1e-5)
+    want = ce + (1 - dice).mean()
+    (want * 1.7).backward()
+    assert int(n_kept) == int(keep.sum())
+    assert abs(float(loss) - float(want)) < 2e-6 * abs(float(want)) + 1e-7
+    gmax = float(xd.grad.abs().max())
+    assert float((x.grad.double() - xd.grad).abs().max()) < 1e-5 * gmax + 1e-9
+    assert float(x.grad[~keep].abs().sum()) == 0.0
+    # deterministic
+    x2 = x.detach().clone().requires_grad_(True)
+    l2, _ = wsis_ops.semantic_point_loss(x2, y, -100)
+    (l2 * 1.7).backward()
+    assert torch.equal(l2, loss) and torch.equal(x2.grad, x.grad)
