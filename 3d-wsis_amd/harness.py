@@ -11,6 +11,8 @@
 """
 import types
 
+import os
+
 import numpy as np
 import torch
 
@@ -314,9 +316,14 @@ def build_model(cfg, device, seed=123):
     torch.manual_seed(seed)   # config/ScanNet_v2_3D_WSIS.yaml:3
     model = backbone_3D_WSIS.Network(cfg.model).to(device)
     criterion = losses_3D_WSIS.MultiTaskLoss(None, cfg.loss, cfg.model)
-    # yaml:58-61; on the GPU the multi-tensor fused AdamW (same update rule, one launch, no per-parameter .item())
-    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4,
-                                  fused=torch.device(device).type == "cuda")
+    # yaml:58-61.  On the GPU: optim.FlatAdamW (the same update rule in ONE launch over all 361 tensors;
+    # WSIS_FLAT_ADAMW=0 selects torch's multi-tensor fused AdamW: 6 launches at a third of the CUs)
+    if torch.device(device).type == "cuda" and os.environ.get("WSIS_FLAT_ADAMW", "1") != "0":
+        import optim
+        optimizer = optim.FlatAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    else:
+        optimizer = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4,
+                                      fused=torch.device(device).type == "cuda")
     return model, criterion, optimizer
 
 

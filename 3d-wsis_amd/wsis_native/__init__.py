@@ -12,7 +12,7 @@ import ``oracle/``.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int32, c_int64, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
@@ -23,6 +23,7 @@ _hip = None
 I32 = c_int32
 I64 = c_int64
 F32 = c_float
+F64 = c_double
 P = c_void_p
 
 
@@ -105,6 +106,9 @@ _HIP_SIGS = {
     "wsis_semantic_loss_workspace_bytes": (I64, [I64]),
     "wsis_semantic_loss_fwd": (I32, [P, P, I64, I32, I64, P, P, P, I64, P]),
     "wsis_semantic_loss_bwd": (I32, [P, P, I64, I32, I64, P, P, P, P]),
+    "wsis_adamw_segment_bytes": (I32, []),
+    "wsis_adamw_chunk": (I32, []),
+    "wsis_adamw_step": (I32, [P, P, I64, F64, F64, F64, F64, F64, P]),
     "wsis_run_ops_workspace_bytes": (I64, [P, I32]),
     "wsis_run_ops": (I32, [P, I32, P, I64, P]),
 }

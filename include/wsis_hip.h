@@ -334,6 +334,17 @@ int wsis_semantic_loss_fwd(const float* d_scores, const int64_t* d_labels, int64
 int wsis_semantic_loss_bwd(const float* d_scores, const int64_t* d_labels, int64_t N, int32_t C, int64_t ignore_label,
                            const float* d_saved, const float* d_grad_loss, float* d_dscores, void* stream);
 
+/* ---- optimizer step (train_scannetv2.py:251; AdamW of config/ScanNet_v2_3D_WSIS.yaml:58-61) in one launch.
+ * d_segments: device array of {float* p; const float* g; float* m; float* v; int64_t n; float step_size;
+ * float inv_sqrt_bc2;} (wsis_adamw_segment_bytes() bytes each; n == 0 skips the parameter; step_size =
+ * lr / (1 - beta1^t), inv_sqrt_bc2 = 1 / sqrt(1 - beta2^t) with t = updates of that parameter so far, this one
+ * included); d_blocks int32 [n_blocks,2] = (segment, chunk of wsis_adamw_chunk() elements) for every chunk of every
+ * segment.  Update rule of torch.optim.AdamW (decoupled weight decay), fp32. */
+int32_t wsis_adamw_segment_bytes(void);
+int32_t wsis_adamw_chunk(void);
+int wsis_adamw_step(const void* d_segments, const int32_t* d_blocks, int64_t n_blocks, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, void* stream);
+
 /* ---- op-list executor: one C call issues a recorded forward or backward pass of the sparse UNet ------------
  * Replaces the Python-dispatched module walk of sparse_unet3d.py:103-350 (ResidualBlock.forward / UBlock.forward
  * and their autograd backward): the host records the pass as wsis_op records (plain device pointers + sizes) and

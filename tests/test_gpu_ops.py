@@ -741,3 +741,46 @@ def test_fused_semantic_loss_matches_torch_formulation(N, C, frac_ignored):
     l2, _ = wsis_ops.semantic_point_loss(x2, y, -100)
     (l2 * 1.7).backward()
     assert torch.equal(l2, loss) and torch.equal(x2.grad, x.grad)
+
+
+@pytest.mark.gpu
+def test_flat_adamw_matches_torch_adamw_step_by_step():
+    """optim.FlatAdamW (wsis_adamw_step: every tensor in one launch) against torch.optim.AdamW (for-loop
+    implementation) on odd-sized tensors, a parameter without gradient, a non-16-byte-aligned gradient view, five
+    steps; tolerance 2e-6 of the parameter scale per step (fp32 rounding of a different but equivalent expression)."""
+    import optim
+    g = torch.Generator().manual_seed(3)
+    shapes = [(3, 3, 3, 6, 32), (32,), (7, 64), (1,), (1025,), (96, 32), (20,)]
+    a = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    mine = optim.FlatAdamW(a, lr=1e-3, weight_decay=1e-4)
+    ref = torch.optim.AdamW(b, lr=1e-3, weight_decay=1e-4, foreach=False, fused=False)
+    flat = torch.empty(sum(t.numel() for t in a) + 3, device="cuda")
+    for step in range(5):
+        off = 1                                           # views that start 4 bytes into the buffer: unaligned
+        for i, (p, q) in enumerate(zip(a, b)):
+            if i == 3 and step % 2 == 0:
+                p.grad, q.grad = None, None               # skipped by both
+                continue
+            gr = torch.randn(p.shape, generator=g).cuda() * (10.0 ** (i - 3))
+            view = flat[off:off + p.numel()].view(p.shape)
+            view.copy_(gr)
+            off += p.numel()
+            p.grad, q.grad = view, gr.clone()
+        mine.step()
+        ref.step()
+        for p, q in zip(a, b):
+            assert float((p - q).abs().max()) <= 2e-6 * float(q.abs().max()) + 1e-9, (step, p.shape)
+    sd = mine.state_dict()
+    rs = ref.state_dict()["state"]
+    for i in range(len(a)):
+        if i in rs:
+            for name in ("exp_avg", "exp_avg_sq"):       # fp32 rounding (torch contracts to fma, this build does not)
+                want = rs[i][name]
+                assert float((sd["state"][i][name] - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-30
+            assert float(sd["state"][i]["step"]) == float(rs[i]["step"])
+    other = optim.FlatAdamW([t.detach().clone().requires_grad_(True) for t in a], lr=1e-3, weight_decay=1e-4)
+    other.load_state_dict(sd)
+    assert (other.steps == mine.steps).all() and torch.equal(other.exp_avg, mine.exp_avg)
+    with pytest.raises(Exception):
+        optim.FlatAdamW([torch.zeros(3, requires_grad=True)])        # CPU parameters are refused
