@@ -228,6 +228,10 @@ def to_device(batch, device):
     out["superpoint_csr"] = SegmentCSR(out["superpoint"], S)
     out["p2v_csr"] = SegmentCSR(out["p2v_map"], int(batch["voxel_locs"].shape[0]))
     out["edge_graph"] = wsis_ops.EdgeGraph(out["edge_u_list"], out["edge_v_list"], S)
+    # bound of the superpoint instance ids per scene, read while the labels are still host tensors: lets the loss
+    # place the instances in fixed slots instead of torch.unique (sync) or an [S, S] same-instance matrix
+    lab, offs = batch["superpoint_instance_labels"], [int(o) for o in batch["sp_batch_offsets"]]
+    out["sp_instance_slots"] = [max(int(lab[b:e].max()) + 1, 1) if e > b else 1 for b, e in zip(offs[:-1], offs[1:])]
     return out
 
 
@@ -263,6 +267,8 @@ def forward_loss(model, criterion, batch, cfg, epoch=5):
         "sp_instance_size": (ret["pred_sp_ins_size"], batch["superpoint_instance_size"]),
         "sp_discriminative_features": (ret["sp_discriminative_feats"], batch["sp_batch_offsets"]),
     }
+    if "sp_instance_slots" in batch and os.environ.get("WSIS_LOSS_SLOTS", "1") != "0":
+        loss_inp["sp_instance_slots"] = batch["sp_instance_slots"]
     loss, loss_out = criterion(loss_inp, epoch)
     return loss, ret
 

@@ -97,12 +97,15 @@ class MultiTaskLoss(nn.Module):
 
             feats, sp_batch_offsets = loss_inp["sp_discriminative_features"]
             offs = [int(o) for o in sp_batch_offsets]
+            slots = loss_inp.get("sp_instance_slots")      # host-known bound of the instance ids per scene (optional)
             d_losses = []
             for i in range(1, len(offs)):
                 b, e = offs[i - 1], offs[i]
                 valid = sp_valid[b:e]
                 if indexed:
                     d_loss, _, _, _ = self.discriminative_loss(feats[b:e][valid], sp_ins_labels[b:e][valid])
+                elif slots is not None and 1 <= int(slots[i - 1]) <= 512:
+                    d_loss = self.discriminative_loss_slots(feats[b:e], sp_ins_labels[b:e], valid, int(slots[i - 1]))
                 else:
                     d_loss = self.discriminative_loss_masked(feats[b:e], sp_ins_labels[b:e], valid)
                 d_losses.append(d_loss.view(-1))
@@ -165,6 +168,31 @@ class MultiTaskLoss(nn.Module):
         l_dist = self.param_dist * l_dist
         l_reg = self.param_reg * l_reg
         return l_var + l_dist + l_reg, l_var, l_dist, l_reg
+
+    def discriminative_loss_slots(self, prediction, label, valid, n_slots):
+        """the same terms with the instances in ``n_slots`` fixed slots (slot = instance id; ``n_slots`` is a bound the
+        HOST knows from the batch, so no ``unique`` and no sync): a one-hot [S, n_slots] membership matrix replaces
+        the [S, S] same-instance matrix of ``discriminative_loss_masked`` -- instance means by one small GEMM, the
+        push term on [n_slots, n_slots] instead of [S, S].  Empty slots carry weight 0.  Deterministic (no atomics)."""
+        pred = torch.reshape(prediction, [-1, self.discriminative_feature_dim])
+        slot = torch.arange(n_slots, device=pred.device, dtype=label.dtype)
+        oh = ((label.unsqueeze(1) == slot.unsqueeze(0)) & valid.unsqueeze(1)).to(pred.dtype)      # [S, I]
+        cnt = oh.sum(0)                                          # members per slot
+        present = (cnt > 0).to(pred.dtype)
+        n = present.sum()                                        # number of instances (0-dim tensor, no sync)
+        inv = 1.0 / cnt.clamp(min=1.0)
+        mu = (oh.t() @ pred) * inv.unsqueeze(1)                  # [I, D] instance means (0 for empty slots)
+        mu_rows = oh @ mu                                        # [S, D] the mean of the row's instance
+        dist = torch.norm(pred - mu_rows, p=2, dim=1)
+        dist = torch.square(torch.clamp(dist - self.delta_v, min=0.))
+        w = oh @ inv                                             # [S] 1 / size of the row's instance, 0 if dropped
+        l_var = torch.sum(dist * w) / n
+        l1 = (mu.unsqueeze(0) - mu.unsqueeze(1)).abs().sum(-1)   # [I, I]
+        d = 2. * self.delta_d - l1
+        pair = present.unsqueeze(0) * present.unsqueeze(1) * (1.0 - torch.eye(n_slots, device=pred.device, dtype=pred.dtype))
+        l_dist = torch.sum(torch.square(torch.clamp(d, min=0.)) * pair) / torch.clamp(n * (n - 1), min=1.0)
+        l_reg = torch.sum(torch.norm(mu, p=2, dim=1) * present)
+        return self.param_var * l_var + self.param_dist * l_dist + self.param_reg * l_reg
 
     def discriminative_loss_masked(self, prediction, label, valid):
         """the same pull / push / reg terms (losses_3D_WSIS.py:157-230) without ``unique`` / mask indexing: rows with

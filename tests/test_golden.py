@@ -29,13 +29,17 @@ def _loss_inputs(z, device="cpu"):
     return leaves, loss_inp
 
 
-def _check_loss(device):
+def _check_loss(device, slots=False):
     z = np.load(os.path.join(G, "loss_golden.npz"))
     pl = types.SimpleNamespace(ignore_label=-100, supervise_instance_size=True, joint_training_epoch=0,
                                semantic_dice=True, supervise_sp_offset=True)
     crit = losses_3D_WSIS.MultiTaskLoss(None, pl, types.SimpleNamespace(classes=20))
     for epoch, tag in ((0, "sem"), (5, "joint")):
         leaves, loss_inp = _loss_inputs(z, device)
+        if slots:       # host-known bound of the instance ids per scene -> slot formulation of the push/pull terms
+            ins, off = z["in_sp_ins"], z["in_sp_off"]
+            loss_inp["sp_instance_slots"] = [max(int(ins[off[i]:off[i + 1]].max()) + 1, 1) + 3 * i
+                                             for i in range(len(off) - 1)]      # a loose bound is as good
         loss, loss_out = crit(loss_inp, epoch)
         loss.backward()
         assert np.allclose(loss.item(), z[f"{tag}_loss"], rtol=1e-5, atol=1e-6)
@@ -55,9 +59,14 @@ def test_loss_matches_reference_golden_cpu():
     _check_loss("cpu")
 
 
+def test_loss_slot_formulation_matches_reference_golden_cpu():
+    _check_loss("cpu", slots=True)
+
+
 @pytest.mark.gpu
 def test_loss_matches_reference_golden_gpu():
     _check_loss("cuda")
+    _check_loss("cuda", slots=True)
 
 
 def _expected_labels(z, final):
