@@ -67,8 +67,11 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=8)
     ap.add_argument("--cpu-timeout", type=int, default=150)
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--setup-steps", type=int, default=3,
-                    help="untimed initialisation passes before the warm-up (lazy code-object loads, allocator growth)")
+    ap.add_argument("--setup-steps", type=int, default=300,
+                    help="untimed initialisation passes before the W warm-up steps: lazy code-object loads, allocator "
+                         "growth and -- the long part -- the engine clock: the step time of this MFMA-heavy job keeps "
+                         "falling for the first few hundred steps of a process (13.1 ms after 3 passes, 12.0 ms after "
+                         "300 or 600, DESIGN section 5); a training run sits in that steady state")
     ap.add_argument("--no-stages", action="store_true",
                     help="skip the side measurements (copy/triad bandwidth, optimizer step, clustering stage)")
     ap.add_argument("--scene-seed", type=int, default=1)
@@ -349,7 +352,9 @@ def main():
         return out
 
     # initialisation (not part of the W warm-up steps): the first passes load code objects lazily (hipBLASLt /
-    # rocPRIM / this library), grow the caching allocator to the step's footprint and ramp the clocks
+    # rocPRIM / this library), grow the caching allocator to the step's footprint and ramp the clocks -- the step
+    # time keeps falling for the first few hundred steps (a fixed COUNT, not a duration: every rank must run the
+    # same number of steps, each holds a gradient collective)
     for _ in range(args.setup_steps):
         step()
     for _ in range(args.warmup):
