@@ -292,3 +292,56 @@ def synthetic_scene_to_reference_format(sc):
                     "instance_voxel_num": sc["sp_voxnum"], "instance_size": sc["sp_size"]},
                    sc["edges"], sc["edge_feats"])
     return tup, g
+
+
+def _segment_mode(seg, values, n_seg):
+    """per-segment mode of ``values`` (ties -> the smallest value, as ``scipy.stats.mode``)"""
+    vals, inv = np.unique(values, return_inverse=True)
+    pair = seg.astype(np.int64) * len(vals) + inv.reshape(-1)
+    up, cnt = np.unique(pair, return_counts=True)
+    s, v = up // len(vals), up % len(vals)
+    order = np.lexsort((v, -cnt, s))                 # segment, then count descending, then value ascending
+    first = np.ones(len(order), dtype=bool)
+    first[1:] = s[order][1:] != s[order][:-1]
+    out = np.full(n_seg, -100, dtype=vals.dtype)
+    out[s[order][first]] = vals[v[order][first]]
+    return out
+
+
+def acquire_weak_label(xyz, semantic_labels, instance_labels, superpoint, graph, annotation_num=1, rng=None):
+    """``ScanNetV2Inst_spg.acquire_weak_label`` (scannetv2_dataset.py:970-1036): per instance, ``annotation_num``
+    superpoints are drawn with probability proportional to their point count (all of them if the instance has no
+    more); the drawn ones keep their labels and get the offset to the centre of the drawn points of their instance,
+    every other superpoint of ``graph`` (a PlainGraph, modified in place) is reset to label -100 / offset 0.
+    ``rng``: ``numpy.random.RandomState`` (the reference draws from numpy's global state: ``RandomState(seed)``
+    reproduces ``np.random.seed(seed)``).  Returns the list of annotated superpoint ids in drawing order."""
+    rng = rng if rng is not None else np.random.RandomState()
+    superpoint = np.asarray(superpoint).astype("int")
+    sp_ids, sp_size = np.unique(superpoint, return_counts=True)
+    n_sp = int(sp_ids.max()) + 1 if len(sp_ids) else 0
+    sp_instance = _segment_mode(superpoint, np.asarray(instance_labels), n_sp)
+    members = {}                                        # instance label -> [(superpoint, size)] in ascending id order
+    for sp, size in zip(sp_ids, sp_size):
+        members.setdefault(sp_instance[sp], []).append((sp, size))
+    chosen_all = []
+    off = np.array(graph.vs["superpoint_offset_vector"], dtype=np.float64, copy=True)
+    for ins in np.unique(instance_labels):
+        if ins not in members:
+            continue
+        ids = np.array([m[0] for m in members[ins]])
+        num = np.array([m[1] for m in members[ins]])
+        prob = num / num.sum()
+        chosen = rng.choice(ids, size=annotation_num, p=prob, replace=False) if annotation_num < ids.shape[0] else ids
+        chosen_all.extend(list(chosen))
+        centre = np.mean(xyz[np.isin(superpoint, chosen)], axis=0)
+        for sp in chosen:
+            if graph.vs["v"][sp] != sp:
+                raise ValueError("graph vertex ids must equal the superpoint ids (:1018)")
+            off[sp] = centre - np.mean(xyz[superpoint == sp], axis=0)
+    keep = np.zeros(graph.vcount, dtype=bool)
+    keep[np.asarray(chosen_all, dtype=np.int64)] = True
+    graph.vs["semantic_label"] = np.where(keep, graph.vs["semantic_label"], -100)
+    graph.vs["instance_label"] = np.where(keep, graph.vs["instance_label"], -100)
+    off[~keep] = 0.0
+    graph.vs["superpoint_offset_vector"] = off
+    return [int(c) for c in chosen_all]

@@ -32,7 +32,7 @@ import harness                      # noqa: E402
 
 REF = "/root/reference/modules/datasets/scannetv2_dataset.py"
 METHODS = ("__getitem__", "data_aug_with_graph", "data_aug", "elastic", "crop", "get_instance_info",
-           "get_cropped_inst_label")
+           "get_cropped_inst_label", "acquire_weak_label")
 
 
 class GraphStub(object):
@@ -60,7 +60,17 @@ def reference_object(**attrs):
         np.bool = bool
     if not hasattr(scipy.ndimage, "filters"):
         scipy.ndimage.filters = scipy.ndimage
-    ns = {"np": np, "math": math, "scipy": scipy, "torch": torch, "copy": copy}
+    import collections
+
+    class _Stats(object):          # scipy < 1.9 API the reference was written for: mode() returns arrays
+        @staticmethod
+        def mode(x):
+            import scipy.stats
+            r = scipy.stats.mode(x, keepdims=True)
+            return r.mode, r.count
+
+    ns = {"np": np, "math": math, "scipy": scipy, "torch": torch, "copy": copy, "collections": collections,
+          "stats": _Stats}
     exec(code, ns)
     obj = types.SimpleNamespace(**attrs)
     for name in METHODS:
@@ -120,6 +130,29 @@ def main():
         out[tag + "_g_edges"] = G.edges
         out[tag + "_cfg"] = np.asarray([int(aug), int(test_mode), max_npoint, seed])
         print(tag, "points", loc.shape[0], "of", len(tup[0]), "superpoints", len(G.vs["v"]), "edges", len(G.edges))
+    # --- acquire_weak_label (:970-1036): GT-labelled synthetic scene, 1 and 2 annotated superpoints per instance ------
+    sc = harness.make_scene(9, room=(1.0, 0.9, 0.8), n_box=3)
+    rs = np.random.RandomState(9)
+    sem_gt = rs.randint(0, 20, sc["S"])[sc["superpoint"]].astype(np.float64)
+    ins_gt = (sc["superpoint"] % 7).astype(np.float64)            # 7 instances made of many superpoints each
+    ins_gt[rs.rand(len(ins_gt)) < 0.05] = -100                    # some unlabelled points
+    sem_gt[rs.rand(len(sem_gt)) < 0.1] = rs.randint(0, 20)        # label noise inside superpoints -> real modes
+    for tag, k, seed in (("w1", 1, 41), ("w2", 2, 42)):
+        _, plain = datasets.synthetic_scene_to_reference_format(sc)
+        plain.vs["semantic_label"] = rs.randint(0, 20, sc["S"])
+        plain.vs["instance_label"] = np.arange(sc["S"]) % 7
+        stub = GraphStub(plain)
+        ref = reference_object()
+        np.random.seed(seed)
+        ref.acquire_weak_label(sc["xyz"], sem_gt, ins_gt, sc["superpoint"], stub, k)
+        out[tag + "_sem"] = np.asarray([v["semantic_label"] for v in stub.vs])
+        out[tag + "_ins"] = np.asarray([v["instance_label"] for v in stub.vs])
+        out[tag + "_off"] = np.asarray([np.asarray(v["superpoint_offset_vector"], dtype=np.float64) for v in stub.vs])
+        out[tag + "_in_sem"] = plain.vs["semantic_label"]
+        out[tag + "_in_ins"] = plain.vs["instance_label"]
+        out[tag + "_cfg"] = np.asarray([k, seed])
+        print(tag, "annotated superpoints", int((out[tag + "_ins"] != -100).sum()), "of", sc["S"])
+    out["w_sem_gt"], out["w_ins_gt"] = sem_gt, ins_gt
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dataset_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

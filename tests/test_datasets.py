@@ -140,3 +140,28 @@ def test_plain_graph_roundtrip_and_scene_file(tmp_path):
     torch.save((1, 2, 3), tmp_path / "bad.pth")
     with pytest.raises(ValueError):
         datasets.load_scene_file(tmp_path / "bad.pth")
+
+
+@pytest.mark.parametrize("tag", ["w1", "w2"])
+def test_acquire_weak_label_matches_reference(tag):
+    """datasets.acquire_weak_label against the reference's own method (scannetv2_dataset.py:970-1036) run on the same
+    scene with numpy's global state seeded: same drawn superpoints, same labels kept, same offset vectors."""
+    k, seed = [int(x) for x in G[tag + "_cfg"]]
+    sc = harness.make_scene(9, room=(1.0, 0.9, 0.8), n_box=3)
+    _, graph = datasets.synthetic_scene_to_reference_format(sc)
+    graph.vs["semantic_label"] = G[tag + "_in_sem"].copy()
+    graph.vs["instance_label"] = G[tag + "_in_ins"].copy()
+    chosen = datasets.acquire_weak_label(sc["xyz"], G["w_sem_gt"], G["w_ins_gt"], sc["superpoint"], graph, k,
+                                         rng=np.random.RandomState(seed))
+    np.testing.assert_array_equal(graph.vs["semantic_label"], G[tag + "_sem"])
+    np.testing.assert_array_equal(graph.vs["instance_label"], G[tag + "_ins"])
+    np.testing.assert_array_equal(graph.vs["superpoint_offset_vector"], G[tag + "_off"])
+    kept = np.flatnonzero(G[tag + "_ins"] != -100)
+    assert sorted(chosen) == kept.tolist() and len(chosen) == len(set(chosen))
+    assert len(chosen) == k * 7                      # 7 instances (no superpoint has -100 as its majority label)
+
+
+def test_segment_mode_ties_take_the_smallest_value():
+    seg = np.array([0, 0, 0, 0, 1, 1, 2])
+    val = np.array([5.0, 3.0, 5.0, 3.0, -100.0, 7.0, 2.0])
+    np.testing.assert_array_equal(datasets._segment_mode(seg, val, 4), [3.0, -100.0, 2.0, -100.0])
