@@ -50,7 +50,7 @@ run("gc disabled")
 run("gc disabled again")
 gc.enable()
 run("default again")
-for k, cpus in []:
+for k, cpus in nodes.items():
     cp = [c for c in cpus if c in full]
     if not cp:
         continue
