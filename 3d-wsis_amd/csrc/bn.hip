@@ -144,33 +144,43 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const bool fixed_c = (stride % C4) == 0;      // then the channel group of a thread never changes
     unsigned cg = (unsigned)(t % C4);
-    float sc[4], sh[4];
+    float sc[4], mu[4], bt[4];
     auto coef = [&](unsigned g) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int c = (int)g * 4 + e;
         sc[e] = (gamma ? gamma[c] : 1.0f) * rsqrtf(var[c] + eps);
-        sh[e] = (beta ? beta[c] : 0.0f) - mean[c] * sc[e];
+        mu[e] = mean[c];
+        bt[e] = beta ? beta[c] : 0.0f;
       }
     };
     coef(cg);
-    for (; t < total4; t += stride) {
-      if (!fixed_c) {
-        cg = (unsigned)(t % C4);
-        coef(cg);
-      }
-      float4 v = reinterpret_cast<const float4*>(x)[t];
+    // (x - mean)*sc + beta, written as x*sc + (beta - mean*sc) would change rounding: keep the torch order
+    auto body = [&](const float4 v) {
       float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        // (x - mean)*sc + beta, written as x*sc + (beta - mean*sc) would change rounding: keep the torch order
-        float z = (o[e] - mean[(int)cg * 4 + e]) * sc[e] + (beta ? beta[(int)cg * 4 + e] : 0.0f);
+        float z = (o[e] - mu[e]) * sc[e] + bt[e];
         if (relu) z = fmaxf(z, 0.0f);
         o[e] = z;
       }
-      reinterpret_cast<float4*>(y)[t] = make_float4(o[0], o[1], o[2], o[3]);
+      return make_float4(o[0], o[1], o[2], o[3]);
+    };
+    if (fixed_c) {   // two float4 per trip in flight (the launcher rounds the grid so that this branch is taken)
+      for (; t + stride < total4; t += 2 * stride) {
+        const float4 v0 = reinterpret_cast<const float4*>(x)[t];
+        const float4 v1 = reinterpret_cast<const float4*>(x)[t + stride];
+        reinterpret_cast<float4*>(y)[t] = body(v0);
+        reinterpret_cast<float4*>(y)[t + stride] = body(v1);
+      }
+      if (t < total4) reinterpret_cast<float4*>(y)[t] = body(reinterpret_cast<const float4*>(x)[t]);
+    } else {
+      for (; t < total4; t += stride) {
+        cg = (unsigned)(t % C4);
+        coef(cg);
+        reinterpret_cast<float4*>(y)[t] = body(reinterpret_cast<const float4*>(x)[t]);
+      }
     }
-    (void)sh;
   } else {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * blockDim.x) {
@@ -314,6 +324,39 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
     }
   };
   if (t < totalw) coef((int)(t % Cw) * W);
+  auto one = [&](const float (&xv)[4], const float (&dv)[4], const float (&av)[4], float (&ov)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e < W) {
+        const float xh = (xv[e] - mu[e]) * rstd[e];
+        float dz = dv[e];
+        if (relu && xh * gm[e] + bt[e] <= 0.0f) dz = 0.0f;
+        float r = dz;
+        if (training) r = dz - k1[e] - xh * k2[e];
+        ov[e] = gm[e] * rstd[e] * r;
+        if (addend) ov[e] += av[e];
+      }
+    }
+  };
+  if (vec && fixed_c) {   // two float4 triples per trip in flight
+    for (; t + stride < totalw; t += 2 * stride) {
+      const int64_t u = t + stride;
+      const f4 tx0 = ld4(x + t * 4, true), td0 = ld4(dy + t * 4, true);
+      const f4 tx1 = ld4(x + u * 4, true), td1 = ld4(dy + u * 4, true);
+      f4 ta0, ta1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ta0.v[e] = ta1.v[e] = 0.f;
+      if (addend) {
+        ta0 = ld4(addend + t * 4, true);
+        ta1 = ld4(addend + u * 4, true);
+      }
+      float o0[4], o1[4];
+      one(tx0.v, td0.v, ta0.v, o0);
+      one(tx1.v, td1.v, ta1.v, o1);
+      reinterpret_cast<float4*>(dx)[t] = make_float4(o0[0], o0[1], o0[2], o0[3]);
+      reinterpret_cast<float4*>(dx)[u] = make_float4(o1[0], o1[1], o1[2], o1[3]);
+    }
+  }
   for (; t < totalw; t += stride) {
     if (!fixed_c) coef((int)(t % Cw) * W);
     float xv[4], dv[4], av[4] = {0.f, 0.f, 0.f, 0.f}, ov[4];
@@ -334,18 +377,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
       dv[0] = dy[t];
       if (addend) av[0] = addend[t];
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (e < W) {
-        const float xh = (xv[e] - mu[e]) * rstd[e];
-        float dz = dv[e];
-        if (relu && xh * gm[e] + bt[e] <= 0.0f) dz = 0.0f;
-        float r = dz;
-        if (training) r = dz - k1[e] - xh * k2[e];
-        ov[e] = gm[e] * rstd[e] * r;
-        if (addend) ov[e] += av[e];
-      }
-    }
+    one(xv, dv, av, ov);
     if (vec)
       reinterpret_cast<float4*>(dx)[t] = make_float4(ov[0], ov[1], ov[2], ov[3]);
     else
@@ -546,7 +578,11 @@ int wsis_bn_apply(const float* d_x, const float* d_mean, const float* d_var, con
   if (M == 0) return WSIS_OK;
   WSIS_REQUIRE(d_x && d_mean && d_var && d_y, "null pointer");
   const int64_t work = (C & 3) == 0 ? (M * C) >> 2 : M * C;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(work, 256)), dim3(256), 0, as_stream(stream), d_x, d_mean, d_var,
+  // grid rounded to a multiple of the channel groups: a thread then keeps one channel group for its whole walk
+  const int cw = (C & 3) == 0 ? C >> 2 : C;
+  int grid = grid_for(work, 256);
+  if (grid > cw) grid -= grid % cw;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, as_stream(stream), d_x, d_mean, d_var,
                      d_gamma, d_beta, eps, relu, d_y, M, C);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
