@@ -170,6 +170,108 @@ __global__ __launch_bounds__(SL_THREADS) void sem_loss_bwd_kernel(const float* _
   }
 }
 
+// ---- superpoint regression terms of MultiTaskLoss (losses_3D_WSIS.py:79-96 offset L1 + cosine, :113-127 occupancy and
+// instance-size L1): rows count when both superpoint labels differ from ignore_label.  One workgroup walks the S rows
+// (S ~ 1-10 k), fp32 per-thread sums folded in fp64 in a fixed order; ~80 small torch launches otherwise.
+//   out[0] = sum_valid |p - g|_1 / (n + 1e-6)          out[1] = sum_valid -(g/(|g|+1e-8)) . (p/(|p|+1e-8)) / (n + 1e-6)
+//   out[2] = sum_valid |occ_p - occ_g| / n              out[3] = sum_valid |size_p - size_g| / n      out[4] = n
+// Dropped rows are skipped by selection, not multiplied by 0 (the log voxel count of an unlabelled superpoint is -inf).
+constexpr int SR_THREADS = 1024;
+
+__global__ __launch_bounds__(SR_THREADS) void sp_reg_fwd_kernel(
+    const float* __restrict__ p_off, const float* __restrict__ g_off, const float* __restrict__ p_occ,
+    const float* __restrict__ g_occ, const float* __restrict__ p_size, const float* __restrict__ g_size,
+    const int64_t* __restrict__ sem, const int64_t* __restrict__ ins, int64_t S, int64_t ignore,
+    float* __restrict__ out) {
+  __shared__ double sh[SR_THREADS / 64][5];
+  float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = threadIdx.x; r < S; r += SR_THREADS) {
+    if (sem[r] == ignore || ins[r] == ignore) continue;
+    float l1 = 0.f, pp = 0.f, gg = 0.f;
+    float p[3], g[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      p[k] = p_off[r * 3 + k];
+      g[k] = g_off[r * 3 + k];
+      l1 += fabsf(p[k] - g[k]);
+      pp += p[k] * p[k];
+      gg += g[k] * g[k];
+    }
+    const float ip = 1.0f / (sqrtf(pp) + 1e-8f), ig = 1.0f / (sqrtf(gg) + 1e-8f);
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dot += (g[k] * ig) * (p[k] * ip);
+    a[0] += l1;
+    a[1] += -dot;
+    a[2] += fabsf(p_occ[r] - g_occ[r]);
+    a[3] += fabsf(p_size[r] - g_size[r]);
+    a[4] += 1.0f;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    double v = (double)a[q];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) sh[wave][q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < SR_THREADS / 64; ++w)
+      for (int q = 0; q < 5; ++q) t[q] += sh[w][q];
+    const double n = t[4];
+    out[0] = (float)(t[0] / (n + 1e-6));
+    out[1] = (float)(t[1] / (n + 1e-6));
+    out[2] = (float)(t[2] / n);          // n == 0 -> nan, as nn.L1Loss on an empty selection
+    out[3] = (float)(t[3] / n);
+    out[4] = (float)n;
+  }
+}
+
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+// d_off [S,3], d_occ [S], d_size [S] from the four upstream gradients (device scalars) and n = out[4]
+__global__ void sp_reg_bwd_kernel(const float* __restrict__ p_off, const float* __restrict__ g_off,
+                                  const float* __restrict__ p_occ, const float* __restrict__ g_occ,
+                                  const float* __restrict__ p_size, const float* __restrict__ g_size,
+                                  const int64_t* __restrict__ sem, const int64_t* __restrict__ ins, int64_t S,
+                                  int64_t ignore, const float* __restrict__ out, const float* __restrict__ g0,
+                                  const float* __restrict__ g1, const float* __restrict__ g2,
+                                  const float* __restrict__ g3, float* __restrict__ d_off,
+                                  float* __restrict__ d_occ, float* __restrict__ d_size) {
+  const float n = out[4];
+  const float w01 = 1.0f / (n + 1e-6f), w23 = 1.0f / n;
+  const float c0 = g0[0] * w01, c1 = g1[0] * w01, c2 = g2[0] * w23, c3 = g3[0] * w23;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < S; r += (int64_t)gridDim.x * blockDim.x) {
+    if (sem[r] == ignore || ins[r] == ignore) {
+      d_off[r * 3] = d_off[r * 3 + 1] = d_off[r * 3 + 2] = 0.f;
+      d_occ[r] = 0.f;
+      d_size[r] = 0.f;
+      continue;
+    }
+    float p[3], g[3], pp = 0.f, gg = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      p[k] = p_off[r * 3 + k];
+      g[k] = g_off[r * 3 + k];
+      pp += p[k] * p[k];
+      gg += g[k] * g[k];
+    }
+    const float np_ = sqrtf(pp), ip = 1.0f / (np_ + 1e-8f), ig = 1.0f / (sqrtf(gg) + 1e-8f);
+    float gdp = 0.f;                               // (g/(|g|+eps)) . p
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gdp += g[k] * ig * p[k];
+    // d/dp_k [ p_k/(|p|+eps) ] = 1/(|p|+eps) - p p^T / (|p| (|p|+eps)^2); torch's norm backward is 0 at |p| = 0
+    const float tail = np_ > 0.f ? gdp * ip * ip / np_ : 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      d_off[r * 3 + k] = c0 * sgn(p[k] - g[k]) - c1 * (g[k] * ig * ip - tail * p[k]);
+    d_occ[r] = c2 * sgn(p_occ[r] - g_occ[r]);
+    d_size[r] = c3 * sgn(p_size[r] - g_size[r]);
+  }
+}
+
 int sl_blocks(int64_t N) {
   int64_t b = ceil_div(N > 0 ? N : 1, SL_THREADS);
   if (b > SL_MAX_BLOCKS) b = SL_MAX_BLOCKS;
@@ -212,6 +314,37 @@ int wsis_semantic_loss_bwd(const float* d_scores, const int64_t* d_labels, int64
   WSIS_REQUIRE(d_scores && d_labels && d_saved && d_grad_loss && d_dscores, "null pointer");
   hipLaunchKernelGGL(sem_loss_bwd_kernel, dim3(grid_for(N, SL_THREADS)), dim3(SL_THREADS), 0, as_stream(stream),
                      d_scores, d_labels, N, (int)C, ignore_label, d_saved, d_grad_loss, d_dscores);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_sp_regression_loss_fwd(const float* d_pred_off, const float* d_gt_off, const float* d_pred_occ,
+                                const float* d_gt_occ, const float* d_pred_size, const float* d_gt_size,
+                                const int64_t* d_sem_label, const int64_t* d_ins_label, int64_t S,
+                                int64_t ignore_label, float* d_out5, void* stream) {
+  WSIS_REQUIRE(S >= 0 && d_out5, "bad args");
+  WSIS_REQUIRE(S == 0 || (d_pred_off && d_gt_off && d_pred_occ && d_gt_occ && d_pred_size && d_gt_size &&
+                          d_sem_label && d_ins_label), "null pointer");
+  hipLaunchKernelGGL(sp_reg_fwd_kernel, dim3(1), dim3(SR_THREADS), 0, as_stream(stream), d_pred_off, d_gt_off,
+                     d_pred_occ, d_gt_occ, d_pred_size, d_gt_size, d_sem_label, d_ins_label, S, ignore_label, d_out5);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_sp_regression_loss_bwd(const float* d_pred_off, const float* d_gt_off, const float* d_pred_occ,
+                                const float* d_gt_occ, const float* d_pred_size, const float* d_gt_size,
+                                const int64_t* d_sem_label, const int64_t* d_ins_label, int64_t S,
+                                int64_t ignore_label, const float* d_out5, const float* d_g_norm,
+                                const float* d_g_dir, const float* d_g_occ, const float* d_g_size, float* d_doff,
+                                float* d_docc, float* d_dsize, void* stream) {
+  WSIS_REQUIRE(S >= 0, "bad args");
+  if (S == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_pred_off && d_gt_off && d_pred_occ && d_gt_occ && d_pred_size && d_gt_size && d_sem_label &&
+               d_ins_label && d_out5 && d_g_norm && d_g_dir && d_g_occ && d_g_size && d_doff && d_docc && d_dsize,
+               "null pointer");
+  hipLaunchKernelGGL(sp_reg_bwd_kernel, dim3(grid_for(S, 256)), dim3(256), 0, as_stream(stream), d_pred_off, d_gt_off,
+                     d_pred_occ, d_gt_occ, d_pred_size, d_gt_size, d_sem_label, d_ins_label, S, ignore_label, d_out5,
+                     d_g_norm, d_g_dir, d_g_occ, d_g_size, d_doff, d_docc, d_dsize);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

@@ -84,7 +84,21 @@ class MultiTaskLoss(nn.Module):
             superpoint_semantic_loss = self.superpoint_semantic_criterion(sp_semantic_scores, sp_sem_labels)
             loss_out["superpoint_semantic_loss"] = (superpoint_semantic_loss, sp_semantic_scores.sum())
 
-            if self.supervise_sp_offset:
+            fused_reg = (not indexed and self.supervise_sp_offset and self.supervise_instance_size
+                         and loss_inp["sp_offset_vector"][0].is_cuda
+                         and os.environ.get("WSIS_FUSE_SP_LOSS", "1") != "0")
+            if fused_reg:   # offset L1 + cosine, occupancy and size L1 in one launch (csrc/loss.hip)
+                import wsis_ops
+                pred_off, gt_off = loss_inp["sp_offset_vector"]
+                pred_occ, gt_occ = loss_inp["sp_occupancy"]
+                pred_size, gt_size = loss_inp["sp_instance_size"]
+                offset_norm_loss, offset_dir_loss, occupancy_loss, instance_size_loss, n_reg = \
+                    wsis_ops.sp_regression_losses(pred_off, gt_off, pred_occ, gt_occ, pred_size, gt_size,
+                                                  sp_sem_labels, sp_ins_labels, self.ignore_label)
+                loss_out["offset_norm_loss"] = (offset_norm_loss, n_reg)
+                loss_out["offset_dir_loss"] = (offset_dir_loss, n_reg)
+
+            if self.supervise_sp_offset and not fused_reg:
                 pred_off, gt_off = loss_inp["sp_offset_vector"]
                 pt_dist = torch.sum(torch.abs(pred_off - gt_off), dim=-1)
                 offset_norm_loss = torch.sum(pt_dist * sp_valid) / (n_valid + 1e-6)
@@ -112,7 +126,10 @@ class MultiTaskLoss(nn.Module):
             sp_d_loss = torch.mean(torch.cat(d_losses))
             loss_out["superpoint_discriminative_loss"] = (sp_d_loss, feats.shape[0])
 
-            if self.supervise_instance_size:
+            if fused_reg:
+                loss_out["occupancy_loss"] = (occupancy_loss, n_reg)
+                loss_out["instance_size_loss"] = (instance_size_loss, n_reg)
+            elif self.supervise_instance_size:
                 pred_occ, gt_occ = loss_inp["sp_occupancy"]
                 pred_size, gt_size = loss_inp["sp_instance_size"]
                 if indexed:

@@ -434,3 +434,50 @@ class _SemanticPointLoss(Function):
 
 def semantic_point_loss(scores, labels, ignore_label=-100):
     return _SemanticPointLoss.apply(scores, labels, ignore_label)
+
+
+class _SpRegressionLoss(Function):
+    """offset L1 + cosine, occupancy L1 and instance-size L1 over the labelled superpoints in one launch
+    (``csrc/loss.hip``; reference ``losses_3D_WSIS.py:79-96,113-127``).  Returns the four losses and the row count."""
+
+    @staticmethod
+    def forward(ctx, pred_off, gt_off, pred_occ, gt_occ, pred_size, gt_size, sem_label, ins_label, ignore_label):
+        _n.require_cuda(pred_off, gt_off, pred_occ, gt_occ, pred_size, gt_size, sem_label, ins_label)
+        f = lambda t: t.contiguous().float()
+        pred_off, gt_off, pred_occ, gt_occ, pred_size, gt_size = (f(pred_off), f(gt_off), f(pred_occ), f(gt_occ),
+                                                                  f(pred_size), f(gt_size))
+        sem_label, ins_label = sem_label.contiguous().long(), ins_label.contiguous().long()
+        S = pred_off.shape[0]
+        assert pred_off.shape == (S, 3) and gt_off.shape == (S, 3) and pred_occ.numel() == S and pred_size.numel() == S
+        out = torch.empty(5, dtype=torch.float32, device=pred_off.device)
+        _n.check(_n.hip().wsis_sp_regression_loss_fwd(
+            _n.ptr(pred_off), _n.ptr(gt_off), _n.ptr(pred_occ), _n.ptr(gt_occ), _n.ptr(pred_size), _n.ptr(gt_size),
+            _n.ptr(sem_label), _n.ptr(ins_label), S, int(ignore_label), _n.ptr(out), _n.stream_ptr()),
+            "sp_regression_loss_fwd")
+        ctx.save_for_backward(pred_off, gt_off, pred_occ, gt_occ, pred_size, gt_size, sem_label, ins_label, out)
+        ctx.ignore_label = int(ignore_label)
+        ctx.shapes = (pred_occ.shape, pred_size.shape)
+        n_valid = out[4]
+        ctx.mark_non_differentiable(n_valid)
+        return out[0], out[1], out[2], out[3], n_valid
+
+    @staticmethod
+    def backward(ctx, g_norm, g_dir, g_occ, g_size, _g_n):
+        pred_off, gt_off, pred_occ, gt_occ, pred_size, gt_size, sem_label, ins_label, out = ctx.saved_tensors
+        S = pred_off.shape[0]
+        d_off = torch.empty_like(pred_off)
+        d_occ = torch.empty_like(pred_occ)
+        d_size = torch.empty_like(pred_size)
+        g = [t.contiguous().float() for t in (g_norm, g_dir, g_occ, g_size)]
+        _n.check(_n.hip().wsis_sp_regression_loss_bwd(
+            _n.ptr(pred_off), _n.ptr(gt_off), _n.ptr(pred_occ), _n.ptr(gt_occ), _n.ptr(pred_size), _n.ptr(gt_size),
+            _n.ptr(sem_label), _n.ptr(ins_label), S, ctx.ignore_label, _n.ptr(out), _n.ptr(g[0]), _n.ptr(g[1]),
+            _n.ptr(g[2]), _n.ptr(g[3]), _n.ptr(d_off), _n.ptr(d_occ), _n.ptr(d_size), _n.stream_ptr()),
+            "sp_regression_loss_bwd")
+        return d_off, None, d_occ, None, d_size, None, None, None, None
+
+
+def sp_regression_losses(pred_off, gt_off, pred_occ, gt_occ, pred_size, gt_size, sem_label, ins_label,
+                         ignore_label=-100):
+    return _SpRegressionLoss.apply(pred_off, gt_off, pred_occ, gt_occ, pred_size, gt_size, sem_label, ins_label,
+                                   ignore_label)

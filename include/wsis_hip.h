@@ -334,6 +334,20 @@ int wsis_semantic_loss_fwd(const float* d_scores, const int64_t* d_labels, int64
 int wsis_semantic_loss_bwd(const float* d_scores, const int64_t* d_labels, int64_t N, int32_t C, int64_t ignore_label,
                            const float* d_saved, const float* d_grad_loss, float* d_dscores, void* stream);
 
+/* Superpoint regression terms of the same loss (losses_3D_WSIS.py:79-96 offset L1 + cosine, :113-127 occupancy and
+ * instance-size L1) over the rows whose two labels both differ from ignore_label: d_out5 = {offset_norm, offset_dir,
+ * occupancy, instance_size, n_valid}.  bwd: gradients of the three predictions from four upstream scalars. */
+int wsis_sp_regression_loss_fwd(const float* d_pred_off, const float* d_gt_off, const float* d_pred_occ,
+                                const float* d_gt_occ, const float* d_pred_size, const float* d_gt_size,
+                                const int64_t* d_sem_label, const int64_t* d_ins_label, int64_t S,
+                                int64_t ignore_label, float* d_out5, void* stream);
+int wsis_sp_regression_loss_bwd(const float* d_pred_off, const float* d_gt_off, const float* d_pred_occ,
+                                const float* d_gt_occ, const float* d_pred_size, const float* d_gt_size,
+                                const int64_t* d_sem_label, const int64_t* d_ins_label, int64_t S,
+                                int64_t ignore_label, const float* d_out5, const float* d_g_norm,
+                                const float* d_g_dir, const float* d_g_occ, const float* d_g_size, float* d_doff,
+                                float* d_docc, float* d_dsize, void* stream);
+
 /* ---- optimizer step (train_scannetv2.py:251; AdamW of config/ScanNet_v2_3D_WSIS.yaml:58-61) in one launch.
  * d_segments: device array of {float* p; const float* g; float* m; float* v; int64_t n; float step_size;
  * float inv_sqrt_bc2;} (wsis_adamw_segment_bytes() bytes each; n == 0 skips the parameter; step_size =

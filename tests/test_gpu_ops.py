@@ -784,3 +784,45 @@ def test_flat_adamw_matches_torch_adamw_step_by_step():
     assert (other.steps == mine.steps).all() and torch.equal(other.exp_avg, mine.exp_avg)
     with pytest.raises(Exception):
         optim.FlatAdamW([torch.zeros(3, requires_grad=True)])        # CPU parameters are refused
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S", [1190, 5, 3000])
+def test_fused_superpoint_regression_losses_match_torch_formulation(S):
+    """wsis_sp_regression_loss_fwd/bwd against the torch evaluation of losses_3D_WSIS.py:79-96,113-127 in fp64
+    (boolean-indexed, as the reference): offset L1 / cosine, occupancy and size L1, and the gradients of the three
+    predictions; a zero prediction vector (norm backward = 0) and -inf targets on dropped rows included."""
+    g = torch.Generator().manual_seed(S)
+    pred_off = torch.randn(S, 3, generator=g)
+    pred_off[1] = 0.0
+    gt_off = torch.randn(S, 3, generator=g)
+    pred_occ, gt_occ = torch.randn(S, generator=g), torch.randn(S, generator=g)
+    pred_size, gt_size = torch.randn(S, generator=g), torch.rand(S, generator=g)
+    sem = torch.randint(0, 20, (S,), generator=g)
+    ins = torch.randint(0, 9, (S,), generator=g)
+    sem[torch.rand(S, generator=g) < 0.3] = -100
+    ins[torch.rand(S, generator=g) < 0.5] = -100
+    sem[:2], ins[:2] = 3, 1                                   # the zero-vector row is a kept row
+    valid = (sem != -100) & (ins != -100)
+    gt_occ[~valid] = float("-inf")                            # log(0) of unlabelled superpoints
+    leaves = [t.cuda().requires_grad_(True) for t in (pred_off, pred_occ, pred_size)]
+    outs = wsis_ops.sp_regression_losses(leaves[0], gt_off.cuda(), leaves[1], gt_occ.cuda(), leaves[2],
+                                         gt_size.cuda(), sem.cuda(), ins.cuda(), -100)
+    w = [0.7, 1.3, 0.9, 1.1]
+    sum(wi * o for wi, o in zip(w, outs[:4])).backward()
+    ref = [t.double().requires_grad_(True) for t in (pred_off, pred_occ, pred_size)]
+    n = valid.sum()
+    po, go = ref[0][valid], gt_off.double()[valid]
+    l_norm = (po - go).abs().sum(-1).sum() / (n + 1e-6)
+    gd = go / (go.norm(p=2, dim=1).unsqueeze(-1) + 1e-8)
+    pd = po / (po.norm(p=2, dim=1).unsqueeze(-1) + 1e-8)
+    l_dir = (-(gd * pd).sum(-1)).sum() / (n + 1e-6)
+    l_occ = torch.nn.functional.l1_loss(ref[1][valid], gt_occ.double()[valid])
+    l_size = torch.nn.functional.l1_loss(ref[2][valid], gt_size.double()[valid])
+    (w[0] * l_norm + w[1] * l_dir + w[2] * l_occ + w[3] * l_size).backward()
+    assert float(outs[4]) == float(n)
+    for got, want in zip(outs[:4], (l_norm, l_dir, l_occ, l_size)):
+        assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want)) + 1e-7
+    for a, b in zip(leaves, ref):
+        assert torch.isfinite(a.grad).all()
+        assert float((a.grad.double().cpu() - b.grad).abs().max()) <= 1e-5 * float(b.grad.abs().max()) + 1e-12
