@@ -272,6 +272,182 @@ __global__ void sp_reg_bwd_kernel(const float* __restrict__ p_off, const float* 
   }
 }
 
+// ---- discriminative (pull / push / regularisation) loss of one scene's superpoint embeddings
+// (losses_3D_WSIS.py:157-230): instances in n_slots <= 64 fixed slots (slot = instance id, bound known on the host),
+// S <= 1536 rows of D = 7 features, everything in one workgroup: rows and slots staged in LDS, instance sums by one
+// thread per (slot, feature) walking the rows in order (deterministic), the three terms folded in fp64.
+//   loss = l_var + l_dist + 0.001 l_reg,  l_var = (1/n) sum_a (1/c_a) sum_{i in a} max(|x_i - mu_a|_2 - 0.1, 0)^2,
+//   l_dist = sum_{a != b} max(3 - |mu_a - mu_b|_1, 0)^2 / (n (n - 1)),  l_reg = sum_a |mu_a|_2.
+// saved: mu [64][8] (column 7 = member count), k [S] = 2 max(t - dv, 0) / t per row, n.  The backward kernel is the
+// analytic gradient (checked against autograd in fp64 on the host before it was written).
+constexpr int DL_D = 7, DL_SLOTS = 64, DL_ROWS = 1536, DL_THREADS = 1024;
+
+struct DlParams {
+  float delta_v, delta_d, p_var, p_dist, p_reg;
+};
+
+__device__ __forceinline__ void dl_stage(const float* __restrict__ x, const int64_t* __restrict__ ins,
+                                         const int64_t* __restrict__ sem, int S, int I, int64_t ignore, float* xs,
+                                         short* slot) {
+  for (int t = threadIdx.x; t < S * DL_D; t += DL_THREADS) xs[t] = x[t];
+  for (int r = threadIdx.x; r < S; r += DL_THREADS) {
+    const int64_t a = ins[r];
+    slot[r] = (a != ignore && sem[r] != ignore && a >= 0 && a < I) ? (short)a : (short)-1;
+  }
+}
+
+__device__ __forceinline__ double dl_block_sum(double v, double* sh) {   // sh: [DL_THREADS / 64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < DL_THREADS / 64; ++w) s += sh[w];
+  return s;
+}
+
+__global__ __launch_bounds__(DL_THREADS) void disc_loss_fwd_kernel(const float* __restrict__ x,
+                                                                   const int64_t* __restrict__ ins,
+                                                                   const int64_t* __restrict__ sem, int S, int I,
+                                                                   int64_t ignore, DlParams P, float* __restrict__ out,
+                                                                   float* __restrict__ saved) {
+  __shared__ float xs[DL_ROWS * DL_D];
+  __shared__ short slot[DL_ROWS];
+  __shared__ float mu[DL_SLOTS][8];
+  __shared__ double red[DL_THREADS / 64];
+  dl_stage(x, ins, sem, S, I, ignore, xs, slot);
+  __syncthreads();
+  if (threadIdx.x < I * 8) {
+    const int a = threadIdx.x >> 3, d = threadIdx.x & 7;
+    float s = 0.f;
+    if (d < DL_D) {
+      for (int r = 0; r < S; ++r)
+        if (slot[r] == a) s += xs[r * DL_D + d];
+    } else {
+      for (int r = 0; r < S; ++r)
+        if (slot[r] == a) s += 1.0f;
+    }
+    mu[a][d] = s;
+  }
+  __syncthreads();
+  {
+    const bool act = threadIdx.x < I * 8;
+    const int a = threadIdx.x >> 3, d = threadIdx.x & 7;
+    const float c = act ? mu[a][7] : 1.0f, sv = act ? mu[a][d] : 0.0f;
+    __syncthreads();
+    if (act && d < DL_D) mu[a][d] = sv / fmaxf(c, 1.0f);
+  }
+  __syncthreads();
+  double lvar = 0.0, ldist = 0.0, lreg = 0.0, n = 0.0;
+  float* kk = saved + DL_SLOTS * 8;
+  for (int r = threadIdx.x; r < S; r += DL_THREADS) {
+    const int a = slot[r];
+    float k = 0.f;
+    if (a >= 0) {
+      float t2 = 0.f;
+#pragma unroll
+      for (int d = 0; d < DL_D; ++d) {
+        const float e = xs[r * DL_D + d] - mu[a][d];
+        t2 += e * e;
+      }
+      const float t = sqrtf(t2), h = fmaxf(t - P.delta_v, 0.f);
+      lvar += (double)(h * h / mu[a][7]);
+      k = t > 0.f ? 2.0f * h / t : 0.f;
+    }
+    kk[r] = k;
+  }
+  for (int q = threadIdx.x; q < I * I; q += DL_THREADS) {
+    const int a = q / I, b = q - a * I;
+    if (a != b && mu[a][7] > 0.f && mu[b][7] > 0.f) {
+      float l1 = 0.f;
+#pragma unroll
+      for (int d = 0; d < DL_D; ++d) l1 += fabsf(mu[a][d] - mu[b][d]);
+      const float h = fmaxf(2.0f * P.delta_d - l1, 0.f);
+      ldist += (double)(h * h);
+    }
+  }
+  if (threadIdx.x < I && mu[threadIdx.x][7] > 0.f) {
+    float t2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < DL_D; ++d) t2 += mu[threadIdx.x][d] * mu[threadIdx.x][d];
+    lreg = (double)sqrtf(t2);
+    n = 1.0;
+  }
+  lvar = dl_block_sum(lvar, red);
+  ldist = dl_block_sum(ldist, red);
+  lreg = dl_block_sum(lreg, red);
+  n = dl_block_sum(n, red);
+  for (int t = threadIdx.x; t < DL_SLOTS * 8; t += DL_THREADS) saved[t] = (t >> 3) < I ? mu[t >> 3][t & 7] : 0.f;
+  if (threadIdx.x == 0) {
+    const double den = n * (n - 1.0) > 1.0 ? n * (n - 1.0) : 1.0;
+    out[0] = (float)(P.p_var * (lvar / n) + P.p_dist * (ldist / den) + P.p_reg * lreg);   // n == 0 -> nan (0/0), as torch
+    saved[DL_SLOTS * 8 + DL_ROWS] = (float)n;
+  }
+}
+
+__global__ __launch_bounds__(DL_THREADS) void disc_loss_bwd_kernel(const float* __restrict__ x,
+                                                                   const int64_t* __restrict__ ins,
+                                                                   const int64_t* __restrict__ sem, int S, int I,
+                                                                   int64_t ignore, DlParams P,
+                                                                   const float* __restrict__ saved,
+                                                                   const float* __restrict__ gout,
+                                                                   float* __restrict__ dx) {
+  __shared__ float xs[DL_ROWS * DL_D];
+  __shared__ short slot[DL_ROWS];
+  __shared__ float mu[DL_SLOTS][8];
+  __shared__ float gmu[DL_SLOTS][8];
+  __shared__ float kk[DL_ROWS];
+  dl_stage(x, ins, sem, S, I, ignore, xs, slot);
+  for (int t = threadIdx.x; t < DL_SLOTS * 8; t += DL_THREADS) mu[t >> 3][t & 7] = saved[t];
+  for (int r = threadIdx.x; r < S; r += DL_THREADS) kk[r] = saved[DL_SLOTS * 8 + r];
+  __syncthreads();
+  const float n = saved[DL_SLOTS * 8 + DL_ROWS];
+  const float den = n * (n - 1.0f) > 1.0f ? n * (n - 1.0f) : 1.0f;
+  if (threadIdx.x < I * 8) {
+    const int a = threadIdx.x >> 3, d = threadIdx.x & 7;
+    float gsum = 0.f;
+    const float c = mu[a][7];
+    if (d < DL_D && c > 0.f) {
+      // push term: every unordered pair appears twice in the ordered sum
+      for (int b = 0; b < I; ++b) {
+        if (b == a || !(mu[b][7] > 0.f)) continue;
+        float l1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < DL_D; ++e) l1 += fabsf(mu[a][e] - mu[b][e]);
+        const float h = fmaxf(2.0f * P.delta_d - l1, 0.f);
+        const float df = mu[a][d] - mu[b][d];
+        const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+        gsum += (P.p_dist / den) * 4.0f * h * (-sg);
+      }
+      float t2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < DL_D; ++e) t2 += mu[a][e] * mu[a][e];
+      const float nm = sqrtf(t2);
+      if (nm > 0.f) gsum += P.p_reg * mu[a][d] / nm;
+      // pull term through the mean
+      float via = 0.f;
+      for (int r = 0; r < S; ++r)
+        if (slot[r] == a) via += kk[r] * (xs[r * DL_D + d] - mu[a][d]);
+      gsum += -(P.p_var / (n * c)) * via;
+    }
+    gmu[a][d] = gsum;
+  }
+  __syncthreads();
+  const float g = gout[0];
+  for (int t = threadIdx.x; t < S * DL_D; t += DL_THREADS) {
+    const int r = t / DL_D, d = t - r * DL_D;
+    const int a = slot[r];
+    float v = 0.f;
+    if (a >= 0) {
+      const float c = mu[a][7];
+      v = g * ((P.p_var / (n * c)) * kk[r] * (xs[t] - mu[a][d]) + gmu[a][d] / c);
+    }
+    dx[t] = v;
+  }
+}
+
 int sl_blocks(int64_t N) {
   int64_t b = ceil_div(N > 0 ? N : 1, SL_THREADS);
   if (b > SL_MAX_BLOCKS) b = SL_MAX_BLOCKS;
@@ -345,6 +521,35 @@ int wsis_sp_regression_loss_bwd(const float* d_pred_off, const float* d_gt_off, 
   hipLaunchKernelGGL(sp_reg_bwd_kernel, dim3(grid_for(S, 256)), dim3(256), 0, as_stream(stream), d_pred_off, d_gt_off,
                      d_pred_occ, d_gt_occ, d_pred_size, d_gt_size, d_sem_label, d_ins_label, S, ignore_label, d_out5,
                      d_g_norm, d_g_dir, d_g_occ, d_g_size, d_doff, d_docc, d_dsize);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int32_t wsis_disc_loss_saved_floats(void) { return DL_SLOTS * 8 + DL_ROWS + 1; }
+
+int wsis_disc_loss_fwd(const float* d_x, const int64_t* d_ins_label, const int64_t* d_sem_label, int64_t S,
+                       int32_t D, int32_t n_slots, int64_t ignore_label, float delta_v, float delta_d, float p_var,
+                       float p_dist, float p_reg, float* d_out1, float* d_saved, void* stream) {
+  WSIS_REQUIRE(S >= 1 && S <= DL_ROWS && D == DL_D && n_slots >= 1 && n_slots <= DL_SLOTS,
+               "1 <= rows <= 1536, 7 features, 1 <= slots <= 64");
+  WSIS_REQUIRE(d_x && d_ins_label && d_sem_label && d_out1 && d_saved, "null pointer");
+  const DlParams P = {delta_v, delta_d, p_var, p_dist, p_reg};
+  hipLaunchKernelGGL(disc_loss_fwd_kernel, dim3(1), dim3(DL_THREADS), 0, as_stream(stream), d_x, d_ins_label,
+                     d_sem_label, (int)S, (int)n_slots, ignore_label, P, d_out1, d_saved);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_disc_loss_bwd(const float* d_x, const int64_t* d_ins_label, const int64_t* d_sem_label, int64_t S,
+                       int32_t D, int32_t n_slots, int64_t ignore_label, float delta_v, float delta_d, float p_var,
+                       float p_dist, float p_reg, const float* d_saved, const float* d_grad_loss, float* d_dx,
+                       void* stream) {
+  WSIS_REQUIRE(S >= 1 && S <= DL_ROWS && D == DL_D && n_slots >= 1 && n_slots <= DL_SLOTS,
+               "1 <= rows <= 1536, 7 features, 1 <= slots <= 64");
+  WSIS_REQUIRE(d_x && d_ins_label && d_sem_label && d_saved && d_grad_loss && d_dx, "null pointer");
+  const DlParams P = {delta_v, delta_d, p_var, p_dist, p_reg};
+  hipLaunchKernelGGL(disc_loss_bwd_kernel, dim3(1), dim3(DL_THREADS), 0, as_stream(stream), d_x, d_ins_label,
+                     d_sem_label, (int)S, (int)n_slots, ignore_label, P, d_saved, d_grad_loss, d_dx);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

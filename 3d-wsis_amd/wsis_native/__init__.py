@@ -108,6 +108,9 @@ _HIP_SIGS = {
     "wsis_semantic_loss_bwd": (I32, [P, P, I64, I32, I64, P, P, P, P]),
     "wsis_sp_regression_loss_fwd": (I32, [P] * 8 + [I64, I64, P, P]),
     "wsis_sp_regression_loss_bwd": (I32, [P] * 8 + [I64, I64] + [P] * 8 + [P]),
+    "wsis_disc_loss_saved_floats": (I32, []),
+    "wsis_disc_loss_fwd": (I32, [P, P, P, I64, I32, I32, I64, F32, F32, F32, F32, F32, P, P, P]),
+    "wsis_disc_loss_bwd": (I32, [P, P, P, I64, I32, I32, I64, F32, F32, F32, F32, F32, P, P, P, P]),
     "wsis_adamw_segment_bytes": (I32, []),
     "wsis_adamw_chunk": (I32, []),
     "wsis_adamw_step": (I32, [P, P, I64, F64, F64, F64, F64, F64, P]),

@@ -481,3 +481,42 @@ def sp_regression_losses(pred_off, gt_off, pred_occ, gt_occ, pred_size, gt_size,
                          ignore_label=-100):
     return _SpRegressionLoss.apply(pred_off, gt_off, pred_occ, gt_occ, pred_size, gt_size, sem_label, ins_label,
                                    ignore_label)
+
+
+DISC_MAX_ROWS, DISC_MAX_SLOTS = 1536, 64
+
+
+class _DiscriminativeLoss(Function):
+    """pull / push / regularisation loss of one scene's superpoint embeddings in one launch each way
+    (``csrc/loss.hip``; reference ``losses_3D_WSIS.py:157-230``), instances in host-bounded slots."""
+
+    @staticmethod
+    def forward(ctx, x, ins_label, sem_label, n_slots, ignore_label, delta_v, delta_d, p_var, p_dist, p_reg):
+        _n.require_cuda(x, ins_label, sem_label)
+        lib = _n.hip()
+        x = x.contiguous().float()
+        ins_label, sem_label = ins_label.contiguous().long(), sem_label.contiguous().long()
+        S, D = x.shape
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        saved = torch.empty(lib.wsis_disc_loss_saved_floats(), dtype=torch.float32, device=x.device)
+        ctx.args = (S, D, int(n_slots), int(ignore_label), float(delta_v), float(delta_d), float(p_var), float(p_dist),
+                    float(p_reg))
+        _n.check(lib.wsis_disc_loss_fwd(_n.ptr(x), _n.ptr(ins_label), _n.ptr(sem_label), *ctx.args, _n.ptr(out),
+                                        _n.ptr(saved), _n.stream_ptr()), "disc_loss_fwd")
+        ctx.save_for_backward(x, ins_label, sem_label, saved)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, ins_label, sem_label, saved = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        g = g.contiguous().float()
+        _n.check(_n.hip().wsis_disc_loss_bwd(_n.ptr(x), _n.ptr(ins_label), _n.ptr(sem_label), *ctx.args,
+                                             _n.ptr(saved), _n.ptr(g), _n.ptr(dx), _n.stream_ptr()), "disc_loss_bwd")
+        return (dx,) + (None,) * 9
+
+
+def discriminative_loss(x, ins_label, sem_label, n_slots, ignore_label=-100, delta_v=0.1, delta_d=1.5, p_var=1.0,
+                        p_dist=1.0, p_reg=0.001):
+    return _DiscriminativeLoss.apply(x, ins_label, sem_label, n_slots, ignore_label, delta_v, delta_d, p_var, p_dist,
+                                     p_reg)

@@ -348,6 +348,19 @@ int wsis_sp_regression_loss_bwd(const float* d_pred_off, const float* d_gt_off, 
                                 const float* d_g_dir, const float* d_g_occ, const float* d_g_size, float* d_doff,
                                 float* d_docc, float* d_dsize, void* stream);
 
+/* Discriminative loss of one scene's superpoint embeddings (losses_3D_WSIS.py:157-230: pull delta_v, push on the L1
+ * distance of the instance means with delta_d, regularisation), instances in n_slots <= 64 slots (slot = instance id;
+ * the bound is known on the host), S <= 1536 rows, D = 7.  Rows count when both labels differ from ignore_label.
+ * d_saved: wsis_disc_loss_saved_floats() floats, feeds bwd.  One workgroup, deterministic. */
+int32_t wsis_disc_loss_saved_floats(void);
+int wsis_disc_loss_fwd(const float* d_x, const int64_t* d_ins_label, const int64_t* d_sem_label, int64_t S,
+                       int32_t D, int32_t n_slots, int64_t ignore_label, float delta_v, float delta_d, float p_var,
+                       float p_dist, float p_reg, float* d_out1, float* d_saved, void* stream);
+int wsis_disc_loss_bwd(const float* d_x, const int64_t* d_ins_label, const int64_t* d_sem_label, int64_t S,
+                       int32_t D, int32_t n_slots, int64_t ignore_label, float delta_v, float delta_d, float p_var,
+                       float p_dist, float p_reg, const float* d_saved, const float* d_grad_loss, float* d_dx,
+                       void* stream);
+
 /* ---- optimizer step (train_scannetv2.py:251; AdamW of config/ScanNet_v2_3D_WSIS.yaml:58-61) in one launch.
  * d_segments: device array of {float* p; const float* g; float* m; float* v; int64_t n; float step_size;
  * float inv_sqrt_bc2;} (wsis_adamw_segment_bytes() bytes each; n == 0 skips the parameter; step_size =

@@ -826,3 +826,44 @@ def test_fused_superpoint_regression_losses_match_torch_formulation(S):
     for a, b in zip(leaves, ref):
         assert torch.isfinite(a.grad).all()
         assert float((a.grad.double().cpu() - b.grad).abs().max()) <= 1e-5 * float(b.grad.abs().max()) + 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,I,keep", [(1190, 12, 0.6), (1536, 64, 0.9), (40, 1, 1.0), (9, 5, 0.5), (300, 33, 0.05)])
+def test_fused_discriminative_loss_matches_torch_formulation(S, I, keep):
+    """wsis_disc_loss_fwd/bwd against MultiTaskLoss.discriminative_loss_slots (itself pinned by the reference's
+    golden vectors) evaluated in fp64: loss to 3e-6 relative, gradient to 2e-5 of its largest entry; single-member
+    instances (zero distance), empty slots and ids beyond the bound included; deterministic."""
+    import types
+    import losses_3D_WSIS
+    pl = types.SimpleNamespace(ignore_label=-100, supervise_instance_size=True, joint_training_epoch=0,
+                               semantic_dice=True, supervise_sp_offset=True)
+    crit = losses_3D_WSIS.MultiTaskLoss(None, pl, types.SimpleNamespace(classes=20))
+    g = torch.Generator().manual_seed(S * 100 + I)
+    x = torch.randn(S, 7, generator=g) * 0.7
+    ins = torch.randint(0, max(I - 1, 1), (S,), generator=g)
+    ins[0] = I - 1                                        # a single-member instance: distance to its own mean is 0
+    if S > 20:
+        ins[5] = I + 3                                    # beyond the bound: dropped by both
+    sem = torch.randint(0, 20, (S,), generator=g)
+    drop = torch.rand(S, generator=g) > keep
+    drop[0] = False
+    sem[drop & (torch.rand(S, generator=g) < 0.5)] = -100
+    ins[drop & (sem != -100)] = -100
+    valid = (sem != -100) & (ins != -100)
+    xg = x.cuda().requires_grad_(True)
+    loss = wsis_ops.discriminative_loss(xg, ins.cuda(), sem.cuda(), I, -100, crit.delta_v, crit.delta_d,
+                                        crit.param_var, crit.param_dist, crit.param_reg)
+    (loss * 1.3).backward()
+    xd = x.double().requires_grad_(True)
+    want = crit.discriminative_loss_slots(xd, ins, valid, I)
+    (want * 1.3).backward()
+    assert abs(float(loss) - float(want)) <= 3e-6 * abs(float(want)) + 1e-7, (float(loss), float(want))
+    gmax = float(xd.grad.abs().max())
+    assert float((xg.grad.double().cpu() - xd.grad).abs().max()) <= 2e-5 * gmax + 1e-10
+    assert float(xg.grad[(~valid).cuda()].abs().sum()) == 0.0
+    x2 = x.cuda().requires_grad_(True)
+    l2 = wsis_ops.discriminative_loss(x2, ins.cuda(), sem.cuda(), I, -100, crit.delta_v, crit.delta_d,
+                                      crit.param_var, crit.param_dist, crit.param_reg)
+    (l2 * 1.3).backward()
+    assert torch.equal(l2, loss) and torch.equal(x2.grad, xg.grad)
