@@ -88,7 +88,12 @@ class ScenePrep(object):
     ``full_scale`` [128, 512], ``scale`` 50, ``max_npoint`` 250000 are the values of
     ``config/ScanNet_v2_3D_WSIS.yaml`` (read at ``scannetv2_dataset.py:36-38``)."""
 
-    def __init__(self, full_scale=(128, 512), scale=50, max_npoint=250000, aug=True, test_mode=False, seed=None):
+    def __init__(self, full_scale=(128, 512), scale=50, max_npoint=250000, aug=True, test_mode=False, seed=None,
+                 crop_version=1, subsample_train=False):
+        """``crop_version=2`` / ``subsample_train=True``: the S3DIS variant (``s3dis_dataset.py``: block crop around a
+        random point, :285-319, and a random quarter of the points per training item, :135-144)."""
+        self.crop_version = int(crop_version)
+        self.subsample_train = bool(subsample_train)
         self.full_scale = [int(full_scale[0]), int(full_scale[1])]
         self.scale = scale
         self.max_npoint = max_npoint
@@ -152,6 +157,34 @@ class ScenePrep(object):
             full_scale[:2] -= 32
         return xyz_offset, valid
 
+    # -- s3dis_dataset.py:285-319 ------------------------------------------------------------------------------------
+    def crop_v2(self, xyz):
+        """S3DIS rooms: an x/y block around a random point, its half-widths the largest of 20 scale steps (binary
+        search) that keeps at most ``max_npoint`` points; coordinates are shifted to the block's minimum."""
+        out = xyz.copy()
+        if (out.min(1) >= 0).sum() != xyz.shape[0]:
+            raise ValueError("crop_v2 expects coordinates already shifted to be non-negative")
+        room_max = xyz.max(0)
+        center = xyz[self.rng.choice(len(xyz))][:3]
+        half_x, half_y = max(room_max[0] - center[0], center[0]), max(room_max[1] - center[1], center[1])
+        scale = np.arange(0, 1, 0.05)
+
+        def inside(s):
+            dx, dy = half_x * s, half_y * s
+            lo, hi = center - [dx, dy, 0], center + [dx, dy, 0]
+            return (xyz[:, 0] >= lo[0]) & (xyz[:, 0] <= hi[0]) & (xyz[:, 1] >= lo[1]) & (xyz[:, 1] <= hi[1])
+
+        low, high = 0, len(scale) - 1
+        while low < high:
+            mid = int(math.ceil((low + high) / 2))
+            if inside(scale[mid]).sum() <= self.max_npoint:
+                low = mid
+            else:
+                high = mid - 1
+        keep = inside(scale[high])
+        out -= xyz[keep].min(0)
+        return out, keep
+
     # -- :311-330 ------------------------------------------------------------------------------------------------
     @staticmethod
     def get_cropped_inst_label(instance_label, valid_idxs):
@@ -188,6 +221,11 @@ class ScenePrep(object):
     def __call__(self, scene_tuple, graph):
         """(coords, colors, sem, inst, superpoint, scene), PlainGraph -> the 12-tuple ``__getitem__`` returns."""
         xyz_origin, rgb, semantic_label, instance_label, superpoint, scene = scene_tuple
+        if self.subsample_train:                         # s3dis_dataset.py:135-144, before any other draw
+            pick = self.rng.choice(len(xyz_origin), size=len(xyz_origin) // 4, replace=False)
+            xyz_origin, rgb = np.asarray(xyz_origin)[pick], np.asarray(rgb)[pick]
+            semantic_label, instance_label = np.asarray(semantic_label)[pick], np.asarray(instance_label)[pick]
+            superpoint = np.asarray(superpoint)[pick]
         graph = graph.copy()
         flag = bool(self.aug_flag)
         xyz_middle = self.data_aug_with_graph(np.asarray(xyz_origin), graph, flag, flag, flag)
@@ -196,7 +234,7 @@ class ScenePrep(object):
         xyz = xyz - xyz_offset
         valid = np.ones(len(xyz_middle), dtype=bool)
         if not self.test_mode:
-            xyz, valid = self.crop(xyz)
+            xyz, valid = self.crop(xyz) if self.crop_version == 1 else self.crop_v2(xyz)
         xyz_middle = xyz_middle[valid]
         xyz = xyz[valid]
         rgb = np.asarray(rgb)[valid]

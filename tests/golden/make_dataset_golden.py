@@ -47,15 +47,18 @@ class GraphStub(object):
         return datasets.PlainGraph(vs, self.plain.edges, self.plain.f, self.plain.is1ins).subgraph(subset)
 
 
-def reference_object(**attrs):
-    tree = ast.parse(open(REF).read())
-    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "ScanNetV2Inst_spg"][0]
-    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in METHODS]
+REF_S3DIS = "/root/reference/modules/datasets/s3dis_dataset.py"
+
+
+def reference_object(_path=REF, _cls="ScanNetV2Inst_spg", **attrs):
+    tree = ast.parse(open(_path).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == _cls][0]
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in METHODS + ("crop_v2",)]
     for f in fns:
         f.returns = None
         for a in f.args.args:
             a.annotation = None
-    code = compile(ast.Module(body=fns, type_ignores=[]), REF, "exec")
+    code = compile(ast.Module(body=fns, type_ignores=[]), _path, "exec")
     if not hasattr(np, "bool"):
         np.bool = bool
     if not hasattr(scipy.ndimage, "filters"):
@@ -73,8 +76,9 @@ def reference_object(**attrs):
           "stats": _Stats}
     exec(code, ns)
     obj = types.SimpleNamespace(**attrs)
-    for name in METHODS:
-        setattr(obj, name if name != "__getitem__" else "getitem", types.MethodType(ns[name], obj))
+    for name in METHODS + ("crop_v2",):
+        if name in ns:
+            setattr(obj, name if name != "__getitem__" else "getitem", types.MethodType(ns[name], obj))
     return obj
 
 
@@ -130,6 +134,27 @@ def main():
         out[tag + "_g_edges"] = G.edges
         out[tag + "_cfg"] = np.asarray([int(aug), int(test_mode), max_npoint, seed])
         print(tag, "points", loc.shape[0], "of", len(tup[0]), "superpoints", len(G.vs["v"]), "edges", len(G.edges))
+    # --- S3DIS variant (s3dis_dataset.py): train item with the random quarter of the points and the block crop ------
+    sc = harness.make_scene(5, room=(1.0, 0.9, 0.8), n_box=2)
+    tup, plain = datasets.synthetic_scene_to_reference_format(sc)
+    for tag, sub, max_npoint, seed in (("s3a", True, 250000, 51), ("s3b", False, 6000, 52), ("s3c", True, 2000, 53)):
+        ref = reference_object(REF_S3DIS, "S3DIS_Inst_spg", full_scale=[128, 512], scale=50, max_npoint=max_npoint,
+                               aug_flag=True, test_mode=False, task="train", files=[tup], subsample_train=sub,
+                               scene_point_level_weak_label={"synthetic": (tup[2], tup[3])},
+                               weak_label_spg={"synthetic": GraphStub(plain)}, superpoints={"synthetic": tup[4]})
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        item = ref.getitem(0)
+        scene, loc, loc_offset, loc_float, feat, sem, ins, sp, G, inst_num, inst_info, inst_pointnum = item
+        out[tag + "_loc"] = loc.numpy(); out[tag + "_loc_offset"] = loc_offset.numpy()
+        out[tag + "_loc_float"] = loc_float.numpy()
+        out[tag + "_sem"] = sem.numpy(); out[tag + "_ins"] = ins.numpy(); out[tag + "_sp"] = sp.numpy()
+        out[tag + "_inst_num"] = np.int64(inst_num); out[tag + "_inst_info"] = inst_info.numpy()
+        out[tag + "_g_off"] = G.vs["superpoint_offset_vector"]; out[tag + "_g_v"] = G.vs["v"]
+        out[tag + "_g_edges"] = G.edges
+        out[tag + "_cfg"] = np.asarray([int(sub), max_npoint, seed])
+        print(tag, "points", loc.shape[0], "of", len(tup[0]), "superpoints", len(G.vs["v"]))
+
     # --- acquire_weak_label (:970-1036): GT-labelled synthetic scene, 1 and 2 annotated superpoints per instance ------
     sc = harness.make_scene(9, room=(1.0, 0.9, 0.8), n_box=3)
     rs = np.random.RandomState(9)

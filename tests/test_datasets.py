@@ -165,3 +165,27 @@ def test_segment_mode_ties_take_the_smallest_value():
     seg = np.array([0, 0, 0, 0, 1, 1, 2])
     val = np.array([5.0, 3.0, 5.0, 3.0, -100.0, 7.0, 2.0])
     np.testing.assert_array_equal(datasets._segment_mode(seg, val, 4), [3.0, -100.0, 2.0, -100.0])
+
+
+@pytest.mark.parametrize("tag", ["s3a", "s3b", "s3c"])
+def test_s3dis_item_matches_reference_getitem(tag):
+    """the S3DIS variant (s3dis_dataset.py: random quarter of the points per training item :135-144, block crop
+    ``crop_v2`` :285-319) against the reference's own ``__getitem__`` run with numpy's global state seeded"""
+    sub, max_npoint, seed = [int(x) for x in G[tag + "_cfg"]]
+    sc = harness.make_scene(5, room=(1.0, 0.9, 0.8), n_box=2)
+    tup, graph = datasets.synthetic_scene_to_reference_format(sc)
+    prep = datasets.ScenePrep(max_npoint=max_npoint, aug=True, test_mode=False, seed=seed, crop_version=2,
+                              subsample_train=bool(sub))
+    scene, loc, loc_offset, loc_float, feat, sem, ins, sp, g, inst_num, inst_info, inst_pointnum = prep(tup, graph)
+    np.testing.assert_array_equal(loc.numpy(), G[tag + "_loc"])
+    np.testing.assert_array_equal(loc_offset.numpy(), G[tag + "_loc_offset"])
+    np.testing.assert_array_equal(loc_float.numpy(), G[tag + "_loc_float"])
+    np.testing.assert_array_equal(sem.numpy(), G[tag + "_sem"])
+    np.testing.assert_array_equal(ins.numpy(), G[tag + "_ins"])
+    np.testing.assert_array_equal(sp.numpy(), G[tag + "_sp"])
+    assert inst_num == int(G[tag + "_inst_num"])
+    np.testing.assert_array_equal(inst_info.numpy(), G[tag + "_inst_info"])
+    np.testing.assert_array_equal(g.vs["superpoint_offset_vector"], G[tag + "_g_off"])
+    np.testing.assert_array_equal(g.vs["v"], G[tag + "_g_v"])
+    np.testing.assert_array_equal(g.edges, G[tag + "_g_edges"])
+    assert loc.shape[0] <= max_npoint and (loc.numpy() >= 0).all()
