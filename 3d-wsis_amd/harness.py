@@ -343,3 +343,34 @@ def train_step_smoke(device="cuda:0"):
     assert torch.isfinite(loss).item(), "non-finite loss in smoke step"
     assert ret["edge_affinity"].shape[0] == batch["edge_u_list"].shape[0]
     return float(loss)
+
+
+def save_checkpoint(model, filename, optimizer=None, meta=None):
+    """checkpoint in the reference's container (utils/checkpoint.py:205-262): ``{"meta", "model", "optimizer"}``,
+    weights on the CPU, a DataParallel-style wrapper unwrapped."""
+    import time as _time
+    model = getattr(model, "module", model)
+    meta = dict(meta or {})
+    meta.update(time=_time.asctime())
+    ck = {"meta": meta, "model": {k: v.detach().cpu() for k, v in model.state_dict().items()}}
+    if optimizer is not None:
+        ck["optimizer"] = optimizer.state_dict()
+    os.makedirs(os.path.dirname(os.path.abspath(filename)), exist_ok=True)
+    torch.save(ck, filename)
+    return ck
+
+
+def load_checkpoint(model, filename, map_location="cpu", strict=True, optimizer=None):
+    """``utils/checkpoint.py:105-135``: the state dict sits under "model" (or "state_dict", or is the file itself),
+    a leading "module." is stripped; the published checkpoints of the reference load this way (the layout is pinned
+    by tests/test_state_dict_layout.py).  Returns the whole checkpoint dict."""
+    ck = torch.load(filename, map_location=map_location, weights_only=False)
+    if not isinstance(ck, dict):
+        raise RuntimeError(f"No state_dict found in checkpoint file {filename}")
+    sd = ck.get("model", ck.get("state_dict", ck))
+    if sd and next(iter(sd)).startswith("module."):
+        sd = {k[7:]: v for k, v in sd.items()}
+    getattr(model, "module", model).load_state_dict(sd, strict=strict)
+    if optimizer is not None and "optimizer" in ck:
+        optimizer.load_state_dict(ck["optimizer"])
+    return ck

@@ -94,3 +94,38 @@ def test_checkpoint_dict_loads_strictly(tmp_path):
     b.load_state_dict(ck["model"], strict=True)
     for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert ka == kb and torch.equal(va, vb)
+
+
+def test_checkpoint_helpers_follow_the_reference_container(tmp_path):
+    """harness.save_checkpoint / load_checkpoint (utils/checkpoint.py:105-135,205-262): "model" / "state_dict" / bare
+    containers, the "module." prefix of a wrapped model, optimizer state, strictness."""
+    import pytest
+    a, _, opt = harness.build_model(harness.default_cfg(), torch.device("cpu"), seed=3)
+    b, _, opt_b = harness.build_model(harness.default_cfg(), torch.device("cpu"), seed=4)
+    for p in a.parameters():                     # one optimizer step so that there is state to carry
+        p.grad = torch.full_like(p, 0.01)
+    opt.step()
+    ck = harness.save_checkpoint(a, tmp_path / "run" / "epoch_1.pth", optimizer=opt, meta={"epoch": 1})
+    assert set(ck) == {"meta", "model", "optimizer"} and ck["meta"]["epoch"] == 1 and "time" in ck["meta"]
+    got = harness.load_checkpoint(b, tmp_path / "run" / "epoch_1.pth", optimizer=opt_b)
+    assert got["meta"]["epoch"] == 1
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    sa, sb = opt.state_dict()["state"], opt_b.state_dict()["state"]
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) for k in sa)
+    # "state_dict" container with a DataParallel prefix, and the bare dict
+    c, _, _ = harness.build_model(harness.default_cfg(), torch.device("cpu"), seed=5)
+    torch.save({"state_dict": {"module." + k: v for k, v in a.state_dict().items()}}, tmp_path / "dp.pth")
+    harness.load_checkpoint(c, tmp_path / "dp.pth")
+    assert all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), c.state_dict().values()))
+    torch.save(a.state_dict(), tmp_path / "bare.pth")
+    harness.load_checkpoint(c, tmp_path / "bare.pth")
+    bad = dict(a.state_dict())
+    bad.pop("input_conv.0.weight")
+    torch.save({"model": bad}, tmp_path / "bad.pth")
+    with pytest.raises(RuntimeError):
+        harness.load_checkpoint(c, tmp_path / "bad.pth")
+    harness.load_checkpoint(c, tmp_path / "bad.pth", strict=False)
+    torch.save([1, 2], tmp_path / "list.pth")
+    with pytest.raises(RuntimeError):
+        harness.load_checkpoint(c, tmp_path / "list.pth")
