@@ -248,7 +248,14 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
   ws_bytes -= dw_bytes;
   SideStream* side = (dw_bytes > 0 && dw_stream_enabled()) ? side_stream_for(st) : nullptr;
   if (side) side->next = 0;
+  // inside the op loop nothing returns directly: an error after the fork still has to reach the join below
+#define RUN_LAUNCH_CHECK()                                                                              \
+  do {                                                                                                  \
+    const hipError_t le_ = hipGetLastError();                                                           \
+    if (le_ != hipSuccess) rc = fail(WSIS_ERR_HIP, "wsis_run_ops: launch failed: %s", hipGetErrorString(le_)); \
+  } while (0)
   bool forked = false;
+  int first_err = WSIS_OK;
   for (int i = 0; i < n; ++i) {
     const wsis_op& op = ops[i];
     int rc = WSIS_OK;
@@ -285,7 +292,7 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
             hipLaunchKernelGGL(cat_rows_kernel<1>, dim3(grid_for(op.M_in * (op.Cin + op.Cout), 256)), dim3(256), 0, st,
                                (const float*)op.in[0], (const float*)op.in[1], (float*)op.out[0], op.M_in, op.Cin,
                                op.Cout);
-          WSIS_LAUNCH_CHECK();
+          RUN_LAUNCH_CHECK();
         }
         break;
       case WSIS_OP_SPLIT:
@@ -297,14 +304,14 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
           else
             hipLaunchKernelGGL(split_rows_kernel<1>, dim3(grid_for(op.M_in * (op.Cin + op.Cout), 256)), dim3(256), 0, st,
                                (const float*)op.in[0], (float*)op.out[0], (float*)op.out[1], op.M_in, op.Cin, op.Cout);
-          WSIS_LAUNCH_CHECK();
+          RUN_LAUNCH_CHECK();
         }
         break;
       case WSIS_OP_ADD:
         if (op.M_in * op.Cin > 0) {
           hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(op.M_in * op.Cin, 256)), dim3(256), 0, st,
                              (float*)op.out[0], (const float*)op.in[0], op.M_in * op.Cin);
-          WSIS_LAUNCH_CHECK();
+          RUN_LAUNCH_CHECK();
         }
         break;
       case WSIS_OP_CONV_BWD: {
@@ -322,9 +329,12 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
           void* dw_stream = stream;
           if (side) {   // dY is complete once everything enqueued so far on the caller's stream has run
             hipEvent_t e = next_fork_event(side);
-            WSIS_REQUIRE(e, "event creation failed");
-            WSIS_HIP_CHECK(hipEventRecord(e, st));
-            WSIS_HIP_CHECK(hipStreamWaitEvent(side->stream, e, 0));
+            hipError_t he = e ? hipEventRecord(e, st) : hipErrorOutOfMemory;
+            if (he == hipSuccess) he = hipStreamWaitEvent(side->stream, e, 0);
+            if (he != hipSuccess) {
+              rc = fail(WSIS_ERR_HIP, "dW side-stream fork failed: %s", hipGetErrorString(he));
+              break;
+            }
             dw_stream = side->stream;
             forked = true;
           }
@@ -341,15 +351,22 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
                          (const float*)op.in[6], op.M_in, op.Cin, ws, ws_bytes, stream);
         break;
       default:
-        return fail(WSIS_ERR_ARG, "wsis_run_ops: unknown op kind");
+        rc = fail(WSIS_ERR_ARG, "wsis_run_ops: unknown op kind");
     }
-    if (rc != WSIS_OK) return rc;
+    if (rc != WSIS_OK) {
+      first_err = rc;
+      break;
+    }
   }
-  if (forked) {   // join: whatever follows on the caller's stream (optimizer, gradient all-reduce) sees every dW
-    WSIS_HIP_CHECK(hipEventRecord(side->join, side->stream));
-    WSIS_HIP_CHECK(hipStreamWaitEvent(st, side->join, 0));
+#undef RUN_LAUNCH_CHECK
+  if (forked) {   // join on EVERY exit path once forked: whatever follows on the caller's stream (optimizer, gradient
+                  // all-reduce, the caller's error handling) is ordered behind every dW launch already issued
+    const hipError_t e1 = hipEventRecord(side->join, side->stream);
+    const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(st, side->join, 0) : e1;
+    if (e2 != hipSuccess && first_err == WSIS_OK)
+      return fail(WSIS_ERR_HIP, "side-stream join failed: %s", hipGetErrorString(e2));
   }
-  return WSIS_OK;
+  return first_err;
 }
 
 }  // extern "C"

@@ -274,13 +274,19 @@ __global__ void sp_reg_bwd_kernel(const float* __restrict__ p_off, const float* 
 
 // ---- discriminative (pull / push / regularisation) loss of one scene's superpoint embeddings
 // (losses_3D_WSIS.py:157-230): instances in n_slots <= 64 fixed slots (slot = instance id, bound known on the host),
-// S <= 1536 rows of D = 7 features, everything in one workgroup: rows and slots staged in LDS, instance sums by one
-// thread per (slot, feature) walking the rows in order (deterministic), the three terms folded in fp64.
+// S <= 4096 rows of D = 7 features, everything in one workgroup: rows and slots staged in LDS, instance sums by
+// (row chunk, slot, feature) threads walking their chunk in order + a chunk-ordered combine (deterministic), the three terms folded in fp64.
 //   loss = l_var + l_dist + 0.001 l_reg,  l_var = (1/n) sum_a (1/c_a) sum_{i in a} max(|x_i - mu_a|_2 - 0.1, 0)^2,
 //   l_dist = sum_{a != b} max(3 - |mu_a - mu_b|_1, 0)^2 / (n (n - 1)),  l_reg = sum_a |mu_a|_2.
 // saved: mu [64][8] (column 7 = member count), k [S] = 2 max(t - dv, 0) / t per row, n.  The backward kernel is the
 // analytic gradient (checked against autograd in fp64 on the host before it was written).
-constexpr int DL_D = 7, DL_SLOTS = 64, DL_ROWS = 1536, DL_THREADS = 1024;
+constexpr int DL_D = 7, DL_SLOTS = 64, DL_ROWS = 4096, DL_THREADS = 1024;
+
+// row chunks of the per-instance walks: as many as fit 1024 threads at I*8 threads per chunk (<= 16)
+__device__ __forceinline__ int dl_chunks(int I) {
+  const int c = DL_THREADS / (I * 8);
+  return c > 16 ? 16 : (c < 1 ? 1 : c);
+}
 
 struct DlParams {
   float delta_v, delta_d, p_var, p_dist, p_reg;
@@ -316,20 +322,30 @@ __global__ __launch_bounds__(DL_THREADS) void disc_loss_fwd_kernel(const float* 
   __shared__ float xs[DL_ROWS * DL_D];
   __shared__ short slot[DL_ROWS];
   __shared__ float mu[DL_SLOTS][8];
+  __shared__ float psum[DL_THREADS];
   __shared__ double red[DL_THREADS / 64];
   dl_stage(x, ins, sem, S, I, ignore, xs, slot);
   __syncthreads();
-  if (threadIdx.x < I * 8) {
-    const int a = threadIdx.x >> 3, d = threadIdx.x & 7;
+  const int nch = dl_chunks(I), per = I * 8;
+  if (threadIdx.x < nch * per) {
+    const int ch = threadIdx.x / per, u = threadIdx.x - ch * per;
+    const int a = u >> 3, d = u & 7;
+    const int r0 = (int)((int64_t)S * ch / nch), r1 = (int)((int64_t)S * (ch + 1) / nch);
     float s = 0.f;
     if (d < DL_D) {
-      for (int r = 0; r < S; ++r)
+      for (int r = r0; r < r1; ++r)
         if (slot[r] == a) s += xs[r * DL_D + d];
     } else {
-      for (int r = 0; r < S; ++r)
+      for (int r = r0; r < r1; ++r)
         if (slot[r] == a) s += 1.0f;
     }
-    mu[a][d] = s;
+    psum[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < per) {
+    float s = 0.f;
+    for (int ch = 0; ch < nch; ++ch) s += psum[ch * per + threadIdx.x];
+    mu[threadIdx.x >> 3][threadIdx.x & 7] = s;
   }
   __syncthreads();
   {
@@ -398,6 +414,7 @@ __global__ __launch_bounds__(DL_THREADS) void disc_loss_bwd_kernel(const float* 
   __shared__ short slot[DL_ROWS];
   __shared__ float mu[DL_SLOTS][8];
   __shared__ float gmu[DL_SLOTS][8];
+  __shared__ float psum[DL_THREADS];
   __shared__ float kk[DL_ROWS];
   dl_stage(x, ins, sem, S, I, ignore, xs, slot);
   for (int t = threadIdx.x; t < DL_SLOTS * 8; t += DL_THREADS) mu[t >> 3][t & 7] = saved[t];
@@ -405,6 +422,21 @@ __global__ __launch_bounds__(DL_THREADS) void disc_loss_bwd_kernel(const float* 
   __syncthreads();
   const float n = saved[DL_SLOTS * 8 + DL_ROWS];
   const float den = n * (n - 1.0f) > 1.0f ? n * (n - 1.0f) : 1.0f;
+  // pull term through the mean: sum_{i in a} k_i (x_i - mu_a), chunked over the rows like the forward sums
+  const int nch = dl_chunks(I), per = I * 8;
+  if (threadIdx.x < nch * per) {
+    const int ch = threadIdx.x / per, u = threadIdx.x - ch * per;
+    const int a = u >> 3, d = u & 7;
+    const int r0 = (int)((int64_t)S * ch / nch), r1 = (int)((int64_t)S * (ch + 1) / nch);
+    float via = 0.f;
+    if (d < DL_D && mu[a][7] > 0.f) {
+      const float m = mu[a][d];
+      for (int r = r0; r < r1; ++r)
+        if (slot[r] == a) via += kk[r] * (xs[r * DL_D + d] - m);
+    }
+    psum[threadIdx.x] = via;
+  }
+  __syncthreads();
   if (threadIdx.x < I * 8) {
     const int a = threadIdx.x >> 3, d = threadIdx.x & 7;
     float gsum = 0.f;
@@ -426,10 +458,8 @@ __global__ __launch_bounds__(DL_THREADS) void disc_loss_bwd_kernel(const float* 
       for (int e = 0; e < DL_D; ++e) t2 += mu[a][e] * mu[a][e];
       const float nm = sqrtf(t2);
       if (nm > 0.f) gsum += P.p_reg * mu[a][d] / nm;
-      // pull term through the mean
       float via = 0.f;
-      for (int r = 0; r < S; ++r)
-        if (slot[r] == a) via += kk[r] * (xs[r * DL_D + d] - mu[a][d]);
+      for (int ch = 0; ch < nch; ++ch) via += psum[ch * per + threadIdx.x];
       gsum += -(P.p_var / (n * c)) * via;
     }
     gmu[a][d] = gsum;
@@ -531,7 +561,7 @@ int wsis_disc_loss_fwd(const float* d_x, const int64_t* d_ins_label, const int64
                        int32_t D, int32_t n_slots, int64_t ignore_label, float delta_v, float delta_d, float p_var,
                        float p_dist, float p_reg, float* d_out1, float* d_saved, void* stream) {
   WSIS_REQUIRE(S >= 1 && S <= DL_ROWS && D == DL_D && n_slots >= 1 && n_slots <= DL_SLOTS,
-               "1 <= rows <= 1536, 7 features, 1 <= slots <= 64");
+               "1 <= rows <= 4096, 7 features, 1 <= slots <= 64");
   WSIS_REQUIRE(d_x && d_ins_label && d_sem_label && d_out1 && d_saved, "null pointer");
   const DlParams P = {delta_v, delta_d, p_var, p_dist, p_reg};
   hipLaunchKernelGGL(disc_loss_fwd_kernel, dim3(1), dim3(DL_THREADS), 0, as_stream(stream), d_x, d_ins_label,
@@ -545,7 +575,7 @@ int wsis_disc_loss_bwd(const float* d_x, const int64_t* d_ins_label, const int64
                        float p_dist, float p_reg, const float* d_saved, const float* d_grad_loss, float* d_dx,
                        void* stream) {
   WSIS_REQUIRE(S >= 1 && S <= DL_ROWS && D == DL_D && n_slots >= 1 && n_slots <= DL_SLOTS,
-               "1 <= rows <= 1536, 7 features, 1 <= slots <= 64");
+               "1 <= rows <= 4096, 7 features, 1 <= slots <= 64");
   WSIS_REQUIRE(d_x && d_ins_label && d_sem_label && d_saved && d_grad_loss && d_dx, "null pointer");
   const DlParams P = {delta_v, delta_d, p_var, p_dist, p_reg};
   hipLaunchKernelGGL(disc_loss_bwd_kernel, dim3(1), dim3(DL_THREADS), 0, as_stream(stream), d_x, d_ins_label,

@@ -36,9 +36,38 @@ def _face_voxels(origin, u, v, lu, lv, voxel):
     return origin[None, :] + a.reshape(-1, 1) * u[None, :] + b.reshape(-1, 1) * v[None, :]
 
 
+def _touching_superpoints(pts, superpoint, voxel):
+    """undirected superpoint pairs whose voxels touch (26-neighbourhood) -- the synthetic counterpart of the
+    mesh-face adjacency of data/ScanNetV2/prepare_data_inst_ScanNetV2.py:191-212"""
+    v = np.floor(pts / voxel + 1e-6).astype(np.int64)
+    v = v - v.min(0) + 1
+    dims = v.max(0) + 2
+    lin = (v[:, 0] * dims[1] + v[:, 1]) * dims[2] + v[:, 2]
+    vkey, first = np.unique(lin, return_index=True)
+    vsp = superpoint[first]
+    pairs = []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                if (dx, dy, dz) <= (0, 0, 0):
+                    continue                       # half space: every unordered voxel pair once
+                nkey = vkey + (dx * dims[1] + dy) * dims[2] + dz
+                pos = np.minimum(np.searchsorted(vkey, nkey), len(vkey) - 1)
+                ok = vkey[pos] == nkey
+                a, b = vsp[ok], vsp[pos[ok]]
+                ne = a != b
+                pairs.append(np.stack([np.minimum(a[ne], b[ne]), np.maximum(a[ne], b[ne])], 1))
+    if not pairs:
+        return np.zeros((0, 2), dtype=np.int64)
+    return np.unique(np.concatenate(pairs), axis=0)
+
+
 def make_scene(seed, room=(4.6, 3.6, 2.2), n_box=8, dup=0.3, voxel=0.02, sp_cell=0.25, classes=20,
-               max_points=None):
-    """returns a dict of numpy arrays describing one scene (all host side)."""
+               max_points=None, graph="knn8"):
+    """returns a dict of numpy arrays describing one scene (all host side).
+    ``graph``: "knn8" = both directions between centres closer than 0.3 m, <= 8 nearest (round-1 generator, the
+    golden fixtures use it); "mesh" = superpoints whose voxels touch PLUS <= 5 KD-tree neighbours within 0.3 m, the
+    rule of prepare_data_inst_ScanNetV2.py:191-225 (with ``sp_cell=0.19`` a C2 room has S ~ 2 k, E ~ 25 k)."""
     from scipy.spatial import cKDTree
     rng = np.random.default_rng(seed)
     L, W, H = room
@@ -98,8 +127,12 @@ def make_scene(seed, room=(4.6, 3.6, 2.2), n_box=8, dup=0.3, voxel=0.02, sp_cell
 
     # superpoint graph: both directions between centres closer than 0.3 m (<= 8 nearest), sorted tuples
     tree = cKDTree(centre)
-    dist, nbr = tree.query(centre, k=min(9, S), distance_upper_bound=0.3)
+    dist, nbr = tree.query(centre, k=min(9 if graph == "knn8" else 6, S), distance_upper_bound=0.3)
     und = set()
+    if graph == "mesh":
+        und.update((int(a), int(b)) for a, b in _touching_superpoints(pts, superpoint, voxel))
+    else:
+        assert graph == "knn8", graph
     for s in range(S):
         for dd, t in zip(dist[s][1:], nbr[s][1:]):
             if np.isfinite(dd) and t < S and t != s:
@@ -214,8 +247,6 @@ _DEVICE_KEYS = ("voxel_locs", "p2v_map", "v2p_map", "locs_float", "feats", "sema
 def to_device(batch, device):
     """H2D of train_scannetv2.py:149-172 plus the per-batch graph structures (CSR of the superpoint ids and of
     the edge lists) that are constant for the batch."""
-    from torch_scatter import SegmentCSR
-    import wsis_ops
     out = dict(batch)
     for k in _DEVICE_KEYS:
         out[k] = batch[k].to(device)
@@ -224,15 +255,35 @@ def to_device(batch, device):
     ev.record()
     out["coords_ready_event"] = ev
     out["GIs"][0].cuda()
-    S = int(batch["sp_batch_offsets"][-1])
-    out["superpoint_csr"] = SegmentCSR(out["superpoint"], S)
-    out["p2v_csr"] = SegmentCSR(out["p2v_map"], int(batch["voxel_locs"].shape[0]))
-    out["edge_graph"] = wsis_ops.EdgeGraph(out["edge_u_list"], out["edge_v_list"], S)
+    build_batch_graphs(out)
     # bound of the superpoint instance ids per scene, read while the labels are still host tensors: lets the loss
     # place the instances in fixed slots instead of torch.unique (sync) or an [S, S] same-instance matrix
     lab, offs = batch["superpoint_instance_labels"], [int(o) for o in batch["sp_batch_offsets"]]
     out["sp_instance_slots"] = [max(int(lab[b:e].max()) + 1, 1) if e > b else 1 for b, e in zip(offs[:-1], offs[1:])]
     return out
+
+
+def build_batch_graphs(batch):
+    """per-batch device structures of the segmented reductions: CSR of the superpoint ids and of the point->voxel
+    map, both edge directions of the superpoint graph.  Part of this build's ``scatter`` cost for every NEW batch
+    (upstream torch_scatter pays it as atomics inside every call), so ``bench.py`` rebuilds them inside the timed
+    step."""
+    from torch_scatter import SegmentCSR
+    import wsis_ops
+    S = int(batch["sp_batch_offsets"][-1])
+    batch["superpoint_csr"] = SegmentCSR(batch["superpoint"], S)
+    batch["p2v_csr"] = SegmentCSR(batch["p2v_map"], int(batch["voxel_locs"].shape[0]))
+    batch["edge_graph"] = wsis_ops.EdgeGraph(batch["edge_u_list"], batch["edge_v_list"], S)
+    return batch
+
+
+def bench_scene(seed, **kw):
+    """the bench workload's scene: the C2 room of SURVEY 8d with the superpoint graph sized like a prepared ScanNet
+    scene (S ~ 2.3 k superpoints, E ~ 20 k directed edges: touching superpoints + <= 5 KD-tree neighbours within
+    0.3 m, prepare_data_inst_ScanNetV2.py:191-225)"""
+    kw.setdefault("sp_cell", 0.19)
+    kw.setdefault("graph", "mesh")
+    return make_scene(seed, **kw)
 
 
 def forward_loss(model, criterion, batch, cfg, epoch=5):
@@ -325,7 +376,7 @@ def build_model(cfg, device, seed=123):
     # yaml:58-61.  On the GPU: optim.FlatAdamW (the same update rule in ONE launch over all 361 tensors;
     # WSIS_FLAT_ADAMW=0 selects torch's multi-tensor fused AdamW: 6 launches at a third of the CUs)
     if torch.device(device).type == "cuda" and os.environ.get("WSIS_FLAT_ADAMW", "1") != "0":
-        import optim
+        import wsis_optim as optim
         optimizer = optim.FlatAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
     else:
         optimizer = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-4,

@@ -118,7 +118,7 @@ class MultiTaskLoss(nn.Module):
                 valid = sp_valid[b:e]
                 if indexed:
                     d_loss, _, _, _ = self.discriminative_loss(feats[b:e][valid], sp_ins_labels[b:e][valid])
-                elif (slots is not None and feats.is_cuda and 1 <= int(slots[i - 1]) <= 64 and 1 <= e - b <= 1536
+                elif (slots is not None and feats.is_cuda and 1 <= int(slots[i - 1]) <= 64 and 1 <= e - b <= 4096
                       and self.discriminative_feature_dim == 7 and os.environ.get("WSIS_FUSE_DISC_LOSS", "1") != "0"):
                     import wsis_ops          # one launch each way (csrc/loss.hip)
                     d_loss = wsis_ops.discriminative_loss(feats[b:e], sp_ins_labels[b:e], sp_sem_labels[b:e],

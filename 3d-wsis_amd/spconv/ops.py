@@ -532,9 +532,15 @@ def prebuild_unet_rulebooks(tensor, n_levels, subm_key="subm{}", down_key="spcon
     side = _side_stream(dev) if side_stream else None
     ctx = torch.cuda.stream(side) if side is not None else _NullCtx()
     if side is not None:
+        # the side stream must see complete coordinates: an explicit ``_ready_event`` (recorded right after the
+        # producer of ``indices``, lets the build overlap whatever else is queued on the main stream) or, without
+        # one, everything enqueued on the current stream so far (a drop-in caller that built the tensor the
+        # reference's way: ``SparseConvTensor(feats, coords.int(), ...)`` on the main stream)
         ev = getattr(tensor, "_ready_event", None)
         if ev is not None:
             side.wait_event(ev)
+        else:
+            side.wait_stream(main)
     with ctx:
         built = _build_pyramid(tensor, n_levels, subm_key, down_key, first_id)
     if side is not None:
@@ -602,8 +608,10 @@ class RulebookPipeline(object):
         assert self._gen is None and self._rs is None, "one batch in flight at a time"
         _check_indices(indices)
         self._rs = RulebookSet(indices, spatial_shape)
-        if ready_event is not None:
-            _side_stream(indices.device).wait_event(ready_event)
+        if ready_event is None:     # no explicit event: order behind everything queued on the current stream
+            ready_event = torch.cuda.Event()
+            ready_event.record(torch.cuda.current_stream(indices.device))
+        _side_stream(indices.device).wait_event(ready_event)
         self._gen = _build_pyramid_gen(self._rs, *self.args)
         self._advance()
 
@@ -656,6 +664,9 @@ class RulebookPrefetcher(object):
         assert self._thread is None, "one batch in flight at a time"
         _check_indices(indices)
         rs = RulebookSet(indices, spatial_shape)
+        if ready_event is None:     # recorded HERE, on the submitting thread's current stream (the producer's)
+            ready_event = torch.cuda.Event()
+            ready_event.record(torch.cuda.current_stream(indices.device))
         self._out = self._err = None
         self._thread = threading.Thread(target=self._work, args=(rs, ready_event, indices.device), daemon=True)
         self._thread.start()

@@ -483,7 +483,7 @@ def sp_regression_losses(pred_off, gt_off, pred_occ, gt_occ, pred_size, gt_size,
                                    ignore_label)
 
 
-DISC_MAX_ROWS, DISC_MAX_SLOTS = 1536, 64
+DISC_MAX_ROWS, DISC_MAX_SLOTS = 4096, 64
 
 
 class _DiscriminativeLoss(Function):

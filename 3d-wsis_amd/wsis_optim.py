@@ -13,11 +13,23 @@ import wsis_native as _n
 _RING = 4
 
 
-class FlatAdamW(object):
+class FlatAdamW(torch.optim.Optimizer):
+    """A ``torch.optim.Optimizer`` (one parameter group): ``param_groups[0]`` is live -- the step reads ``lr``,
+    ``betas``, ``eps`` and ``weight_decay`` from it, so the reference's ``PolyLR`` (an ``_LRScheduler``, stepped per
+    epoch, ``utils/lr_scheduler.py``) and its ``save_checkpoint`` isinstance check work on it unchanged."""
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
-        self.params = [p for p in params if p.requires_grad]
-        if not self.params:
+        params = list(params)
+        if params and isinstance(params[0], dict):
+            if len(params) != 1:
+                raise ValueError("FlatAdamW takes ONE parameter group (one set of hyper-parameters per launch)")
+            params = list(params[0]["params"])
+        params = [p for p in params if p.requires_grad]
+        if not params:
             raise ValueError("no parameters to optimise")
+        super().__init__(params, dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps),
+                                      weight_decay=float(weight_decay)))
+        self.params = self.param_groups[0]["params"]
         dev = self.params[0].device
         if dev.type != "cuda":
             raise _n.WsisError("FlatAdamW runs on the MI355X only (there is no CPU fallback)")
@@ -25,8 +37,6 @@ class FlatAdamW(object):
             if p.dtype != torch.float32 or not p.is_contiguous() or p.device != dev:
                 raise ValueError("FlatAdamW expects contiguous fp32 parameters on one device")
         lib = _n.hip()
-        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), \
-            float(weight_decay)
         self.steps = np.zeros(len(self.params), dtype=np.int64)    # updates per parameter (torch counts per parameter)
         numel = [p.numel() for p in self.params]
         # moments: one flat buffer each; slices start at multiples of 4 floats so the float4 path applies
@@ -55,6 +65,13 @@ class FlatAdamW(object):
         self._done = [None] * _RING
         self._slot = 0
 
+    # hyper-parameters live in param_groups[0] (schedulers write there); the attributes are views of it
+    lr = property(lambda self: float(self.param_groups[0]["lr"]),
+                  lambda self, v: self.param_groups[0].__setitem__("lr", float(v)))
+    betas = property(lambda self: tuple(float(b) for b in self.param_groups[0]["betas"]))
+    eps = property(lambda self: float(self.param_groups[0]["eps"]))
+    weight_decay = property(lambda self: float(self.param_groups[0]["weight_decay"]))
+
     def zero_grad(self, set_to_none=True):
         for p in self.params:
             if set_to_none:
@@ -63,7 +80,13 @@ class FlatAdamW(object):
                 p.grad.zero_()
 
     @torch.no_grad()
-    def step(self):
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if len(self.param_groups) != 1:
+            raise ValueError("FlatAdamW takes ONE parameter group")
         tab = self._table
         grads = [p.grad for p in self.params]
         for i, g in enumerate(grads):                 # slow path only for a gradient the kernel cannot read as is
@@ -90,6 +113,7 @@ class FlatAdamW(object):
         _n.check(_n.hip().wsis_adamw_step(_n.ptr(self._dev[k]), _n.ptr(self._blocks), self._n_blocks, self.lr,
                                           self.betas[0], self.betas[1], self.eps, self.weight_decay,
                                           _n.stream_ptr()), "adamw_step")
+        return loss
 
     # state in the layout of torch.optim.AdamW.state_dict()["state"] (checkpoint interchange)
     def state_dict(self):
@@ -103,9 +127,9 @@ class FlatAdamW(object):
                         "exp_avg": self.exp_avg[off:off + n].view_as(p).clone(),
                         "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
             off += (n + 3) // 4 * 4
-        return {"state": state, "param_groups": [{"lr": self.lr, "betas": self.betas, "eps": self.eps,
-                                                  "weight_decay": self.weight_decay,
-                                                  "params": list(range(len(self.params)))}]}
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}   # incl. a scheduler's initial_lr
+        group["params"] = list(range(len(self.params)))
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
         off = 0
@@ -116,7 +140,12 @@ class FlatAdamW(object):
                 self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
                 self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
                 self.steps[i] = int(st["step"])
+            else:       # absent from the checkpoint = never updated there: no stale moments survive a resume
+                self.exp_avg[off:off + n].zero_()
+                self.exp_avg_sq[off:off + n].zero_()
+                self.steps[i] = 0
             off += (n + 3) // 4 * 4
         g = sd["param_groups"][0]
-        self.lr, self.betas, self.eps, self.weight_decay = float(g["lr"]), tuple(g["betas"]), float(g["eps"]), \
-            float(g["weight_decay"])
+        for k, v in g.items():
+            if k != "params":
+                self.param_groups[0][k] = tuple(v) if k == "betas" else v

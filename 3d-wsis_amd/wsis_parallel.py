@@ -51,6 +51,9 @@ class GradSync(object):
             size += nbytes
         if cur:
             self.buckets.append(cur)
+        # path agreement (see _agree): the plan of the first calls is negotiated, then frozen
+        self._agreed = None
+        self._agree_calls = 0
 
     @staticmethod
     def _flat_source(model):
@@ -75,20 +78,60 @@ class GradSync(object):
             covered = {id(p) for p in prog.params}
             prog.tail_floats = sum(p.numel() for b in self.buckets for p in b if id(p) not in covered)
 
+    AGREE_CALLS = 3     # the plan changes over the first steps (the tail is reserved in step 1, used from step 2)
+
+    def _agree(self, plan):
+        """The choice between the zero-copy flat all-reduce (+ tail packing) and the bucket path is made from
+        rank-local state (do the gradients still live in the flat buffer? how large is the tail?).  Ranks that chose
+        differently would issue a different number / size of collectives -- a hang or silent corruption -- so the
+        choice is COLLECTIVE: during the first ``AGREE_CALLS`` calls every rank contributes its local plan
+        (flat elements or 0, tail elements or 0) and the element-wise minimum / maximum over ranks decide: any rank
+        without the flat path, or a disagreement on a size, puts every rank on the bucket path for that step.  That
+        costs one tiny all-reduce and a host read per negotiated step; afterwards the plan is frozen and a rank whose
+        local state no longer supports it fails loudly instead of diverging."""
+        if self._agree_calls >= self.AGREE_CALLS:
+            ok = self._agreed == (0, 0) or (self._agreed[0] == plan[0] and self._agreed[1] in (0, plan[1]))
+            if not ok:
+                raise RuntimeError(f"GradSync: this rank's gradient layout {plan} no longer matches the plan agreed "
+                                   f"across ranks {self._agreed}; gradients were replaced or accumulated outside the "
+                                   f"native UNet pass")
+            return self._agreed
+        self._agree_calls += 1
+        dev = next(p for b in self.buckets for p in b).device
+        t = torch.tensor([plan[0], plan[1], -plan[0], -plan[1]], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        lo_f, lo_t, hi_f, hi_t = (int(v) for v in t.tolist())
+        hi_f, hi_t = -hi_f, -hi_t
+        if lo_f != hi_f or lo_f == 0:
+            self._agreed = (0, 0)                      # some rank cannot use the flat path: buckets everywhere
+        elif lo_t != hi_t:
+            self._agreed = (lo_f, 0)                   # flat buffer yes, tail sizes differ: no tail packing
+        else:
+            self._agreed = (lo_f, lo_t)
+        return self._agreed
+
     def __call__(self, model=None):
         if self.world == 1 and os.environ.get("WSIS_FORCE_DIST", "0") != "1":
             return
         work = []
         flat_src, covered = self._flat_source(model)
-        self.last_flat_params = len(covered)        # diagnostics / tests: parameters synchronised without a copy
         flat_handle = None
         self._reserve_tail(model)
         tail_job = None
+        # rank-local plan -> collective decision
+        local_tail = 0
         if flat_src is not None:
             prog = model._native_prog
             rest = [p for b in self.buckets for p in b if id(p) not in covered]
             n_rest = sum(p.numel() for p in rest)
             if prog.flat_tail is not None and prog.flat_tail.numel() == n_rest and n_rest > 0:
+                local_tail = n_rest
+        use_flat, use_tail = self._agree((int(flat_src.numel()) if flat_src is not None else 0, local_tail))
+        if not use_flat:
+            flat_src, covered = None, set()
+        self.last_flat_params = len(covered)        # diagnostics / tests: parameters synchronised without a copy
+        if flat_src is not None:
+            if use_tail:
                 grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in rest]
                 torch.cat([g.reshape(-1) for g in grads], out=prog.flat_tail)
                 tail_job = (rest, grads, prog.flat_tail)

@@ -1,11 +1,14 @@
 #!/usr/bin/env python
 """bench.py -- scenes/s, forward+backward(+AdamW step) of the 3D-WSIS per-scene hot path on MI355X.
 
-Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): one synthetic ScanNet-shaped scene per GPU
-(~150 k active voxels at 2 cm, seed 1 + rank), inputs resident in HBM before the timed region; one step =
-superpoint centres -> voxelization -> SparseConvTensor -> Network (SubMConv3d UNet + ECC GNN + edge affinity) ->
-MultiTaskLoss (stage-3 switches) -> backward -> [RCCL gradient all-reduce when N > 1] -> ECC grad clamp ->
-AdamW step (train_scannetv2.py:143-252).  N > 1: weak scaling, one scene per rank, no data-path collective.
+Workload at N = 1 (BASELINE.json configs[1], SURVEY.md 8d "C2"): one synthetic ScanNet-shaped scene
+(~150 k active voxels at 2 cm, ~2.3 k superpoints, ~20 k graph edges), inputs resident in HBM before the timed
+region; one step = per-batch segment / graph structures -> superpoint centres -> voxelization -> rulebooks ->
+SparseConvTensor -> Network (SubMConv3d UNet + ECC GNN + edge affinity) -> MultiTaskLoss (stage-3 switches) ->
+backward -> [RCCL gradient all-reduce when N > 1] -> ECC grad clamp -> AdamW step (train_scannetv2.py:143-252).
+N > 1 (BASELINE.json configs[4], "C5"): --scenes-per-gpu defaults to 4 (batch 32 over 8 GPUs), scenes sharded by
+rank, no data-path collective, weak scaling.  `python bench.py --gpus N` without a launcher starts the N ranks itself
+(a torch.distributed.run child, before anything touches the GPU) and fails non-zero if the RCCL world is not N.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      -- dominant kernel (spconv_fwd_kernel: every forward and dIn pass of the 49 sparse convs):
@@ -63,7 +66,7 @@ def parse():
                     help="build the next step's rulebooks from a helper thread (measured slower: GIL contention)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra event-instrumented steps for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=8)
     ap.add_argument("--cpu-timeout", type=int, default=150)
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
@@ -75,13 +78,41 @@ def parse():
     ap.add_argument("--no-stages", action="store_true",
                     help="skip the side measurements (copy/triad bandwidth, optimizer step, clustering stage)")
     ap.add_argument("--scene-seed", type=int, default=1)
+    ap.add_argument("--scenes-per-gpu", type=int, default=0,
+                    help="scenes per rank and step; default 1 at --gpus 1 (C2), 4 at --gpus > 1 (C5: batch 32 / 8 GPUs)")
+    ap.add_argument("--hoist-graphs", action="store_true",
+                    help="build the per-batch segment CSRs / edge graph once outside the step (round-1 behaviour) "
+                         "instead of inside every timed step")
     ap.add_argument("--small", action="store_true", help="debug: a small room instead of the C2 scene")
     return ap.parse_args()
 
 
 MFMA_FP32_PEAK_TFLOPS = 157.3      # dense fp32 matrix peak (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU x 256 CUs x 2.4 GHz)
-CPU_SAMPLE_ROOM = (2.3, 1.8, 2.2)   # quarter-area room of the C2 scene: the bounded cpu_baseline sample
-CPU_SAMPLE_BOXES = 2
+C1_ROOM, C1_POINTS = (3.0, 3.0, 2.4), 10000      # BASELINE configs[0] / SURVEY 8d C1: single 10 k-pt room (seed 0)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without torchrun's environment: start the N ranks as ONE child job
+    (python -m torch.distributed.run, one process per GPU) BEFORE this process touches the GPU, relay its output and
+    exit with its code.  Returns only when no launch is needed."""
+    if args.gpus <= 1 or args.cpu_worker:
+        return
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}\n")
+            sys.exit(2)
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def cpu_worker(args):
@@ -92,7 +123,9 @@ def cpu_worker(args):
     threads = args.cpu_threads
     torch.set_num_threads(threads)
     cfg = harness.default_cfg()
-    scene = harness.make_scene(args.scene_seed, room=CPU_SAMPLE_ROOM, n_box=CPU_SAMPLE_BOXES)
+    c1 = c1_cpu_leg(harness)
+    print(json.dumps({"c1": c1}), flush=True)          # survives a time-out of the C2 passes below
+    scene = harness.bench_scene(args.scene_seed)        # the SAME scene the GPU leg steps on
     batch_host = harness.collate([scene])
     torch.manual_seed(123)
     ref = network_ref.RefNetwork()
@@ -106,13 +139,48 @@ def cpu_worker(args):
     t0 = time.time()
     one()                       # warm-up (first-touch page faults dominate it)
     warm = time.time() - t0
-    iters = args.cpu_iters if warm < 40 else 1
+    out = {"c1": c1, "warm": warm, "iters": 0, "dt": warm, "voxels": int(batch_host["voxel_locs"].shape[0]),
+           "threads": threads}
+    print(json.dumps(out), flush=True)
     t0 = time.time()
-    for _ in range(iters):
+    for it in range(args.cpu_iters):
         one()
-    dt = (time.time() - t0) / iters
-    print(json.dumps({"dt": dt, "warm": warm, "iters": iters, "voxels": int(batch_host["voxel_locs"].shape[0]),
-                      "threads": threads}), flush=True)
+        out.update(iters=it + 1, dt=(time.time() - t0) / (it + 1))
+        print(json.dumps(out), flush=True)              # the parent keeps the last complete line
+
+
+def c1_cpu_leg(harness):
+    """BASELINE configs[0]: single 10 k-pt room, voxelize + superpoint scatter-mean + affinity on the
+    host cores -- the oracle's functions (oracle/pg_ops, scatter_ref, affinity_ref), the reference's CPU plumbing."""
+    import numpy as np
+    from oracle import affinity_ref, pg_ops, scatter_ref
+    sc = harness.make_scene(0, room=C1_ROOM, n_box=2, max_points=C1_POINTS)
+    b = harness.collate([sc])
+    S = int(b["sp_batch_offsets"][-1])
+    rng = np.random.default_rng(0)
+    q, k, v = (torch.from_numpy(rng.standard_normal((S, 64)).astype("float32")) for _ in range(3))
+    pos = torch.from_numpy(rng.standard_normal(int(b["edge_u_list"].shape[0])).astype("float32"))
+    feats = torch.cat([b["feats"], b["locs_float"]], 1)
+
+    def one():
+        vl, p2v, v2p = pg_ops.voxelization_idx(b["locs"].numpy(), 1, 4)
+        vf = torch.from_numpy(pg_ops.voxelization(feats.numpy(), v2p, 4))
+        pooled = scatter_ref.scatter(vf[torch.from_numpy(p2v).long()], b["superpoint"], dim=0, reduce="mean")
+        aff, res = affinity_ref.edge_affinity(q, k, v, pos, b["edge_u_list"], b["edge_v_list"])
+        A = affinity_ref.affinity_matrix(b["edge_u_list"].numpy(), b["edge_v_list"].numpy(), aff.numpy(), S)
+        return vl.shape[0], pooled, A
+
+    one()
+    t0 = time.time()
+    n = 0
+    while n < 3 or (time.time() - t0 < 2.0 and n < 50):
+        M, _, _ = one()
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"workload": "C1: single 10 k-pt room, voxelization_idx + voxelization + superpoint scatter-mean + edge "
+                        "affinity + dense affinity matrix on the host (oracle)", "points": int(b["locs"].shape[0]),
+            "voxels": int(M), "superpoints": S, "edges": int(b["edge_u_list"].shape[0]), "passes": n,
+            "ms_per_pass": round(dt * 1e3, 2), "rooms_per_s": round(1.0 / dt, 2)}
 
 
 def _gpu_ms(fn, iters):
@@ -170,7 +238,7 @@ def side_measurements(harness, optimizer, device, args):
 
     # test-time grouping on the superpoint graph (test_scannetv2.py:281-455) on the C2 scene, synthetic predictions
     import inference
-    sc = harness.make_scene(args.scene_seed)
+    sc = harness.bench_scene(args.scene_seed)
     sem, off, occ, size = harness.synthetic_predictions(sc, args.scene_seed)
     graph = (sc["edges"][:, 0], sc["edges"][:, 1])
     xyz = sc["xyz"].astype("float32")
@@ -227,18 +295,18 @@ def other_configs(harness, device, args):
     out = {}
     cfg = harness.default_cfg()
     cfg.batch_size = 4
-    scenes = [harness.make_scene(s, room=(3.2, 2.6, 2.2), n_box=4) for s in (1, 2, 3, 4)]
+    scenes = [harness.bench_scene(s) for s in (1, 2, 3, 4)]         # seeds 1-4, <= 250 k points each
     b = harness.to_device(harness.collate(scenes), device)
     model, crit, opt = harness.build_model(cfg, device)
     for _ in range(3):
         harness.train_step(model, crit, opt, b, cfg)
     ms = _gpu_ms(lambda: harness.train_step(model, crit, opt, b, cfg), 5)
-    out["c3_batch4_train"] = {"workload": "C3: 4 scenes per step, fwd+bwd+AdamW, full loss",
+    out["c3_batch4_train"] = {"workload": "C3: 4 C2-sized scenes (seeds 1-4) per step, fwd+bwd+AdamW, full loss",
                               "active_voxels": int(b["voxel_locs"].shape[0]), "ms_per_step": round(ms, 3),
                               "scenes_per_s": round(4e3 / ms, 2)}
     del b
     cfg.batch_size = 1
-    big = harness.to_device(harness.collate([harness.make_scene(5, room=(13.0, 10.0, 3.0), n_box=36)]), device)
+    big = harness.to_device(harness.collate([harness.bench_scene(5, room=(13.0, 10.0, 3.0), n_box=36)]), device)
     model.eval()
 
     def infer():
@@ -255,8 +323,9 @@ def other_configs(harness, device, args):
 
 def cpu_baseline(full_voxels, args):
     """The oracle (torch-CPU port of the upstream gather -> mm -> scatter-add algorithm, oracle/network_ref.py)
-    timed on this box's host cores in a child process with a hard time limit, on a bounded sample: a
-    quarter-area room generated like the C2 scene; the rate is scaled to C2 scenes by the voxel ratio."""
+    timed on this box's host cores in a child process with a hard time limit, on the SAME C2 scene the GPU leg
+    steps on: one warm-up pass + up to --cpu-iters timed passes (the child reports after every pass, so a time-out
+    keeps the passes that finished); the C1 leg (10 k-pt room, host plumbing) runs first in the same child."""
     import subprocess
     cores = os.cpu_count() or 1
     threads = max(1, min(cores, 32))
@@ -274,19 +343,30 @@ def cpu_baseline(full_voxels, args):
                     break
     except OSError:
         pass
+    note = ""
     try:
-        res = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
-        line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-        r = json.loads(line)
-    except Exception as e:   # noqa: BLE001 -- a failed/timed-out baseline must not take the GPU result down
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+        try:
+            stdout, _ = proc.communicate(timeout=args.cpu_timeout)
+        except subprocess.TimeoutExpired:
+            proc.kill()                      # the exact child started above
+            stdout, _ = proc.communicate()
+            note = f" (child stopped at the {args.cpu_timeout} s limit)"
+        lines = [l for l in stdout.splitlines() if l.startswith("{")]
+        r = json.loads(lines[-1])
+    except Exception as e:   # noqa: BLE001 -- a failed baseline must not take the GPU result down
         return {"value": None, "unit": "scenes/s", "cores": threads, "kind": "port",
-                "sample": f"cpu baseline child failed or exceeded {args.cpu_timeout} s: {type(e).__name__}"}
-    scale = r["voxels"] / float(full_voxels)
-    return {"value": round(scale / r["dt"], 5), "unit": "scenes/s", "cores": r["threads"], "kind": "port",
-            "sample": f"{r['iters']} fwd+bwd pass(es) of a {r['voxels']}-voxel quarter-area room (same generator) "
-                      f"after a {r['warm']:.1f} s warm-up pass, {r['dt']:.2f} s per pass, scaled to the "
-                      f"{full_voxels}-voxel C2 scene by the voxel ratio; torch-CPU oracle, {r['threads']} threads of "
-                      f"{cores} logical cores, {model_name}"}
+                "sample": f"cpu baseline child failed: {type(e).__name__}"}
+    if "dt" not in r:
+        return {"value": None, "unit": "scenes/s", "cores": threads, "kind": "port", "c1": r.get("c1"),
+                "sample": f"no C2 pass finished within {args.cpu_timeout} s"}
+    timed = r["iters"] > 0
+    return {"value": round(1.0 / r["dt"], 5), "unit": "scenes/s", "cores": r["threads"], "kind": "port",
+            "c1": r.get("c1"),
+            "sample": (f"{r['iters']} timed fwd+bwd pass(es)" if timed else "the warm-up pass only") +
+                      f" of the {r['voxels']}-voxel C2 scene itself (the scene of the GPU leg; {full_voxels} voxels) "
+                      f"after a {r['warm']:.1f} s warm-up pass, {r['dt']:.2f} s per pass{note}; torch-CPU oracle, "
+                      f"{r['threads']} threads of {cores} logical cores, {model_name}"}
 
 
 def main():
@@ -294,25 +374,32 @@ def main():
     if args.cpu_worker:
         cpu_worker(args)
         return
+    self_launch(args)           # --gpus N > 1 without a launcher: the ranks run in a child job, this process exits
     import harness
-    import parallel
+    import wsis_parallel as parallel
     from spconv import ops as sp_ops
 
     if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION", "WARN"):
         os.environ["NCCL_DEBUG"] = "NONE"          # nothing from RCCL on stdout next to the JSON line
     rank, local_rank, world = parallel.init_distributed()
-    assert world == max(args.gpus, 1) or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    real_world = dist.get_world_size() if dist.is_initialized() else 1
+    if real_world != max(args.gpus, 1) and os.environ.get("WSIS_FORCE_DIST", "0") != "1":
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the process group has {real_world} rank(s)\n")
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the product path)"
     dev_index = local_rank % torch.cuda.device_count()     # > 1 rank per GPU only in gloo control-flow tests
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
 
     cfg = harness.default_cfg()
+    spg = args.scenes_per_gpu if args.scenes_per_gpu > 0 else (1 if world == 1 else 4)
+    cfg.batch_size = spg
+    seeds = [args.scene_seed + rank * spg + i for i in range(spg)]      # C5: seeds 1..32, 4 per GPU
     if args.small:
-        scene = harness.make_scene(args.scene_seed + rank, room=(2.0, 1.6, 1.2), n_box=2)
+        scenes = [harness.bench_scene(sd, room=(2.0, 1.6, 1.2), n_box=2) for sd in seeds]
     else:
-        scene = harness.make_scene(args.scene_seed + rank)
-    batch_host = harness.collate([scene])
+        scenes = [harness.bench_scene(sd) for sd in seeds]
+    batch_host = harness.collate(scenes)
     batch = harness.to_device(batch_host, device)
     model, criterion, optimizer = harness.build_model(cfg, device)
     use_dist = dist.is_initialized()
@@ -340,6 +427,8 @@ def main():
         batch["rulebooks"] = pipe.finish()
 
     def step():
+        if not args.hoist_graphs:          # a new batch needs its segment CSRs / edge graph: part of the step
+            harness.build_batch_graphs(batch)
         if pre is not None:
             harness.prefetch_rulebooks(pre, batch)
         if pipe is not None:
@@ -376,7 +465,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    scenes_per_s = world * args.steps / elapsed
+    scenes_per_s = world * spg * args.steps / elapsed
 
     # ---- roofline of the dominant kernel: event-instrumented extra steps (same inputs, same process) ----
     roof = None
@@ -430,7 +519,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(int(batch_host["voxel_locs"].shape[0]), args)
+        cpu = cpu_baseline(int(batch_host["voxel_locs"].shape[0]), args) if spg == 1 else None
 
     # the JSON line must be the LAST thing on stdout: anything a library printed through C stdio (fully buffered on
     # a pipe) is flushed now, by every rank, before rank 0 prints
@@ -444,13 +533,21 @@ def main():
         out = {
             "metric": "scenes/sec fwd+bwd ScanNet 2cm (~150k voxels) @1/8 GPU; HBM GB/s vs roofline",
             "value": round(scenes_per_s, 3), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: 1 synthetic ScanNet-shaped scene per GPU, 2 cm voxels, fwd+bwd+AdamW step "
-                                   "(SubMConv3d UNet 32..160 + ECC GNN + edge affinity + MultiTaskLoss)",
+            "warmup": args.warmup, "setup_steps": args.setup_steps, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("C2: 1 synthetic ScanNet-shaped scene on 1 GPU" if (world == 1 and spg == 1) else
+                                    f"C5-shaped: {spg} synthetic ScanNet-shaped scene(s) per GPU x {world} GPU(s) = "
+                                    f"batch {spg * world}, scenes sharded by rank, one RCCL gradient all-reduce per "
+                                    f"step") + ", 2 cm voxels, fwd+bwd+AdamW step (SubMConv3d UNet 32..160 + ECC GNN "
+                                    "+ edge affinity + MultiTaskLoss); per-batch segment CSRs / edge graph and all "
+                                    "rulebooks are rebuilt inside every step" +
+                                    (" EXCEPT the segment CSRs / edge graph (--hoist-graphs)" if args.hoist_graphs
+                                     else ""),
                        "active_voxels": M, "points": int(batch_host["locs"].shape[0]),
                        "superpoints": int(batch_host["sp_batch_offsets"][-1]),
-                       "edges": int(batch_host["edge_u_list"].shape[0]), "scenes_per_gpu": 1,
+                       "edges": int(batch_host["edge_u_list"].shape[0]), "scenes_per_gpu": spg,
+                       "global_batch": spg * world, "scene_seeds_rank0": seeds,
+                       "untimed_setup_steps": args.setup_steps,
                        "parallelism": f"scene-sharded dp{world}", "loss": float(loss)},
             "roofline": roof, "cpu_baseline": cpu,
         }

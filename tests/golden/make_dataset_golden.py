@@ -27,7 +27,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 importlib.import_module("3d-wsis_amd")
-import datasets                     # noqa: E402
+import wsis_datasets as datasets                     # noqa: E402
 import harness                      # noqa: E402
 
 REF = "/root/reference/modules/datasets/scannetv2_dataset.py"

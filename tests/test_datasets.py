@@ -9,7 +9,7 @@ import pytest
 import torch
 
 importlib.import_module("3d-wsis_amd")
-import datasets  # noqa: E402
+import wsis_datasets as datasets  # noqa: E402
 import harness  # noqa: E402
 
 G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_golden.npz"))

@@ -164,7 +164,7 @@ def test_gradsync_allreduces_the_flat_unet_gradient_buffer_in_place():
     """single-rank RCCL process group: the native UNet pass leaves its parameter gradients in one dense buffer and
     parallel.GradSync all-reduces that buffer without flatten / copy-back; gradients are unchanged at world 1"""
     import torch.distributed as dist
-    import parallel
+    import wsis_parallel as parallel
     if dist.is_initialized():
         pytest.skip("process group already initialised in this process")
     cfg = harness.default_cfg()
@@ -266,7 +266,7 @@ def test_rulebook_pipeline_slices_give_the_inline_pyramid_and_the_same_step():
 def test_augmented_cropped_batch_from_the_reference_pipeline_matches_oracle():
     """The reference's host pipeline (datasets.ScenePrep: jitter/flip/rotation, crop, id re-compaction, graph
     restriction; datasets.collate_fn) feeds the HIP path; forward tensors and the loss against the CPU oracle."""
-    import datasets
+    import wsis_datasets as datasets
     cfg = harness.default_cfg()
     cfg.batch_size = 2
     scenes = [harness.make_scene(5 + i, room=(1.0, 0.9, 0.8), n_box=2) for i in range(2)]

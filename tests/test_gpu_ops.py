@@ -513,6 +513,20 @@ def test_voxelization_idx_gpu_matches_host(N):
     d_locs, d_p2v, d_v2p = pointgroup_ops.voxelization_idx(torch.from_numpy(coords).to(DEV), 3, 4)
     assert d_locs.is_cuda and d_locs.dtype == torch.int64 and d_p2v.dtype == torch.int32
     assert torch.equal(d_p2v.cpu(), h_p2v) and torch.equal(d_locs.cpu(), h_locs) and torch.equal(d_v2p.cpu(), h_v2p)
+    # both product paths (host library and device kernels) against the checkers, on the GPU box as well:
+    # np.unique re-ordered by first occurrence at every size, the oracle's dict walk where it finishes in seconds
+    u, first, inv = np.unique(coords, axis=0, return_index=True, return_inverse=True)
+    order = np.argsort(first)
+    rank = np.empty_like(order)
+    rank[order] = np.arange(len(order))
+    cnt = np.bincount(rank[inv.ravel()])
+    for locs, p2v, v2p in ((h_locs, h_p2v, h_v2p), (d_locs.cpu(), d_p2v.cpu(), d_v2p.cpu())):
+        assert np.array_equal(p2v.numpy(), rank[inv.ravel()]) and np.array_equal(locs.numpy(), u[order])
+        assert np.array_equal(v2p[:, 0].numpy(), cnt) and v2p.shape[1] == 1 + cnt.max()
+        if N <= 5000:
+            rl, rp, rv = pg_ops.voxelization_idx(coords, 3, 4)
+            assert np.array_equal(locs.numpy(), rl) and np.array_equal(p2v.numpy(), rp)
+            assert np.array_equal(v2p.numpy(), rv)
 
 
 def test_voxelization_idx_gpu_empty():
@@ -748,7 +762,7 @@ def test_flat_adamw_matches_torch_adamw_step_by_step():
     """optim.FlatAdamW (wsis_adamw_step: every tensor in one launch) against torch.optim.AdamW (for-loop
     implementation) on odd-sized tensors, a parameter without gradient, a non-16-byte-aligned gradient view, five
     steps; tolerance 2e-6 of the parameter scale per step (fp32 rounding of a different but equivalent expression)."""
-    import optim
+    import wsis_optim as optim
     g = torch.Generator().manual_seed(3)
     shapes = [(3, 3, 3, 6, 32), (32,), (7, 64), (1,), (1025,), (96, 32), (20,)]
     a = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]

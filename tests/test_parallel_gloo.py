@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 import torch.nn as nn
 
-import parallel
+import wsis_parallel as parallel
 
 
 def _free_port():
@@ -35,7 +35,7 @@ def _worker(rank, world, port, out_dir):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     importlib.import_module("3d-wsis_amd")
-    import parallel as par
+    import wsis_parallel as par
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     r, lr, w = par.init_distributed("gloo")
