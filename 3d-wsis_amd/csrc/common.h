@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../../include/wsis_hip.h"
 
@@ -39,6 +40,34 @@ inline int grid_for(int64_t work_items, int block) {
   if (g > 256 * 8) g = 256 * 8;
   return (int)g;
 }
+
+// ---- live kernel timing for bench.py's roofline: HIP events recorded on the launch stream directly around the
+// dominant kernels (not around the host wrapper), enabled by wsis_prof_enable().
+struct ProfRec {
+  hipEvent_t a, b;
+};
+inline bool g_prof_on = false;
+inline std::vector<ProfRec> g_prof[2];   // 0 = spconv_fwd_kernel, 1 = spconv_dw_kernel
+
+struct ProfScope {
+  int which;
+  hipStream_t st;
+  ProfRec r{};
+  bool live = false;
+  ProfScope(int w, hipStream_t s) : which(w), st(s) {
+    if (g_prof_on && hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess) {
+      live = hipEventRecord(r.a, st) == hipSuccess;
+    }
+  }
+  void stop() {
+    if (live) {
+      (void)hipEventRecord(r.b, st);
+      g_prof[which].push_back(r);
+      live = false;
+    }
+  }
+};
+
 
 // ---- device-side hash (linear-index keys) --------------------------------------------------
 constexpr int64_t kEmptyKey = -1;

@@ -157,16 +157,35 @@ inline int64_t wt_bytes_of(const wsis_op& op) {
   return up((int64_t)op.K * op.Cin * op.Cout * (int64_t)sizeof(float));
 }
 
-int64_t op_ws_bytes(const wsis_op& op) {
+// wave-autonomous kernel (csrc/spconv2.hip) for a product with Cin input and Cout output channels; WSIS_FWD2=0 keeps
+// every convolution on spconv_fwd_kernel
+bool fwd2_enabled() {
+  const char* e = getenv("WSIS_FWD2");
+  return e ? atoi(e) != 0 : true;
+}
+inline bool use_fwd2(const wsis_op& op, bool on) {
+  return on && wsis_spconv_fwd_t_supported(op.K, op.Cin, op.Cout) != 0;
+}
+// does op need a transposed copy of its weights?  forward on the new kernel (B^T layout); dIn on the old one
+inline bool needs_wt(const wsis_op& op, bool on) {
+  if (op.kind == WSIS_OP_CONV) return use_fwd2(op, on);
+  if (op.kind == WSIS_OP_CONV_BWD) return op.out[0] != nullptr && !use_fwd2(op, on);
+  return false;
+}
+
+int64_t op_ws_bytes(const wsis_op& op, bool on) {
   switch (op.kind) {
     case WSIS_OP_CONV:
+      if (use_fwd2(op, on)) return up(wsis_spconv_fwd_t_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout));
       return up(wsis_spconv_fwd_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout));
     case WSIS_OP_BN_RELU:
       return (op.flags & WSIS_OPF_TRAINING) ? up(wsis_bn_workspace_bytes(op.M_in, op.Cin)) : 0;
     case WSIS_OP_BN_RELU_BWD:
       return up(wsis_bn_workspace_bytes(op.M_in, op.Cin));
     case WSIS_OP_CONV_BWD:     // the transposed weights and the dW slabs live in their own regions, not here
-      return op.out[0] ? up(wsis_spconv_fwd_workspace_bytes(op.M_in, op.K, op.Cout, op.Cin)) : 0;
+      if (!op.out[0]) return 0;
+      if (use_fwd2(op, on)) return up(wsis_spconv_fwd_t_workspace_bytes(op.M_in, op.K, op.Cout, op.Cin));
+      return up(wsis_spconv_fwd_workspace_bytes(op.M_in, op.K, op.Cout, op.Cin));
     default:
       return 0;
   }
@@ -179,11 +198,12 @@ extern "C" {
 int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n) {
   if (!ops || n < 0) return -1;
   int64_t need = ALIGN, wt = 0, dw = 0;
+  const bool on = fwd2_enabled();
   for (int i = 0; i < n; ++i) {
-    const int64_t b = op_ws_bytes(ops[i]);
+    const int64_t b = op_ws_bytes(ops[i], on);
     if (b < 0) return -1;
     if (b > need) need = b;
-    if (ops[i].kind == WSIS_OP_CONV_BWD && ops[i].out[0]) wt += wt_bytes_of(ops[i]);
+    if (needs_wt(ops[i], on)) wt += wt_bytes_of(ops[i]);
     if (ops[i].kind == WSIS_OP_CONV_BWD && ops[i].out[1]) {
       const int64_t d = up(wsis_spconv_dw_workspace_bytes(ops[i].M_out, ops[i].K, ops[i].Cin, ops[i].Cout));
       if (d > dw) dw = d;
@@ -198,6 +218,7 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
   hipStream_t st = as_stream(stream);
   char* ws = static_cast<char*>(d_ws);
   // ---- all transposed weights of the pass, WT_MAX layers per launch; wt_off[i] = offset of op i's W^T
+  const bool on = fwd2_enabled();
   std::vector<int64_t> wt_off(n, -1);
   int64_t wt_total = 0;
   {
@@ -213,15 +234,17 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
     };
     for (int i = 0; i < n; ++i) {
       const wsis_op& op = ops[i];
-      if (op.kind != WSIS_OP_CONV_BWD || !op.out[0]) continue;
-      WSIS_REQUIRE(op.in[1], "CONV_BWD without weights");
+      if (!needs_wt(op, on)) continue;
+      const bool fwd = op.kind == WSIS_OP_CONV;
+      const void* wsrc = fwd ? op.in[3] : op.in[1];
+      WSIS_REQUIRE(wsrc, "convolution without weights");
       wt_off[i] = wt_total;
-      b.src[b.n] = (const float*)op.in[1];
+      b.src[b.n] = (const float*)wsrc;
       b.dst[b.n] = reinterpret_cast<float*>(ws + wt_total);
       b.K[b.n] = op.K;
       b.Cin[b.n] = op.Cin;
       b.Cout[b.n] = op.Cout;
-      b.flip[b.n] = (op.flags & WSIS_OPF_FLIP) ? 1 : 0;
+      b.flip[b.n] = (!fwd && (op.flags & WSIS_OPF_FLIP)) ? 1 : 0;
       b.start[b.n + 1] = b.start[b.n] + op.K * ((op.Cin + WT_TILE - 1) / WT_TILE) * ((op.Cout + WT_TILE - 1) / WT_TILE);
       ++b.n;
       wt_total += wt_bytes_of(op);
@@ -261,9 +284,15 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
     int rc = WSIS_OK;
     switch (op.kind) {
       case WSIS_OP_CONV:
-        rc = wsis_spconv_fwd((const float*)op.in[0], (const int32_t*)op.in[1], (const int32_t*)op.in[2],
-                             (const float*)op.in[3], (const float*)op.in[4], (const float*)op.in[5],
-                             (float*)op.out[0], op.M_in, op.M_out, op.K, op.Cin, op.Cout, ws, ws_bytes, stream);
+        if (wt_off[i] >= 0)
+          rc = wsis_spconv_fwd_t((const float*)op.in[0], (const int32_t*)op.in[1], (const int32_t*)op.in[2],
+                                 reinterpret_cast<const float*>(wt_base + wt_off[i]), 0, (const float*)op.in[4],
+                                 (const float*)op.in[5], (float*)op.out[0], op.M_in, op.M_out, op.K, op.Cin, op.Cout,
+                                 ws, ws_bytes, stream);
+        else
+          rc = wsis_spconv_fwd((const float*)op.in[0], (const int32_t*)op.in[1], (const int32_t*)op.in[2],
+                               (const float*)op.in[3], (const float*)op.in[4], (const float*)op.in[5],
+                               (float*)op.out[0], op.M_in, op.M_out, op.K, op.Cin, op.Cout, ws, ws_bytes, stream);
         break;
       case WSIS_OP_BN_RELU: {
         const float* mean = (const float*)op.out[1];
@@ -319,10 +348,16 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
         char* rest = ws;
         const int64_t rest_bytes = ws_bytes;
         if (op.out[0]) {
-          const float* WT = reinterpret_cast<const float*>(wt_base + wt_off[i]);
-          rc = wsis_spconv_fwd((const float*)op.in[2], (const int32_t*)op.in[5], (const int32_t*)op.in[6], WT, nullptr,
-                               nullptr, (float*)op.out[0], op.M_out, op.M_in, op.K, op.Cout, op.Cin, rest, rest_bytes,
-                               stream);
+          if (wt_off[i] >= 0) {
+            const float* WT = reinterpret_cast<const float*>(wt_base + wt_off[i]);
+            rc = wsis_spconv_fwd((const float*)op.in[2], (const int32_t*)op.in[5], (const int32_t*)op.in[6], WT, nullptr,
+                                 nullptr, (float*)op.out[0], op.M_out, op.M_in, op.K, op.Cout, op.Cin, rest, rest_bytes,
+                                 stream);
+          } else {   // the weight [K, Cin, Cout] is the B^T operand of the dIn product as it stands
+            rc = wsis_spconv_fwd_t((const float*)op.in[2], (const int32_t*)op.in[5], (const int32_t*)op.in[6],
+                                   (const float*)op.in[1], (op.flags & WSIS_OPF_FLIP) ? 1 : 0, nullptr, nullptr,
+                                   (float*)op.out[0], op.M_out, op.M_in, op.K, op.Cout, op.Cin, rest, rest_bytes, stream);
+          }
           if (rc != WSIS_OK) break;
         }
         if (op.out[1]) {

@@ -505,31 +505,6 @@ __global__ void spconv_reduce4_kernel(const float4* __restrict__ partial, const 
 
 // ---- live kernel timing for bench.py's roofline: HIP events recorded on the launch stream directly around
 // the dominant kernels (not around the host wrapper), enabled by wsis_prof_enable().
-struct ProfRec {
-  hipEvent_t a, b;
-};
-bool g_prof_on = false;
-std::vector<ProfRec> g_prof[2];   // 0 = spconv_fwd_kernel, 1 = spconv_dw_kernel
-
-struct ProfScope {
-  int which;
-  hipStream_t st;
-  ProfRec r{};
-  bool live = false;
-  ProfScope(int w, hipStream_t s) : which(w), st(s) {
-    if (g_prof_on && hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess) {
-      live = hipEventRecord(r.a, st) == hipSuccess;
-    }
-  }
-  void stop() {
-    if (live) {
-      (void)hipEventRecord(r.b, st);
-      g_prof[which].push_back(r);
-      live = false;
-    }
-  }
-};
-
 // output-channel blocks (of 32) one workgroup owns.  Levels with <= 100 row tiles run one block per workgroup:
 // more workgroups and fewer MFMAs per step on each workgroup's latency chain (measured on the C2 pyramid:
 // 96 ch 55->48 us, 128 ch 44->33 us, 160 ch 41->25 us).  WSIS_FWD_NB_SMALL / WSIS_FWD_SMALL_TILES: tuning knobs.

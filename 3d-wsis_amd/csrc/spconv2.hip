@@ -1,0 +1,569 @@
+// Sparse convolution, wave-autonomous form (the kernel of every forward and dIn pass whose channel
+// counts are multiples of 32 -- all UNet layers but the 6-channel input conv).
+//
+//   out[r,:] = sum_k X[nbr[k][r],:] @ W[k]      with the weights given as B^T: WT[k][cout][cin]
+//
+// Work item = (32 output rows in tile order) x (NB blocks of 32 output channels).  ONE WAVE owns a work item (NW = 1),
+// or NW waves of a workgroup split its (active offset, 32-channel chunk) steps round-robin and add their accumulators
+// through LDS in wave order at the end (small pyramid levels: parallelism from the offsets instead of a second
+// "partial slab + reduce" launch).  There is no workgroup barrier inside the walk and no register staging:
+//   * the gathered input rows (A, 32 rows x 128 B) and the weight rows (B^T, 32*NB columns x 128 B) of a step go
+//     global -> LDS by LDS-DMA (global_load_lds_dwordx4, per-lane source address = the gather), three steps (A) and two
+//     steps (B) ahead, into the wave's private rings; completion is tracked with a counted s_waitcnt vmcnt -- never 0
+//     inside the loop;
+//   * the MFMA fragments of step t+1 are read from LDS (conflict-free ds_read_b128: the 16-byte pieces of a row are
+//     XOR-swizzled on the SOURCE side, the LDS image stays lane-linear as the DMA requires) while the 16*NB
+//     v_mfma_f32_32x32x2_f32 of step t run from registers;
+//   * inactive (slice, offset) pairs cost nothing at all (the wave walks only its own slice's active offsets).
+// Exact fp32 (k-ordered fma chain); the order of additions is fixed by (offset, chunk, wave), so results are
+// run-to-run identical; with NW = 1 they are bit-identical to spconv_fwd_kernel.
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+using namespace wsis;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int SL = 32;            // rows per work item
+constexpr int KMAX = 32;          // kernel offsets (mask width)
+constexpr int DB = 2;             // ring depth of the weight rows (steps); the gathered rows: template DA
+constexpr int A_BYTES = SL * 128;
+constexpr int HDR_BYTES = (KMAX + 2) * 128;   // nbT [32][32] + rowId [32] + klist [32]: ONE per workgroup (the waves of a
+                                              // work item share the slice; each writes the identical header itself)
+
+__device__ __attribute__((aligned(256))) float g_zero_row[64];   // source of masked rows (never written)
+
+// BD: the weight fragments go global -> registers directly (no LDS ring for B: 8 NB KB less LDS per wave, more waves
+// per CU); otherwise they take the same LDS-DMA ring path as the gathered rows
+template <int NB, int DA, bool BD>
+struct Layout {
+  static constexpr int B_BYTES = NB * 32 * 128;
+  static constexpr int WAVE_BYTES = DA * A_BYTES + (BD ? 0 : DB * B_BYTES);
+};
+
+__device__ __forceinline__ void dma16(const void* src, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// swizzle of the 16-byte pieces of a 128-byte row: piece p of row r lives in slot p ^ swz(r); a 16-lane group of a
+// ds_read_b128 (rows 0-3,12-15,20-27 / 4-11,16-19,28-31 of one half) then covers 16 distinct 16-byte bank groups
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+template <int NB, int NW, int DA, bool BD, bool DIAG = false>
+__global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
+    const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
+    const float* __restrict__ WT, const float* __restrict__ bias, const float* __restrict__ residual,
+    float* __restrict__ out, float* __restrict__ partial, int64_t M_out, int K, int Cin, int Cout, int flip,
+    unsigned long long* __restrict__ dbg = nullptr) {
+  // DIAG build only (tools/conv2_stamps.py): per-workgroup stamps, dbg[blockIdx.x * 8 + i] =
+  // {realtime at entry, realtime at exit, cycles: prologue, walk, epilogue, steps, HW_ID, 0}
+  unsigned long long d_t0 = 0, d_r0 = 0, d_t1 = 0, d_t2 = 0;
+  if (DIAG) {
+    d_r0 = __builtin_amdgcn_s_memrealtime();
+    d_t0 = __builtin_amdgcn_s_memtime();
+  }
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  using L = Layout<NB, DA, BD>;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r31 = lane & 31, half = lane >> 5;
+  int32_t* const nbT = reinterpret_cast<int32_t*>(lds);
+  int32_t* const rowId = nbT + KMAX * 32;
+  int32_t* const klist = rowId + 32;
+  unsigned char* const Aring = lds + HDR_BYTES + wave * L::WAVE_BYTES;
+  unsigned char* const Bring = Aring + DA * A_BYTES;
+
+  const int64_t t0 = (int64_t)blockIdx.x * SL;
+  const int col0 = blockIdx.y * (NB * 32);
+  const int nchunk = Cin >> 5;
+
+  // ---- the slice's rows and its column of the packed gather table (every load in flight at once)
+  const int64_t t = t0 + r31;
+  int32_t my_row = -1;
+  if (t < M_out) my_row = order ? order[t] : (int32_t)t;
+  uint32_t mask = 0u;
+  {
+    // branch-free: every lane always issues its 16 loads (clamped address), masking happens afterwards -- with
+    // conditional loads hipcc waits for each one before issuing the next
+    int32_t v[KMAX / 2];
+    const int32_t* tab = nbrS ? nbrS : order;      // any readable address for the masked lanes
+#pragma unroll
+    for (int j = 0; j < KMAX / 2; ++j) {
+      const int k = 2 * j + half;
+      const bool ok = k < K && my_row >= 0 && nbrS != nullptr;
+      v[j] = tab ? tab[ok ? (int64_t)k * M_out + t : 0] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX / 2; ++j) {
+      const int k = 2 * j + half;
+      const bool ok = k < K && my_row >= 0;
+      const int32_t g = ok ? (nbrS ? v[j] : my_row) : -1;
+      nbT[k * 32 + r31] = g;
+      const unsigned long long b = __ballot(g >= 0);
+      if ((uint32_t)b) mask |= 1u << (2 * j);
+      if ((uint32_t)(b >> 32)) mask |= 1u << (2 * j + 1);
+    }
+  }
+  if (lane < 32) rowId[lane] = my_row;
+  // offsets of this wave: the slice's active offsets are numbered 0 .. nact-1; blockIdx.z owns the numbers
+  // [q_begin, q_end) (levels with very few work items: partial slabs, added in z order by spconv2_reduce_kernel), and
+  // inside the workgroup wave w takes every NW-th of them.  All scalar: the walk below needs no LDS list.
+  uint32_t mymask = 0u;
+  {
+    const int nact = __builtin_popcount(mask);
+    const int q_begin = (int)((int64_t)nact * blockIdx.z / gridDim.z);
+    const int q_end = (int)((int64_t)nact * (blockIdx.z + 1) / gridDim.z);
+    uint32_t m = mask;
+    for (int q = 0; m; ++q) {
+      const uint32_t bit = m & (0u - m);
+      m ^= bit;
+      if (q >= q_begin && q < q_end && (q - q_begin) % NW == wave) mymask |= bit;
+    }
+  }
+  mymask = __builtin_amdgcn_readfirstlane(mymask);
+  const int T = __builtin_popcount(mymask) * nchunk;               // steps of this wave: (offset, chunk), chunk inner
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[cb][i] = 0.0f;
+
+  // per-lane constants of the DMA pieces: instruction i of a 32-row image covers rows i*8 + (lane >> 3)
+  const int d_row = lane >> 3, d_piece = lane & 7;
+  const char* const Xb = reinterpret_cast<const char*>(X);
+  const char* const Wb = reinterpret_cast<const char*>(WT);
+  const char* const zrow = reinterpret_cast<const char*>(g_zero_row) + d_piece * 16;
+  const int64_t a_pitch = (int64_t)Cin * 4;
+
+  // step generators (wave-uniform scalars): next (offset, chunk) of the gathered-row stream / of the weight stream
+  struct Gen {
+    uint32_t rem;
+    int k, c;
+    bool valid;
+  };
+  auto gen_init = [&](Gen& g) {
+    g.rem = mymask;
+    g.c = 0;
+    g.valid = g.rem != 0u;
+    g.k = g.valid ? __builtin_ctz(g.rem) : 0;
+    g.rem &= g.rem - 1u;
+  };
+  auto gen_next = [&](Gen& g) {
+    if (++g.c == nchunk) {
+      g.c = 0;
+      g.valid = g.valid && g.rem != 0u;
+      g.k = g.rem ? __builtin_ctz(g.rem) : g.k;
+      g.rem &= g.rem - 1u;
+    }
+  };
+  // DMA of a step, branch-free: a finished stream re-reads the zero row (the piece count per iteration stays fixed,
+  // which keeps the counted vmcnt waits valid in the tail)
+  auto loadNb = [&](const Gen& g, int32_t (&nb)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nb[i] = nbT[g.k * 32 + i * 8 + d_row];
+  };
+  auto issueA1 = [&](const Gen& g, const int32_t (&nb)[4], int slot, int i) {
+    const int row = i * 8 + d_row;
+    const bool ok = g.valid && nb[i] >= 0;
+    const char* src = ok ? Xb + (int64_t)nb[i] * a_pitch + g.c * 128 + ((d_piece ^ swz(row)) << 4) : zrow;
+    dma16(src, Aring + slot * A_BYTES + i * 1024);
+  };
+  auto issueB1 = [&](const Gen& g, int slot, int i) {
+    const int kk = flip ? K - 1 - g.k : g.k;
+    const int n = i * 8 + d_row;                                   // output column inside the block group
+    const char* src = g.valid ? Wb + (((int64_t)kk * Cout + col0 + n) * Cin + g.c * 32) * 4 + ((d_piece ^ swz(n & 31)) << 4)
+                              : zrow;
+    dma16(src, Bring + slot * L::B_BYTES + i * 1024);
+  };
+  // fragments: lane (row / column r31, half) takes channels half*16 .. +15 of its row: MFMA k index (step s, half)
+  // <-> channel half*16 + s, the mapping of spconv_fwd_kernel (same order of additions)
+  auto readfrag = [&](int aslot, int bslot, f32x4 (&a)[4], f32x4 (&b)[NB][4]) {
+    const unsigned char* arow = Aring + aslot * A_BYTES + r31 * 128;
+    const int sw = swz(r31);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(arow + (((half * 4 + q) ^ sw) << 4));
+    if (BD) return;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      const unsigned char* brow = Bring + bslot * L::B_BYTES + (cb * 32 + r31) * 128;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[cb][q] = *reinterpret_cast<const f32x4*>(brow + (((half * 4 + q) ^ sw) << 4));
+    }
+  };
+  // BD: the lane's 16 weights of output column cb*32 + r31 (channels half*16 .. +15 of the step's chunk) straight from
+  // WT [K][Cout][Cin]: 64 contiguous bytes; a finished stream reads the zero row
+  auto loadB = [&](const Gen& g, f32x4 (&b)[NB][4]) {
+    const int kk = flip ? K - 1 - g.k : g.k;
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+      const char* src = g.valid ? Wb + (((int64_t)kk * Cout + col0 + cb * 32 + r31) * Cin + g.c * 32 + half * 16) * 4
+                                : reinterpret_cast<const char*>(g_zero_row);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[cb][q] = *reinterpret_cast<const f32x4*>(src + q * 16);
+    }
+  };
+  // MFMAs [s0, s1) of a step (k-ordered chain per output block)
+  auto mfma = [&](const f32x4 (&a)[4], const f32x4 (&b)[NB][4], int s0, int s1) {
+#pragma unroll
+    for (int s = s0; s < s1; ++s)
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb)
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s >> 2][s & 3], b[cb][s >> 2][s & 3], acc[cb], 0, 0, 0);
+  };
+
+  if (DIAG) d_t1 = __builtin_amdgcn_s_memtime();
+  if (T > 0) {
+    // issue order (DA = 3): A0 B0 A1 B1 A2 | B2 A3 | B3 A4 | ...   iteration t issues B(t+2), A(t+DA);
+    // at the top of iteration t the pieces younger than B(t+1) are A(t+2) .. A(t+DA-1): 4 (DA - 2) of them.
+    // BD: A0 B0 A1 [A2] | B1 A(DA) | B2 A(DA+1) ...  iteration t loads the registers of B(t+1) and issues A(t+DA);
+    // the same count holds (the compiler adds its own wait for the B registers where they are first used).
+    constexpr int VM_TOP = 4 * (DA - 2);
+    constexpr int VM_PRE = BD ? 4 * (DA - 1) : 4 + 4 * NB + 4 * (DA - 2);     // A0, B0 landed
+    Gen gA, gB;
+    gen_init(gA);
+    gen_init(gB);
+    int32_t nb[4];
+    int aS = 0, bS = 0;          // ring slots the NEXT issue goes to
+    auto issueA = [&]() {
+      loadNb(gA, nb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) issueA1(gA, nb, aS, i);
+      gen_next(gA);
+      aS = aS + 1 == DA ? 0 : aS + 1;
+    };
+    auto issueB = [&]() {
+#pragma unroll
+      for (int i = 0; i < 4 * NB; ++i) issueB1(gB, bS, i);
+      gen_next(gB);
+      bS ^= 1;
+    };
+    f32x4 a0[4], a1[4], b0[NB][4], b1[NB][4];
+    issueA();
+    if (BD) {
+      loadB(gB, b0);
+      gen_next(gB);
+      issueA();
+    } else {
+      issueB();
+      issueA();
+      issueB();
+    }
+    if (DA >= 3) issueA();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM_PRE) : "memory");
+    readfrag(0, 0, a0, b0);
+    int arS = 1, brS = 1;        // ring slots the NEXT fragment read takes
+    // one iteration: fragments of step s+1 <- LDS, DMA of B(s+2) and A(s+DA), MFMAs of step s -- interleaved by hand
+    // (left alone hipcc puts all 16 MFMAs behind the whole issue block and waits lgkmcnt(0) after every table read)
+    auto iter = [&](const f32x4 (&ac)[4], const f32x4 (&bc)[NB][4], f32x4 (&an)[4], f32x4 (&bn)[NB][4]) {
+      // A(s+1), B(s+1) landed; the fragment reads of step s are back
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(VM_TOP) : "memory");
+      // the first MFMAs go ahead of the new LDS reads: hipcc cannot see that the asm wait above covered the current
+      // fragments and puts its own lgkmcnt(0) in front of the first MFMA -- with nothing pending there it is free
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(ac, bc, 0, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      readfrag(arS, brS, an, bn);
+      arS = arS + 1 == DA ? 0 : arS + 1;
+      brS ^= 1;
+      loadNb(gA, nb);
+      __builtin_amdgcn_sched_barrier(0);
+      if (BD) {
+        loadB(gB, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(ac, bc, 4, 8);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4 * NB; ++i) {
+          issueB1(gB, bS, i);
+          if (i % NB == NB - 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(ac, bc, 4 + i / NB, 5 + i / NB);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        bS ^= 1;
+      }
+      gen_next(gB);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        issueA1(gA, nb, aS, i);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(ac, bc, 8 + i, 9 + i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      gen_next(gA);
+      aS = aS + 1 == DA ? 0 : aS + 1;
+      mfma(ac, bc, 12, 16);
+    };
+    for (int s = 0; s < T; s += 2) {
+      iter(a0, b0, a1, b1);
+      if (s + 1 < T) iter(a1, b1, a0, b0);
+    }
+  }
+  // every DMA (the dummies of the tail included) must have landed before this wave's LDS is reused or released
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (DIAG) d_t2 = __builtin_amdgcn_s_memtime();
+
+  // ---- epilogue.  C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * half
+  const bool final_pass = gridDim.z == 1;
+  float* const dst = final_pass ? out : partial + (int64_t)blockIdx.z * M_out * Cout;
+  if (!final_pass) {
+    bias = nullptr;
+    residual = nullptr;
+  }
+  if (NW == 1) {
+    // the residual test is hoisted over the whole tile and the values are pinned before the (row-masked) stores: with
+    // a per-element "load or zero" select hipcc branches around every load and waits vmcnt(0) in every store block
+    auto store_tile = [&](auto has_res) {
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) {
+        const int c = col0 + cb * 32 + r31;
+        const float bv = bias ? bias[c] : 0.0f;
+        int32_t rows[16];
+        float val[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) rows[reg] = rowId[(reg & 3) + 8 * (reg >> 2) + 4 * half];
+        if (decltype(has_res)::value) {
+          float rv[16];
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg)    // 16 loads in flight together (row 0 for the masked ones)
+            rv[reg] = residual[(int64_t)(rows[reg] >= 0 ? rows[reg] : 0) * Cout + c];
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) val[reg] = (acc[cb][reg] + bv) + rv[reg];
+        } else {
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) val[reg] = acc[cb][reg] + bv;
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) asm volatile("" : "+v"(val[reg]));
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if (rows[reg] >= 0) dst[(int64_t)rows[reg] * Cout + c] = val[reg];
+      }
+    };
+    if (residual)
+      store_tile(std::true_type{});
+    else
+      store_tile(std::false_type{});
+  } else {
+    // accumulators -> this wave's ring memory as [row][NB*32 cols]; then every thread adds the NW copies in wave order
+    float* red = reinterpret_cast<float*>(Aring);
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        red[rr * (NB * 32) + cb * 32 + r31] = acc[cb][reg];
+      }
+    __syncthreads();
+    const int32_t* rowId0 = rowId;
+    for (int e = threadIdx.x; e < 32 * NB * 32; e += 64 * NW) {
+      const int rr = e / (NB * 32), cc = e - rr * (NB * 32);
+      const int32_t r = rowId0[rr];
+      if (r < 0) continue;
+      float v = 0.0f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        v += reinterpret_cast<const float*>(lds + HDR_BYTES + w * L::WAVE_BYTES)[e];
+      const int c = col0 + cc;
+      if (bias) v += bias[c];
+      const int64_t o = (int64_t)r * Cout + c;
+      if (residual) v += residual[o];
+      dst[o] = v;
+    }
+  }
+  if (DIAG && dbg && threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    unsigned long long* d = dbg + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    d[0] = d_r0;
+    d[1] = __builtin_amdgcn_s_memrealtime();
+    d[2] = d_t1 - d_t0;
+    d[3] = d_t2 - d_t1;
+    d[4] = t3 - d_t2;
+    d[5] = (unsigned long long)T;
+    d[6] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID, 32 bits
+    d[7] = 0;
+  }
+}
+
+// out = sum_z partial[z] (+ bias, + residual), four channels per thread, z order fixed
+__global__ void spconv2_reduce_kernel(const float4* __restrict__ partial, const float4* __restrict__ bias,
+                                      const float4* __restrict__ residual, float4* __restrict__ out, int64_t total4,
+                                      int cout4, int zs) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total4;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll 4
+    for (int z = 0; z < zs; ++z) {
+      const float4 v = partial[(int64_t)z * total4 + t];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) {
+      const float4 v = bias[t % cout4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (residual) {
+      const float4 v = residual[t];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    out[t] = s;
+  }
+}
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// NB: output blocks per work item; NW: waves per work item; ZS: offset groups over blockIdx.z (partial slabs);
+// DA: depth of the gathered-row ring.  Aim for ~2 waves per SIMD over the whole launch.
+struct Plan2 {
+  int NB, NW, ZS, DA, BD;
+};
+
+Plan2 plan2(int64_t M_out, int K, int Cin, int Cout) {
+  static int nb_pref = -1, target = -1, nw_force = -1, zs_force = -1, da_pref = -1, nw_max = -1, bd_pref = -1;
+  if (nb_pref < 0) {
+    bd_pref = env_int("WSIS_FWD2_BD", 1);
+    nb_pref = env_int("WSIS_FWD2_NB", 1);
+    target = env_int("WSIS_FWD2_WAVES", 2048);
+    nw_force = env_int("WSIS_FWD2_NW", 0);
+    zs_force = env_int("WSIS_FWD2_ZS", 0);
+    da_pref = env_int("WSIS_FWD2_DA", 3);
+    nw_max = env_int("WSIS_FWD2_NW_MAX", 4);
+  }
+  Plan2 p;
+  const int nblk = Cout / 32;
+  p.NB = (nb_pref >= 2 && nblk % 2 == 0) ? 2 : 1;
+  const int64_t items = ceil_div(M_out, SL) * (nblk / p.NB);
+  const int steps = K * (Cin / 32);     // steps of a dense work item
+  int nw = 1;
+  while (nw < nw_max && items * nw * 2 <= target && nw * 2 <= steps) nw *= 2;
+  if (nw_force > 0) nw = nw_force;
+  int zs = 1;
+  while (zs < 8 && items * nw * zs * 2 <= target && zs * 2 <= K && steps / (nw * zs * 2) >= 2) zs *= 2;
+  if (zs_force > 0) zs = zs_force;
+  if (zs > K) zs = K;
+  p.NW = nw;
+  p.ZS = zs;
+  p.DA = (da_pref == 2 || nw >= 4) ? 2 : 3;     // 4+ waves per workgroup: two workgroups per CU need the short ring
+  p.BD = bd_pref ? 1 : 0;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t wsis_spconv_fwd_t_supported(int32_t K, int32_t Cin, int32_t Cout) {
+  return (K >= 1 && K <= KMAX && Cin >= 32 && Cin % 32 == 0 && Cout >= 32 && Cout % 32 == 0) ? 1 : 0;
+}
+
+int64_t wsis_spconv_fwd_t_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout) {
+  if (M_out < 0 || !wsis_spconv_fwd_t_supported(K, Cin, Cout)) return -1;
+  const Plan2 p = plan2(M_out, K, Cin, Cout);
+  return p.ZS <= 1 ? 256 : (int64_t)p.ZS * M_out * Cout * (int64_t)sizeof(float) + 256;
+}
+
+int wsis_spconv_fwd_t(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT, int32_t flip,
+                      const float* d_bias, const float* d_residual, float* d_out, int64_t M_in, int64_t M_out,
+                      int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(M_in >= 0 && M_out >= 0, "bad sizes");
+  WSIS_REQUIRE(wsis_spconv_fwd_t_supported(K, Cin, Cout), "needs K <= 32 and channel counts that are multiples of 32");
+  if (M_out == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_X && d_WT && d_out, "null pointer");
+  WSIS_REQUIRE(d_nbr || (K == 1 && M_in == M_out), "nbr may be null only for the dense 1x1 case");
+  WSIS_REQUIRE(M_out < (int64_t)1 << 31 && M_in < (int64_t)1 << 31, "row count exceeds int32");
+  WSIS_REQUIRE(((reinterpret_cast<uintptr_t>(d_X) | reinterpret_cast<uintptr_t>(d_WT)) & 15) == 0,
+               "X and WT must be 16-byte aligned");
+  const Plan2 p = plan2(M_out, K, Cin, Cout);
+  float* partial = nullptr;
+  if (p.ZS > 1) {
+    WSIS_REQUIRE(d_ws && ws_bytes >= (int64_t)p.ZS * M_out * Cout * (int64_t)sizeof(float), "workspace too small");
+    WSIS_REQUIRE((reinterpret_cast<uintptr_t>(d_ws) & 15) == 0, "workspace must be 16-byte aligned");
+    partial = static_cast<float*>(d_ws);
+  }
+  hipStream_t st = as_stream(stream);
+  const dim3 grid((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32 / p.NB), (unsigned)p.ZS);
+  ProfScope prof(0, st);
+#define WSIS_F2X(nb, nw, da, bd)                                                                                 \
+  do {                                                                                                           \
+    const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<nb, da, bd>::WAVE_BYTES * nw;                         \
+    static bool attr_set = false;                                                                                \
+    if (!attr_set) {                                                                                             \
+      WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_fwd2_kernel<nb, nw, da, bd>,                        \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));               \
+      attr_set = true;                                                                                           \
+    }                                                                                                            \
+    hipLaunchKernelGGL((spconv_fwd2_kernel<nb, nw, da, bd>), grid, dim3(64 * nw), ldsb, st, d_X, d_nbr, d_order, \
+                       d_WT, d_bias, d_residual, d_out, partial, M_out, K, Cin, Cout, flip);                     \
+  } while (0)
+#define WSIS_F2(nb, nw, da)      \
+  if (p.BD)                      \
+    WSIS_F2X(nb, nw, da, true);  \
+  else                           \
+    WSIS_F2X(nb, nw, da, false)
+  const int key = p.NB * 100 + p.NW * 10 + p.DA;
+  switch (key) {
+    case 113: WSIS_F2(1, 1, 3); break;
+    case 112: WSIS_F2(1, 1, 2); break;
+    case 123: WSIS_F2(1, 2, 3); break;
+    case 122: WSIS_F2(1, 2, 2); break;
+    case 142: WSIS_F2(1, 4, 2); break;
+    case 182: WSIS_F2(1, 8, 2); break;
+    case 213: WSIS_F2(2, 1, 3); break;
+    case 212: WSIS_F2(2, 1, 2); break;
+    case 223: WSIS_F2(2, 2, 3); break;
+    case 222: WSIS_F2(2, 2, 2); break;
+    case 242: WSIS_F2(2, 4, 2); break;
+    default:
+      return fail(WSIS_ERR_ARG, "spconv_fwd_t: unsupported plan NB=%d NW=%d DA=%d", p.NB, p.NW, p.DA);
+  }
+#undef WSIS_F2
+#undef WSIS_F2X
+  prof.stop();
+  WSIS_LAUNCH_CHECK();
+  if (p.ZS > 1) {
+    const int64_t total4 = M_out * Cout / 4;
+    hipLaunchKernelGGL(spconv2_reduce_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(partial), reinterpret_cast<const float4*>(d_bias),
+                       reinterpret_cast<const float4*>(d_residual), reinterpret_cast<float4*>(d_out), total4, Cout / 4,
+                       p.ZS);
+    WSIS_LAUNCH_CHECK();
+  }
+  return WSIS_OK;
+}
+
+// diagnostic (not part of the ABI header): the NW = 1 kernel with per-workgroup stamps, dbg[ceil(M/32) * Cout/32 * 8];
+// variant 0: weights direct to registers, ring depth 2; 1: both operands through LDS rings, depth 3
+int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT,
+                            float* d_out, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, int32_t variant,
+                            unsigned long long* d_dbg, void* stream) {
+  WSIS_REQUIRE(wsis_spconv_fwd_t_supported(K, Cin, Cout) && d_dbg, "bad args");
+  const dim3 grid((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32), 1);
+  hipStream_t st = as_stream(stream);
+  if (variant == 0) {
+    const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES;
+    hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 2, true, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order, d_WT,
+                       (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, 0,
+                       d_dbg);
+  } else {
+    const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 3, false>::WAVE_BYTES;
+    hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 3, false, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order, d_WT,
+                       (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, 0,
+                       d_dbg);
+  }
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+}  // extern "C"

@@ -380,6 +380,38 @@ def _conv(X, nbr, order, W, bias, residual, M_out):
     return out
 
 
+def _use_fwd2(K, Cin, Cout):
+    """the wave-autonomous LDS-DMA kernel (csrc/spconv2.hip) where it applies; WSIS_FWD2=0 keeps the round-1 kernel"""
+    return os.environ.get("WSIS_FWD2", "1") != "0" and bool(_n.hip().wsis_spconv_fwd_t_supported(K, Cin, Cout))
+
+
+_WS2_CACHE = {}
+
+
+def _conv_t(X, nbr, order, WT, flip, bias, residual, M_out):
+    """out[r] = sum_k X[nbr[k][r]] @ W[k] with the weights as B^T: WT [K,Cout,Cin] (slice K-1-k when ``flip``)."""
+    K, Cout, Cin = WT.shape
+    out = torch.empty((M_out, Cout), dtype=torch.float32, device=X.device)
+    prof = PROFILER
+    if prof is not None:
+        P = prof.pairs(nbr, M_out)
+    lib = _n.hip()
+    key = (M_out, K, Cin, Cout)
+    ws_bytes = _WS2_CACHE.get(key)
+    if ws_bytes is None:
+        ws_bytes = lib.wsis_spconv_fwd_t_workspace_bytes(M_out, K, Cin, Cout)
+        if len(_WS2_CACHE) > 4096:
+            _WS2_CACHE.clear()
+        _WS2_CACHE[key] = ws_bytes
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device) if ws_bytes > 256 else None
+    _n.check(lib.wsis_spconv_fwd_t(_n.ptr(X), _n.ptr(nbr), _n.ptr(order), _n.ptr(WT), int(flip), _n.ptr(bias),
+                                   _n.ptr(residual), _n.ptr(out), X.shape[0], M_out, K, Cin, Cout, _n.ptr(ws),
+                                   ws_bytes, _n.stream_ptr()), "spconv_fwd_t")
+    if prof is not None:
+        prof.end("spconv_fwd_kernel", None, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout)
+    return out
+
+
 def _weight_t(W, flip):
     K, Cin, Cout = W.shape
     WT = torch.empty((K, Cout, Cin), dtype=torch.float32, device=W.device)
@@ -422,7 +454,10 @@ class SparseConvFunction(Function):
             W = W.contiguous().float()
         W = W.view(-1, Cin, Cout)
         b = bias.contiguous().float() if bias is not None else None
-        out = _conv(X, nbr_f, order_f, W, b, None, M_out)
+        if _use_fwd2(W.shape[0], Cin, Cout):
+            out = _conv_t(X, nbr_f, order_f, _weight_t(W, 0), 0, b, None, M_out)
+        else:
+            out = _conv(X, nbr_f, order_f, W, b, None, M_out)
         ctx.save_for_backward(X, W)
         ctx.aux = (nbr_f, order_f, nbr_b, order_b, flip, weight.shape, bias is not None)
         return out
@@ -435,8 +470,11 @@ class SparseConvFunction(Function):
         K, Cin, Cout = W.shape
         dX = dW = db = None
         if ctx.needs_input_grad[0]:
-            WT = _weight_t(W, flip)
-            dX = _conv(dY, nbr_b, order_b, WT, None, None, X.shape[0])
+            if _use_fwd2(K, Cout, Cin):    # dIn: the weight itself is the B^T operand ([K, Cin, Cout]: rows = dIn outputs)
+                dX = _conv_t(dY, nbr_b, order_b, W, flip, None, None, X.shape[0])
+            else:
+                WT = _weight_t(W, flip)
+                dX = _conv(dY, nbr_b, order_b, WT, None, None, X.shape[0])
         if ctx.needs_input_grad[1]:
             dW = _dw(X, nbr_f, order_f, dY, K, Cin, Cout).view(wshape)
         if has_bias and ctx.needs_input_grad[2]:

@@ -193,6 +193,20 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
                     const float* d_bias, const float* d_residual, float* d_out, int64_t M_in,
                     int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
                     void* stream);
+/* The same product with the weights given as B^T, d_WT [K,Cout,Cin] (row = output channel, Cin contiguous) -- the
+ * wave-autonomous LDS-DMA kernel (csrc/spconv2.hip) that every UNet layer with channel counts that are multiples of 32
+ * runs on (wsis_spconv_fwd_t_supported; K <= 32).  Replaces the same upstream call sites as wsis_spconv_fwd:
+ *   forward (sparse_unet3d.py:130,261,292) : d_WT = wsis_weight_transpose(weight, flip=0), flip = 0
+ *   dIn (autograd backward)    : d_WT = the layer's own weight [K,Cin_fwd,Cout_fwd] (its rows ARE the dIn
+ *                                            output channels), flip = 1 for submanifold tables (offset k uses
+ *                                            slice K-1-k), 0 for the coupled strided / inverse tables
+ * with NW = 1 bit-identical to wsis_spconv_fwd; small levels split the offsets over the waves of a workgroup (added
+ * through LDS in wave order) and, below that, over blockIdx.z into partial slabs in d_ws (fixed order). */
+int32_t wsis_spconv_fwd_t_supported(int32_t K, int32_t Cin, int32_t Cout);
+int64_t wsis_spconv_fwd_t_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout);
+int wsis_spconv_fwd_t(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT, int32_t flip,
+                      const float* d_bias, const float* d_residual, float* d_out, int64_t M_in, int64_t M_out,
+                      int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes, void* stream);
 /* WT[k'] = W[k]^T with k' = (flip ? K-1-k : k); W [K,Cin,Cout] -> WT [K,Cout,Cin]. */
 int wsis_weight_transpose(const float* d_W, float* d_WT, int32_t K, int32_t Cin, int32_t Cout,
                           int32_t flip, void* stream);

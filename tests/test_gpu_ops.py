@@ -881,3 +881,74 @@ def test_fused_discriminative_loss_matches_torch_formulation(S, I, keep):
                                       crit.param_var, crit.param_dist, crit.param_reg)
     (l2 * 1.3).backward()
     assert torch.equal(l2, loss) and torch.equal(x2.grad, xg.grad)
+
+
+@pytest.mark.gpu
+def test_flat_adamw_is_a_torch_optimizer_with_live_param_groups():
+    """the reference's schedule (PolyLR, an _LRScheduler of power 0.9 stepped per epoch: train_scannetv2.py:93-115,269)
+    drives FlatAdamW through ``param_groups``; the state dict survives a round trip into a USED optimizer without stale
+    moments (parameters absent from the checkpoint are reset)."""
+    import wsis_optim as optim
+    g = torch.Generator().manual_seed(5)
+    shapes = [(3, 3, 3, 6, 32), (32,), (7, 64)]
+    a = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    mine = optim.FlatAdamW(a, lr=1e-3, weight_decay=1e-4)
+    ref = torch.optim.AdamW(b, lr=1e-3, weight_decay=1e-4, foreach=False, fused=False)
+    assert isinstance(mine, torch.optim.Optimizer) and len(mine.param_groups) == 1
+    poly = lambda e: (1 - e / 8) ** 0.9            # noqa: E731 -- utils/lr_scheduler.py PolyLR
+    s_mine = torch.optim.lr_scheduler.LambdaLR(mine, poly)
+    s_ref = torch.optim.lr_scheduler.LambdaLR(ref, poly)
+    for epoch in range(4):
+        for p, q in zip(a, b):
+            gr = torch.randn(p.shape, generator=g).cuda()
+            p.grad, q.grad = gr, gr.clone()
+        mine.step()
+        ref.step()
+        s_mine.step()
+        s_ref.step()
+        assert abs(mine.param_groups[0]["lr"] - ref.param_groups[0]["lr"]) < 1e-12 and mine.lr < 1e-3
+        for p, q in zip(a, b):
+            assert float((p - q).abs().max()) <= 2e-6 * float(q.abs().max()) + 1e-9, epoch
+    sd = mine.state_dict()
+    assert "initial_lr" in sd["param_groups"][0] and abs(sd["param_groups"][0]["lr"] - mine.lr) < 1e-15
+    # resume into a USED optimizer from a checkpoint that lacks parameter 1: its moments and step count are reset
+    del sd["state"][1]
+    other = optim.FlatAdamW(a, lr=5e-4, weight_decay=1e-4)
+    for p in a:
+        p.grad = torch.ones_like(p)
+    other.step()
+    other.load_state_dict(sd)
+    assert abs(other.lr - mine.lr) < 1e-15 and other.steps.tolist() == [4, 0, 4]
+    n0, n1 = a[0].numel(), a[1].numel()
+    off1 = (n0 + 3) // 4 * 4
+    assert float(other.exp_avg[off1:off1 + n1].abs().max()) == 0.0
+    assert torch.equal(other.exp_avg[:n0], mine.exp_avg[:n0])
+
+
+@pytest.mark.gpu
+def test_rulebooks_wait_for_coordinates_produced_late_on_the_main_stream():
+    """a drop-in caller builds ``SparseConvTensor(feats, coords.int(), ...)`` on the main stream, which may still hold
+    a backlog; the side-stream rulebook build must be ordered behind the producer of the coordinates even without
+    the harness's private ready event"""
+    from spconv import ops as sp_ops
+    rng = np.random.default_rng(9)
+    shape = (40, 36, 30)
+    occ = np.argwhere(rng.random(shape) < 0.08)
+    idx_h = np.concatenate([np.zeros((len(occ), 1), np.int64), occ], 1)
+    want = ref.subm_pairs_fast(idx_h.astype(np.int32), shape, 3, 1)
+    for _ in range(3):
+        big = torch.randn(4096, 4096, device=DEV)
+        for _ in range(30):                               # tens of milliseconds of backlog on the main stream
+            big = (big @ big) * 1e-3
+        pinned = torch.from_numpy(idx_h).pin_memory()
+        coords = torch.empty(idx_h.shape, dtype=torch.int64, device=DEV).fill_(-7)     # garbage until the copy lands
+        coords.copy_(pinned, non_blocking=True)
+        t = spconv.SparseConvTensor(torch.zeros(len(occ), 4, device=DEV), coords.int(), np.array(shape), 1)
+        sp_ops.prebuild_unet_rulebooks(t, 2)
+        rb = t.indice_dict["subm1"]
+        torch.cuda.synchronize()
+        pairs, num = rb.to_pairs()
+        for k in range(27):
+            got = set(map(tuple, pairs[k, :, :int(num[k])].t().cpu().numpy().tolist()))
+            assert got == set(map(tuple, np.asarray(want[k]).T.tolist())), k

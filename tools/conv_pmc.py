@@ -8,10 +8,11 @@ if len(sys.argv) > 2 and sys.argv[1] == "--parse":
     acc = {}
     for f in glob.glob(os.path.join(sys.argv[2], "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "spconv_fwd_kernel" in r["Kernel_Name"]:
-                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            for kn in ("spconv_fwd_kernel", "spconv_fwd2_kernel"):
+                if kn + "<" in r["Kernel_Name"]:
+                    acc.setdefault((kn, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     for k, v in sorted(acc.items()):
-        print(f"{k:32s} launches {len(v):4d}  mean {sum(v)/len(v):16.1f}")
+        print(f"{k[0]:20s} {k[1]:32s} launches {len(v):4d}  mean {sum(v)/len(v):16.1f}")
     sys.exit(0)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); importlib.import_module("3d-wsis_amd")
 import torch, harness
@@ -25,6 +26,8 @@ for l in range(level):
 rb = ops.build_subm_rulebook(idx, shape, [3]*3, [1]*3)
 C = 32 * (level + 1); M = idx.shape[0]
 X = torch.randn(M, C, device=dev); W = torch.randn(27, C, C, device=dev) * 0.05
+WT = ops._weight_t(W, 0)
 for _ in range(10):
     ops._conv(X, rb.nbr_p, rb.order, W, None, None, M)
+    ops._conv_t(X, rb.nbr_p, rb.order, WT, 0, None, None, M)
 torch.cuda.synchronize()
