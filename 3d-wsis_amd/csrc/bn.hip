@@ -132,6 +132,41 @@ __global__ __launch_bounds__(64) void bn_stats_final_kernel(const float* __restr
   }
 }
 
+// the same from CENTRED partials of 32-row slices (written by the convolution epilogues, csrc/spconv2.hip): slice i
+// holds S_i = sum and Q_i = sum of squared deviations from ITS mean over n_i = min(32, M - 32 i) rows;
+// mean = sum S_i / M, var = (sum Q_i + sum S_i^2 / n_i - M mean^2) / M, all in fp64 (Chan's pairwise combination)
+__global__ __launch_bounds__(64) void bn_stats_final_centred_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                                    int64_t M, float* __restrict__ mean,
+                                                                    float* __restrict__ var,
+                                                                    float* __restrict__ running_mean,
+                                                                    float* __restrict__ running_var, float momentum) {
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0, w = 0.0;
+#pragma unroll 4
+  for (int b = threadIdx.x; b < nblk; b += 64) {
+    const double si = partial[(int64_t)b * 2 * C + c];
+    const int64_t left = M - (int64_t)b * 32;
+    const double ni = (double)(left < 32 ? left : 32);
+    s += si;
+    q += partial[(int64_t)b * 2 * C + C + c];
+    w += si * si / ni;
+  }
+  const double S = wave_sum_f64(s), Q = wave_sum_f64(q), W = wave_sum_f64(w);
+  if (threadIdx.x == 0) {
+    const double n = (double)M;
+    const double mu = S / n;
+    double v = (Q + (W - n * mu * mu)) / n;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)mu;
+    var[c] = (float)v;
+    if (running_mean) {
+      const double unb = n > 1 ? v * n / (n - 1) : v;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+  }
+}
+
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                 const float* __restrict__ var, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, int relu, float* __restrict__ y,
@@ -568,6 +603,18 @@ int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* 
   WSIS_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, st, partial, nblk, C, Cp, M, d_mean,
                      d_var, d_running_mean, d_running_var, momentum);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, int32_t C, float* d_mean, float* d_var,
+                           float* d_running_mean, float* d_running_var, float momentum, void* stream) {
+  WSIS_REQUIRE(n_part >= 1 && M >= 1 && C >= 1 && d_partials && d_mean && d_var, "bad args");
+  WSIS_REQUIRE(n_part < ((int64_t)1 << 31), "too many partials");
+  WSIS_REQUIRE((d_running_mean == nullptr) == (d_running_var == nullptr), "running stats come in pairs");
+  WSIS_REQUIRE(n_part == (M + 31) / 32, "one partial per 32-row slice");
+  hipLaunchKernelGGL(bn_stats_final_centred_kernel, dim3(C), dim3(64), 0, as_stream(stream), d_partials, (int)n_part, C,
+                     M, d_mean, d_var, d_running_mean, d_running_var, momentum);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

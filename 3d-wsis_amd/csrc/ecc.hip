@@ -149,6 +149,145 @@ int waves_grid(int64_t n) {
   return (int)g;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Edge-conditioned messages WITHOUT the per-edge filter tensor.  The filter of edge e is an affine map
+// of its fnet hidden state h_e in R^64: W_e[a,b] = sum_c Wl[a*32+b, c] h_e[c] + bl[a*32+b] (graphnet.py:19-36, last
+// Linear), so   m_e = x_t @ W_e = sum_c h_e[c] U_t[c,:] + U_t[64,:]   with   U_t[c,b] = sum_a x_t[a] Wl[a*32+b, c]
+// (row 64: the bias term) -- a per-NODE tensor U [S, 65*32] from one small GEMM per GRU step instead of a per-EDGE
+// [E, 1024] tensor read 7 times each way.  One wavefront per target node t: U_t stays in registers while the wave
+// walks the in-edges of t (h_e rows through a per-wave LDS slot, broadcast reads); the mean over the out-edges of
+// the source follows as the segmented mean the rest of the path already uses.
+constexpr int EH = 64;           // fnet hidden width
+constexpr int EU = (EH + 1) * EC;   // floats of U per node
+constexpr int EBATCH = 8;        // in-edges staged per trip
+
+// m[e,b] = sum_c h[e,c] U[t,c,b] + U[t,64,b]   for the in-edges e of t (CSR over targets)
+__global__ __launch_bounds__(256) void ecc_contract_fwd_kernel(const float* __restrict__ h, const float* __restrict__ U,
+                                                               const int32_t* __restrict__ perm_dst,
+                                                               const int32_t* __restrict__ off_dst,
+                                                               float* __restrict__ m, int64_t S) {
+  __shared__ __attribute__((aligned(16))) float hs[4][EBATCH][EH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = lane & 31, half = lane >> 5;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < S; t += nwaves) {
+    const int beg = off_dst[t], end = off_dst[t + 1];
+    if (beg == end) continue;
+    const float* Ut = U + t * EU;
+    float u[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) u[j] = Ut[(half * 32 + j) * EC + b];
+    const float ub = Ut[EH * EC + b];
+    for (int j0 = beg; j0 < end; j0 += EBATCH) {
+      const int n = min(EBATCH, end - j0);
+      int32_t eid[EBATCH];
+#pragma unroll
+      for (int i = 0; i < EBATCH; ++i) eid[i] = perm_dst[i < n ? j0 + i : j0];
+      float hv[EBATCH];
+#pragma unroll
+      for (int i = 0; i < EBATCH; ++i) hv[i] = h[(int64_t)eid[i] * EH + lane];
+#pragma unroll
+      for (int i = 0; i < EBATCH; ++i) hs[wave][i][lane] = hv[i];
+#pragma unroll
+      for (int i = 0; i < EBATCH; ++i) {
+        if (i < n) {       // wave-uniform
+          float p = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(&hs[wave][i][half * 32 + q * 4]);
+            p += v.x * u[q * 4 + 0];
+            p += v.y * u[q * 4 + 1];
+            p += v.z * u[q * 4 + 2];
+            p += v.w * u[q * 4 + 3];
+          }
+          p += __shfl_xor(p, 32, 64);
+          if (half == 0) m[(int64_t)eid[i] * EC + b] = p + ub;
+        }
+      }
+    }
+  }
+}
+
+// dU[t,c,b] = sum_{e in in(t)} haug[e,c] dm[e,b] (haug[e,64] = 1);  dh[e,c] = sum_b dm[e,b] U[t,c,b]
+__global__ __launch_bounds__(256) void ecc_contract_bwd_kernel(const float* __restrict__ h, const float* __restrict__ U,
+                                                               const float* __restrict__ dm,
+                                                               const int32_t* __restrict__ perm_dst,
+                                                               const int32_t* __restrict__ off_dst,
+                                                               float* __restrict__ dU, float* __restrict__ dh, int64_t S) {
+  __shared__ __attribute__((aligned(16))) float hs[4][EBATCH][EH];
+  __shared__ __attribute__((aligned(16))) float ds[4][EBATCH][EC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = lane & 31, half = lane >> 5;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < S; t += nwaves) {
+    const int beg = off_dst[t], end = off_dst[t + 1];
+    float* dUt = dU + t * EU;
+    if (beg == end) {      // no in-edge: the node's U is unused
+      for (int i = lane; i < EU; i += 64) dUt[i] = 0.0f;
+      continue;
+    }
+    const float* Ut = U + t * EU;
+    // lane c (0..63) keeps row c of U_t for the dh pass: 32 contiguous floats
+    float ur[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(Ut + lane * EC + q * 4);
+      ur[q * 4 + 0] = v.x; ur[q * 4 + 1] = v.y; ur[q * 4 + 2] = v.z; ur[q * 4 + 3] = v.w;
+    }
+    float du[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) du[j] = 0.0f;
+    float dub = 0.0f;
+    for (int j0 = beg; j0 < end; j0 += EBATCH) {
+      const int n = min(EBATCH, end - j0);
+      int32_t eid[EBATCH];
+#pragma unroll
+      for (int i = 0; i < EBATCH; ++i) eid[i] = perm_dst[i < n ? j0 + i : j0];
+      float hv[EBATCH], dv[EBATCH];
+#pragma unroll
+      for (int i = 0; i < EBATCH; ++i) {
+        hv[i] = h[(int64_t)eid[i] * EH + lane];
+        dv[i] = dm[(int64_t)eid[i] * EC + b];
+      }
+#pragma unroll
+      for (int i = 0; i < EBATCH; ++i) {
+        hs[wave][i][lane] = hv[i];
+        if (half == 0) ds[wave][i][b] = dv[i];
+      }
+#pragma unroll
+      for (int i = 0; i < EBATCH; ++i) {
+        if (i < n) {       // wave-uniform; edges in CSR order: a fixed order of additions
+          // dU: lane (b, half) adds h[e, half*32 + j] * dm[e, b]
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(&hs[wave][i][half * 32 + q * 4]);
+            du[q * 4 + 0] += v.x * dv[i];
+            du[q * 4 + 1] += v.y * dv[i];
+            du[q * 4 + 2] += v.z * dv[i];
+            du[q * 4 + 3] += v.w * dv[i];
+          }
+          dub += dv[i];
+          // dh: lane c adds dm[e, :] . U_t[c, :]
+          float p = 0.0f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(&ds[wave][i][q * 4]);
+            p += v.x * ur[q * 4 + 0];
+            p += v.y * ur[q * 4 + 1];
+            p += v.z * ur[q * 4 + 2];
+            p += v.w * ur[q * 4 + 3];
+          }
+          dh[(int64_t)eid[i] * EH + lane] = p;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) dUt[(half * 32 + j) * EC + b] = du[j];
+    if (half == 0) dUt[EH * EC + b] = dub;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -179,6 +318,31 @@ int wsis_ecc_message_bwd(const float* d_x, const float* d_w, const float* d_dout
   else
     hipLaunchKernelGGL(ecc_msg_bwd_kernel, dim3(waves_grid(S)), dim3(256), 0, as_stream(stream), d_x, d_w, d_dout,
                        d_src, d_perm_dst, d_off_dst, d_off_src, d_dx, d_dw, S, C);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+
+int wsis_ecc_contract_fwd(const float* d_h, const float* d_U, const int32_t* d_perm_dst, const int32_t* d_off_dst,
+                          float* d_m, int64_t S, int64_t E, void* stream) {
+  WSIS_REQUIRE(S >= 0 && E >= 0, "bad sizes");
+  if (S == 0 || E == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_h && d_U && d_perm_dst && d_off_dst && d_m, "null pointer");
+  WSIS_REQUIRE(((reinterpret_cast<uintptr_t>(d_U) | reinterpret_cast<uintptr_t>(d_h)) & 15) == 0, "16-byte alignment");
+  hipLaunchKernelGGL(ecc_contract_fwd_kernel, dim3(waves_grid(S)), dim3(256), 0, as_stream(stream), d_h, d_U, d_perm_dst,
+                     d_off_dst, d_m, S);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_ecc_contract_bwd(const float* d_h, const float* d_U, const float* d_dm, const int32_t* d_perm_dst,
+                          const int32_t* d_off_dst, float* d_dU, float* d_dh, int64_t S, int64_t E, void* stream) {
+  WSIS_REQUIRE(S >= 0 && E >= 0, "bad sizes");
+  if (S == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_U && d_off_dst && d_dU && (E == 0 || (d_h && d_dm && d_perm_dst && d_dh)), "null pointer");
+  WSIS_REQUIRE(((reinterpret_cast<uintptr_t>(d_U) | reinterpret_cast<uintptr_t>(d_h)) & 15) == 0, "16-byte alignment");
+  hipLaunchKernelGGL(ecc_contract_bwd_kernel, dim3(waves_grid(S)), dim3(256), 0, as_stream(stream), d_h, d_U, d_dm,
+                     d_perm_dst, d_off_dst, d_dU, d_dh, S);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void weight_transpose_batch_kernel(WtBatch b) 
 struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t join = nullptr;
+  hipEvent_t mark_main = nullptr, mark_side = nullptr;   // milestone of wsis_run_ops_marked
   std::vector<hipEvent_t> fork;
   size_t next = 0;
 };
@@ -135,6 +136,8 @@ SideStream* side_stream_for(hipStream_t main) {
   if (!s.stream) {
     if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.mark_main, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.mark_side, hipEventDisableTiming) != hipSuccess) return nullptr;
   }
   return &s;
 }
@@ -213,7 +216,13 @@ int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n) {
 }
 
 int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* stream) {
+  return wsis_run_ops_marked(ops, n, d_ws, ws_bytes, stream, -1, nullptr);
+}
+
+int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* stream, int32_t mark_op,
+                        void* waiter_stream) {
   WSIS_REQUIRE(ops && n >= 0, "bad op list");
+  WSIS_REQUIRE(mark_op < n && (mark_op < 0 || waiter_stream), "bad milestone");
   WSIS_REQUIRE(ws_bytes >= wsis_run_ops_workspace_bytes(ops, n) && (d_ws || n == 0), "workspace too small");
   hipStream_t st = as_stream(stream);
   char* ws = static_cast<char*>(d_ws);
@@ -287,8 +296,9 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
         if (wt_off[i] >= 0)
           rc = wsis_spconv_fwd_t((const float*)op.in[0], (const int32_t*)op.in[1], (const int32_t*)op.in[2],
                                  reinterpret_cast<const float*>(wt_base + wt_off[i]), 0, (const float*)op.in[4],
-                                 (const float*)op.in[5], (float*)op.out[0], op.M_in, op.M_out, op.K, op.Cin, op.Cout,
-                                 ws, ws_bytes, stream);
+                                 (const float*)op.in[5], (float*)op.out[0],
+                                 (op.flags & WSIS_OPF_STATS) ? (float*)op.out[1] : nullptr, op.M_in, op.M_out, op.K,
+                                 op.Cin, op.Cout, ws, ws_bytes, stream);
         else
           rc = wsis_spconv_fwd((const float*)op.in[0], (const int32_t*)op.in[1], (const int32_t*)op.in[2],
                                (const float*)op.in[3], (const float*)op.in[4], (const float*)op.in[5],
@@ -299,9 +309,22 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
         const float* var = (const float*)op.out[2];
         if (op.flags & WSIS_OPF_TRAINING) {
           const bool upd = (op.flags & WSIS_OPF_UPDATE_RUNNING) != 0;
-          rc = wsis_bn_stats((const float*)op.in[0], op.M_in, op.Cin, (float*)op.out[1], (float*)op.out[2],
-                             upd ? (float*)op.in[3] : nullptr, upd ? (float*)op.in[4] : nullptr, op.momentum, ws,
-                             ws_bytes, stream);
+          float* rm = upd ? (float*)op.in[3] : nullptr;
+          float* rv = upd ? (float*)op.in[4] : nullptr;
+          if ((op.flags & WSIS_OPF_STATS) && op.M_in > 0) {
+            // the producers' epilogues left (sum, sum of squares) partials per 32-row slice: no pass over x
+            const int64_t n_part = (op.M_in + 31) / 32;
+            const int C0 = op.in[6] ? op.K : op.Cin;
+            rc = wsis_bn_stats_finalize((const float*)op.in[5], n_part, op.M_in, C0, (float*)op.out[1],
+                                        (float*)op.out[2], rm, rv, op.momentum, stream);
+            if (rc == WSIS_OK && op.in[6])
+              rc = wsis_bn_stats_finalize((const float*)op.in[6], n_part, op.M_in, op.Cin - C0, (float*)op.out[1] + C0,
+                                          (float*)op.out[2] + C0, rm ? rm + C0 : nullptr, rv ? rv + C0 : nullptr,
+                                          op.momentum, stream);
+          } else {
+            rc = wsis_bn_stats((const float*)op.in[0], op.M_in, op.Cin, (float*)op.out[1], (float*)op.out[2], rm, rv,
+                               op.momentum, ws, ws_bytes, stream);
+          }
           if (rc != WSIS_OK) break;
         } else {
           mean = (const float*)op.in[3];
@@ -356,7 +379,8 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
           } else {   // the weight [K, Cin, Cout] is the B^T operand of the dIn product as it stands
             rc = wsis_spconv_fwd_t((const float*)op.in[2], (const int32_t*)op.in[5], (const int32_t*)op.in[6],
                                    (const float*)op.in[1], (op.flags & WSIS_OPF_FLIP) ? 1 : 0, nullptr, nullptr,
-                                   (float*)op.out[0], op.M_out, op.M_in, op.K, op.Cout, op.Cin, rest, rest_bytes, stream);
+                                   (float*)op.out[0], nullptr, op.M_out, op.M_in, op.K, op.Cout, op.Cin, rest, rest_bytes,
+                                   stream);
           }
           if (rc != WSIS_OK) break;
         }
@@ -391,6 +415,22 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
     if (rc != WSIS_OK) {
       first_err = rc;
       break;
+    }
+    if (i == mark_op) {
+      // milestone: waiter_stream continues once everything issued so far -- on the caller's stream AND on the
+      // weight-gradient side stream -- has run (gradient exchange of the finished part of the flat buffer while the
+      // rest of the pass still executes)
+      SideStream* ms = side ? side : side_stream_for(st);
+      hipError_t e = ms ? hipEventRecord(ms->mark_main, st) : hipErrorOutOfMemory;
+      if (e == hipSuccess) e = hipStreamWaitEvent(as_stream(waiter_stream), ms->mark_main, 0);
+      if (e == hipSuccess && forked) {
+        e = hipEventRecord(ms->mark_side, side->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(as_stream(waiter_stream), ms->mark_side, 0);
+      }
+      if (e != hipSuccess) {
+        first_err = fail(WSIS_ERR_HIP, "wsis_run_ops: milestone failed: %s", hipGetErrorString(e));
+        break;
+      }
     }
   }
 #undef RUN_LAUNCH_CHECK

@@ -395,6 +395,10 @@ __global__ void tile_permute_batch_kernel(TileBatch b, const int32_t* __restrict
 int sched_band() {
   static int cus = 0;
   if (cus == 0) {
+    const char* e = getenv("WSIS_TILE_BAND");     // tuning knob: snake period (a huge value = plain heaviest-first)
+    if (e && atoi(e) > 0) cus = atoi(e);
+  }
+  if (cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)

@@ -60,7 +60,11 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ WT, const float* __restrict__ bias, const float* __restrict__ residual,
     float* __restrict__ out, float* __restrict__ partial, int64_t M_out, int K, int Cin, int Cout, int flip,
-    unsigned long long* __restrict__ dbg = nullptr) {
+    float* __restrict__ stats, unsigned long long* __restrict__ dbg = nullptr) {
+  // stats (optional, final pass only): per-slice BatchNorm partials of the FINISHED output rows (bias and residual
+  // included), stats[(slice * 2 + {0: sum, 1: sum of squared deviations from the SLICE mean}) * Cout + channel] -- the
+  // statistics pass of the BatchNorm that consumes this tensor (sparse_unet3d.py:128-137) without re-reading it.
+  // Centred per slice (and combined in fp64 by wsis_bn_stats_finalize): no E[x^2] - mean^2 cancellation in fp32.
   // DIAG build only (tools/conv2_stamps.py): per-workgroup stamps, dbg[blockIdx.x * 8 + i] =
   // {realtime at entry, realtime at exit, cycles: prologue, walk, epilogue, steps, HW_ID, 0}
   unsigned long long d_t0 = 0, d_r0 = 0, d_t1 = 0, d_t2 = 0;
@@ -96,13 +100,13 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
 #pragma unroll
     for (int j = 0; j < KMAX / 2; ++j) {
       const int k = 2 * j + half;
-      const bool ok = k < K && my_row >= 0 && nbrS != nullptr;
+      const bool ok = k < K && t < M_out && nbrS != nullptr;      // (independent of the order[] load above)
       v[j] = tab ? tab[ok ? (int64_t)k * M_out + t : 0] : 0;
     }
 #pragma unroll
     for (int j = 0; j < KMAX / 2; ++j) {
       const int k = 2 * j + half;
-      const bool ok = k < K && my_row >= 0;
+      const bool ok = k < K && t < M_out;
       const int32_t g = ok ? (nbrS ? v[j] : my_row) : -1;
       nbT[k * 32 + r31] = g;
       const unsigned long long b = __ballot(g >= 0);
@@ -111,19 +115,18 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
     }
   }
   if (lane < 32) rowId[lane] = my_row;
-  // offsets of this wave: the slice's active offsets are numbered 0 .. nact-1; blockIdx.z owns the numbers
-  // [q_begin, q_end) (levels with very few work items: partial slabs, added in z order by spconv2_reduce_kernel), and
-  // inside the workgroup wave w takes every NW-th of them.  All scalar: the walk below needs no LDS list.
+  // offsets of this wave: kernel offset k belongs to slab z = k % ZS (levels with very few work items: partial slabs,
+  // added in z order by spconv2_reduce_kernel) and, inside the workgroup, to wave (k / ZS) % NW.  The assignment
+  // depends on k alone, so the order of additions of an output row -- and with it the result, bit for bit -- does
+  // not depend on which other rows share its slice (tile order independent).  All scalar: the walk needs no LDS list.
   uint32_t mymask = 0u;
   {
-    const int nact = __builtin_popcount(mask);
-    const int q_begin = (int)((int64_t)nact * blockIdx.z / gridDim.z);
-    const int q_end = (int)((int64_t)nact * (blockIdx.z + 1) / gridDim.z);
+    const int zs = gridDim.z, z = blockIdx.z;
     uint32_t m = mask;
-    for (int q = 0; m; ++q) {
-      const uint32_t bit = m & (0u - m);
-      m ^= bit;
-      if (q >= q_begin && q < q_end && (q - q_begin) % NW == wave) mymask |= bit;
+    while (m) {
+      const int k = __builtin_ctz(m);
+      m &= m - 1u;
+      if (k % zs == z && (k / zs) % NW == wave) mymask |= 1u << k;
     }
   }
   mymask = __builtin_amdgcn_readfirstlane(mymask);
@@ -219,7 +222,109 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
   };
 
   if (DIAG) d_t1 = __builtin_amdgcn_s_memtime();
-  if (T > 0) {
+  if (BD && T > 0) {
+    // ---- weights straight to registers, gathered rows through the DA-deep LDS ring.  Every vector-memory operation
+    // of the walk is counted by hand: the weight loads are inline asm (beside LDS-DMA pieces in flight hipcc waits
+    // vmcnt(0) for any load it can see, which would drain the ring every step), nothing is issued for steps that do
+    // not exist (no dummy pieces in the tail).  Iteration t issues B(t+1) then A(t+DA) and needs A(t+1), B(t) at its
+    // top: the pieces allowed to be in flight there are A(t+2) .. A(t+DA-1).
+    Gen gA, gB;
+    gen_init(gA);
+    gen_init(gB);
+    int32_t nb[4];
+    int aS = 0, arS = 0;                     // ring slot of the next A issue / of the next fragment read
+    const uint32_t b_voff = (uint32_t)(r31 * Cin + half * 16) * 4u;
+    auto loadB = [&](const Gen& g, f32x4 (&b)[NB][4]) {
+      const int kk = flip ? K - 1 - g.k : g.k;
+      const uint64_t bp = reinterpret_cast<uint64_t>(Wb) + (uint64_t)((((int64_t)kk * Cout + col0) * Cin + g.c * 32) * 4);
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bp);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32));
+      const char* base = reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb) {
+        const uint32_t voff = b_voff + (uint32_t)(cb * 32 * Cin * 4);
+        // s_nop 4: the SGPR base comes fresh from v_readfirstlane (5 wait states before a VMEM reads it; hipcc pads
+        // nothing around an asm statement)
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(b[cb][0]) : "v"(voff), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(b[cb][1]) : "v"(voff), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(b[cb][2]) : "v"(voff), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:48" : "=v"(b[cb][3]) : "v"(voff), "s"(base) : "memory");
+      }
+    };
+    // the compiler must not touch the registers of an asm load before the counted wait that covers it
+    auto tie = [&](f32x4 (&b)[NB][4]) {
+#pragma unroll
+      for (int cb = 0; cb < NB; ++cb)
+        asm volatile("" : "+v"(b[cb][0]), "+v"(b[cb][1]), "+v"(b[cb][2]), "+v"(b[cb][3])::"memory");
+    };
+    auto issueA_all = [&]() {
+      loadNb(gA, nb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) issueA1(gA, nb, aS, i);
+      gen_next(gA);
+      aS = aS + 1 == DA ? 0 : aS + 1;
+    };
+    f32x4 a0[4], a1[4], b0[NB][4], b1[NB][4];
+    issueA_all();                                   // A0
+    loadB(gB, b0);                                  // B0
+    gen_next(gB);
+    if (T > 1) issueA_all();                        // A1
+    if (DA >= 3 && T > 2) issueA_all();             // A2
+    {   // A0, B0 landed; A1 [A2] may fly
+      const int young = (T > DA ? DA : T) - 1;
+      if (young >= 2)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (young == 1)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    tie(b0);
+    readfrag(0, 0, a0, b0);
+    arS = 1 == DA ? 0 : 1;
+    int t = 0;
+    auto iter = [&](const f32x4 (&ac)[4], f32x4 (&bc)[NB][4], f32x4 (&an)[4], f32x4 (&bn)[NB][4]) {
+      // top: A(t+1) and B(t) landed, the fragment reads of step t are back; A(t+2) (DA = 3) may still fly
+      if (DA >= 3 && t + 2 < T)
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      tie(bc);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(ac, bc, 0, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < T) {
+        readfrag(arS, 0, an, bn);
+        arS = arS + 1 == DA ? 0 : arS + 1;
+        loadB(gB, bn);
+        gen_next(gB);
+      }
+      const bool more = t + DA < T;
+      if (more) loadNb(gA, nb);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma(ac, bc, 4, 8);
+      __builtin_amdgcn_sched_barrier(0);
+      // ONE MFMA chain whatever the tail does (MFMAs duplicated into both arms of the branch made hipcc keep the
+      // accumulator in two register ranges and copy it every iteration)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (more) issueA1(gA, nb, aS, i);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(ac, bc, 8 + i, 9 + i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (more) {
+        gen_next(gA);
+        aS = aS + 1 == DA ? 0 : aS + 1;
+      }
+      mfma(ac, bc, 12, 16);
+      ++t;
+    };
+    while (t < T) {
+      iter(a0, b0, a1, b1);
+      if (t < T) iter(a1, b1, a0, b0);
+    }
+  } else if (T > 0) {
     // issue order (DA = 3): A0 B0 A1 B1 A2 | B2 A3 | B3 A4 | ...   iteration t issues B(t+2), A(t+DA);
     // at the top of iteration t the pieces younger than B(t+1) are A(t+2) .. A(t+DA-1): 4 (DA - 2) of them.
     // BD: A0 B0 A1 [A2] | B1 A(DA) | B2 A(DA+1) ...  iteration t loads the registers of B(t+1) and issues A(t+DA);
@@ -347,6 +452,24 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
           if (rows[reg] >= 0) dst[(int64_t)rows[reg] * Cout + c] = val[reg];
+        if (stats && final_pass) {      // rows in register order, then the two halves: a fixed order
+          float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) sa += rows[reg] >= 0 ? val[reg] : 0.0f;
+          sa += __shfl_xor(sa, 32, 64);
+          const int64_t left = M_out - t0;
+          const float mean_s = sa / (float)(left < SL ? left : SL);     // rows of the slice (tile order: a prefix)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const float d = rows[reg] >= 0 ? val[reg] - mean_s : 0.0f;
+            sb += d * d;
+          }
+          sb += __shfl_xor(sb, 32, 64);
+          if (half == 0) {
+            stats[((int64_t)blockIdx.x * 2 + 0) * Cout + c] = sa;
+            stats[((int64_t)blockIdx.x * 2 + 1) * Cout + c] = sb;
+          }
+        }
       }
     };
     if (residual)
@@ -365,9 +488,17 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
       }
     __syncthreads();
     const int32_t* rowId0 = rowId;
-    for (int e = threadIdx.x; e < 32 * NB * 32; e += 64 * NW) {
+    constexpr int PER = (32 * NB * 32) / (64 * NW);      // elements of this thread (its column is fixed: 64 NW is a
+    float keep[PER];                                     // multiple of NB * 32)
+    bool live[PER];
+    float sa = 0.0f;
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+      const int e = threadIdx.x + it * 64 * NW;
       const int rr = e / (NB * 32), cc = e - rr * (NB * 32);
       const int32_t r = rowId0[rr];
+      live[it] = r >= 0;
+      keep[it] = 0.0f;
       if (r < 0) continue;
       float v = 0.0f;
 #pragma unroll
@@ -378,6 +509,35 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
       const int64_t o = (int64_t)r * Cout + c;
       if (residual) v += residual[o];
       dst[o] = v;
+      keep[it] = v;
+      sa += v;
+    }
+    if (stats && final_pass) {      // threads of one column: t, t + NB*32, ...; added in that order
+      __syncthreads();              // the accumulator copies in the rings are no longer needed
+      float* sred = reinterpret_cast<float*>(lds + HDR_BYTES);
+      const int colw = NB * 32, me = threadIdx.x % colw;
+      sred[threadIdx.x] = sa;
+      __syncthreads();
+      float ta = 0.0f;
+      for (int j = me; j < 64 * NW; j += colw) ta += sred[j];         // every thread: its column's sum
+      const int64_t left = M_out - t0;
+      const float mean_s = ta / (float)(left < SL ? left : SL);
+      float sb = 0.0f;
+#pragma unroll
+      for (int it = 0; it < PER; ++it) {
+        const float d = live[it] ? keep[it] - mean_s : 0.0f;
+        sb += d * d;
+      }
+      __syncthreads();
+      sred[threadIdx.x] = sb;
+      __syncthreads();
+      if (threadIdx.x < colw) {
+        float tb = 0.0f;
+        for (int j = threadIdx.x; j < 64 * NW; j += colw) tb += sred[j];
+        const int c = col0 + threadIdx.x;
+        stats[((int64_t)blockIdx.x * 2 + 0) * Cout + c] = ta;
+        stats[((int64_t)blockIdx.x * 2 + 1) * Cout + c] = tb;
+      }
     }
   }
   if (DIAG && dbg && threadIdx.x == 0) {
@@ -424,6 +584,82 @@ int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+// the same sum for levels whose consumer is a BatchNorm: one workgroup per 32 output rows (the slice granularity of
+// the statistics partials), thread = (4 channels, row lane); also writes the slice's (sum, sum of squares) partials
+__global__ __launch_bounds__(256) void spconv2_reduce_stats_kernel(const float4* __restrict__ partial,
+                                                                  const float4* __restrict__ bias,
+                                                                  const float4* __restrict__ residual,
+                                                                  float4* __restrict__ out, int64_t M_out, int cout4,
+                                                                  int zs, float* __restrict__ stats) {
+  __shared__ float sred[256 * 4];
+  const int64_t total4 = M_out * cout4;
+  const int lanes = 256 / cout4;                         // row lanes (cout4 <= 64)
+  const int c4 = threadIdx.x % cout4, rl = threadIdx.x / cout4;
+  const int64_t r0 = (int64_t)blockIdx.x * 32;
+  const int nrows = (int)min((int64_t)32, M_out - r0);
+  constexpr int MAXR = 8;                                // rows per thread: ceil(32 / lanes), lanes >= 4
+  float4 keep[MAXR];
+  float sa[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < MAXR; ++it) {
+    keep[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int rr = rl + it * lanes;
+    if (rl < lanes && rr < nrows) {
+      const int64_t t = (r0 + rr) * cout4 + c4;
+      float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      for (int z = 0; z < zs; ++z) {
+        const float4 v = partial[(int64_t)z * total4 + t];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      if (bias) {
+        const float4 v = bias[c4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      if (residual) {
+        const float4 v = residual[t];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      out[t] = s;
+      keep[it] = s;
+      sa[0] += s.x; sa[1] += s.y; sa[2] += s.z; sa[3] += s.w;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) sred[threadIdx.x * 4 + e] = sa[e];
+  __syncthreads();
+  float ta[4] = {0.f, 0.f, 0.f, 0.f};
+  if (rl < lanes)
+    for (int j = 0; j < lanes; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ta[e] += sred[(j * cout4 + c4) * 4 + e];
+  float sb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < MAXR; ++it) {
+    const int rr = rl + it * lanes;
+    if (rl < lanes && rr < nrows) {
+      const float d0 = keep[it].x - ta[0] / (float)nrows, d1 = keep[it].y - ta[1] / (float)nrows;
+      const float d2 = keep[it].z - ta[2] / (float)nrows, d3 = keep[it].w - ta[3] / (float)nrows;
+      sb[0] += d0 * d0; sb[1] += d1 * d1; sb[2] += d2 * d2; sb[3] += d3 * d3;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) sred[threadIdx.x * 4 + e] = sb[e];
+  __syncthreads();
+  if (threadIdx.x < cout4) {
+    float tb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < lanes; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tb[e] += sred[(j * cout4 + threadIdx.x) * 4 + e];
+    const int Cout = cout4 * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      stats[((int64_t)blockIdx.x * 2 + 0) * Cout + threadIdx.x * 4 + e] = ta[e];
+      stats[((int64_t)blockIdx.x * 2 + 1) * Cout + threadIdx.x * 4 + e] = tb[e];
+    }
+  }
+}
+
 // NB: output blocks per work item; NW: waves per work item; ZS: offset groups over blockIdx.z (partial slabs);
 // DA: depth of the gathered-row ring.  Aim for ~2 waves per SIMD over the whole launch.
 struct Plan2 {
@@ -435,10 +671,10 @@ Plan2 plan2(int64_t M_out, int K, int Cin, int Cout) {
   if (nb_pref < 0) {
     bd_pref = env_int("WSIS_FWD2_BD", 1);
     nb_pref = env_int("WSIS_FWD2_NB", 1);
-    target = env_int("WSIS_FWD2_WAVES", 2048);
+    target = env_int("WSIS_FWD2_WAVES", 8192);
     nw_force = env_int("WSIS_FWD2_NW", 0);
     zs_force = env_int("WSIS_FWD2_ZS", 0);
-    da_pref = env_int("WSIS_FWD2_DA", 3);
+    da_pref = env_int("WSIS_FWD2_DA", 2);
     nw_max = env_int("WSIS_FWD2_NW_MAX", 4);
   }
   Plan2 p;
@@ -475,8 +711,9 @@ int64_t wsis_spconv_fwd_t_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin,
 }
 
 int wsis_spconv_fwd_t(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT, int32_t flip,
-                      const float* d_bias, const float* d_residual, float* d_out, int64_t M_in, int64_t M_out,
-                      int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes, void* stream) {
+                      const float* d_bias, const float* d_residual, float* d_out, float* d_stats, int64_t M_in,
+                      int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
+                      void* stream) {
   WSIS_REQUIRE(M_in >= 0 && M_out >= 0, "bad sizes");
   WSIS_REQUIRE(wsis_spconv_fwd_t_supported(K, Cin, Cout), "needs K <= 32 and channel counts that are multiples of 32");
   if (M_out == 0) return WSIS_OK;
@@ -505,7 +742,7 @@ int wsis_spconv_fwd_t(const float* d_X, const int32_t* d_nbr, const int32_t* d_o
       attr_set = true;                                                                                           \
     }                                                                                                            \
     hipLaunchKernelGGL((spconv_fwd2_kernel<nb, nw, da, bd>), grid, dim3(64 * nw), ldsb, st, d_X, d_nbr, d_order, \
-                       d_WT, d_bias, d_residual, d_out, partial, M_out, K, Cin, Cout, flip);                     \
+                       d_WT, d_bias, d_residual, d_out, partial, M_out, K, Cin, Cout, flip, d_stats);            \
   } while (0)
 #define WSIS_F2(nb, nw, da)      \
   if (p.BD)                      \
@@ -532,7 +769,13 @@ int wsis_spconv_fwd_t(const float* d_X, const int32_t* d_nbr, const int32_t* d_o
 #undef WSIS_F2X
   prof.stop();
   WSIS_LAUNCH_CHECK();
-  if (p.ZS > 1) {
+  if (p.ZS > 1 && d_stats) {
+    hipLaunchKernelGGL(spconv2_reduce_stats_kernel, dim3((unsigned)ceil_div(M_out, SL)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(partial), reinterpret_cast<const float4*>(d_bias),
+                       reinterpret_cast<const float4*>(d_residual), reinterpret_cast<float4*>(d_out), M_out, Cout / 4,
+                       p.ZS, d_stats);
+    WSIS_LAUNCH_CHECK();
+  } else if (p.ZS > 1) {
     const int64_t total4 = M_out * Cout / 4;
     hipLaunchKernelGGL(spconv2_reduce_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, st,
                        reinterpret_cast<const float4*>(partial), reinterpret_cast<const float4*>(d_bias),
@@ -555,12 +798,12 @@ int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 2, true, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, 0,
-                       d_dbg);
+                       (float*)nullptr, d_dbg);
   } else {
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 3, false>::WAVE_BYTES;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 3, false, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, 0,
-                       d_dbg);
+                       (float*)nullptr, d_dbg);
   }
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;

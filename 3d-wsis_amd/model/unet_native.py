@@ -14,6 +14,8 @@ Activations live in one arena per pass (bump allocation, nothing is freed before
 rematerialisation pointless at these sizes), parameter gradients densely in one flat buffer whose views become
 ``p.grad`` (and which ``parallel.GradSync`` all-reduces in place).
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -24,7 +26,7 @@ import wsis_ops
 from spconv import ops as sp_ops
 
 OP_CONV, OP_BN_RELU, OP_CAT, OP_SPLIT, OP_ADD, OP_CONV_BWD, OP_BN_RELU_BWD = 1, 2, 3, 4, 5, 6, 7
-F_RELU, F_TRAINING, F_UPDATE, F_FLIP = 1, 2, 4, 8
+F_RELU, F_TRAINING, F_UPDATE, F_FLIP, F_STATS = 1, 2, 4, 8, 16
 
 OP_DTYPE = np.dtype([("kind", "<i4"), ("flags", "<i4"), ("M_in", "<i8"), ("M_out", "<i8"), ("K", "<i4"),
                      ("Cin", "<i4"), ("Cout", "<i4"), ("reserved", "<i4"), ("eps", "<f4"), ("momentum", "<f4"),
@@ -41,6 +43,12 @@ _TAGS = (_FWD, _BWD, _PAR, _TBL, _EXT)
 _ID_MASK = (1 << 58) - 1
 
 
+def _fuse_stats_enabled():
+    """BatchNorm statistics from the producing convolution's epilogue (WSIS_FUSE_BN_STATS=0: separate pass over x,
+    bit-identical to the per-module walk)"""
+    return os.environ.get("WSIS_FUSE_BN_STATS", "1") != "0"
+
+
 def _lvl(level):
     """symbolic row count of a pyramid level (negative code, resolved per scene)"""
     return -(level + 1)
@@ -52,12 +60,14 @@ class _Recorder(object):
     def __init__(self, tag, align=256):
         self.tag, self.align = tag, align
         self.rows = []
-        self.alloc_level, self.alloc_mult = [], []
+        self.alloc_level, self.alloc_mult, self.alloc_slices = [], [], []
 
-    def alloc(self, level, mult):
-        """``mult`` floats per row of pyramid level ``level`` (level < 0: ``mult`` floats in total)"""
+    def alloc(self, level, mult, per_slice=False):
+        """``mult`` floats per row of pyramid level ``level`` (level < 0: ``mult`` floats in total); ``per_slice``:
+        per 32-row slice of the level instead (BatchNorm partials of a convolution output)"""
         self.alloc_level.append(level)
         self.alloc_mult.append(int(mult))
+        self.alloc_slices.append(bool(per_slice))
         return self.tag | (len(self.alloc_level) - 1)
 
     def op(self, kind, flags=0, M_in=0, M_out=0, K=0, Cin=0, Cout=0, eps=0.0, momentum=0.0, inp=(), out=()):
@@ -70,12 +80,14 @@ class _Arena(object):
     def __init__(self, rec):
         self.level = np.asarray(rec.alloc_level, dtype=np.int64)
         self.mult = np.asarray(rec.alloc_mult, dtype=np.int64)
+        self.slices = np.asarray(rec.alloc_slices, dtype=bool)
         self.align = rec.align
 
     def layout(self, Mvec):
         if len(self.level) == 0:
             return np.zeros(0, dtype=np.int64), 0
         rows = np.where(self.level >= 0, Mvec[np.maximum(self.level, 0)], 1)
+        rows = np.where(self.slices, (rows + 31) // 32, rows)
         size = (rows * self.mult * 4 + self.align - 1) // self.align * self.align
         end = np.cumsum(size)
         return end - size, int(end[-1])
@@ -160,18 +172,25 @@ class UNetProgram(object):
         self.flat_grad, self.flat_params = None, []
         self.flat_tail = None        # spare floats behind the gradients (parallel.GradSync packs the other
         self.tail_floats = 0         # parameters' gradients there: ONE collective per step)
+        self.overlap = None          # wsis_parallel.GradSync: early all-reduce of the finished first part (see backward)
         self._cache = {}
 
     # ---- symbolic recording: every helper returns (out_handle, backward_closure) -----------------------------
-    def _conv(self, rec, x, conv, table, lvl_in, lvl_out, residual=0):
+    def _conv(self, rec, x, conv, table, lvl_in, lvl_out, residual=0, stats=True):
         K = int(np.prod(conv.kernel_size))
         Cin, Cout = conv.in_channels, conv.out_channels
         W = conv.weight
         assert conv.bias is None, "the UNet convolutions carry no bias (sparse_unet3d.py)"
         y = rec.alloc(lvl_out, Cout)
         t = table if table is not None else _Table()
-        rec.op(OP_CONV, 0, _lvl(lvl_in), _lvl(lvl_out), K, Cin, Cout,
-               inp=(x, t.nbr_f, t.order_f, W.data_ptr(), 0, residual), out=(y,))
+        # BatchNorm statistics of the output from the convolution's own epilogue (training passes, layers on the
+        # wave-autonomous kernel): per-slice (sum, sum of squares) partials next to the output
+        part = 0
+        if stats and self._fuse_stats and sp_ops._use_fwd2(K, Cin, Cout):
+            part = rec.alloc(lvl_out, 2 * Cout, per_slice=True)
+            self._stats_src[y] = [(part, Cout)]
+        rec.op(OP_CONV, F_STATS if part else 0, _lvl(lvl_in), _lvl(lvl_out), K, Cin, Cout,
+               inp=(x, t.nbr_f, t.order_f, W.data_ptr(), 0, residual), out=(y, part))
         self._acc_f.append(("spconv_fwd_kernel", t.nbr_f, lvl_out, Cin, Cout))
 
         def bwd(recb, dy, need_dx=True):
@@ -196,8 +215,14 @@ class UNetProgram(object):
         y = rec.alloc(lvl, C)
         mean = rec.alloc(-1, C) if training else bn.running_mean.data_ptr()
         var = rec.alloc(-1, C) if training else bn.running_var.data_ptr()
-        rec.op(OP_BN_RELU, flags, _lvl(lvl), _lvl(lvl), 0, C, C, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
-               inp=(x, _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var)),
+        src = self._stats_src.get(x) if training else None
+        K0, parts = 0, (0, 0)
+        if src is not None and sum(c for _, c in src) == C and len(src) <= 2:
+            flags |= F_STATS             # the producers' epilogues wrote the partials: no statistics pass over x
+            K0 = src[0][1]
+            parts = (src[0][0], src[1][0] if len(src) == 2 else 0)
+        rec.op(OP_BN_RELU, flags, _lvl(lvl), _lvl(lvl), K0, C, C, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+               inp=(x, _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var), parts[0], parts[1]),
                out=(y, mean if training else 0, var if training else 0))
 
         def bwd(recb, dy, addend=0):
@@ -222,7 +247,7 @@ class UNetProgram(object):
         if isinstance(first, nn.Identity):
             res, b_i = x, None
         else:
-            res, b_i = self._conv(rec, x, first, None, lvl, lvl)          # 1x1 projection of the skip path
+            res, b_i = self._conv(rec, x, first, None, lvl, lvl, stats=False)   # 1x1 projection of the skip path
         out, b_c2 = self._conv(rec, a2, conv2, table, lvl, lvl, residual=res)
 
         def bwd(recb, d_out):
@@ -253,6 +278,8 @@ class UNetProgram(object):
         up, b_up = self._conv(rec, a2, ub.deconv[2], _up(lvl), lvl + 1, lvl)
         cat = rec.alloc(lvl, 2 * C0)
         rec.op(OP_CAT, 0, _lvl(lvl), _lvl(lvl), 0, C0, C0, inp=(identity, up), out=(cat,))
+        if identity in self._stats_src and up in self._stats_src:      # statistics of a concatenation = both halves'
+            self._stats_src[cat] = self._stats_src[identity] + self._stats_src[up]
         x = cat
         tails = []
         for blk in ub.blocks_tail:
@@ -285,7 +312,8 @@ class UNetProgram(object):
 
     # ---- compile (once per mode) / bind (per scene) ------------------------------------------------------------
     def _mode_key(self, need_dx):
-        return (need_dx, tuple(bn.training for bn in self.bns), tuple(p.data_ptr() for p in self.params),
+        return (need_dx, _fuse_stats_enabled(), os.environ.get("WSIS_FWD2", "1"),
+                tuple(bn.training for bn in self.bns), tuple(p.data_ptr() for p in self.params),
                 tuple(bn.running_mean.data_ptr() if bn.running_mean is not None else 0 for bn in self.bns))
 
     def compiled(self, need_dx):
@@ -300,6 +328,7 @@ class UNetProgram(object):
         rec, recb = _Recorder(_FWD), _Recorder(_BWD)
         self._prec, self._grad = _Recorder(_PAR, align=16), {}
         self._acc_f, self._acc_b, self._count = [], [], []
+        self._stats_src, self._fuse_stats = {}, _fuse_stats_enabled()
         y, b_in = self._conv(rec, _EXT | 0, net.input_conv[0], _subm(0), 0, 0)
         y, b_u = self._ublock(rec, y, net.unet, 0)
         out, b_out = self._bn_relu(rec, y, net.output_layer[0], 0)
@@ -311,6 +340,16 @@ class UNetProgram(object):
         c.out_id, c.dx_id = out & _ID_MASK, (dx & _ID_MASK) if need_dx else -1
         c.grad_ids = [(self._grad[id(p)] & _ID_MASK) if id(p) in self._grad else -1 for p in self.params]
         c.acc_f, c.acc_b, c.count = self._acc_f, self._acc_b, self._count
+        # milestone of the backward list: the op after which the first ~half of the flat parameter-gradient buffer is
+        # final (gradients are allocated in the order the backward pass produces them)
+        done = np.zeros(len(recb.rows), dtype=np.int64)
+        hw = 0
+        for i, r in enumerate(recb.rows):
+            for h in r[10]:
+                if h & _PAR:
+                    hw = max(hw, (h & _ID_MASK) + 1)
+            done[i] = hw
+        c.bwd_grads_done = done
         c.out_channels = net.output_layer[0].num_features
         self._cache[key] = c
         return c
@@ -396,10 +435,21 @@ class UNetFunction(Function):
         luts = {_FWD: ctx.fwd_lut, _BWD: boffs.astype(np.uint64) + np.uint64(gbase),
                 _PAR: poffs.astype(np.uint64) + np.uint64(pbase), _TBL: ctx.table_lut,
                 _EXT: np.array([ctx.x.data_ptr(), d_out.data_ptr()], dtype=np.uint64)}
-        _run(_n.hip(), c.bwd.instantiate(Mvec, luts), dev)
-        prog.account(c.acc_b, Mvec, ctx.tensors)
         pflat = parena.view(torch.float32)
         first = (pbase - parena.data_ptr()) // 4
+        hook = prog.overlap
+        if hook is not None and hook.ready() and len(poffs) > 1:
+            # all-reduce of the first part of the gradient buffer starts while the rest of the pass still runs
+            starts = np.append(poffs, ptotal)
+            want = ptotal // 2
+            op_i = int(np.searchsorted(starts[c.bwd_grads_done], want))          # first op with >= half final
+            op_i = min(op_i, len(c.bwd_grads_done) - 2)
+            split = int(starts[c.bwd_grads_done[op_i]]) // 4
+            _run(_n.hip(), c.bwd.instantiate(Mvec, luts), dev, mark_op=op_i, waiter=hook.comm_stream_ptr())
+            hook.early(pflat[first:first + split], first + split)
+        else:
+            _run(_n.hip(), c.bwd.instantiate(Mvec, luts), dev)
+        prog.account(c.acc_b, Mvec, ctx.tensors)
         grads, covered = [], []
         for i, p in enumerate(prog.params):
             gid = c.grad_ids[i]
@@ -417,14 +467,17 @@ class UNetFunction(Function):
         return (dx, None) + tuple(grads)
 
 
-def _run(lib, ops, device):
+def _run(lib, ops, device, mark_op=-1, waiter=None):
     n = len(ops)
     p = ops.ctypes.data
     ws_bytes = lib.wsis_run_ops_workspace_bytes(p, n)
     if ws_bytes < 0:
         raise _n.WsisError("run_ops workspace query failed")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-    _n.check(lib.wsis_run_ops(p, n, _n.ptr(ws), ws_bytes, _n.stream_ptr()), "run_ops")
+    if mark_op >= 0:
+        _n.check(lib.wsis_run_ops_marked(p, n, _n.ptr(ws), ws_bytes, _n.stream_ptr(), int(mark_op), waiter), "run_ops")
+    else:
+        _n.check(lib.wsis_run_ops(p, n, _n.ptr(ws), ws_bytes, _n.stream_ptr()), "run_ops")
 
 
 def run_unet(net, input_tensor):

@@ -388,8 +388,9 @@ def _use_fwd2(K, Cin, Cout):
 _WS2_CACHE = {}
 
 
-def _conv_t(X, nbr, order, WT, flip, bias, residual, M_out):
-    """out[r] = sum_k X[nbr[k][r]] @ W[k] with the weights as B^T: WT [K,Cout,Cin] (slice K-1-k when ``flip``)."""
+def _conv_t(X, nbr, order, WT, flip, bias, residual, M_out, stats=None):
+    """out[r] = sum_k X[nbr[k][r]] @ W[k] with the weights as B^T: WT [K,Cout,Cin] (slice K-1-k when ``flip``).
+    ``stats``: optional fp32 [ceil(M_out/32), 2, Cout] buffer that receives the BatchNorm partials of the output."""
     K, Cout, Cin = WT.shape
     out = torch.empty((M_out, Cout), dtype=torch.float32, device=X.device)
     prof = PROFILER
@@ -405,7 +406,7 @@ def _conv_t(X, nbr, order, WT, flip, bias, residual, M_out):
         _WS2_CACHE[key] = ws_bytes
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device) if ws_bytes > 256 else None
     _n.check(lib.wsis_spconv_fwd_t(_n.ptr(X), _n.ptr(nbr), _n.ptr(order), _n.ptr(WT), int(flip), _n.ptr(bias),
-                                   _n.ptr(residual), _n.ptr(out), X.shape[0], M_out, K, Cin, Cout, _n.ptr(ws),
+                                   _n.ptr(residual), _n.ptr(out), _n.ptr(stats), X.shape[0], M_out, K, Cin, Cout, _n.ptr(ws),
                                    ws_bytes, _n.stream_ptr()), "spconv_fwd_t")
     if prof is not None:
         prof.end("spconv_fwd_kernel", None, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout)

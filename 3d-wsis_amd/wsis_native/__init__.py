@@ -75,7 +75,8 @@ _HIP_SIGS = {
     "wsis_spconv_fwd": (I32, [P, P, P, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
     "wsis_spconv_fwd_t_supported": (I32, [I32, I32, I32]),
     "wsis_spconv_fwd_t_workspace_bytes": (I64, [I64, I32, I32, I32]),
-    "wsis_spconv_fwd_t": (I32, [P, P, P, P, I32, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
+    "wsis_spconv_fwd_t": (I32, [P, P, P, P, I32, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
+    "wsis_bn_stats_finalize": (I32, [P, I64, I64, I32, P, P, P, P, F32, P]),
     "wsis_weight_transpose": (I32, [P, P, I32, I32, I32, I32, P]),
     "wsis_spconv_dw_workspace_bytes": (I64, [I64, I32, I32, I32]),
     "wsis_spconv_dw": (I32, [P, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
@@ -96,6 +97,8 @@ _HIP_SIGS = {
     "wsis_edge_affinity_bwd": (I32, [P] * 11 + [F32] + [P] * 7 + [I64, I64, I64, I32, P]),
     "wsis_ecc_message_fwd": (I32, [P, P, P, P, P, P, I64, I64, I32, P]),
     "wsis_ecc_message_bwd": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I32, P]),
+    "wsis_ecc_contract_fwd": (I32, [P, P, P, P, P, I64, I64, P]),
+    "wsis_ecc_contract_bwd": (I32, [P, P, P, P, P, P, P, I64, I64, P]),
     "wsis_gru_cell_workspace_bytes": (I64, [I64]),
     "wsis_gru_cell_fwd": (I32, [P] * 9 + [I64, I32, P]),
     "wsis_gru_cell_bwd": (I32, [P] * 17 + [I64, I32, P, I64, P]),
@@ -119,6 +122,7 @@ _HIP_SIGS = {
     "wsis_adamw_step": (I32, [P, P, I64, F64, F64, F64, F64, F64, P]),
     "wsis_run_ops_workspace_bytes": (I64, [P, I32]),
     "wsis_run_ops": (I32, [P, I32, P, I64, P]),
+    "wsis_run_ops_marked": (I32, [P, I32, P, I64, P, I32, P]),
 }
 
 

@@ -281,6 +281,40 @@ def ecc_message(x, weights, src, dst, csr_src, csr_dst):
     return _EccMessage.apply(x, weights, src, dst, csr_src, csr_dst)
 
 
+class _EccContract(Function):
+    """m[e] = sum_c h[e,c] U[dst_e, c, :] + U[dst_e, 64, :]  -- the edge-conditioned message x_t @ W_e without the
+    per-edge filter tensor (csrc/ecc.hip; reference spg_modules.py:97-121 with the fnet of
+    graphnet.py:19-36)."""
+
+    @staticmethod
+    def forward(ctx, h, U, csr_dst):
+        _n.require_cuda(h, U)
+        h, U = h.contiguous().float(), U.contiguous().float()
+        E, S = h.shape[0], U.shape[0]
+        assert h.shape[1] == 64 and U.shape[1] == 65 * 32 and csr_dst.S == S
+        m = torch.empty((E, 32), dtype=torch.float32, device=h.device)
+        _n.check(_n.hip().wsis_ecc_contract_fwd(_n.ptr(h), _n.ptr(U), _n.ptr(csr_dst.perm), _n.ptr(csr_dst.offsets),
+                                                _n.ptr(m), S, E, _n.stream_ptr()), "ecc_contract_fwd")
+        ctx.save_for_backward(h, U)
+        ctx.csr = csr_dst
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        h, U = ctx.saved_tensors
+        csr = ctx.csr
+        dm = dm.contiguous().float()
+        dU, dh = torch.empty_like(U), torch.empty_like(h)
+        _n.check(_n.hip().wsis_ecc_contract_bwd(_n.ptr(h), _n.ptr(U), _n.ptr(dm), _n.ptr(csr.perm), _n.ptr(csr.offsets),
+                                                _n.ptr(dU), _n.ptr(dh), U.shape[0], h.shape[0], _n.stream_ptr()),
+                 "ecc_contract_bwd")
+        return dh, dU, None
+
+
+def ecc_contract(h, U, csr_dst):
+    return _EccContract.apply(h, U, csr_dst)
+
+
 # ---- a21: fused GRUCellEx -------------------------------------------------------------------------------------
 
 class _GruCellEx(Function):

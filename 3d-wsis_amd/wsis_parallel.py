@@ -54,6 +54,41 @@ class GradSync(object):
         # path agreement (see _agree): the plan of the first calls is negotiated, then frozen
         self._agreed = None
         self._agree_calls = 0
+        # gradient exchange under the backward pass (see enable_overlap)
+        self._comm_stream = None
+        self._early = None          # (handle, tensor, first element of the remainder) of this step's early all-reduce
+
+    # ---- overlap: the native UNet backward reports when the first ~half of its flat gradient buffer is final
+    # (csrc/executor.hip wsis_run_ops_marked); the all-reduce of that part is issued right there, on a communication
+    # stream that waits for the milestone only, and runs under the second half of the pass (the reference
+    # relies on DDP's bucket hooks for the same effect, train_scannetv2.py:738).  WSIS_SYNC_OVERLAP=0 switches it off.
+    def enable_overlap(self, model):
+        prog = getattr(model, "_native_prog", None)
+        if prog is None or os.environ.get("WSIS_SYNC_OVERLAP", "1") == "0":
+            return False
+        dev = next(p for b in self.buckets for p in b).device
+        if dev.type != "cuda":
+            return False
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=dev)
+        prog.overlap = self
+        return True
+
+    def ready(self):
+        """early exchange only once the collective plan is frozen on the flat path (all ranks issue the same calls)"""
+        return (self._comm_stream is not None and self._agree_calls >= self.AGREE_CALLS
+                and self._agreed is not None and self._agreed[0] > 0)
+
+    def comm_stream_ptr(self):
+        return self._comm_stream.cuda_stream
+
+    def early(self, part, rest_first):
+        """called from inside the backward pass: ``part`` (a view of the flat buffer) is final once the milestone the
+        communication stream waits for has passed"""
+        with torch.cuda.stream(self._comm_stream):
+            h = dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._early = (h, part, rest_first)
+        self.early_count = getattr(self, "early_count", 0) + 1
 
     @staticmethod
     def _flat_source(model):
@@ -136,7 +171,15 @@ class GradSync(object):
                 torch.cat([g.reshape(-1) for g in grads], out=prog.flat_tail)
                 tail_job = (rest, grads, prog.flat_tail)
                 covered = covered | {id(p) for p in rest}
-            flat_handle = dist.all_reduce(flat_src, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            early = self._early
+            self._early = None
+            remainder = flat_src
+            if early is not None:       # the first part is already on the wire: exchange the remainder (+ tail)
+                remainder = flat_src[early[2]:]
+            flat_handle = dist.all_reduce(remainder, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if early is not None:
+                early[0].wait()
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
         # flatten every bucket with ONE cat kernel, all-reduce asynchronously, copy back with ONE multi-tensor copy
         for bucket in self.buckets:
             bucket = [p for p in bucket if id(p) not in covered]

@@ -204,9 +204,14 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
  * through LDS in wave order) and, below that, over blockIdx.z into partial slabs in d_ws (fixed order). */
 int32_t wsis_spconv_fwd_t_supported(int32_t K, int32_t Cin, int32_t Cout);
 int64_t wsis_spconv_fwd_t_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout);
+/* d_stats (optional): BatchNorm partials of the finished output, [ceil(M_out / 32)][2][Cout] floats per 32-row slice
+ * in tile order: (sum, sum of squared deviations from the SLICE's own mean), fixed order of additions -- the
+ * statistics pass of the BatchNorm that consumes this tensor (sparse_unet3d.py:128-137) fused into the producer's
+ * epilogue; combined in fp64 (Chan) by wsis_bn_stats_finalize, so nothing cancels in fp32. */
 int wsis_spconv_fwd_t(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT, int32_t flip,
-                      const float* d_bias, const float* d_residual, float* d_out, int64_t M_in, int64_t M_out,
-                      int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes, void* stream);
+                      const float* d_bias, const float* d_residual, float* d_out, float* d_stats, int64_t M_in,
+                      int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
+                      void* stream);
 /* WT[k'] = W[k]^T with k' = (flip ? K-1-k : k); W [K,Cin,Cout] -> WT [K,Cout,Cin]. */
 int wsis_weight_transpose(const float* d_W, float* d_WT, int32_t K, int32_t Cin, int32_t Cout,
                           int32_t flip, void* stream);
@@ -230,6 +235,11 @@ int wsis_prof_summary(int32_t which, double* total_ms, int64_t* launches);
 int64_t wsis_bn_workspace_bytes(int64_t M, int32_t C);
 int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* d_var, float* d_running_mean,
                   float* d_running_var, float momentum, void* d_ws, int64_t ws_bytes, void* stream);
+/* mean / biased variance (and the running-statistics update) of C channels from the n_part = ceil(M / 32) rows of
+ * (sum, centred sum of squares) partials with row pitch 2*C floats written by wsis_spconv_fwd_t(d_stats): fp64,
+ * fixed order. */
+int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, int32_t C, float* d_mean, float* d_var,
+                           float* d_running_mean, float* d_running_var, float momentum, void* stream);
 /* y = relu?( (x-mean)*rsqrt(var+eps)*gamma + beta )   (gamma/beta may be NULL = 1/0) */
 int wsis_bn_apply(const float* d_x, const float* d_mean, const float* d_var, const float* d_gamma,
                   const float* d_beta, float eps, int32_t relu, float* d_y, int64_t M, int32_t C, void* stream);
@@ -285,6 +295,16 @@ int wsis_edge_affinity_bwd(const float* d_q, const float* d_k, const float* d_v,
  *   out[s,:] = mean_{e: src_e = s} x[dst_e,:] @ W_e,  W_e = d_w[e] in R^{C x C}, C <= 32.
  * CSR over the sources (forward) and over the targets (backward) from wsis_segment_csr.  Backward writes
  * dx [S,C] and the per-edge filter gradient dw [E,C,C] (every entry written). */
+/* The same messages WITHOUT the per-edge [E, C*C] filter tensor: the filter is affine in the fnet hidden
+ * state h_e in R^64 (graphnet.py:19-36: W_e = reshape(Wl h_e + bl)), so m_e = x_t @ W_e = sum_c h_e[c] U_t[c,:] + U_t[64,:]
+ * with the per-NODE tensor U [S, 65*32], U_t[c,b] = sum_a x_t[a] Wl[a*32+b, c], row 64 = the bias term (one small GEMM
+ * per GRU step, done by the caller).  d_h [E,64], d_U [S,65*32], CSR over the targets; forward writes m [E,32]
+ * (every in-edge of every target), backward writes dU [S,65*32] (zeros for targets without in-edge) and dh [E,64].
+ * C = 32, hidden width 64 (the model's 'gru_7_0' configuration); one wavefront per target, fixed order. */
+int wsis_ecc_contract_fwd(const float* d_h, const float* d_U, const int32_t* d_perm_dst, const int32_t* d_off_dst,
+                          float* d_m, int64_t S, int64_t E, void* stream);
+int wsis_ecc_contract_bwd(const float* d_h, const float* d_U, const float* d_dm, const int32_t* d_perm_dst,
+                          const int32_t* d_off_dst, float* d_dU, float* d_dh, int64_t S, int64_t E, void* stream);
 int wsis_ecc_message_fwd(const float* d_x, const float* d_w, const int64_t* d_dst, const int32_t* d_perm_src,
                          const int32_t* d_off_src, float* d_out, int64_t S, int64_t E, int32_t C, void* stream);
 int wsis_ecc_message_bwd(const float* d_x, const float* d_w, const float* d_dout, const int64_t* d_src,
@@ -404,7 +424,11 @@ enum {
   WSIS_OP_CONV = 1, WSIS_OP_BN_RELU = 2, WSIS_OP_CAT = 3, WSIS_OP_SPLIT = 4, WSIS_OP_ADD = 5, WSIS_OP_CONV_BWD = 6,
   WSIS_OP_BN_RELU_BWD = 7
 };
-enum { WSIS_OPF_RELU = 1, WSIS_OPF_TRAINING = 2, WSIS_OPF_UPDATE_RUNNING = 4, WSIS_OPF_FLIP = 8 };
+/* WSIS_OPF_STATS on CONV: out[1] = BatchNorm partials of the output (wsis_spconv_fwd_t d_stats).
+ * WSIS_OPF_STATS on BN_RELU (training): the statistics come from partials instead of a pass over x: in[5] = partials
+ * of channels [0, K), in[6] = partials of channels [K, Cin) (NULL when K == Cin; the input is a concatenation of two
+ * producers' outputs), ceil(M_in / 32) rows each. */
+enum { WSIS_OPF_RELU = 1, WSIS_OPF_TRAINING = 2, WSIS_OPF_UPDATE_RUNNING = 4, WSIS_OPF_FLIP = 8, WSIS_OPF_STATS = 16 };
 typedef struct wsis_op {
   int32_t kind, flags;
   int64_t M_in, M_out;
@@ -415,6 +439,12 @@ typedef struct wsis_op {
 } wsis_op;
 int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n);
 int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* stream);
+/* The same with a milestone: once op `mark_op` (0-based) has been issued, `waiter_stream` is made to wait for
+ * everything issued so far on `stream` and on the library's weight-gradient side stream.  The data-parallel step uses
+ * it to start the RCCL all-reduce of the finished first part of the flat gradient buffer while the rest of the backward
+ * pass still runs (the reference's DDP buckets, train_scannetv2.py:738).  mark_op < 0: no milestone. */
+int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* stream, int32_t mark_op,
+                        void* waiter_stream);
 #ifdef __cplusplus
 }
 #endif

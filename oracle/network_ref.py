@@ -208,24 +208,35 @@ class RefNetwork(nn.Module):
         return ret
 
 
-def forward_loss_cpu(ref_model, criterion, batch, mode=4, epoch=5):
-    """the iteration of train_scannetv2.py:174-232 entirely on the oracle (host batch dict from harness.collate)"""
+def forward_loss_cpu(ref_model, criterion, batch, mode=4, epoch=5, dtype=None):
+    """the iteration of train_scannetv2.py:174-232 entirely on the oracle (host batch dict from harness.collate).
+    ``dtype=torch.float64`` (with ``ref_model.double()``) evaluates the same graph in double precision: the
+    reference against which fp32 rounding drift of the HIP path is measured (tests/test_gpu_network.py)."""
     from . import pg_ops
-    coords_float, superpoint = batch["locs_float"], batch["superpoint"]
+    f = (lambda t: t.to(dtype)) if dtype is not None else (lambda t: t)
+    coords_float, superpoint = f(batch["locs_float"]), batch["superpoint"]
     centre = scatter(coords_float, superpoint, 0, None, "mean")
-    feats = torch.cat((batch["feats"], coords_float), 1)
-    voxel_feats = torch.from_numpy(pg_ops.voxelization(feats.numpy(), batch["v2p_map"].numpy(), mode))
+    feats = torch.cat((f(batch["feats"]), coords_float), 1)
+    if dtype is not None and dtype != torch.float32:      # mean pooling of the voxel's points in the working precision
+        v2p = batch["v2p_map"].long()
+        n = v2p[:, 0].clamp(min=1)
+        voxel_feats = torch.zeros(v2p.shape[0], feats.shape[1], dtype=dtype)
+        for i in range(v2p.shape[1] - 1):
+            live = v2p[:, 0] > i
+            voxel_feats[live] += feats[v2p[live, 1 + i]] / n[live, None].to(dtype)
+    else:
+        voxel_feats = torch.from_numpy(pg_ops.voxelization(feats.numpy(), batch["v2p_map"].numpy(), mode))
     gi = batch["GIs"][0]
     ret = ref_model(voxel_feats, batch["voxel_locs"].numpy(), batch["spatial_shape"], batch["p2v_map"], superpoint,
-                    centre, gi._edge_indexes.cpu(), gi._edgefeats.cpu(), batch["edge_u_list"], batch["edge_v_list"])
+                    centre, gi._edge_indexes.cpu(), f(gi._edgefeats.cpu()), batch["edge_u_list"], batch["edge_v_list"])
     loss_inp = {
         "point_labels": (batch["semantic_labels"], batch["instance_labels"]),
         "semantic_scores": ret["semantic_scores"],
         "superpoint_labels": (batch["superpoint_semantic_labels"], batch["superpoint_instance_labels"]),
         "sp_semantic": ret["sp_semantic_scores"],
-        "sp_offset_vector": (ret["pred_sp_offset_vectors"], batch["superpoint_offset_vector"]),
-        "sp_occupancy": (ret["pred_sp_occupancy"], batch["superpoint_instance_voxel_num"]),
-        "sp_instance_size": (ret["pred_sp_ins_size"], batch["superpoint_instance_size"]),
+        "sp_offset_vector": (ret["pred_sp_offset_vectors"], f(batch["superpoint_offset_vector"])),
+        "sp_occupancy": (ret["pred_sp_occupancy"], f(batch["superpoint_instance_voxel_num"])),
+        "sp_instance_size": (ret["pred_sp_ins_size"], f(batch["superpoint_instance_size"])),
         "sp_discriminative_features": (ret["sp_discriminative_feats"], batch["sp_batch_offsets"]),
     }
     loss, _ = criterion(loss_inp, epoch)

@@ -182,3 +182,96 @@ def test_c4_one_million_points_inference_slice():
         o1 = conv2(conv1(t)).features
         o2 = conv2(conv1(t)).features
     assert o1.shape == (M, 32) and torch.isfinite(o1).all() and torch.equal(o1, o2)
+
+
+# ---------------------------------------------------------------- full-size VALUE checks against the oracle's tables
+def _oracle_rows_check(indices_host, shape, cin, cout, n_rows, seed, kind="subm"):
+    """sparse conv forward / dIn / two offsets of dW of a full-size level against an fp64 gather-GEMM whose pair lists
+    come from the ORACLE (oracle/spconv_ref.subm_pairs_fast / down_pairs_fast: numpy, independent of csrc/rulebook.hip),
+    on ``n_rows`` random output rows; tolerance 1e-5 of the tensor scale (fp32 fma chains of <= 27 * cin terms)."""
+    from oracle import spconv_ref as ref
+    g = torch.Generator().manual_seed(seed)
+    idx_d = torch.from_numpy(indices_host).to(DEV)
+    M = indices_host.shape[0]
+    if kind == "subm":
+        pairs = ref.subm_pairs_fast(indices_host, shape, 3, 1)
+        mod = spconv.SubMConv3d(cin, cout, 3, padding=1, bias=False, indice_key="v").to(DEV)
+        M_out = M
+    else:
+        out_idx, out_shape, pairs = ref.down_pairs_fast(indices_host, shape, 2, 2, 0)
+        mod = spconv.SparseConv3d(cin, cout, 2, stride=2, bias=False, indice_key="v").to(DEV)
+        M_out = out_idx.shape[0]
+    K = len(pairs)
+    x = torch.randn(M, cin, generator=g).to(DEV).requires_grad_(True)
+    t = spconv.SparseConvTensor(x, idx_d, np.array(shape), int(indices_host[:, 0].max()) + 1)
+    out = mod(t)
+    y = out.features
+    assert y.shape == (M_out, cout)
+    if kind != "subm":      # strided conv: output rows in ascending linear index = the oracle's order
+        assert np.array_equal(out.indices.cpu().numpy(), np.asarray(out_idx, dtype=np.int32))
+    gy = torch.randn(M_out, cout, generator=g).to(DEV)
+    y.backward(gy)
+    W = mod.weight.detach().view(K, cin, cout).double()
+    xd, gyd = x.detach().double(), gy.double()
+    rows_o = torch.randint(0, M_out, (n_rows,), generator=g).to(DEV)
+    rows_i = torch.randint(0, M, (n_rows,), generator=g).to(DEV)
+    want_y = torch.zeros(n_rows, cout, dtype=torch.float64, device=DEV)
+    want_dx = torch.zeros(n_rows, cin, dtype=torch.float64, device=DEV)
+    pos_o = torch.full((M_out,), -1, dtype=torch.long, device=DEV)
+    pos_o[rows_o] = torch.arange(n_rows, device=DEV)           # duplicates: the last position wins; handled below
+    pos_i = torch.full((M,), -1, dtype=torch.long, device=DEV)
+    pos_i[rows_i] = torch.arange(n_rows, device=DEV)
+    dw_checked = 0
+    for k, (pi, po) in enumerate(pairs):
+        pi_d, po_d = torch.from_numpy(np.asarray(pi)).to(DEV), torch.from_numpy(np.asarray(po)).to(DEV)
+        sel = pos_o[po_d] >= 0
+        want_y.index_add_(0, pos_o[po_d[sel]], xd[pi_d[sel]] @ W[k])
+        sel = pos_i[pi_d] >= 0
+        want_dx.index_add_(0, pos_i[pi_d[sel]], gyd[po_d[sel]] @ W[k].t())
+        if k in (0, K // 2):
+            dw = xd[pi_d].t() @ gyd[po_d]
+            got = mod.weight.grad.view(K, cin, cout)[k].double()
+            assert float((got - dw).abs().max()) <= 1e-5 * max(float(dw.abs().max()), 1.0), f"dW offset {k}"
+            dw_checked += 1
+    assert dw_checked == 2
+    uo, ui = pos_o[rows_o], pos_i[rows_i]                          # the surviving position of every sampled row
+    sy, sx = float(want_y.abs().max()), float(want_dx.abs().max())
+    assert float((y.detach()[rows_o].double() - want_y[uo]).abs().max()) <= 1e-5 * max(sy, 1.0), "forward values"
+    assert float((x.grad[rows_i].double() - want_dx[ui]).abs().max()) <= 1e-5 * max(sx, 1.0), "dIn values"
+
+
+def _level_indices(batch, level):
+    idx = batch["voxel_locs"].int().to(DEV).contiguous()
+    shape = [int(s) for s in batch["spatial_shape"]]
+    for _ in range(level):
+        rd = ops.build_down_rulebook(idx, shape, [2] * 3, [2] * 3, [0] * 3)
+        idx, shape = rd.out_indices, rd.out_shape
+    return idx.cpu().numpy().astype(np.int32), shape
+
+
+@pytest.mark.parametrize("level,cin,cout", [(0, 32, 32), (1, 64, 64), (2, 96, 96), (3, 128, 128), (4, 160, 160), (0, 64, 32)])
+def test_c2_conv_values_against_oracle_tables(c2_batch, level, cin, cout):
+    idx, shape = _level_indices(c2_batch, level)
+    _oracle_rows_check(idx, shape, cin, cout, 4096, 100 + level)
+
+
+@pytest.mark.parametrize("level,cin,cout", [(0, 32, 64), (2, 96, 128)])
+def test_c2_strided_conv_values_against_oracle_tables(c2_batch, level, cin, cout):
+    idx, shape = _level_indices(c2_batch, level)
+    _oracle_rows_check(idx, shape, cin, cout, 4096, 200 + level, kind="down")
+
+
+@pytest.mark.parametrize("level,cin,cout", [(0, 32, 32), (1, 64, 64)])
+def test_c3_conv_values_against_oracle_tables(c3_batch, level, cin, cout):
+    idx, shape = _level_indices(c3_batch, level)
+    _oracle_rows_check(idx, shape, cin, cout, 4096, 300 + level)
+
+
+def test_c4_conv_values_against_oracle_tables():
+    scene = harness.make_scene(5, room=(13.0, 10.0, 3.0), n_box=36)
+    b = harness.collate([scene])
+    idx, shape = _level_indices(b, 0)
+    assert idx.shape[0] > 600000
+    _oracle_rows_check(idx, shape, 32, 32, 4096, 400)
+    idx1, shape1 = _level_indices(b, 1)
+    _oracle_rows_check(idx1, shape1, 64, 64, 4096, 401)

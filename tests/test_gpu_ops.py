@@ -952,3 +952,73 @@ def test_rulebooks_wait_for_coordinates_produced_late_on_the_main_stream():
         for k in range(27):
             got = set(map(tuple, pairs[k, :, :int(num[k])].t().cpu().numpy().tolist()))
             assert got == set(map(tuple, np.asarray(want[k]).T.tolist())), k
+
+
+# ---------------------------------------------------------------- ECC without the [E, 1024] filter tensor (8f-1)
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,deg", [(60, 4), (700, 9)])
+def test_ecc_contraction_matches_oracle_and_never_forms_the_filter_tensor(S, deg, monkeypatch):
+    """graphnet.RNNGraphConvModule with the filter-free evaluation (m_e = h_e . U_t, U = x @ W') against the oracle's
+    RefRNNGraphConv in fp64 (which forms W_e = fnet(f_e) like spg_modules.py:168-183): outputs and every gradient at
+    1e-4 of the tensor scale; while it runs no tensor of E * 1024 elements is allocated."""
+    import graphnet
+    from oracle import network_ref
+    eu, ev = _graph(S + 3, S, deg)
+    order = np.argsort(ev, kind="stable")
+    edge_indexes = torch.from_numpy(np.stack([eu[order], ev[order]]))
+    E = edge_indexes.shape[1]
+    g = torch.Generator().manual_seed(S)
+    feats = torch.randn(E, 13, generator=g)
+    x = torch.randn(S, 32, generator=g)
+    torch.manual_seed(S)
+    ref = network_ref.RefRNNGraphConv(32, 7).double().train()
+    net = graphnet.GraphNetwork("gru_7_0", 32, [13, 32, 128, 64], fnet_orthoinit=True, fnet_llbias=True, fnet_bnidx=2)
+    mod = net.gconvs[0]
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()}, strict=True)
+    mod = mod.to(DEV).train()
+    gi = graphnet.GraphConvInfo(edge_indexes.to(DEV), feats.to(DEV), S)
+    mod.set_info(gi)
+    assert mod._contract_ok(x.to(DEV))
+    big = []
+
+    class Spy(torch.utils._python_dispatch.TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            out = func(*args, **(kwargs or {}))
+            for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                if isinstance(t, torch.Tensor) and t.is_floating_point() and t.numel() >= E * 1024:
+                    big.append((str(func), tuple(t.shape)))
+            return out
+
+    xg = x.clone().to(DEV).requires_grad_(True)
+    go = torch.randn(S, 32 * 8, generator=g)
+    with Spy():
+        out = mod(xg)
+        out.backward(go.to(DEV))
+    assert not big, big
+    xr = x.clone().double().requires_grad_(True)
+    want = ref(xr, edge_indexes, feats.double())
+    want.backward(go.double())
+
+    def ok(a, b, name):
+        scale = max(float(b.abs().max()), 1e-6)
+        err = float((a.detach().cpu().double() - b).abs().max()) / scale
+        assert err <= 1e-4, (name, err)
+
+    ok(out, want.detach(), "out")
+    ok(xg.grad, xr.grad, "dx")
+    refp = dict(ref.named_parameters())
+    gmax = max(float(q.grad.abs().max()) for q in ref.parameters())
+    for name, p in mod.named_parameters():
+        # a bias that feeds a BatchNorm has a true gradient of zero (rounding noise only): measured against the
+        # largest parameter gradient as well
+        b = refp[name].grad
+        err = float((p.grad.detach().cpu().double() - b).abs().max()) / max(float(b.abs().max()), 5e-2 * gmax)
+        assert err <= 1e-4, (name, err)
+    # the filter-materialising path gives the same numbers to fp32 rounding
+    monkeypatch.setenv("WSIS_ECC_CONTRACT", "0")
+    mod.zero_grad()
+    x2 = x.clone().to(DEV).requires_grad_(True)
+    out2 = mod(x2)
+    out2.backward(go.to(DEV))
+    ok(out2, want.detach(), "out (filters materialised)")
+    ok(x2.grad, xr.grad, "dx (filters materialised)")
