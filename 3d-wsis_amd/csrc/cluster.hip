@@ -319,3 +319,180 @@ int wsis_ballquery_fill(const float* d_xyz, const int32_t* d_batch_idx, const in
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// bfs_cluster on the device (upstream PointGroup runs it on the host).  Same results as the
+// host FIFO walk, element for element:
+//   1. connected components of the ball-query graph restricted to equal semantic labels by lock-free union-find
+//      (the larger root is hooked under the smaller one, so a component's root is its SMALLEST point index = the
+//      seed the host walk starts it from);
+//   2. the caller keeps the components with >= threshold points, numbers them in seed order and lays their point
+//      lists out back to back (a few torch calls + the one host read of the output sizes);
+//   3. one workgroup per kept component replays the FIFO order level by level, with its slice of the output as the
+//      queue: every frontier point stamps its unvisited neighbours with atomicMin(its queue position); a neighbour
+//      belongs to the parent whose stamp survived; parents append their own children in list order (ball-query lists
+//      are ascending) at offsets from a prefix sum over the frontier -- exactly the order in which the host queue would
+//      have received them.
+namespace {
+
+__device__ __forceinline__ int32_t uf_find(int32_t* parent, int32_t v) {
+  int32_t p = parent[v];
+  while (p != v) {          // path halving
+    const int32_t g = parent[p];
+    if (g != p) parent[v] = g;
+    v = p;
+    p = g;
+  }
+  return v;
+}
+
+__global__ void cc_init_kernel(int32_t* __restrict__ parent, int64_t N) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+    parent[i] = (int32_t)i;
+}
+
+// one thread per point: union with every same-label neighbour of larger index (each undirected pair once)
+__global__ void cc_union_kernel(const int32_t* __restrict__ sem, const int32_t* __restrict__ idx,
+                                const int32_t* __restrict__ start_len, int32_t* parent, int64_t N) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t s = start_len[2 * i], n = start_len[2 * i + 1], lab = sem[i];
+    for (int32_t j = 0; j < n; ++j) {
+      const int32_t v = idx[s + j];
+      if (v <= (int32_t)i || sem[v] != lab) continue;
+      int32_t a = uf_find(parent, (int32_t)i), b = uf_find(parent, v);
+      while (a != b) {
+        if (a < b) {
+          const int32_t t = a;
+          a = b;
+          b = t;
+        }                                     // hook the larger root a under the smaller root b
+        const int32_t old = atomicCAS(&parent[a], a, b);
+        if (old == a) break;
+        a = uf_find(parent, old);
+        b = uf_find(parent, b);
+      }
+    }
+  }
+}
+
+__global__ void cc_flatten_kernel(int32_t* parent, int32_t* __restrict__ root, int32_t* __restrict__ size, int64_t N) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t r = uf_find(parent, (int32_t)i);
+    root[i] = r;
+    atomicAdd(&size[r], 1);
+  }
+}
+
+constexpr int BFS_THREADS = 256;
+
+// one workgroup per kept component c: queue = out[offset[c] .. offset[c+1]) (second column of cluster_idxs)
+__global__ __launch_bounds__(BFS_THREADS) void bfs_order_kernel(const int32_t* __restrict__ idx,
+                                                                const int32_t* __restrict__ start_len,
+                                                                const int32_t* __restrict__ sem,
+                                                                const int32_t* __restrict__ seeds,
+                                                                const int32_t* __restrict__ offsets, int32_t* pos,
+                                                                int32_t* stamp, int32_t* __restrict__ cluster_idxs) {
+  __shared__ int32_t scan[BFS_THREADS];
+  __shared__ int32_t carry;
+  const int c = blockIdx.x;
+  const int32_t base = offsets[c], total = offsets[c + 1] - base;
+  const int32_t seed = seeds[c], lab = sem[seed];
+  int32_t* queue = cluster_idxs;       // rows (cluster id, point): queue[2 * (base + i) + 1]
+  if (threadIdx.x == 0) {
+    queue[2 * base] = c;
+    queue[2 * base + 1] = seed;
+    pos[seed] = 0;
+  }
+  __syncthreads();
+  int32_t lo = 0, hi = 1;
+  while (lo < hi && hi < total) {
+    // pass 1: stamp the unvisited same-label neighbours with the parent's queue position
+    for (int32_t i = lo + threadIdx.x; i < hi; i += BFS_THREADS) {
+      const int32_t p = queue[2 * (base + i) + 1];
+      const int32_t s = start_len[2 * p], n = start_len[2 * p + 1];
+      for (int32_t j = 0; j < n; ++j) {
+        const int32_t v = idx[s + j];
+        if (sem[v] == lab && pos[v] < 0) atomicMin(&stamp[v], i);
+      }
+    }
+    __syncthreads();
+    // pass 2 + 3: children per parent, prefix sum over the frontier in queue order, append
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int32_t i0 = lo; i0 < hi; i0 += BFS_THREADS) {
+      const int32_t i = i0 + threadIdx.x;
+      int32_t cnt = 0, p = -1, s = 0, n = 0;
+      if (i < hi) {
+        p = queue[2 * (base + i) + 1];
+        s = start_len[2 * p];
+        n = start_len[2 * p + 1];
+        for (int32_t j = 0; j < n; ++j) {
+          const int32_t v = idx[s + j];
+          if (sem[v] == lab && pos[v] < 0 && stamp[v] == i) ++cnt;
+        }
+      }
+      scan[threadIdx.x] = cnt;
+      __syncthreads();
+      for (int off = 1; off < BFS_THREADS; off <<= 1) {     // inclusive scan
+        const int32_t t = threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+        __syncthreads();
+        scan[threadIdx.x] += t;
+        __syncthreads();
+      }
+      const int32_t before = carry + scan[threadIdx.x] - cnt;
+      const int32_t chunk_total = scan[BFS_THREADS - 1];
+      __syncthreads();
+      if (i < hi && cnt > 0) {
+        int32_t w = hi + before;
+        for (int32_t j = 0; j < n; ++j) {
+          const int32_t v = idx[s + j];
+          // pos[v] is written only by the parent that owns v (stamp[v] == i) -- every v exactly once per level
+          if (sem[v] == lab && stamp[v] == i && pos[v] < 0) {
+            queue[2 * (base + w)] = c;
+            queue[2 * (base + w) + 1] = v;
+            pos[v] = w;
+            ++w;
+          }
+        }
+      }
+      if (threadIdx.x == 0) carry += chunk_total;
+      __syncthreads();
+    }
+    lo = hi;
+    hi += carry;
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int wsis_cc_same_label(const int32_t* d_sem, const int32_t* d_idx, const int32_t* d_start_len, int64_t N,
+                       int32_t* d_parent, int32_t* d_root, int32_t* d_size, void* stream) {
+  WSIS_REQUIRE(N >= 0, "bad size");
+  if (N == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_sem && d_start_len && d_parent && d_root && d_size, "null pointer");
+  WSIS_REQUIRE(N < ((int64_t)1 << 31), "point count exceeds int32");
+  hipStream_t st = as_stream(stream);
+  WSIS_HIP_CHECK(hipMemsetAsync(d_size, 0, sizeof(int32_t) * (size_t)N, st));
+  hipLaunchKernelGGL(cc_init_kernel, dim3(grid_for(N, 256)), dim3(256), 0, st, d_parent, N);
+  hipLaunchKernelGGL(cc_union_kernel, dim3(grid_for(N, 256)), dim3(256), 0, st, d_sem, d_idx, d_start_len, d_parent, N);
+  hipLaunchKernelGGL(cc_flatten_kernel, dim3(grid_for(N, 256)), dim3(256), 0, st, d_parent, d_root, d_size, N);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_bfs_order(const int32_t* d_idx, const int32_t* d_start_len, const int32_t* d_sem, const int32_t* d_seeds,
+                   const int32_t* d_offsets, int64_t n_clusters, int32_t* d_pos, int32_t* d_stamp,
+                   int32_t* d_cluster_idxs, void* stream) {
+  WSIS_REQUIRE(n_clusters >= 0, "bad size");
+  if (n_clusters == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_start_len && d_sem && d_seeds && d_offsets && d_pos && d_stamp && d_cluster_idxs, "null pointer");
+  hipLaunchKernelGGL(bfs_order_kernel, dim3((unsigned)n_clusters), dim3(BFS_THREADS), 0, as_stream(stream), d_idx,
+                     d_start_len, d_sem, d_seeds, d_offsets, d_pos, d_stamp, d_cluster_idxs);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+}  // extern "C"

@@ -144,13 +144,49 @@ class BallQueryBatchP(Function):
 ballquery_batch_p = BallQueryBatchP.apply
 
 
+def _bfs_cluster_device(sem, idx, start_len, threshold):
+    _n.require_cuda(sem, idx, start_len)
+    for t in (sem, idx, start_len):
+        assert t.dtype == torch.int32 and t.is_contiguous()
+    lib, dev, N = _n.hip(), sem.device, sem.size(0)
+    if N and int(start_len[:, 1].max()) >= 1000:
+        # a list truncated at upstream's 1000-neighbour cap makes the graph asymmetric (p lists q, q does not list p);
+        # the union-find components assume symmetric lists, so that (pathological) case takes the host walk
+        ci, co = BFSCluster.apply(sem.cpu(), idx.cpu(), start_len.cpu(), threshold)
+        return ci.to(dev), co.to(dev)
+    st = _n.stream_ptr()
+    parent = torch.empty(N, dtype=torch.int32, device=dev)
+    root = torch.empty(N, dtype=torch.int32, device=dev)
+    size = torch.empty(N, dtype=torch.int32, device=dev)
+    _n.check(lib.wsis_cc_same_label(_n.ptr(sem), _n.ptr(idx), _n.ptr(start_len), N, _n.ptr(parent), _n.ptr(root),
+                                    _n.ptr(size), st), "cc_same_label")
+    ar = torch.arange(N, dtype=torch.int32, device=dev)
+    seeds = torch.nonzero((root == ar) & (size >= threshold)).flatten().int()   # ascending = the host's seed order
+    n_c = int(seeds.numel())                                                      # the one host read
+    sizes = size[seeds.long()]
+    offsets = torch.zeros(n_c + 1, dtype=torch.int32, device=dev)
+    offsets[1:] = torch.cumsum(sizes, 0).int()
+    total = int(offsets[-1].item()) if n_c else 0
+    cluster_idxs = torch.empty((total, 2), dtype=torch.int32, device=dev)
+    if n_c:
+        pos = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        stamp = torch.full((N,), 2 ** 31 - 1, dtype=torch.int32, device=dev)
+        _n.check(lib.wsis_bfs_order(_n.ptr(idx), _n.ptr(start_len), _n.ptr(sem), _n.ptr(seeds), _n.ptr(offsets), n_c,
+                                    _n.ptr(pos), _n.ptr(stamp), _n.ptr(cluster_idxs), st), "bfs_order")
+    return cluster_idxs, offsets
+
+
 class BFSCluster(Function):
     @staticmethod
     def forward(ctx, semantic_label, ball_query_idxs, start_len, threshold):
-        """all CPU int tensors (as upstream) -> cluster_idxs int [sumNPoint,2], cluster_offsets int [nCluster+1]"""
+        """int tensors -> cluster_idxs int [sumNPoint,2], cluster_offsets int [nCluster+1].  CPU tensors (the upstream
+        contract) run the host walk of libwsis_host.so; CUDA tensors run the device version (csrc/cluster.hip: union-find
+        components + one workgroup per kept cluster replaying the FIFO order) -- same output, element for element."""
+        if semantic_label.is_cuda:
+            return _bfs_cluster_device(semantic_label, ball_query_idxs, start_len, int(threshold))
         for t in (semantic_label, ball_query_idxs, start_len):
             if t.is_cuda:
-                raise _n.WsisError("bfs_cluster takes CPU tensors (upstream contract)")
+                raise _n.WsisError("bfs_cluster: all tensors on one device")
             assert t.dtype == torch.int32 and t.is_contiguous()
         import ctypes
         N = semantic_label.size(0)

@@ -109,6 +109,8 @@ _HIP_SIGS = {
     "wsis_ballquery_workspace_bytes": (I64, [I64]),
     "wsis_ballquery_count": (I32, [P, P, P, I64, I32, F32, P, P, P, I64, P]),
     "wsis_ballquery_fill": (I32, [P, P, P, I64, I32, F32, P, P, I64, P, I64, P]),
+    "wsis_cc_same_label": (I32, [P, P, P, I64, P, P, P, P]),
+    "wsis_bfs_order": (I32, [P, P, P, P, P, I64, P, P, P, P]),
     "wsis_semantic_loss_workspace_bytes": (I64, [I64]),
     "wsis_semantic_loss_fwd": (I32, [P, P, I64, I32, I64, P, P, P, I64, P]),
     "wsis_semantic_loss_bwd": (I32, [P, P, I64, I32, I64, P, P, P, P]),

@@ -233,6 +233,13 @@ def side_measurements(harness, optimizer, device, args):
     t0 = time.perf_counter()
     cl_idx, cl_off = pointgroup_ops.bfs_cluster(sem_keep, idx_c, sl_c, 50)
     ms_bfs = (time.perf_counter() - t0) * 1e3
+    sem_d = sem_keep.to(device)
+
+    def bfs_dev():
+        res["cl"] = pointgroup_ops.bfs_cluster(sem_d, res["idx"], res["start_len"], 50)
+
+    ms_bfs_dev = _gpu_ms(bfs_dev, 5)
+    same = bool(torch.equal(res["cl"][0].cpu(), cl_idx) and torch.equal(res["cl"][1].cpu(), cl_off))
     # BASELINE configs C3 / C4 as side numbers (same process, after the timed region)
     out.update(other_configs(harness, device, args))
 
@@ -251,7 +258,8 @@ def side_measurements(harness, optimizer, device, args):
     out["cluster_stage"] = {"workload": "C3: 4 synthetic scenes, non floor/wall points, r=0.03 m, threshold 50",
                             "points": int(coords.shape[0]), "neighbour_pairs": int(idx_c.numel()),
                             "clusters": int(cl_off.numel() - 1), "ballquery_ms": round(ms_bq, 3),
-                            "bfs_cluster_host_ms": round(ms_bfs, 3)}
+                            "bfs_cluster_ms": round(ms_bfs_dev, 3), "bfs_cluster_host_ms": round(ms_bfs, 3),
+                            "device_equals_host": same}
     return out
 
 

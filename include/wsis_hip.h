@@ -357,6 +357,19 @@ int wsis_ballquery_fill(const float* d_xyz, const int32_t* d_batch_idx, const in
                         int64_t N, int32_t B, float radius, const int32_t* d_start_len, int32_t* d_idx,
                         int64_t total, void* d_ws, int64_t ws_bytes, void* stream);
 
+/* ---- a20 on the device: pointgroup_ops.bfs_cluster(semantic_label, ball_query_idxs, start_len, threshold) [UPSTREAM
+ * PointGroup, host code] with CUDA tensors.  wsis_cc_same_label: connected components of the ball-query graph
+ * restricted to equal labels, d_root[i] = smallest point index of i's component (the host walk's seed),
+ * d_size[root] = its point count (d_parent: int32 [N] scratch).  The caller keeps the components of >= threshold
+ * points, numbers them in seed order (d_seeds, exclusive prefix d_offsets [n+1]) and wsis_bfs_order writes
+ * cluster_idxs [sum, 2] = (cluster id, point) in the host walk's FIFO discovery order: one workgroup per cluster,
+ * d_pos int32 [N] preset to -1, d_stamp int32 [N] preset to INT32_MAX. */
+int wsis_cc_same_label(const int32_t* d_sem, const int32_t* d_idx, const int32_t* d_start_len, int64_t N,
+                       int32_t* d_parent, int32_t* d_root, int32_t* d_size, void* stream);
+int wsis_bfs_order(const int32_t* d_idx, const int32_t* d_start_len, const int32_t* d_sem, const int32_t* d_seeds,
+                   const int32_t* d_offsets, int64_t n_clusters, int32_t* d_pos, int32_t* d_stamp,
+                   int32_t* d_cluster_idxs, void* stream);
+
 /* ---- a18 (point-level part): semantic loss of MultiTaskLoss.forward (losses_3D_WSIS.py:52-67 of the reference):
  * CrossEntropyLoss(ignore_index) + mean_c(1 - dice_c) with dice_c = (2 sum p_c y_c + 1e-5) / (sum p_c^2 + sum y_c
  * + 1e-4 + 1e-5) over the rows whose label != ignore_label, p = softmax(scores).  d_scores fp32 [N,C] (C <= 32),

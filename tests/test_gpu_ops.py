@@ -339,6 +339,39 @@ def test_ballquery_and_bfs(N, B, r):
     ci, co = pointgroup_ops.bfs_cluster(torch.from_numpy(sem), idx.cpu(), sl.cpu(), 3)
     ri, ro = pg_ops.bfs_cluster(sem, e_idx, e_sl, 3)
     assert np.array_equal(ci.numpy(), ri) and np.array_equal(co.numpy(), ro)
+    # device version (CUDA tensors): the same clusters, the same FIFO discovery order, element for element
+    for thr in (3, 1, 40):
+        di, do = pointgroup_ops.bfs_cluster(torch.from_numpy(sem).to(DEV), idx, sl, thr)
+        ri, ro = pg_ops.bfs_cluster(sem, e_idx, e_sl, thr)
+        assert di.is_cuda and di.dtype == torch.int32 and do.dtype == torch.int32
+        assert np.array_equal(do.cpu().numpy(), ro), thr
+        assert np.array_equal(di.cpu().numpy().reshape(-1, 2), np.asarray(ri).reshape(-1, 2)), thr
+
+
+def test_bfs_cluster_device_on_long_thin_components_and_large_frontiers():
+    """deep BFS (a 1-D chain: one point per level), a wide one (a dense blob: frontiers of several hundred points, more
+    than one 256-thread chunk) and label boundaries, against the FIFO oracle"""
+    rng = np.random.default_rng(5)
+    chain = np.stack([np.arange(600) * 0.02, np.zeros(600), np.zeros(600)], 1)
+    blob = rng.normal(0, 0.06, (4000, 3)) + np.array([5.0, 0, 0])
+    sheet = np.concatenate([rng.random((3000, 2)) * 1.0, np.zeros((3000, 1))], 1) + np.array([0, 5.0, 0])
+    xyz = np.concatenate([chain, blob, sheet]).astype(np.float32)
+    perm = rng.permutation(len(xyz))
+    xyz = xyz[perm]
+    N = len(xyz)
+    bi = np.zeros(N, dtype=np.int32)
+    off = np.array([0, N], dtype=np.int32)
+    sem = (xyz[:, 1] > 5.5).astype(np.int32)              # splits the sheet into two labels
+    idx, sl = pointgroup_ops.ballquery_batch_p(torch.from_numpy(xyz).to(DEV), torch.from_numpy(bi).to(DEV),
+                                               torch.from_numpy(off).to(DEV), 0.03, 50)
+    assert int(sl[:, 1].max()) < 1000
+    di, do = pointgroup_ops.bfs_cluster(torch.from_numpy(sem).to(DEV), idx, sl, 20)
+    ri, ro = pg_ops.bfs_cluster(sem, idx.cpu().numpy(), sl.cpu().numpy(), 20)
+    assert len(ro) - 1 >= 3
+    assert np.array_equal(do.cpu().numpy(), ro)
+    assert np.array_equal(di.cpu().numpy().reshape(-1, 2), np.asarray(ri).reshape(-1, 2))
+    hi, ho = pointgroup_ops.bfs_cluster(torch.from_numpy(sem), idx.cpu(), sl.cpu(), 20)
+    assert torch.equal(hi, di.cpu()) and torch.equal(ho, do.cpu())
 
 
 def test_ballquery_cap_1000():
