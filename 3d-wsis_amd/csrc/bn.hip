@@ -134,37 +134,87 @@ __global__ __launch_bounds__(64) void bn_stats_final_kernel(const float* __restr
 
 // the same from CENTRED partials of 32-row slices (written by the convolution epilogues, csrc/spconv2.hip): slice i
 // holds S_i = sum and Q_i = sum of squared deviations from ITS mean over n_i = min(32, M - 32 i) rows;
-// mean = sum S_i / M, var = (sum Q_i + sum S_i^2 / n_i - M mean^2) / M, all in fp64 (Chan's pairwise combination)
-__global__ __launch_bounds__(64) void bn_stats_final_centred_kernel(const float* __restrict__ partial, int nblk, int C,
-                                                                    int64_t M, float* __restrict__ mean,
-                                                                    float* __restrict__ var,
-                                                                    float* __restrict__ running_mean,
-                                                                    float* __restrict__ running_var, float momentum) {
-  const int c = blockIdx.x;
-  double s = 0.0, q = 0.0, w = 0.0;
-#pragma unroll 4
-  for (int b = threadIdx.x; b < nblk; b += 64) {
-    const double si = partial[(int64_t)b * 2 * C + c];
-    const int64_t left = M - (int64_t)b * 32;
-    const double ni = (double)(left < 32 ? left : 32);
-    s += si;
-    q += partial[(int64_t)b * 2 * C + C + c];
-    w += si * si / ni;
+// mean = sum S_i / M, var = (sum Q_i + sum S_i^2 / n_i - M mean^2) / M, all in fp64 (Chan's pairwise combination).
+// Two levels so that the 1.2 MB of partials of a 150k-row level is read by up to 64 workgroups per 32 channels instead of
+// one: chunk sums (fixed order inside a chunk) -> [G][3][C] doubles, then one thread per channel adds the chunks in order.
+constexpr int BN_FIN_CHUNKS = 64;
+
+__device__ __forceinline__ void bn_finish_centred(double S, double Q, double W, int64_t M, int c, float* mean, float* var,
+                                                  float* running_mean, float* running_var, float momentum) {
+  const double n = (double)M;
+  const double mu = S / n;
+  double v = (Q + (W - n * mu * mu)) / n;
+  if (v < 0.0) v = 0.0;
+  mean[c] = (float)mu;
+  var[c] = (float)v;
+  if (running_mean) {
+    const double unb = n > 1 ? v * n / (n - 1) : v;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
   }
-  const double S = wave_sum_f64(s), Q = wave_sum_f64(q), W = wave_sum_f64(w);
-  if (threadIdx.x == 0) {
-    const double n = (double)M;
-    const double mu = S / n;
-    double v = (Q + (W - n * mu * mu)) / n;
-    if (v < 0.0) v = 0.0;
-    mean[c] = (float)mu;
-    var[c] = (float)v;
-    if (running_mean) {
-      const double unb = n > 1 ? v * n / (n - 1) : v;
-      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
-      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+}
+
+// grid (G, ceil(C / 32)), 256 threads = 32 channel lanes x 8 partial lanes; G == 1 finishes in place
+__global__ __launch_bounds__(256) void bn_stats_chunk_centred_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                                     int64_t M, double* __restrict__ chunk,
+                                                                     float* __restrict__ mean, float* __restrict__ var,
+                                                                     float* __restrict__ running_mean,
+                                                                     float* __restrict__ running_var, float momentum) {
+  __shared__ double red[3][8][33];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.y * 32 + cl;
+  const int per = (nblk + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per;
+  const int hi = lo + per < nblk ? lo + per : nblk;
+  double s = 0.0, q = 0.0, w = 0.0;
+  if (c < C) {
+#pragma unroll 4
+    for (int b = lo + pl; b < hi; b += 8) {
+      const float sf = partial[(int64_t)b * 2 * C + c];
+      const float qf = partial[(int64_t)b * 2 * C + C + c];
+      const int64_t left = M - (int64_t)b * 32;
+      const double si = sf;
+      s += si;
+      q += qf;
+      w += si * si * (left < 32 ? 1.0 / (double)left : 0.03125);
     }
   }
+  red[0][pl][cl] = s;
+  red[1][pl][cl] = q;
+  red[2][pl][cl] = w;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    double S = 0.0, Q = 0.0, W = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {      // fixed order
+      S += red[0][j][cl];
+      Q += red[1][j][cl];
+      W += red[2][j][cl];
+    }
+    if (gridDim.x == 1) {
+      bn_finish_centred(S, Q, W, M, c, mean, var, running_mean, running_var, momentum);
+    } else {
+      double* o = chunk + (int64_t)blockIdx.x * 3 * C;
+      o[c] = S;
+      o[C + c] = Q;
+      o[2 * C + c] = W;
+    }
+  }
+}
+
+__global__ void bn_stats_final_centred_kernel(const double* __restrict__ chunk, int G, int C, int64_t M,
+                                              float* __restrict__ mean, float* __restrict__ var,
+                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                              float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double S = 0.0, Q = 0.0, W = 0.0;
+  for (int g = 0; g < G; ++g) {        // fixed order
+    S += chunk[(int64_t)g * 3 * C + c];
+    Q += chunk[(int64_t)g * 3 * C + C + c];
+    W += chunk[(int64_t)g * 3 * C + 2 * C + c];
+  }
+  bn_finish_centred(S, Q, W, M, c, mean, var, running_mean, running_var, momentum);
 }
 
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
@@ -607,15 +657,35 @@ int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* 
   return WSIS_OK;
 }
 
+static int bn_fin_chunks(int64_t n_part) {
+  int64_t g = n_part / 64;           // at least 64 partials per chunk
+  if (g < 1) g = 1;
+  if (g > BN_FIN_CHUNKS) g = BN_FIN_CHUNKS;
+  return (int)g;
+}
+
+int64_t wsis_bn_stats_finalize_workspace_bytes(int64_t n_part, int32_t C) {
+  return (int64_t)bn_fin_chunks(n_part) * 3 * C * (int64_t)sizeof(double) + 256;
+}
+
 int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, int32_t C, float* d_mean, float* d_var,
-                           float* d_running_mean, float* d_running_var, float momentum, void* stream) {
+                           float* d_running_mean, float* d_running_var, float momentum, void* d_ws, int64_t ws_bytes,
+                           void* stream) {
   WSIS_REQUIRE(n_part >= 1 && M >= 1 && C >= 1 && d_partials && d_mean && d_var, "bad args");
   WSIS_REQUIRE(n_part < ((int64_t)1 << 31), "too many partials");
   WSIS_REQUIRE((d_running_mean == nullptr) == (d_running_var == nullptr), "running stats come in pairs");
   WSIS_REQUIRE(n_part == (M + 31) / 32, "one partial per 32-row slice");
-  hipLaunchKernelGGL(bn_stats_final_centred_kernel, dim3(C), dim3(64), 0, as_stream(stream), d_partials, (int)n_part, C,
-                     M, d_mean, d_var, d_running_mean, d_running_var, momentum);
+  const int G = bn_fin_chunks(n_part);
+  WSIS_REQUIRE(G == 1 || (d_ws && ws_bytes >= wsis_bn_stats_finalize_workspace_bytes(n_part, C)), "workspace too small");
+  double* chunk = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(d_ws) + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(bn_stats_chunk_centred_kernel, dim3(G, (C + 31) / 32), dim3(256), 0, as_stream(stream), d_partials,
+                     (int)n_part, C, M, chunk, d_mean, d_var, d_running_mean, d_running_var, momentum);
   WSIS_LAUNCH_CHECK();
+  if (G > 1) {
+    hipLaunchKernelGGL(bn_stats_final_centred_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), chunk, G, C, M,
+                       d_mean, d_var, d_running_mean, d_running_var, momentum);
+    WSIS_LAUNCH_CHECK();
+  }
   return WSIS_OK;
 }
 

@@ -12,6 +12,8 @@
 #include <utility>
 #include <vector>
 
+#include <algorithm>
+
 #include "common.h"
 
 using namespace wsis;
@@ -182,7 +184,9 @@ int64_t op_ws_bytes(const wsis_op& op, bool on) {
       if (use_fwd2(op, on)) return up(wsis_spconv_fwd_t_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout));
       return up(wsis_spconv_fwd_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout));
     case WSIS_OP_BN_RELU:
-      return (op.flags & WSIS_OPF_TRAINING) ? up(wsis_bn_workspace_bytes(op.M_in, op.Cin)) : 0;
+      if (!(op.flags & WSIS_OPF_TRAINING)) return 0;
+      return up(std::max(wsis_bn_workspace_bytes(op.M_in, op.Cin),
+                         wsis_bn_stats_finalize_workspace_bytes((op.M_in + 31) / 32, op.Cin)));
     case WSIS_OP_BN_RELU_BWD:
       return up(wsis_bn_workspace_bytes(op.M_in, op.Cin));
     case WSIS_OP_CONV_BWD:     // the transposed weights and the dW slabs live in their own regions, not here
@@ -316,11 +320,11 @@ int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
             const int64_t n_part = (op.M_in + 31) / 32;
             const int C0 = op.in[6] ? op.K : op.Cin;
             rc = wsis_bn_stats_finalize((const float*)op.in[5], n_part, op.M_in, C0, (float*)op.out[1],
-                                        (float*)op.out[2], rm, rv, op.momentum, stream);
+                                        (float*)op.out[2], rm, rv, op.momentum, ws, ws_bytes, stream);
             if (rc == WSIS_OK && op.in[6])
               rc = wsis_bn_stats_finalize((const float*)op.in[6], n_part, op.M_in, op.Cin - C0, (float*)op.out[1] + C0,
                                           (float*)op.out[2] + C0, rm ? rm + C0 : nullptr, rv ? rv + C0 : nullptr,
-                                          op.momentum, stream);
+                                          op.momentum, ws, ws_bytes, stream);
           } else {
             rc = wsis_bn_stats((const float*)op.in[0], op.M_in, op.Cin, (float*)op.out[1], (float*)op.out[2], rm, rv,
                                op.momentum, ws, ws_bytes, stream);

@@ -11,6 +11,7 @@
 // and consumed by the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32.  No per-offset gather
 // buffer in HBM and no scatter-add atomics (upstream spconv does both); the reduction order is fixed,
 // so results are run-to-run deterministic and independent of the tile order.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -1061,7 +1062,9 @@ int64_t wsis_spconv_dw_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, in
   DwPlan plan;
   dw_make_plan(M_out, K, plan);
   const int64_t ci_pad = ceil_div(Cin, 32) * 32;
-  return (int64_t)plan.begin[K] * ci_pad * Cout * (int64_t)sizeof(float) + 256;
+  const int64_t old_bytes = (int64_t)plan.begin[K] * ci_pad * Cout * (int64_t)sizeof(float) + 256;
+  if (dw2_supported(K, Cin, Cout)) return std::max(old_bytes, dw2_workspace_bytes(M_out, K, Cin, Cout));
+  return old_bytes;
 }
 
 int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY,
@@ -1079,6 +1082,9 @@ int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_orde
   WSIS_REQUIRE(M_in * Cin * 4 < ((int64_t)1 << 32) && M_out * Cout * 4 < ((int64_t)1 << 32),
                "dW addresses features as 32-bit byte offsets: a feature matrix must stay below 4 GiB");
   WSIS_REQUIRE(ws_bytes >= wsis_spconv_dw_workspace_bytes(M_out, K, Cin, Cout), "workspace too small");
+  if (dw2_supported(K, Cin, Cout) && ((reinterpret_cast<uintptr_t>(d_X) | reinterpret_cast<uintptr_t>(d_dY) |
+                                       reinterpret_cast<uintptr_t>(d_dW) | reinterpret_cast<uintptr_t>(d_ws)) & 15) == 0)
+    return dw2_launch(d_X, d_nbr, d_order, d_dY, d_dW, M_out, K, Cin, Cout, d_ws, st);
   DwPlan plan;
   dw_make_plan(M_out, K, plan);
   const int n_cib = (int)ceil_div(Cin, 32);

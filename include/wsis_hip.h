@@ -237,9 +237,11 @@ int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* 
                   float* d_running_var, float momentum, void* d_ws, int64_t ws_bytes, void* stream);
 /* mean / biased variance (and the running-statistics update) of C channels from the n_part = ceil(M / 32) rows of
  * (sum, centred sum of squares) partials with row pitch 2*C floats written by wsis_spconv_fwd_t(d_stats): fp64,
- * fixed order. */
+ * fixed order, two levels (chunk sums in d_ws, then one thread per channel). */
+int64_t wsis_bn_stats_finalize_workspace_bytes(int64_t n_part, int32_t C);
 int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, int32_t C, float* d_mean, float* d_var,
-                           float* d_running_mean, float* d_running_var, float momentum, void* stream);
+                           float* d_running_mean, float* d_running_var, float momentum, void* d_ws, int64_t ws_bytes,
+                           void* stream);
 /* y = relu?( (x-mean)*rsqrt(var+eps)*gamma + beta )   (gamma/beta may be NULL = 1/0) */
 int wsis_bn_apply(const float* d_x, const float* d_mean, const float* d_var, const float* d_gamma,
                   const float* d_beta, float eps, int32_t relu, float* d_y, int64_t M, int32_t C, void* stream);

@@ -13,7 +13,8 @@ dev = 'cuda:0'
 
 
 def build_levels():
-    sc = harness.make_scene(1); b = harness.collate([sc])
+    ns = int(os.environ.get("CONV2_SCENES", "1"))
+    b = harness.collate([harness.make_scene(1 + i) for i in range(ns)])
     idx = b['voxel_locs'].int().to(dev).contiguous(); shape = [int(s) for s in b['spatial_shape']]
     levels = []
     cur_idx, cur_shape = idx, shape

@@ -15,8 +15,8 @@ rb = ops.build_subm_rulebook(idx, shape, [3]*3, [1]*3)
 C = 32 * (level + 1); M = idx.shape[0]
 X = torch.randn(M, C, device=dev); W = torch.randn(27, C, C, device=dev) * 0.05
 WT = ops._weight_t(W, 0)
-out = torch.empty(M, C, device=dev)
 n_wg = (M + 31) // 32 * (C // 32)
+out = torch.empty(max(variant - 1, 1) * M, C, device=dev)   # variant >= 2: the slabs land here
 dbg = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
 lib = _n.hip()
 fn = lib.wsis_debug_spconv2_diag
