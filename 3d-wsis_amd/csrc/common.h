@@ -71,9 +71,10 @@ struct ProfScope {
 
 // wave-autonomous weight-gradient kernel (csrc/spconv_dw2.hip), dispatched from wsis_spconv_dw
 bool dw2_supported(int K, int Cin, int Cout);
+bool dw2_fits(int64_t M_in, int64_t M_out, int K, int Cin, int Cout);   // 32-bit buffer offsets
 int64_t dw2_workspace_bytes(int64_t M_out, int K, int Cin, int Cout);
 int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY, float* d_dW,
-               int64_t M_out, int K, int Cin, int Cout, void* d_ws, hipStream_t st);
+               int64_t M_in, int64_t M_out, int K, int Cin, int Cout, void* d_ws, hipStream_t st);
 
 // ---- device-side hash (linear-index keys) --------------------------------------------------
 constexpr int64_t kEmptyKey = -1;

@@ -24,23 +24,49 @@ namespace {
 
 constexpr int GS = 8;                 // offsets per worker
 constexpr int TILE = 32 * 128;        // bytes of a 32-row x 32-channel image
-constexpr int HDR = (GS * 32 + 32) * 4;                  // nb[8][32] + row[32]
-constexpr int WAVE_LDS = 2 * HDR + 2 * TILE + 2 * TILE;  // headers, dY tiles, X tiles (double-buffered)
+constexpr int HDR_INTS = GS * 32 + 64;                   // nb[8][32] + row[32] (+ 32 written by the upper half wave)
+constexpr int HDR = HDR_INTS * 4;
+constexpr int DA = 3;                                    // X-tile ring: two gathers in flight behind the one computing
+constexpr int WAVE_LDS = 2 * HDR + TILE + DA * TILE + 256;     // headers (double), dY tile, X-tile ring, a row of -1
+constexpr int WGW = 4;                                   // waves per workgroup (they share a slab)
+constexpr int XSH_DEFAULT = 6;                           // slices per XCD chunk = 64 (2048 rows)
 
-__device__ __attribute__((aligned(256))) float g_dw_zero_row[64];
-
-__device__ __forceinline__ void dma16(const void* src, void* lds_dst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+// LDS-DMA through a raw buffer descriptor: 32-bit byte offsets (one multiply per gathered row instead of 64-bit
+// pointer arithmetic) and out-of-range offsets read as zero, so a missing pair (index -1, offset 2^32 - pitch) needs no
+// select.  The step loop is VALU-issue bound without this: ~2000 cycles of address code against 1024 of MFMA.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void bdma16(rsrc_t r, uint32_t off, void* lds_dst) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, (int)off, 0, 0, 0);
+}
+__device__ __forceinline__ void bdma4(rsrc_t r, uint32_t off, void* lds_dst) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 4, (int)off, 0, 0, 0);
 }
 
-template <bool DIAG>
-__global__ __launch_bounds__(256, 2) void spconv_dw2_kernel(const float* __restrict__ X, const int32_t* __restrict__ nbrS,
-                                                         const int32_t* __restrict__ order, const float* __restrict__ dY,
-                                                         float* __restrict__ partial, int64_t M_out, int K, int Cin,
-                                                         int Cout, int NOG, unsigned long long* dbg) {
+// every global read of the main loop is an LDS-DMA with a known instruction count (header 5, dY tile 4, X tile 4), so
+// the wait for "the tile this step computes on" is a counted s_waitcnt: `after` = DMA instructions issued behind it
+__device__ __forceinline__ void wait_after(int after) {
+  switch (after) {
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+template <bool DIAG, bool XCD>
+__global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const float* __restrict__ X, const int32_t* __restrict__ nbrS,
+                                                            const int32_t* __restrict__ order,
+                                                            const float* __restrict__ dY, float* __restrict__ partial, int64_t M_in,
+                                                            int64_t M_out, int K, int Cin, int Cout, int NOG, int XSH,
+                                                            unsigned long long* dbg) {
   unsigned long long t_start = 0, t_loop = 0, t_end_loop = 0;
   unsigned n_steps = 0, n_slices_done = 0;
+  unsigned long long d_wait = 0, d_top = 0, d_chain = 0, d_bot = 0, t_prev = 0;
   if (DIAG) t_start = __builtin_readcyclecounter();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63;
@@ -49,7 +75,9 @@ __global__ __launch_bounds__(256, 2) void spconv_dw2_kernel(const float* __restr
   unsigned char* const my = lds + wave * WAVE_LDS;
   int32_t* const hdr0 = reinterpret_cast<int32_t*>(my);
   unsigned char* const Bt = my + 2 * HDR;
-  unsigned char* const At = Bt + 2 * TILE;
+  unsigned char* const At = Bt + TILE;
+  int32_t* const negrow = reinterpret_cast<int32_t*>(At + DA * TILE);
+  negrow[lane] = -1;
 
   const int nchunk = Cin >> 5, nblk = Cout >> 5;
   int combo = blockIdx.y;
@@ -57,75 +85,85 @@ __global__ __launch_bounds__(256, 2) void spconv_dw2_kernel(const float* __restr
   combo /= nblk;
   const int c = combo % nchunk;
   const int og = combo / nchunk;
+  // Slice -> worker map, XCD-aware: workgroup id % 8 picks the XCD (gridDim.x is a multiple of 8, so blockIdx.x % 8
+  // does); the slices are dealt to the XCDs in chunks of 2^XSH (a spatial brick of the tile order whose gathered X rows
+  // are shared by its offsets and neighbouring slices, so they stay in that XCD's L2), and inside an XCD its waves take
+  // the XCD's slices round-robin (every wave samples many bricks: the pair density varies along the tile order).
+  // m-th slice of XCD x = ((m >> XSH) * 8 + x) << XSH | (m & (2^XSH - 1)).
   const int64_t n_slices = (M_out + 31) >> 5;
-  // strided share of the slices: every worker samples the whole scene (contiguous runs measured 20-30 % slower: the
-  // pair density varies along the tile order)
-  const int64_t stride = (int64_t)gridDim.x * 4;
-  const int64_t first = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t last = n_slices;
+  const int xcd = XCD ? (int)(blockIdx.x & 7) : 0;
+  const int64_t stride = XCD ? (int64_t)(gridDim.x >> 3) * WGW : (int64_t)gridDim.x * WGW;      // waves per XCD
+  const int64_t first_m = XCD ? (int64_t)(blockIdx.x >> 3) * WGW + wave : (int64_t)blockIdx.x * WGW + wave;
+  auto slice_of = [&](int64_t m) -> int64_t {
+    if (!XCD) return m;
+    const int sh = XSH & 255;
+    return ((((m >> sh) << 3) + xcd) << sh) | (m & ((1 << sh) - 1));
+  };
+  // number of enumerated positions: every position whose slice index is in range is a slice; positions past the
+  // last full chunk round may map beyond n_slices and are skipped as empty
+  const int64_t n_pos = XCD ? ((((n_slices + (1 << (XSH & 255)) - 1) >> (XSH & 255)) + 7) >> 3) << (XSH & 255) : n_slices;
+  const int64_t first = first_m;
 
   f32x16 acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7;
 #pragma unroll
   for (int i = 0; i < 16; ++i)
     acc0[i] = acc1[i] = acc2[i] = acc3[i] = acc4[i] = acc5[i] = acc6[i] = acc7[i] = 0.0f;
 
-  const char* const Xb = reinterpret_cast<const char*>(X) + c * 128;
-  const char* const Yb = reinterpret_cast<const char*>(dY) + cb * 128;
-  const int64_t x_pitch = (int64_t)Cin * 4, y_pitch = (int64_t)Cout * 4;
-  const int d_row = lane >> 3, d_piece = lane & 7;
-  const char* const zrow = reinterpret_cast<const char*>(g_dw_zero_row) + d_piece * 16;
+  const uint32_t x_pitch = (uint32_t)Cin * 4u, y_pitch = (uint32_t)Cout * 4u;
+  const rsrc_t rsX = make_rsrc(reinterpret_cast<const char*>(X) + c * 128, (uint32_t)(M_in * x_pitch) - c * 128);
+  const rsrc_t rsY = make_rsrc(reinterpret_cast<const char*>(dY) + cb * 128, (uint32_t)(M_out * y_pitch) - cb * 128);
+  const rsrc_t rsN = make_rsrc(nbrS, (uint32_t)((int64_t)K * M_out * 4));
+  const rsrc_t rsO = make_rsrc(order, (uint32_t)(M_out * 4));
+  const int d_row = lane >> 3;
+  const uint32_t d_po = (uint32_t)(lane & 7) * 16u;
+  const uint32_t m_last = (uint32_t)(M_out - 1);
 
-  // header of a slice in registers: table entries of this worker's offsets (lane: offset slot lane >> 3, rows
-  // (lane & 7) * 4 .. + 3) and the slice's output rows
-  struct Hreg {
-    int32_t nb[4];
-    int32_t row;
-  };
-  auto load_hdr = [&](int64_t s, Hreg& h) {
-    const int k = og + (lane >> 3) * NOG;
-    const int64_t t0 = s * 32 + (lane & 7) * 4;
+  // header of a slice: table entries of this worker's offsets nb[slot][row] and the slice's output rows, 5 DMA
+  // instructions of 4 bytes per lane (no alignment requirement on M_out); rows past M_out read row M_out - 1 and are
+  // overwritten with -1 by fix_tail before the header is used, slots past K re-read slot 0 and are masked
+  auto issueH = [&](int64_t s, int32_t* hb) {
+    uint32_t t = (uint32_t)s * 32u + (uint32_t)r31;
+    t = t < m_last ? t : m_last;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int64_t t = t0 + q;
-      const bool ok = k < K && t < M_out;
-      int32_t v;
-      if (nbrS)
-        v = nbrS[ok ? (int64_t)k * M_out + t : 0];
-      else
-        v = order ? order[ok ? t : 0] : (int32_t)t;        // dense 1x1: the row pairs with itself
-      h.nb[q] = ok ? v : -1;
+      int k = og + (2 * q + half) * NOG;
+      k = k < K ? k : og;
+      bdma4(rsN, ((uint32_t)k * (uint32_t)M_out + t) * 4u, hb + q * 64);
     }
-    const int64_t tr = s * 32 + r31;
-    h.row = tr < M_out ? (order ? order[tr] : (int32_t)tr) : -1;
+    bdma4(rsO, t * 4u, hb + GS * 32);
   };
-  // registers -> LDS; returns the mask of offset slots with at least one pair in the slice
-  auto store_hdr = [&](int32_t* hb, const Hreg& h) -> uint32_t {
-    int4 v = make_int4(h.nb[0], h.nb[1], h.nb[2], h.nb[3]);
-    *reinterpret_cast<int4*>(hb + lane * 4) = v;            // nb[slot][row]: slot = lane >> 3, rows (lane & 7) * 4 ..
-    if (lane < 32) hb[GS * 32 + lane] = h.row;
-    const bool any = (h.nb[0] & h.nb[1] & h.nb[2] & h.nb[3]) >= 0;    // some entry non-negative
-    const unsigned long long b = __ballot(any);
+  // the last slice only: rows past M_out become missing pairs / missing rows
+  auto fix_tail = [&](int32_t* hb, int64_t s) {
+    if (s * 32 + 32 <= M_out) return;
+    const int64_t t0 = s * 32 + (lane & 7) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (t0 + e >= M_out) hb[lane * 4 + e] = -1;
+    if (lane < 32 && s * 32 + lane >= M_out) hb[GS * 32 + lane] = -1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  // mask of the offset slots with at least one pair in the slice (the header has landed and its tail is fixed)
+  auto readmask = [&](const int32_t* hb) -> uint32_t {
+    const int4 v = *reinterpret_cast<const int4*>(hb + lane * 4);      // slot lane >> 3, rows (lane & 7) * 4 ..
+    const bool any = (og + (lane >> 3) * NOG < K) & ((v.x & v.y & v.z & v.w) >= 0);     // some index non-negative
+    unsigned long long b = __ballot(any);
+    b |= b >> 4;
+    b |= b >> 2;
+    b |= b >> 1;                       // bit 8 j = any lane of slot j
     uint32_t m = 0u;
 #pragma unroll
-    for (int j = 0; j < GS; ++j)
-      if ((b >> (8 * j)) & 0xffull) m |= 1u << j;
+    for (int j = 0; j < GS; ++j) m |= (uint32_t)((b >> (8 * j)) & 1ull) << j;
     return m;
   };
   auto issueB = [&](const int32_t* hb, unsigned char* dst) {
+    const int32_t* p = hb + GS * 32 + d_row;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int32_t r = hb[GS * 32 + i * 8 + d_row];
-      const char* src = r >= 0 ? Yb + (int64_t)r * y_pitch + d_piece * 16 : zrow;
-      dma16(src, dst + i * 1024);
-    }
+    for (int i = 0; i < 4; ++i) bdma16(rsY, (uint32_t)p[i * 8] * y_pitch + d_po, dst + i * 1024);
   };
   auto issueA = [&](const int32_t* hb, int j, unsigned char* dst) {
+    const int32_t* p = hb + j * 32 + d_row;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int32_t g = hb[j * 32 + i * 8 + d_row];
-      const char* src = g >= 0 ? Xb + (int64_t)g * x_pitch + d_piece * 16 : zrow;
-      dma16(src, dst + i * 1024);
-    }
+    for (int i = 0; i < 4; ++i) bdma16(rsX, (uint32_t)p[i * 8] * x_pitch + d_po, dst + i * 1024);
   };
   // MFMA operands: lane (channel r31, half) takes rows 2s + half of a 32-row image, s = 0 .. 15
   auto readfrag = [&](const unsigned char* img, float (&f)[16]) {
@@ -138,82 +176,166 @@ __global__ __launch_bounds__(256, 2) void spconv_dw2_kernel(const float* __restr
     for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
   };
 
-  if (first < last) {
-    Hreg h, hn;
-    int64_t cur = first;
-    uint32_t mask = 0u;
-    int hb = 0;
-    // first non-empty slice of this worker (a slice without any pair in the worker's offsets is skipped)
+  if (first < n_pos) {
+    // ---- first slice with work for this worker, loaded synchronously (positions that map past the last slice read
+    // as empty: their rows are masked)
+    int64_t g_pos = first;
+    int64_t g_slice = slice_of(g_pos);
+    uint32_t c_mask = 0u;
     for (;;) {
-      load_hdr(cur, h);
-      mask = store_hdr(hdr0 + hb * (HDR / 4), h);
-      if (mask || cur + stride >= last) break;
-      cur += stride;
+      issueH(g_slice, hdr0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      fix_tail(hdr0, g_slice);
+      c_mask = readmask(hdr0);
+      if (c_mask || g_pos + stride >= n_pos) break;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      g_pos += stride;
+      g_slice = slice_of(g_pos);
     }
-    if (mask) {
-      int bb = 0, ab = 0;
-      issueB(hdr0 + hb * (HDR / 4), Bt);
-      issueA(hdr0 + hb * (HDR / 4), __builtin_ctz(mask), At);
-      int64_t nxt = cur + stride;
-      bool have_next = nxt < last;
-      if (have_next) load_hdr(nxt, hn);
+    if (c_mask) {
+      int g_hb = 0;                              // header buffer of the generator's slice
+      bool g_has_next = g_pos + stride < n_pos;
+      if (g_has_next) issueH(slice_of(g_pos + stride), hdr0 + HDR_INTS);
+      issueB(hdr0, Bt);
+      issueA(hdr0, __builtin_ctz(c_mask), At);
+      uint32_t g_rem = c_mask & (c_mask - 1u);   // offsets of the generator's slice not yet issued
+      uint32_t mask_next = 0u;
+      int gi = 0, ci = 0;                        // slices entered by the generator / by the compute side
+      int F = 0, after0 = 0, after1 = 0;         // tiles in flight behind the current one; DMA counts behind tile t, t+1
+      int c_rd = 0, a_wr = 1;                    // ring slots: compute reads, generator writes
       bool new_slice = true;
       float bfr[16], afr[16];
       if (DIAG) t_loop = __builtin_readcyclecounter();
-      uint32_t mask_n = 0u;
-      bool advance_slice = false;
-      // one (slice, offset slot) step; jslot is a compile-time constant at every call site so that each accumulator is
-      // touched by exactly one MFMA chain
-      auto step = [&](f32x16& acc, int jslot) {
-        // the step's images (and, at a slice change, the next header registers) have landed
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      // generator: keeps two X tiles in flight behind the one computing; it enters the next slice only once the
+      // compute side is in the slice before it (one dY tile, one spare header).  prepare() does everything of one
+      // advance but the X-tile DMAs: returns the header row of the tile to issue and the DMA count of the advance.
+      auto prepare = [&](const int32_t*& p, int& n) -> bool {
+        int32_t* const hb = hdr0 + g_hb * HDR_INTS;
+        if (g_rem) {
+          p = hb + __builtin_ctz(g_rem) * 32 + d_row;
+          g_rem &= g_rem - 1u;
+          n = 4;
+          return true;
+        }
+        if (gi != ci || !g_has_next) return false;
+        // dY fragments and header words of the compute slice are in registers before their LDS is reused
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int32_t* const hn = hdr0 + (g_hb ^ 1) * HDR_INTS;
+        g_pos += stride;
+        g_slice = slice_of(g_pos);
+        fix_tail(hn, g_slice);
+        uint32_t m = readmask(hn);
+        while (m == 0u && g_pos + stride < n_pos) {            // rare: a slice without pairs for this worker
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          g_pos += stride;
+          g_slice = slice_of(g_pos);
+          issueH(g_slice, hn);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          after0 = after1 = 0;
+          fix_tail(hn, g_slice);
+          m = readmask(hn);
+        }
+        if (m == 0u) {
+          g_has_next = false;
+          return false;
+        }
+        g_hb ^= 1;
+        ++gi;
+        mask_next = m;
+        n = 8;
+        g_has_next = g_pos + stride < n_pos;
+        if (g_has_next) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          issueH(slice_of(g_pos + stride), hb);                       // into the header the generator just left
+          n = 13;
+        }
+        issueB(hn, Bt);
+        p = hn + __builtin_ctz(m) * 32 + d_row;
+        g_rem = m & (m - 1u);
+        return true;
+      };
+      auto account = [&](int n, bool real) {
+        after0 += n;
+        if (F == 1) after1 += n;
+        if (real) {
+          ++F;
+          a_wr = a_wr == DA - 1 ? 0 : a_wr + 1;
+        }
+      };
+      // one (slice, offset slot) step; the accumulator is a compile-time choice at every call site so that each is
+      // touched by exactly one MFMA chain.  The X-tile issue of the advance (4 header reads, 4 offset multiplies, 4
+      // DMAs) is interleaved by hand into the 16-MFMA chain: left to itself hipcc runs it in front of the chain and the
+      // wave spends as long in address code as in MFMAs.
+      auto step = [&](f32x16& acc) {
+        unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
+        if (DIAG) { ta = __builtin_readcyclecounter(); if (t_prev) d_bot += ta - t_prev; }
+        wait_after(after0);
+        if (DIAG) tb = __builtin_readcyclecounter();
         if (new_slice) {
-          readfrag(Bt + bb * TILE, bfr);
+          readfrag(Bt, bfr);
           new_slice = false;
         }
-        readfrag(At + ab * TILE, afr);
-        // bring in the next step while this one computes
-        const uint32_t rem = mask & ~((2u << jslot) - 1u);
-        if (rem) {
-          issueA(hdr0 + hb * (HDR / 4), __builtin_ctz(rem), At + (ab ^ 1) * TILE);
-        } else {
-          while (have_next) {       // next slice with work for this worker
-            mask_n = store_hdr(hdr0 + (hb ^ 1) * (HDR / 4), hn);
-            if (mask_n) break;
-            nxt += stride;
-            have_next = nxt < last;
-            if (have_next) load_hdr(nxt, hn);     // rare path (slice without pairs): the load is waited for in place
-          }
-          advance_slice = have_next;
-          if (have_next) {
-            issueB(hdr0 + (hb ^ 1) * (HDR / 4), Bt + (bb ^ 1) * TILE);
-            issueA(hdr0 + (hb ^ 1) * (HDR / 4), __builtin_ctz(mask_n), At + (ab ^ 1) * TILE);
+        readfrag(At + c_rd * TILE, afr);
+        if (F == 0) {        // after a blocked step: catch up outside the chain
+          const int32_t* q;
+          int nq;
+          if (prepare(q, nq)) {
+            unsigned char* dq = At + a_wr * TILE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bdma16(rsX, (uint32_t)q[i * 8] * x_pitch + d_po, dq + i * 1024);
+            account(nq, true);
           }
         }
-        mfma16(acc, afr, bfr);
-        ab ^= 1;
+        const int32_t* p = negrow + d_row;     // nothing to issue: four all-out-of-range DMAs (zero fill, no traffic)
+        int n = 4;
+        const bool real = prepare(p, n);
+        unsigned char* const dst = At + a_wr * TILE;
+#define WSIS_MFMA(s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s_], bfr[s_], acc, 0, 0, 0)
+        if (DIAG) tc = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+        WSIS_MFMA(0); WSIS_MFMA(1); WSIS_MFMA(2); WSIS_MFMA(3);
+        __builtin_amdgcn_sched_barrier(0);
+        const int32_t e0 = p[0], e1 = p[8], e2 = p[16], e3 = p[24];
+        __builtin_amdgcn_sched_barrier(0);
+        WSIS_MFMA(4); WSIS_MFMA(5); WSIS_MFMA(6); WSIS_MFMA(7);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t o0 = (uint32_t)e0 * x_pitch + d_po, o1 = (uint32_t)e1 * x_pitch + d_po;
+        const uint32_t o2 = (uint32_t)e2 * x_pitch + d_po, o3 = (uint32_t)e3 * x_pitch + d_po;
+        __builtin_amdgcn_sched_barrier(0);
+        WSIS_MFMA(8);
+        bdma16(rsX, o0, dst);
+        WSIS_MFMA(9);
+        bdma16(rsX, o1, dst + 1024);
+        WSIS_MFMA(10);
+        bdma16(rsX, o2, dst + 2048);
+        WSIS_MFMA(11);
+        bdma16(rsX, o3, dst + 3072);
+        __builtin_amdgcn_sched_barrier(0);
+        WSIS_MFMA(12); WSIS_MFMA(13); WSIS_MFMA(14); WSIS_MFMA(15);
+        __builtin_amdgcn_sched_barrier(0);
+#undef WSIS_MFMA
+        if (DIAG) { asm volatile("s_nop 0" :: "v"(acc[0])); td = __builtin_readcyclecounter(); d_wait += tb - ta; d_top += tc - tb; d_chain += td - tc; t_prev = td; }
+        account(n, real);
+        c_rd = c_rd == DA - 1 ? 0 : c_rd + 1;
+        after0 = after1;
+        after1 = 0;
+        if (F > 0) --F;
         if (DIAG) ++n_steps;
       };
       for (;;) {
-        if (mask & 1u) step(acc0, 0);
-        if (mask & 2u) step(acc1, 1);
-        if (mask & 4u) step(acc2, 2);
-        if (mask & 8u) step(acc3, 3);
-        if (mask & 16u) step(acc4, 4);
-        if (mask & 32u) step(acc5, 5);
-        if (mask & 64u) step(acc6, 6);
-        if (mask & 128u) step(acc7, 7);
+        if (c_mask & 1u) step(acc0);
+        if (c_mask & 2u) step(acc1);
+        if (c_mask & 4u) step(acc2);
+        if (c_mask & 8u) step(acc3);
+        if (c_mask & 16u) step(acc4);
+        if (c_mask & 32u) step(acc5);
+        if (c_mask & 64u) step(acc6);
+        if (c_mask & 128u) step(acc7);
         if (DIAG) ++n_slices_done;
-        if (!advance_slice) break;
-        advance_slice = false;
-        cur = nxt;
-        mask = mask_n;
-        bb ^= 1;
-        hb ^= 1;
+        if (gi == ci) break;            // the generator found no further slice
+        ++ci;
+        c_mask = mask_next;
         new_slice = true;
-        nxt = cur + stride;
-        have_next = nxt < last;
-        if (have_next) load_hdr(nxt, hn);        // prefetch: consumed at the end of the slice just entered
       }
     }
   }
@@ -221,38 +343,42 @@ __global__ __launch_bounds__(256, 2) void spconv_dw2_kernel(const float* __restr
   if (DIAG) t_end_loop = __builtin_readcyclecounter();
   __syncthreads();
 
-  // ---- the 4 waves' accumulators of one offset slot at a time: LDS, added in wave order, one slab per workgroup.
+  // ---- the workgroup's accumulators, four offset slots at a time: LDS, added in wave order, one slab per workgroup.
   // C/D map: col (co) = lane & 31, row (ci) = (reg & 3) + 8 * (reg >> 2) + 4 * half
-  float* const red = reinterpret_cast<float*>(lds);          // [4][32 ci][32 co], stride WAVE_LDS / 4 floats per wave
+  float* const red = reinterpret_cast<float*>(lds);          // per wave [4 slots][32 ci][32 co] at stride WAVE_LDS
   float* const slab = partial + (int64_t)blockIdx.x * K * Cin * Cout;
-  auto flush = [&](const f32x16& acc, int jslot) {
-    const int k = og + jslot * NOG;
-    if (k >= K) return;               // uniform over the workgroup
-    float* mine = red + wave * (WAVE_LDS / 4);
+  auto put = [&](const f32x16& acc, int q) {
+    float* mine = red + wave * (WAVE_LDS / 4) + q * 1024;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * half;
       mine[ci * 32 + r31] = acc[reg];
     }
+  };
+  auto flush4 = [&](const f32x16& a0, const f32x16& a1, const f32x16& a2, const f32x16& a3, int jbase) {
+    if (og + jbase * NOG >= K) return;               // uniform over the workgroup
+    put(a0, 0);
+    put(a1, 1);
+    put(a2, 2);
+    put(a3, 3);
     __syncthreads();
-    for (int e = threadIdx.x; e < 1024; e += 256) {
-      const float v = ((red[e] + red[(WAVE_LDS / 4) + e]) + red[2 * (WAVE_LDS / 4) + e]) + red[3 * (WAVE_LDS / 4) + e];
-      const int ci = e >> 5, co = e & 31;
+    for (int e = threadIdx.x; e < 4096; e += WGW * 64) {
+      const int k = og + (jbase + (e >> 10)) * NOG;
+      if (k >= K) break;                             // e ascends through the slots
+      float v = red[e];
+#pragma unroll
+      for (int w = 1; w < WGW; ++w) v += red[w * (WAVE_LDS / 4) + e];
+      const int ci = (e >> 5) & 31, co = e & 31;
       slab[((int64_t)k * Cin + c * 32 + ci) * Cout + cb * 32 + co] = v;
     }
     __syncthreads();
   };
-  flush(acc0, 0);
-  flush(acc1, 1);
-  flush(acc2, 2);
-  flush(acc3, 3);
-  flush(acc4, 4);
-  flush(acc5, 5);
-  flush(acc6, 6);
-  flush(acc7, 7);
+  flush4(acc0, acc1, acc2, acc3, 0);
+  flush4(acc4, acc5, acc6, acc7, 4);
   if (DIAG && lane == 0) {
-    unsigned long long* d = dbg + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 6;
+    unsigned long long* d = dbg + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * WGW + wave) * 10;
     d[0] = t_start; d[1] = t_loop; d[2] = t_end_loop; d[3] = __builtin_readcyclecounter(); d[4] = n_steps; d[5] = n_slices_done;
+    d[6] = d_wait; d[7] = d_top; d[8] = d_chain; d[9] = d_bot;
   }
 }
 
@@ -281,9 +407,10 @@ int dw2_P(int64_t M_out, int K, int Cin, int Cout) {
   const int NOG = (K + GS - 1) / GS;
   const int64_t combos = (int64_t)NOG * (Cin / 32) * (Cout / 32);
   const int64_t n_slices = (M_out + 31) / 32;
-  int64_t P = (target / 4 + combos - 1) / combos;
-  const int64_t cap = (n_slices + 3) / 4;
+  int64_t P = (target / WGW + combos - 1) / combos;
+  const int64_t cap = (n_slices + WGW - 1) / WGW;
   if (P > cap) P = cap;
+  if (P >= 8) P &= ~(int64_t)7;     // multiple of 8: blockIdx.x % 8 is the XCD for every blockIdx.y
   if (P < 1) P = 1;
   return (int)P;
 }
@@ -298,26 +425,42 @@ bool dw2_supported(int K, int Cin, int Cout) {
   return on && K >= 1 && K <= 32 && Cin >= 32 && Cin % 32 == 0 && Cout >= 32 && Cout % 32 == 0;
 }
 
+bool dw2_fits(int64_t M_in, int64_t M_out, int K, int Cin, int Cout) {
+  const int64_t lim = (int64_t)1 << 31;
+  return M_in * Cin * 4 < lim && M_out * Cout * 4 < lim && (int64_t)K * M_out * 4 < lim && M_in >= 1 && M_out >= 1;
+}
+
 int64_t dw2_workspace_bytes(int64_t M_out, int K, int Cin, int Cout) {
   return (int64_t)dw2_P(M_out, K, Cin, Cout) * K * Cin * Cout * (int64_t)sizeof(float) + 256;
 }
 
 int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY, float* d_dW,
-               int64_t M_out, int K, int Cin, int Cout, void* d_ws, hipStream_t st) {
+               int64_t M_in, int64_t M_out, int K, int Cin, int Cout, void* d_ws, hipStream_t st) {
   const int NOG = (K + GS - 1) / GS;
   const int P = dw2_P(M_out, K, Cin, Cout);
   float* partial = static_cast<float*>(d_ws);
   const dim3 grid((unsigned)P, (unsigned)(NOG * (Cin / 32) * (Cout / 32)), 1);
-  const size_t ldsb = (size_t)WAVE_LDS * 4;
+  const size_t ldsb = (size_t)WAVE_LDS * WGW;
   static bool attr_set = false;
   if (!attr_set) {
-    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_dw2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)ldsb));
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_dw2_kernel<false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_dw2_kernel<false, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     attr_set = true;
   }
+  static int xcd_on = -1, xsh = XSH_DEFAULT;
+  if (xcd_on < 0) {
+    xcd_on = dw2_env("WSIS_DW2_XCD", 0);     // measured: no gain at level 0, slower below (chunk imbalance)
+    xsh = dw2_env("WSIS_DW2_XSH", XSH_DEFAULT);
+  }
   ProfScope prof(1, st);
-  hipLaunchKernelGGL(spconv_dw2_kernel<false>, grid, dim3(256), ldsb, st, d_X, d_nbr, d_order, d_dY, partial, M_out, K,
-                     Cin, Cout, NOG, (unsigned long long*)nullptr);
+  if (xcd_on && P % 8 == 0)
+    hipLaunchKernelGGL((spconv_dw2_kernel<false, true>), grid, dim3(WGW * 64), ldsb, st, d_X, d_nbr, d_order,
+                       d_dY, partial, M_in, M_out, K, Cin, Cout, NOG, xsh, (unsigned long long*)nullptr);
+  else
+    hipLaunchKernelGGL((spconv_dw2_kernel<false, false>), grid, dim3(WGW * 64), ldsb, st, d_X, d_nbr, d_order, d_dY,
+                       partial, M_in, M_out, K, Cin, Cout, NOG, xsh, (unsigned long long*)nullptr);
   prof.stop();
   WSIS_LAUNCH_CHECK();
   const int64_t total4 = (int64_t)K * Cin * Cout / 4;
@@ -332,21 +475,24 @@ int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, c
 // diagnostic build of the kernel: per-wave cycle stamps (start, loop begin, loop end, end) and step / slice counts,
 // 6 x u64 per wave in launch order; *n_waves receives the wave count.  tools/dw2_stamps.py reads it.
 extern "C" int wsis_debug_dw2_diag(const void* d_X, const void* d_nbr, const void* d_order, const void* d_dY,
-                                   int64_t M_out, int K, int Cin, int Cout, void* d_ws, void* d_dbg, int64_t dbg_bytes,
+                                   int64_t M_in, int64_t M_out, int K, int Cin, int Cout, void* d_ws, void* d_dbg, int64_t dbg_bytes,
                                    int64_t* n_waves, void* stream) {
-  WSIS_REQUIRE(wsis::dw2_supported(K, Cin, Cout), "shape not supported by the dw2 kernel");
+  WSIS_REQUIRE(wsis::dw2_supported(K, Cin, Cout) && wsis::dw2_fits(M_in, M_out, K, Cin, Cout) && d_nbr && d_order,
+               "shape not supported by the dw2 kernel");
   const int NOG = (K + GS - 1) / GS;
   const int P = dw2_P(M_out, K, Cin, Cout);
   const dim3 grid((unsigned)P, (unsigned)(NOG * (Cin / 32) * (Cout / 32)), 1);
-  *n_waves = (int64_t)grid.x * grid.y * 4;
-  WSIS_REQUIRE(dbg_bytes >= *n_waves * 48, "stamp buffer too small");
-  const size_t ldsb = (size_t)WAVE_LDS * 4;
-  WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_dw2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  *n_waves = (int64_t)grid.x * grid.y * WGW;
+  WSIS_REQUIRE(dbg_bytes >= *n_waves * 80, "stamp buffer too small");
+  WSIS_REQUIRE(P % 8 == 0, "diagnostic build is the XCD-aware variant");
+  const size_t ldsb = (size_t)WAVE_LDS * WGW;
+  WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_dw2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)ldsb));
-  hipLaunchKernelGGL(spconv_dw2_kernel<true>, grid, dim3(256), ldsb, wsis::as_stream(stream),
+  hipLaunchKernelGGL((spconv_dw2_kernel<true, true>), grid, dim3(WGW * 64), ldsb, wsis::as_stream(stream),
                      static_cast<const float*>(d_X), static_cast<const int32_t*>(d_nbr),
                      static_cast<const int32_t*>(d_order), static_cast<const float*>(d_dY), static_cast<float*>(d_ws),
-                     M_out, K, Cin, Cout, NOG, static_cast<unsigned long long*>(d_dbg));
+                     M_in, M_out, K, Cin, Cout, NOG, dw2_env("WSIS_DW2_XSH", XSH_DEFAULT),
+                     static_cast<unsigned long long*>(d_dbg));
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }
