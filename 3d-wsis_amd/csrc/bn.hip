@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64) void bn_stats_final_kernel(const float* __restr
 // mean = sum S_i / M, var = (sum Q_i + sum S_i^2 / n_i - M mean^2) / M, all in fp64 (Chan's pairwise combination).
 // Two levels so that the 1.2 MB of partials of a 150k-row level is read by up to 64 workgroups per 32 channels instead of
 // one: chunk sums (fixed order inside a chunk) -> [G][3][C] doubles, then one thread per channel adds the chunks in order.
-constexpr int BN_FIN_CHUNKS = 64;
+constexpr int BN_FIN_CHUNKS = 64;      // <= 64: the finish kernels hold one chunk per lane
 
 __device__ __forceinline__ void bn_finish_centred(double S, double Q, double W, int64_t M, int c, float* mean, float* var,
                                                   float* running_mean, float* running_var, float momentum) {
@@ -202,19 +202,20 @@ __global__ __launch_bounds__(256) void bn_stats_chunk_centred_kernel(const float
   }
 }
 
-__global__ void bn_stats_final_centred_kernel(const double* __restrict__ chunk, int G, int C, int64_t M,
-                                              float* __restrict__ mean, float* __restrict__ var,
-                                              float* __restrict__ running_mean, float* __restrict__ running_var,
-                                              float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per channel: lane g holds chunk g (G <= 64), fixed butterfly
+__global__ __launch_bounds__(256) void bn_stats_final_centred_kernel(const double* __restrict__ chunk, int G, int C,
+                                                                     int64_t M, float* __restrict__ mean,
+                                                                     float* __restrict__ var,
+                                                                     float* __restrict__ running_mean,
+                                                                     float* __restrict__ running_var, float momentum) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
-  double S = 0.0, Q = 0.0, W = 0.0;
-  for (int g = 0; g < G; ++g) {        // fixed order
-    S += chunk[(int64_t)g * 3 * C + c];
-    Q += chunk[(int64_t)g * 3 * C + C + c];
-    W += chunk[(int64_t)g * 3 * C + 2 * C + c];
-  }
-  bn_finish_centred(S, Q, W, M, c, mean, var, running_mean, running_var, momentum);
+  const bool in = lane < G;
+  const double S = wave_sum_f64(in ? chunk[(int64_t)lane * 3 * C + c] : 0.0);
+  const double Q = wave_sum_f64(in ? chunk[(int64_t)lane * 3 * C + C + c] : 0.0);
+  const double W = wave_sum_f64(in ? chunk[(int64_t)lane * 3 * C + 2 * C + c] : 0.0);
+  if (lane == 0) bn_finish_centred(S, Q, W, M, c, mean, var, running_mean, running_var, momentum);
 }
 
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
@@ -370,6 +371,60 @@ __global__ __launch_bounds__(64) void bn_bwd_final_kernel(const float* __restric
   }
   const double A = wave_sum_f64(a), B = wave_sum_f64(b);
   if (threadIdx.x == 0) {
+    dbeta[c] = (float)A;
+    dgamma[c] = (float)B;
+  }
+}
+
+// the reduction of the backward pass from per-slice partials (sum dz, sum dz * xhat) written by the epilogue of the
+// dIn convolution that produced dy (wsis_spconv_fwd_t_bn): fp64 sums in a fixed order, two levels like the forward
+// statistics.  grid (G, ceil(C / 32)), 256 threads = 32 channel lanes x 8 partial lanes; G == 1 writes the result.
+__global__ __launch_bounds__(256) void bn_sum_chunk_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                           double* __restrict__ chunk, float* __restrict__ dbeta,
+                                                           float* __restrict__ dgamma) {
+  __shared__ double red[2][8][33];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.y * 32 + cl;
+  const int per = (nblk + gridDim.x - 1) / gridDim.x;
+  const int lo = blockIdx.x * per;
+  const int hi = lo + per < nblk ? lo + per : nblk;
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+#pragma unroll 4
+    for (int k = lo + pl; k < hi; k += 8) {
+      a += partial[(int64_t)k * 2 * C + c];
+      b += partial[(int64_t)k * 2 * C + C + c];
+    }
+  }
+  red[0][pl][cl] = a;
+  red[1][pl][cl] = b;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    double A = 0.0, B = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {      // fixed order
+      A += red[0][j][cl];
+      B += red[1][j][cl];
+    }
+    if (gridDim.x == 1) {
+      dbeta[c] = (float)A;
+      dgamma[c] = (float)B;
+    } else {
+      chunk[(int64_t)blockIdx.x * 2 * C + c] = A;
+      chunk[(int64_t)blockIdx.x * 2 * C + C + c] = B;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_sum_final_kernel(const double* __restrict__ chunk, int G, int C,
+                                                           float* __restrict__ dbeta, float* __restrict__ dgamma) {
+  const int lane = threadIdx.x & 63;            // one wavefront per channel: lane g holds chunk g (G <= 64)
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  const bool in = lane < G;
+  const double A = wave_sum_f64(in ? chunk[(int64_t)lane * 2 * C + c] : 0.0);
+  const double B = wave_sum_f64(in ? chunk[(int64_t)lane * 2 * C + C + c] : 0.0);
+  if (lane == 0) {
     dbeta[c] = (float)A;
     dgamma[c] = (float)B;
   }
@@ -682,7 +737,7 @@ int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, i
                      (int)n_part, C, M, chunk, d_mean, d_var, d_running_mean, d_running_var, momentum);
   WSIS_LAUNCH_CHECK();
   if (G > 1) {
-    hipLaunchKernelGGL(bn_stats_final_centred_kernel, dim3((C + 63) / 64), dim3(64), 0, as_stream(stream), chunk, G, C, M,
+    hipLaunchKernelGGL(bn_stats_final_centred_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), chunk, G, C, M,
                        d_mean, d_var, d_running_mean, d_running_var, momentum);
     WSIS_LAUNCH_CHECK();
   }
@@ -702,6 +757,35 @@ int wsis_bn_apply(const float* d_x, const float* d_mean, const float* d_var, con
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, as_stream(stream), d_x, d_mean, d_var,
                      d_gamma, d_beta, eps, relu, d_y, M, C);
   WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_bn_bwd_from_partials(const float* d_partials, int64_t n_part, const float* d_x, const float* d_dy,
+                              const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta,
+                              float eps, int32_t relu, float* d_dx, float* d_dgamma, float* d_dbeta,
+                              const float* d_addend, int64_t M, int32_t C, void* d_ws, int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(M >= 1 && C >= 1 && d_partials && d_x && d_dy && d_mean && d_var && d_dgamma && d_dbeta, "bad args");
+  WSIS_REQUIRE(n_part == (M + 31) / 32 && n_part < ((int64_t)1 << 31), "one partial per 32-row slice");
+  const int G = bn_fin_chunks(n_part);
+  WSIS_REQUIRE(G == 1 || (d_ws && ws_bytes >= wsis_bn_stats_finalize_workspace_bytes(n_part, C)), "workspace too small");
+  double* chunk = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(d_ws) + 255) & ~(uintptr_t)255);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(bn_sum_chunk_kernel, dim3(G, (C + 31) / 32), dim3(256), 0, st, d_partials, (int)n_part, C, chunk,
+                     d_dbeta, d_dgamma);
+  WSIS_LAUNCH_CHECK();
+  if (G > 1) {
+    hipLaunchKernelGGL(bn_sum_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, chunk, G, C, d_dbeta, d_dgamma);
+    WSIS_LAUNCH_CHECK();
+  }
+  if (d_dx) {
+    const int64_t work = (C & 3) == 0 ? (M * C) >> 2 : M * C;
+    const int cw = (C & 3) == 0 ? C >> 2 : C;
+    int grid = grid_for(work, 256);
+    if (grid > cw) grid -= grid % cw;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, d_x, d_dy, d_mean, d_var, d_gamma, d_beta,
+                       d_dgamma, d_dbeta, d_addend, eps, relu, 1, d_dx, M, C);
+    WSIS_LAUNCH_CHECK();
+  }
   return WSIS_OK;
 }
 

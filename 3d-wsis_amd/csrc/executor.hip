@@ -169,7 +169,9 @@ bool fwd2_enabled() {
   return e ? atoi(e) != 0 : true;
 }
 inline bool use_fwd2(const wsis_op& op, bool on) {
-  return on && wsis_spconv_fwd_t_supported(op.K, op.Cin, op.Cout) != 0;
+  // 32-bit gather offsets: the gathered tensor (input of the forward pass, dY of the dIn pass) stays below 2 GiB
+  const int64_t gathered = op.kind == WSIS_OP_CONV ? op.M_in * op.Cin : op.M_out * op.Cout;
+  return on && wsis_spconv_fwd_t_supported(op.K, op.Cin, op.Cout) != 0 && gathered * 4 < ((int64_t)1 << 31);
 }
 // does op need a transposed copy of its weights?  forward on the new kernel (B^T layout); dIn on the old one
 inline bool needs_wt(const wsis_op& op, bool on) {
@@ -188,7 +190,8 @@ int64_t op_ws_bytes(const wsis_op& op, bool on) {
       return up(std::max(wsis_bn_workspace_bytes(op.M_in, op.Cin),
                          wsis_bn_stats_finalize_workspace_bytes((op.M_in + 31) / 32, op.Cin)));
     case WSIS_OP_BN_RELU_BWD:
-      return up(wsis_bn_workspace_bytes(op.M_in, op.Cin));
+      return up(std::max(wsis_bn_workspace_bytes(op.M_in, op.Cin),
+                         wsis_bn_stats_finalize_workspace_bytes((op.M_in + 31) / 32, op.Cin)));
     case WSIS_OP_CONV_BWD:     // the transposed weights and the dW slabs live in their own regions, not here
       if (!op.out[0]) return 0;
       if (use_fwd2(op, on)) return up(wsis_spconv_fwd_t_workspace_bytes(op.M_in, op.K, op.Cout, op.Cin));
@@ -292,6 +295,7 @@ int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   } while (0)
   bool forked = false;
   int first_err = WSIS_OK;
+  std::vector<char> bn_unfused(n, 0);     // BatchNorm backward ops whose dIn pass did not write partials this run
   for (int i = 0; i < n; ++i) {
     const wsis_op& op = ops[i];
     int rc = WSIS_OK;
@@ -303,6 +307,10 @@ int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
                                  (const float*)op.in[5], (float*)op.out[0],
                                  (op.flags & WSIS_OPF_STATS) ? (float*)op.out[1] : nullptr, op.M_in, op.M_out, op.K,
                                  op.Cin, op.Cout, ws, ws_bytes, stream);
+        else if (op.flags & WSIS_OPF_STATS)
+          // the program was recorded for the kernel that writes BatchNorm partials; this launch cannot use it (input
+          // of 2 GiB or more, or WSIS_FWD2 changed between recording and running)
+          rc = fail(WSIS_ERR_ARG, "op %d: statistics requested from a convolution that is not on wsis_spconv_fwd_t", i);
         else
           rc = wsis_spconv_fwd((const float*)op.in[0], (const int32_t*)op.in[1], (const int32_t*)op.in[2],
                                (const float*)op.in[3], (const float*)op.in[4], (const float*)op.in[5],
@@ -375,11 +383,43 @@ int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
         char* rest = ws;
         const int64_t rest_bytes = ws_bytes;
         if (op.out[0]) {
+          if (wt_off[i] >= 0 && (op.flags & WSIS_OPF_STATS)) {
+            rc = fail(WSIS_ERR_ARG, "op %d: BatchNorm partials requested from a dIn pass that is not on wsis_spconv_fwd_t", i);
+            break;
+          }
           if (wt_off[i] >= 0) {
             const float* WT = reinterpret_cast<const float*>(wt_base + wt_off[i]);
             rc = wsis_spconv_fwd((const float*)op.in[2], (const int32_t*)op.in[5], (const int32_t*)op.in[6], WT, nullptr,
                                  nullptr, (float*)op.out[0], op.M_out, op.M_in, op.K, op.Cout, op.Cin, rest, rest_bytes,
                                  stream);
+          } else if (op.flags & WSIS_OPF_STATS) {
+            // dX is the dy of a BatchNorm backward a few ops on (WSIS_OP_BN_RELU_BWD with in[1] == this dX, flagged
+            // too): the epilogue also makes that op's reduction, into its in[7]
+            const wsis_op* bn = nullptr;
+            for (int j = i + 1; j < n && j <= i + 4 && !bn; ++j)
+              if (ops[j].kind == WSIS_OP_BN_RELU_BWD && ops[j].in[1] == op.out[0] && (ops[j].flags & WSIS_OPF_STATS))
+                bn = &ops[j];
+            if (!bn || !bn->in[7] || bn->M_in != op.M_in || bn->Cin != op.Cin) {
+              rc = fail(WSIS_ERR_ARG, "op %d: no BatchNorm backward takes the partials of this dIn pass", i);
+              break;
+            }
+            if (wsis_spconv_fwd_t_slabs(op.M_in, op.K, op.Cout, op.Cin) > 1) {
+              // few slices: the product is split into offset slabs and summed by a second kernel; the BatchNorm's own
+              // small-level reduction (one launch) is cheaper than a statistics variant of that sum
+              bn_unfused[bn - ops] = 1;
+              rc = wsis_spconv_fwd_t((const float*)op.in[2], (const int32_t*)op.in[5], (const int32_t*)op.in[6],
+                                     (const float*)op.in[1], (op.flags & WSIS_OPF_FLIP) ? 1 : 0, nullptr, nullptr,
+                                     (float*)op.out[0], nullptr, op.M_out, op.M_in, op.K, op.Cout, op.Cin, rest,
+                                     rest_bytes, stream);
+              if (rc != WSIS_OK) break;
+              goto din_done;
+            }
+            rc = wsis_spconv_fwd_t_bn((const float*)op.in[2], (const int32_t*)op.in[5], (const int32_t*)op.in[6],
+                                      (const float*)op.in[1], (op.flags & WSIS_OPF_FLIP) ? 1 : 0, (float*)op.out[0],
+                                      (float*)const_cast<void*>(bn->in[7]), (const float*)bn->in[0],
+                                      (const float*)bn->in[2], (const float*)bn->in[3], (const float*)bn->in[4],
+                                      (const float*)bn->in[5], bn->eps, (bn->flags & WSIS_OPF_RELU) ? 1 : 0, op.M_out,
+                                      op.M_in, op.K, op.Cout, op.Cin, rest, rest_bytes, stream);
           } else {   // the weight [K, Cin, Cout] is the B^T operand of the dIn product as it stands
             rc = wsis_spconv_fwd_t((const float*)op.in[2], (const int32_t*)op.in[5], (const int32_t*)op.in[6],
                                    (const float*)op.in[1], (op.flags & WSIS_OPF_FLIP) ? 1 : 0, nullptr, nullptr,
@@ -388,6 +428,7 @@ int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
           }
           if (rc != WSIS_OK) break;
         }
+      din_done:
         if (op.out[1]) {
           void* dw_stream = stream;
           if (side) {   // dY is complete once everything enqueued so far on the caller's stream has run
@@ -408,6 +449,18 @@ int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
         break;
       }
       case WSIS_OP_BN_RELU_BWD:
+        if ((op.flags & WSIS_OPF_STATS) && !bn_unfused[i]) {      // the producing dIn pass left the slice partials in in[7]
+          if (!op.in[7] || !(op.flags & WSIS_OPF_TRAINING)) {
+            rc = fail(WSIS_ERR_ARG, "op %d: BatchNorm backward from partials needs in[7] and training mode", i);
+            break;
+          }
+          rc = wsis_bn_bwd_from_partials((const float*)op.in[7], (op.M_in + 31) / 32, (const float*)op.in[0],
+                                         (const float*)op.in[1], (const float*)op.in[2], (const float*)op.in[3],
+                                         (const float*)op.in[4], (const float*)op.in[5], op.eps,
+                                         (op.flags & WSIS_OPF_RELU) ? 1 : 0, (float*)op.out[0], (float*)op.out[1],
+                                         (float*)op.out[2], (const float*)op.in[6], op.M_in, op.Cin, ws, ws_bytes, stream);
+          break;
+        }
         rc = wsis_bn_bwd((const float*)op.in[0], (const float*)op.in[1], (const float*)op.in[2], (const float*)op.in[3],
                          (const float*)op.in[4], (const float*)op.in[5], op.eps, (op.flags & WSIS_OPF_RELU) ? 1 : 0,
                          (op.flags & WSIS_OPF_TRAINING) ? 1 : 0, (float*)op.out[0], (float*)op.out[1], (float*)op.out[2],

@@ -46,6 +46,45 @@ struct Layout {
   static constexpr int WAVE_BYTES = DA * A_BYTES + (BD ? 0 : DB * B_BYTES);
 };
 
+// gathered rows come through a raw buffer descriptor: 32-bit byte offsets (the table in LDS holds row * pitch, so an
+// issue is one add) and offsets past the end read as zero, so a missing pair (0x80000000) needs no select
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ void bdma16(rsrc_t r, uint32_t voff, uint32_t soff, void* lds_dst) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, (int)voff, (int)soff,
+                                           0, 0);
+}
+constexpr uint32_t NO_ROW = 0x80000000u;
+
+// optional reduction of the epilogue for a dIn pass whose output dy feeds the backward of a BatchNorm(+ReLU): instead
+// of the (sum, centred sum of squares) statistics the slice partials are (sum dz, sum dz * xhat) with
+// xhat = (x - mean) rstd, dz = dy masked by the ReLU -- the reduction pass of wsis_bn_bwd without re-reading dy and x
+struct BnEpi {
+  const float* x;            // the BatchNorm's input [M_out, Cout]; nullptr = plain statistics
+  const float* mean;
+  const float* var;
+  const float* gamma;        // may be nullptr (1)
+  const float* beta;         // may be nullptr (0)
+  float eps;
+  int relu;
+};
+struct BnCoef {
+  float mu, rstd, gm, bt;
+};
+__device__ __forceinline__ BnCoef bn_coef(const BnEpi& e, int c) {
+  BnCoef k;
+  k.mu = e.mean[c];
+  k.rstd = rsqrtf(e.var[c] + e.eps);
+  k.gm = e.gamma ? e.gamma[c] : 1.0f;
+  k.bt = e.beta ? e.beta[c] : 0.0f;
+  return k;
+}
+// (dz, dz * xhat) of one element, the arithmetic of bn_bwd_partial_kernel
+__device__ __forceinline__ void bn_terms(const BnCoef& k, int relu, float dy, float xv, float& dz, float& dzx) {
+  const float xh = (xv - k.mu) * k.rstd;
+  dz = (relu && xh * k.gm + k.bt <= 0.0f) ? 0.0f : dy;
+  dzx = dz * xh;
+}
+
 __device__ __forceinline__ void dma16(const void* src, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -60,7 +99,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ WT, const float* __restrict__ bias, const float* __restrict__ residual,
     float* __restrict__ out, float* __restrict__ partial, int64_t M_out, int K, int Cin, int Cout, int flip,
-    float* __restrict__ stats, unsigned long long* __restrict__ dbg = nullptr) {
+    uint32_t x_bytes, float* __restrict__ stats, BnEpi epi, unsigned long long* __restrict__ dbg = nullptr) {
   // stats (optional, final pass only): per-slice BatchNorm partials of the FINISHED output rows (bias and residual
   // included), stats[(slice * 2 + {0: sum, 1: sum of squared deviations from the SLICE mean}) * Cout + channel] -- the
   // statistics pass of the BatchNorm that consumes this tensor (sparse_unet3d.py:128-137) without re-reading it.
@@ -89,6 +128,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
 
   // ---- the slice's rows and its column of the packed gather table (every load in flight at once)
   const int64_t t = t0 + r31;
+  const uint32_t a_pitch32 = (uint32_t)Cin * 4u;
   int32_t my_row = -1;
   if (t < M_out) my_row = order ? order[t] : (int32_t)t;
   uint32_t mask = 0u;
@@ -108,7 +148,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
       const int k = 2 * j + half;
       const bool ok = k < K && t < M_out;
       const int32_t g = ok ? (nbrS ? v[j] : my_row) : -1;
-      nbT[k * 32 + r31] = g;
+      nbT[k * 32 + r31] = g >= 0 ? (int32_t)((uint32_t)g * a_pitch32) : (int32_t)NO_ROW;
       const unsigned long long b = __ballot(g >= 0);
       if ((uint32_t)b) mask |= 1u << (2 * j);
       if ((uint32_t)(b >> 32)) mask |= 1u << (2 * j + 1);
@@ -172,11 +212,13 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) nb[i] = nbT[g.k * 32 + i * 8 + d_row];
   };
+  const rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), (short)0, (int)x_bytes, 0x00020000);
+  uint32_t a_po[4];                      // swizzled 16-byte piece of this lane in instruction i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_po[i] = (uint32_t)((d_piece ^ swz(i * 8 + d_row)) << 4);
   auto issueA1 = [&](const Gen& g, const int32_t (&nb)[4], int slot, int i) {
-    const int row = i * 8 + d_row;
-    const bool ok = g.valid && nb[i] >= 0;
-    const char* src = ok ? Xb + (int64_t)nb[i] * a_pitch + g.c * 128 + ((d_piece ^ swz(row)) << 4) : zrow;
-    dma16(src, Aring + slot * A_BYTES + i * 1024);
+    const uint32_t off = g.valid ? (uint32_t)nb[i] + a_po[i] : NO_ROW;
+    bdma16(rsX, off, (uint32_t)g.c * 128u, Aring + slot * A_BYTES + i * 1024);
   };
   auto issueB1 = [&](const Gen& g, int slot, int i) {
     const int kk = flip ? K - 1 - g.k : g.k;
@@ -452,7 +494,26 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
           if (rows[reg] >= 0) dst[(int64_t)rows[reg] * Cout + c] = val[reg];
-        if (stats && final_pass) {      // rows in register order, then the two halves: a fixed order
+        if (stats && final_pass && epi.x) {     // BatchNorm-backward partials of the slice (see BnEpi)
+          const BnCoef kc = bn_coef(epi, c);
+          float xv[16];
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) xv[reg] = epi.x[(int64_t)(rows[reg] >= 0 ? rows[reg] : 0) * Cout + c];
+          float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            float dz, dzx;
+            bn_terms(kc, epi.relu, val[reg], xv[reg], dz, dzx);
+            sa += rows[reg] >= 0 ? dz : 0.0f;
+            sb += rows[reg] >= 0 ? dzx : 0.0f;
+          }
+          sa += __shfl_xor(sa, 32, 64);
+          sb += __shfl_xor(sb, 32, 64);
+          if (half == 0) {
+            stats[((int64_t)blockIdx.x * 2 + 0) * Cout + c] = sa;
+            stats[((int64_t)blockIdx.x * 2 + 1) * Cout + c] = sb;
+          }
+        } else if (stats && final_pass) {      // rows in register order, then the two halves: a fixed order
           float sa = 0.0f, sb = 0.0f;
 #pragma unroll
           for (int reg = 0; reg < 16; ++reg) sa += rows[reg] >= 0 ? val[reg] : 0.0f;
@@ -491,28 +552,65 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
     constexpr int PER = (32 * NB * 32) / (64 * NW);      // elements of this thread (its column is fixed: 64 NW is a
     float keep[PER];                                     // multiple of NB * 32)
     bool live[PER];
-    float sa = 0.0f;
+    float sa = 0.0f, sq = 0.0f;
+    const bool bn_mode = stats && final_pass && epi.x;
+    BnCoef kc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int cc = (int)(threadIdx.x % (NB * 32)), c = col0 + cc;
+    if (bn_mode) kc = bn_coef(epi, c);
+    const float bv = bias ? bias[c] : 0.0f;
+    // every global read of the epilogue in flight before the first use (row 0 for the masked rows): inside the
+    // element loop each one would expose its full latency
+    int64_t off[PER];
+    float rv[PER], xv[PER];
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+      const int rr = (threadIdx.x + it * 64 * NW) / (NB * 32);
+      const int32_t r = rowId0[rr];
+      live[it] = r >= 0;
+      off[it] = (int64_t)(r >= 0 ? r : 0) * Cout + c;
+    }
+#pragma unroll
+    for (int it = 0; it < PER; ++it) rv[it] = residual ? residual[off[it]] : 0.0f;
+#pragma unroll
+    for (int it = 0; it < PER; ++it) xv[it] = bn_mode ? epi.x[off[it]] : 0.0f;
 #pragma unroll
     for (int it = 0; it < PER; ++it) {
       const int e = threadIdx.x + it * 64 * NW;
-      const int rr = e / (NB * 32), cc = e - rr * (NB * 32);
-      const int32_t r = rowId0[rr];
-      live[it] = r >= 0;
-      keep[it] = 0.0f;
-      if (r < 0) continue;
       float v = 0.0f;
 #pragma unroll
       for (int w = 0; w < NW; ++w)
         v += reinterpret_cast<const float*>(lds + HDR_BYTES + w * L::WAVE_BYTES)[e];
-      const int c = col0 + cc;
-      if (bias) v += bias[c];
-      const int64_t o = (int64_t)r * Cout + c;
-      if (residual) v += residual[o];
-      dst[o] = v;
-      keep[it] = v;
-      sa += v;
+      if (bias) v += bv;
+      if (residual) v += rv[it];
+      keep[it] = live[it] ? v : 0.0f;
+      if (live[it]) dst[off[it]] = v;
+      if (bn_mode) {
+        float dz, dzx;
+        bn_terms(kc, epi.relu, v, xv[it], dz, dzx);
+        sa += live[it] ? dz : 0.0f;
+        sq += live[it] ? dzx : 0.0f;
+      } else {
+        sa += live[it] ? v : 0.0f;
+      }
     }
-    if (stats && final_pass) {      // threads of one column: t, t + NB*32, ...; added in that order
+    if (bn_mode) {                  // both sums are plain: one exchange
+      __syncthreads();
+      float* sred = reinterpret_cast<float*>(lds + HDR_BYTES);
+      const int colw = NB * 32;
+      sred[threadIdx.x] = sa;
+      sred[64 * NW + threadIdx.x] = sq;
+      __syncthreads();
+      if (threadIdx.x < colw) {
+        float ta = 0.0f, tb = 0.0f;
+        for (int j = threadIdx.x; j < 64 * NW; j += colw) {
+          ta += sred[j];
+          tb += sred[64 * NW + j];
+        }
+        const int c = col0 + threadIdx.x;
+        stats[((int64_t)blockIdx.x * 2 + 0) * Cout + c] = ta;
+        stats[((int64_t)blockIdx.x * 2 + 1) * Cout + c] = tb;
+      }
+    } else if (stats && final_pass) {      // threads of one column: t, t + NB*32, ...; added in that order
       __syncthreads();              // the accumulator copies in the rings are no longer needed
       float* sred = reinterpret_cast<float*>(lds + HDR_BYTES);
       const int colw = NB * 32, me = threadIdx.x % colw;
@@ -590,7 +688,7 @@ __global__ __launch_bounds__(256) void spconv2_reduce_stats_kernel(const float4*
                                                                   const float4* __restrict__ bias,
                                                                   const float4* __restrict__ residual,
                                                                   float4* __restrict__ out, int64_t M_out, int cout4,
-                                                                  int zs, float* __restrict__ stats) {
+                                                                  int zs, float* __restrict__ stats, BnEpi epi) {
   __shared__ float sred[256 * 4];
   const int64_t total4 = M_out * cout4;
   const int lanes = 256 / cout4;                         // row lanes (cout4 <= 64)
@@ -600,6 +698,10 @@ __global__ __launch_bounds__(256) void spconv2_reduce_stats_kernel(const float4*
   constexpr int MAXR = 8;                                // rows per thread: ceil(32 / lanes), lanes >= 4
   float4 keep[MAXR];
   float sa[4] = {0.f, 0.f, 0.f, 0.f};
+  BnCoef kcs[4] = {};
+  if (epi.x)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) kcs[e] = bn_coef(epi, c4 * 4 + e);
 #pragma unroll
   for (int it = 0; it < MAXR; ++it) {
     keep[it] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -621,7 +723,20 @@ __global__ __launch_bounds__(256) void spconv2_reduce_stats_kernel(const float4*
       }
       out[t] = s;
       keep[it] = s;
-      sa[0] += s.x; sa[1] += s.y; sa[2] += s.z; sa[3] += s.w;
+      if (epi.x) {      // BatchNorm-backward partials: keep <- dz * xhat, sa <- dz
+        const float4 xv = reinterpret_cast<const float4*>(epi.x)[t];
+        const float dyv[4] = {s.x, s.y, s.z, s.w}, xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        float q[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float dz;
+          bn_terms(kcs[e], epi.relu, dyv[e], xs[e], dz, q[e]);
+          sa[e] += dz;
+        }
+        keep[it] = make_float4(q[0], q[1], q[2], q[3]);
+      } else {
+        sa[0] += s.x; sa[1] += s.y; sa[2] += s.z; sa[3] += s.w;
+      }
     }
   }
 #pragma unroll
@@ -637,9 +752,13 @@ __global__ __launch_bounds__(256) void spconv2_reduce_stats_kernel(const float4*
   for (int it = 0; it < MAXR; ++it) {
     const int rr = rl + it * lanes;
     if (rl < lanes && rr < nrows) {
-      const float d0 = keep[it].x - ta[0] / (float)nrows, d1 = keep[it].y - ta[1] / (float)nrows;
-      const float d2 = keep[it].z - ta[2] / (float)nrows, d3 = keep[it].w - ta[3] / (float)nrows;
-      sb[0] += d0 * d0; sb[1] += d1 * d1; sb[2] += d2 * d2; sb[3] += d3 * d3;
+      if (epi.x) {
+        sb[0] += keep[it].x; sb[1] += keep[it].y; sb[2] += keep[it].z; sb[3] += keep[it].w;
+      } else {
+        const float d0 = keep[it].x - ta[0] / (float)nrows, d1 = keep[it].y - ta[1] / (float)nrows;
+        const float d2 = keep[it].z - ta[2] / (float)nrows, d3 = keep[it].w - ta[3] / (float)nrows;
+        sb[0] += d0 * d0; sb[1] += d1 * d1; sb[2] += d2 * d2; sb[3] += d3 * d3;
+      }
     }
   }
   __syncthreads();
@@ -704,22 +823,61 @@ int32_t wsis_spconv_fwd_t_supported(int32_t K, int32_t Cin, int32_t Cout) {
   return (K >= 1 && K <= KMAX && Cin >= 32 && Cin % 32 == 0 && Cout >= 32 && Cout % 32 == 0) ? 1 : 0;
 }
 
+int32_t wsis_spconv_fwd_t_slabs(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout) {
+  if (M_out < 1 || !wsis_spconv_fwd_t_supported(K, Cin, Cout)) return 0;
+  return plan2(M_out, K, Cin, Cout).ZS;
+}
+
 int64_t wsis_spconv_fwd_t_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout) {
   if (M_out < 0 || !wsis_spconv_fwd_t_supported(K, Cin, Cout)) return -1;
   const Plan2 p = plan2(M_out, K, Cin, Cout);
   return p.ZS <= 1 ? 256 : (int64_t)p.ZS * M_out * Cout * (int64_t)sizeof(float) + 256;
 }
 
+static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT,
+                             int32_t flip, const float* d_bias, const float* d_residual, float* d_out, float* d_stats,
+                             const BnEpi& epi, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout,
+                             void* d_ws, int64_t ws_bytes, void* stream);
+
 int wsis_spconv_fwd_t(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT, int32_t flip,
                       const float* d_bias, const float* d_residual, float* d_out, float* d_stats, int64_t M_in,
                       int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
                       void* stream) {
+  return spconv_fwd_t_impl(d_X, d_nbr, d_order, d_WT, flip, d_bias, d_residual, d_out, d_stats, BnEpi{}, M_in, M_out, K,
+                           Cin, Cout, d_ws, ws_bytes, stream);
+}
+
+int wsis_spconv_fwd_t_bn(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT, int32_t flip,
+                         float* d_out, float* d_partials, const float* d_bn_x, const float* d_bn_mean,
+                         const float* d_bn_var, const float* d_bn_gamma, const float* d_bn_beta, float eps, int32_t relu,
+                         int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
+                         void* stream) {
+  WSIS_REQUIRE(d_partials && d_bn_x && d_bn_mean && d_bn_var, "null pointer");
+  WSIS_REQUIRE((reinterpret_cast<uintptr_t>(d_bn_x) & 15) == 0, "bn_x must be 16-byte aligned");
+  BnEpi epi;
+  epi.x = d_bn_x;
+  epi.mean = d_bn_mean;
+  epi.var = d_bn_var;
+  epi.gamma = d_bn_gamma;
+  epi.beta = d_bn_beta;
+  epi.eps = eps;
+  epi.relu = relu;
+  return spconv_fwd_t_impl(d_X, d_nbr, d_order, d_WT, flip, nullptr, nullptr, d_out, d_partials, epi, M_in, M_out, K,
+                           Cin, Cout, d_ws, ws_bytes, stream);
+}
+
+static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT,
+                             int32_t flip, const float* d_bias, const float* d_residual, float* d_out, float* d_stats,
+                             const BnEpi& epi, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout,
+                             void* d_ws, int64_t ws_bytes, void* stream) {
   WSIS_REQUIRE(M_in >= 0 && M_out >= 0, "bad sizes");
   WSIS_REQUIRE(wsis_spconv_fwd_t_supported(K, Cin, Cout), "needs K <= 32 and channel counts that are multiples of 32");
   if (M_out == 0) return WSIS_OK;
   WSIS_REQUIRE(d_X && d_WT && d_out, "null pointer");
   WSIS_REQUIRE(d_nbr || (K == 1 && M_in == M_out), "nbr may be null only for the dense 1x1 case");
   WSIS_REQUIRE(M_out < (int64_t)1 << 31 && M_in < (int64_t)1 << 31, "row count exceeds int32");
+  WSIS_REQUIRE(M_in * Cin * 4 < (int64_t)1 << 31, "input tensor of 2 GiB or more (32-bit gather offsets): use wsis_spconv_fwd");
+  const uint32_t x_bytes = (uint32_t)(M_in * Cin * 4);
   WSIS_REQUIRE(((reinterpret_cast<uintptr_t>(d_X) | reinterpret_cast<uintptr_t>(d_WT)) & 15) == 0,
                "X and WT must be 16-byte aligned");
   const Plan2 p = plan2(M_out, K, Cin, Cout);
@@ -742,7 +900,8 @@ int wsis_spconv_fwd_t(const float* d_X, const int32_t* d_nbr, const int32_t* d_o
       attr_set = true;                                                                                           \
     }                                                                                                            \
     hipLaunchKernelGGL((spconv_fwd2_kernel<nb, nw, da, bd>), grid, dim3(64 * nw), ldsb, st, d_X, d_nbr, d_order, \
-                       d_WT, d_bias, d_residual, d_out, partial, M_out, K, Cin, Cout, flip, d_stats);            \
+                       d_WT, d_bias, d_residual, d_out, partial, M_out, K, Cin, Cout, flip, x_bytes, d_stats, \
+                       epi);                                                                                     \
   } while (0)
 #define WSIS_F2(nb, nw, da)      \
   if (p.BD)                      \
@@ -773,7 +932,7 @@ int wsis_spconv_fwd_t(const float* d_X, const int32_t* d_nbr, const int32_t* d_o
     hipLaunchKernelGGL(spconv2_reduce_stats_kernel, dim3((unsigned)ceil_div(M_out, SL)), dim3(256), 0, st,
                        reinterpret_cast<const float4*>(partial), reinterpret_cast<const float4*>(d_bias),
                        reinterpret_cast<const float4*>(d_residual), reinterpret_cast<float4*>(d_out), M_out, Cout / 4,
-                       p.ZS, d_stats);
+                       p.ZS, d_stats, epi);
     WSIS_LAUNCH_CHECK();
   } else if (p.ZS > 1) {
     const int64_t total4 = M_out * Cout / 4;
@@ -798,18 +957,18 @@ int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 2, true, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, 0,
-                       (float*)nullptr, d_dbg);
+                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, d_dbg);
   } else if (variant >= 2) {      // the production small-level form: 4 waves per work item, `variant - 1` offset slabs
     const dim3 g4((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32), (unsigned)(variant - 1));
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES * 4;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 4, 2, true, true>), g4, dim3(256), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, d_out, M_out, K, Cin, Cout, 0,
-                       (float*)nullptr, d_dbg);
+                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, d_dbg);
   } else {
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 3, false>::WAVE_BYTES;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 3, false, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, 0,
-                       (float*)nullptr, d_dbg);
+                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, d_dbg);
   }
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;

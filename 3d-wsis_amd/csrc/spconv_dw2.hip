@@ -382,13 +382,28 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
   }
 }
 
-// dW = sum over workgroup slabs, slab order fixed; four floats per thread
-__global__ void dw2_reduce_kernel(const float4* __restrict__ partial, float4* __restrict__ dW, int64_t total4, int P) {
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total4; t += (int64_t)gridDim.x * blockDim.x) {
-    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll 8
-    for (int p = 0; p < P; ++p) {
+// dW = sum over workgroup slabs in a fixed order: thread (element quad e, slab lane l) adds slabs l, l + 8, ... in
+// ascending order, the 8 lane sums are then added in lane order through LDS (P slabs of a few hundred KB: one thread
+// per quad walking all P slabs left the reduction latency bound at ~11 us)
+__global__ __launch_bounds__(256) void dw2_reduce_kernel(const float4* __restrict__ partial, float4* __restrict__ dW,
+                                                         int64_t total4, int P) {
+  __shared__ float4 red[8][32];
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t t = (int64_t)blockIdx.x * 32 + el;
+  float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (t < total4) {
+#pragma unroll 4
+    for (int p = sl; p < P; p += 8) {
       const float4 v = partial[(int64_t)p * total4 + t];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  red[sl][el] = s;
+  __syncthreads();
+  if (sl == 0 && t < total4) {
+#pragma unroll
+    for (int l = 1; l < 8; ++l) {
+      const float4 v = red[l][el];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     dW[t] = s;
@@ -464,7 +479,7 @@ int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, c
   prof.stop();
   WSIS_LAUNCH_CHECK();
   const int64_t total4 = (int64_t)K * Cin * Cout / 4;
-  hipLaunchKernelGGL(dw2_reduce_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(dw2_reduce_kernel, dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, st,
                      reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(d_dW), total4, P);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;

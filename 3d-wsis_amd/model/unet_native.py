@@ -231,10 +231,35 @@ class UNetProgram(object):
             dx = recb.alloc(lvl, C)
             dg = self._grad_handle(bn.weight) if bn.weight is not None else recb.alloc(-1, C)
             db = self._grad_handle(bn.bias) if bn.bias is not None else recb.alloc(-1, C)
-            recb.op(OP_BN_RELU_BWD, flags, _lvl(lvl), _lvl(lvl), 0, C, C, bn.eps, 0.0,
+            recb.op(OP_BN_RELU_BWD, flags & ~F_STATS, _lvl(lvl), _lvl(lvl), 0, C, C, bn.eps, 0.0,      # (F_STATS: _fuse_bn_bwd)
                     inp=(x, dy, mean, var, _ptr(bn.weight), _ptr(bn.bias), addend), out=(dx, dg, db))
             return dx
         return y, bwd
+
+    def _fuse_bn_bwd(self, recb):
+        """dIn passes whose output is the dy of a BatchNorm backward a few ops later (training mode, layer on the
+        wave-autonomous kernel) also write that op's (sum dz, sum dz*xhat) slice partials from their epilogue: both
+        ops get F_STATS and the BatchNorm op the partial buffer in inp[7] (WSIS_FUSE_BN_BWD=0: separate pass)"""
+        if os.environ.get("WSIS_FUSE_BN_BWD", "1") == "0" or not self._fuse_stats:
+            return
+        rows = recb.rows
+        for i, r in enumerate(rows):
+            if r[0] != OP_CONV_BWD or not r[10] or not r[10][0]:
+                continue
+            K, Cin, Cout = r[4], r[5], r[6]
+            if not sp_ops._use_fwd2(K, Cout, Cin):          # the dIn product gathers dY: roles of the channels swap
+                continue
+            dx = r[10][0]
+            for j in range(i + 1, min(i + 5, len(rows))):
+                b = rows[j]
+                if b[0] == OP_BN_RELU_BWD and len(b[9]) >= 2 and b[9][1] == dx and (b[1] & F_TRAINING) and b[5] == Cin \
+                        and b[2] == r[2]:
+                    lvl = -b[2] - 1
+                    part = recb.alloc(lvl, 2 * Cin, per_slice=True)
+                    inp = tuple(b[9]) + (0,) * (7 - len(b[9])) + (part,)
+                    rows[j] = b[:1] + (b[1] | F_STATS,) + b[2:9] + (inp, b[10])
+                    rows[i] = r[:1] + (r[1] | F_STATS,) + r[2:]
+                    break
 
     def _residual_block(self, rec, x, blk, lvl):
         seq = blk.conv_branch
@@ -335,6 +360,7 @@ class UNetProgram(object):
         d = b_out(recb, _EXT | 1)
         d = b_u(recb, d)
         dx = b_in(recb, d, need_dx)
+        self._fuse_bn_bwd(recb)
         c.fwd, c.bwd = _Template(rec), _Template(recb)
         c.fwd_arena, c.bwd_arena, c.par_arena = _Arena(rec), _Arena(recb), _Arena(self._prec)
         c.out_id, c.dx_id = out & _ID_MASK, (dx & _ID_MASK) if need_dx else -1

@@ -380,9 +380,11 @@ def _conv(X, nbr, order, W, bias, residual, M_out):
     return out
 
 
-def _use_fwd2(K, Cin, Cout):
-    """the wave-autonomous LDS-DMA kernel (csrc/spconv2.hip) where it applies; WSIS_FWD2=0 keeps the round-1 kernel"""
-    return os.environ.get("WSIS_FWD2", "1") != "0" and bool(_n.hip().wsis_spconv_fwd_t_supported(K, Cin, Cout))
+def _use_fwd2(K, Cin, Cout, rows=0):
+    """the wave-autonomous LDS-DMA kernel (csrc/spconv2.hip) where it applies (channel multiples of 32, K <= 32, gathered
+    tensor of `rows` x Cin floats below 2 GiB: 32-bit gather offsets); WSIS_FWD2=0 keeps the round-1 kernel"""
+    return (os.environ.get("WSIS_FWD2", "1") != "0" and bool(_n.hip().wsis_spconv_fwd_t_supported(K, Cin, Cout))
+            and rows * Cin * 4 < (1 << 31))
 
 
 _WS2_CACHE = {}
@@ -455,7 +457,7 @@ class SparseConvFunction(Function):
             W = W.contiguous().float()
         W = W.view(-1, Cin, Cout)
         b = bias.contiguous().float() if bias is not None else None
-        if _use_fwd2(W.shape[0], Cin, Cout):
+        if _use_fwd2(W.shape[0], Cin, Cout, X.shape[0]):
             out = _conv_t(X, nbr_f, order_f, _weight_t(W, 0), 0, b, None, M_out)
         else:
             out = _conv(X, nbr_f, order_f, W, b, None, M_out)
@@ -471,7 +473,7 @@ class SparseConvFunction(Function):
         K, Cin, Cout = W.shape
         dX = dW = db = None
         if ctx.needs_input_grad[0]:
-            if _use_fwd2(K, Cout, Cin):    # dIn: the weight itself is the B^T operand ([K, Cin, Cout]: rows = dIn outputs)
+            if _use_fwd2(K, Cout, Cin, dY.shape[0]):    # dIn: the weight itself is the B^T operand ([K, Cin, Cout]: rows = dIn outputs)
                 dX = _conv_t(dY, nbr_b, order_b, W, flip, None, None, X.shape[0])
             else:
                 WT = _weight_t(W, flip)

@@ -203,6 +203,8 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
  * with NW = 1 bit-identical to wsis_spconv_fwd; small levels split the offsets over the waves of a workgroup (added
  * through LDS in wave order) and, below that, over blockIdx.z into partial slabs in d_ws (fixed order). */
 int32_t wsis_spconv_fwd_t_supported(int32_t K, int32_t Cin, int32_t Cout);
+/* number of offset slabs the launch plan of wsis_spconv_fwd_t uses for this shape (1 = one kernel, no second pass) */
+int32_t wsis_spconv_fwd_t_slabs(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout);
 int64_t wsis_spconv_fwd_t_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout);
 /* d_stats (optional): BatchNorm partials of the finished output, [ceil(M_out / 32)][2][Cout] floats per 32-row slice
  * in tile order: (sum, sum of squared deviations from the SLICE's own mean), fixed order of additions -- the
@@ -212,6 +214,16 @@ int wsis_spconv_fwd_t(const float* d_X, const int32_t* d_nbr, const int32_t* d_o
                       const float* d_bias, const float* d_residual, float* d_out, float* d_stats, int64_t M_in,
                       int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
                       void* stream);
+/* the same product for a dIn pass whose output dy [M_out, Cout] feeds the backward of a BatchNorm(+ReLU) with input
+ * d_bn_x [M_out, Cout] (reference: spconv's dIn followed by torch's batch_norm backward, sparse_unet3d.py:128-137):
+ * besides d_out the epilogue writes, per 32-row slice, (sum dz, sum dz * xhat) with xhat = (x - mean) rsqrt(var + eps)
+ * and dz = dy masked where relu && xhat * gamma + beta <= 0, into d_partials [ceil(M_out / 32)][2][Cout] -- the
+ * reduction wsis_bn_bwd would otherwise make in a pass of its own (wsis_bn_bwd_from_partials consumes them). */
+int wsis_spconv_fwd_t_bn(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT, int32_t flip,
+                         float* d_out, float* d_partials, const float* d_bn_x, const float* d_bn_mean,
+                         const float* d_bn_var, const float* d_bn_gamma, const float* d_bn_beta, float eps, int32_t relu,
+                         int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
+                         void* stream);
 /* WT[k'] = W[k]^T with k' = (flip ? K-1-k : k); W [K,Cin,Cout] -> WT [K,Cout,Cin]. */
 int wsis_weight_transpose(const float* d_W, float* d_WT, int32_t K, int32_t Cin, int32_t Cout,
                           int32_t flip, void* stream);
@@ -242,6 +254,14 @@ int64_t wsis_bn_stats_finalize_workspace_bytes(int64_t n_part, int32_t C);
 int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, int32_t C, float* d_mean, float* d_var,
                            float* d_running_mean, float* d_running_var, float momentum, void* d_ws, int64_t ws_bytes,
                            void* stream);
+/* backward of the fused BN(+ReLU) when dy was produced by wsis_spconv_fwd_t_bn: d_partials holds the n_part =
+ * ceil(M / 32) rows of (sum dz, sum dz * xhat) slice partials (pitch 2*C floats) that the convolution's epilogue wrote,
+ * so the reduction pass over x and dy of wsis_bn_bwd is replaced by an fp64 sum of the partials (fixed order, chunk
+ * sums in d_ws: wsis_bn_stats_finalize_workspace_bytes); then dx as in wsis_bn_bwd (training mode). */
+int wsis_bn_bwd_from_partials(const float* d_partials, int64_t n_part, const float* d_x, const float* d_dy,
+                              const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta,
+                              float eps, int32_t relu, float* d_dx, float* d_dgamma, float* d_dbeta,
+                              const float* d_addend, int64_t M, int32_t C, void* d_ws, int64_t ws_bytes, void* stream);
 /* y = relu?( (x-mean)*rsqrt(var+eps)*gamma + beta )   (gamma/beta may be NULL = 1/0) */
 int wsis_bn_apply(const float* d_x, const float* d_mean, const float* d_var, const float* d_gamma,
                   const float* d_beta, float eps, int32_t relu, float* d_y, int64_t M, int32_t C, void* stream);

@@ -128,6 +128,32 @@ def test_batchnorm_statistics_from_the_conv_epilogue_match_the_separate_pass(mon
     assert torch.equal(res["1"][0], res["1b"][0]) and all(torch.equal(g1[n], res["1b"][1][n]) for n in g1)
 
 
+def test_batchnorm_backward_reduction_from_the_din_epilogue_matches_the_separate_pass(monkeypatch):
+    """WSIS_FUSE_BN_BWD=1 (default): the (sum dz, sum dz*xhat) reduction of every BatchNorm backward whose dy comes out
+    of a dIn convolution is made by that convolution's epilogue (32-row partials, fp64 sum).  The forward pass is
+    untouched (loss EQUAL); against the separate reduction pass every gradient agrees to 2e-3 of the largest (the
+    sums are re-associated; the accuracy gate is the fp64-oracle test), and the fused mode is bit-deterministic.
+    Full-size scene: on small ones every dIn launch is split into offset slabs and the executor keeps the BatchNorm's
+    own one-launch reduction."""
+    cfg = harness.default_cfg()
+    batch_host = harness.collate([harness.make_scene(21)])
+    res = {}
+    for mode in ("0", "1", "1b"):
+        monkeypatch.setenv("WSIS_FUSE_BN_BWD", mode[0])
+        model, crit, opt = harness.build_model(cfg, "cuda")
+        batch = harness.to_device(batch_host, "cuda")
+        loss, _ = harness.forward_loss(model, crit, batch, cfg)
+        loss.backward()
+        res[mode] = (loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    (l0, g0), (l1, g1) = res["0"], res["1"]
+    assert torch.equal(l0, l1)
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    worst = max(float((g0[n] - g1[n]).abs().max()) for n in g0)
+    assert worst <= 2e-3 * gmax, (worst, gmax)
+    assert any(not torch.equal(g0[n], g1[n]) for n in g0), "the fused reduction did not run"
+    assert all(torch.equal(g1[n], res["1b"][1][n]) for n in g1)
+
+
 def test_train_step_decreases_loss_and_is_deterministic():
     cfg, batch_host, model, crit, opt, ref = _setup(1, 20, (1.4, 1.1, 0.9))
     batch = harness.to_device(batch_host, "cuda")

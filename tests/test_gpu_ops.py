@@ -1055,3 +1055,60 @@ def test_ecc_contraction_matches_oracle_and_never_forms_the_filter_tensor(S, deg
     out2.backward(go.to(DEV))
     ok(out2, want.detach(), "out (filters materialised)")
     ok(x2.grad, xr.grad, "dx (filters materialised)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,rooms", [(32, 1), (64, 1), (128, 3)])
+def test_din_epilogue_writes_the_batchnorm_backward_partials(C, rooms):
+    """wsis_spconv_fwd_t_bn: the dIn product plus, per 32-row slice, (sum dz, sum dz*xhat) of the BatchNorm(+ReLU)
+    behind it; wsis_bn_bwd_from_partials then gives the dgamma / dbeta / dx of wsis_bn_bwd (reduction re-associated:
+    1e-5 relative), on every epilogue variant (one wave per slice, four waves, z-slabs + reduce kernel)."""
+    import wsis_native as _n
+    from spconv import ops
+    lib = _n.hip()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    import harness
+    room = (1.6, 1.3, 1.0) if rooms == 1 else (1.2, 1.0, 0.8)       # the small room: fewer slices, more z-slabs
+    bt = harness.collate([harness.make_scene(41, room=room, n_box=2 if rooms == 1 else 1)])
+    idx = bt["voxel_locs"].int().to(DEV).contiguous()
+    shape = [int(v) for v in bt["spatial_shape"]]
+    rb = ops.build_subm_rulebook(idx, shape, [3] * 3, [1] * 3)
+    M = idx.shape[0]
+    dY = torch.randn(M, C, device=DEV, generator=g)
+    W = torch.randn(27, C, C, device=DEV, generator=g) * 0.05
+    x = torch.randn(M, C, device=DEV, generator=g)
+    gamma = torch.randn(C, device=DEV, generator=g)
+    beta = torch.randn(C, device=DEV, generator=g) * 0.3
+    addend = torch.randn(M, C, device=DEV, generator=g)
+    mean, var = x.mean(0).contiguous(), x.var(0, unbiased=False).contiguous()
+    eps = 1e-4
+    want_dx_in = ops._conv_t(dY, rb.nbr_p, rb.order, W, 1, None, None, M)
+    n_part = (M + 31) // 32
+    part = torch.full((n_part, 2, C), float("nan"), device=DEV)
+    out = torch.empty(M, C, device=DEV)
+    wsb = lib.wsis_spconv_fwd_t_workspace_bytes(M, 27, C, C)
+    ws = torch.empty(max(wsb, 256) + lib.wsis_bn_stats_finalize_workspace_bytes(n_part, C), dtype=torch.uint8, device=DEV)
+    for relu in (1, 0):
+        _n.check(lib.wsis_spconv_fwd_t_bn(_n.ptr(dY), _n.ptr(rb.nbr_p), _n.ptr(rb.order), _n.ptr(W), 1, _n.ptr(out),
+                                          _n.ptr(part), _n.ptr(x), _n.ptr(mean), _n.ptr(var), _n.ptr(gamma), _n.ptr(beta),
+                                          eps, relu, M, M, 27, C, C, _n.ptr(ws), ws.numel(), _n.stream_ptr()), "fwd_t_bn")
+        assert torch.equal(out, want_dx_in)
+        xh = (x - mean) * torch.rsqrt(var + eps)
+        dz = torch.where((xh * gamma + beta <= 0) if relu else torch.zeros_like(xh, dtype=torch.bool), torch.zeros_like(out), out)
+        # which rows form a slice differs between the epilogue variants (tile order / row order): the totals count
+        a, b = dz.double().sum(0), (dz * xh).double().sum(0)
+        sc = max(float(a.abs().max()), float(b.abs().max()), 1.0)
+        assert not torch.isnan(part).any()
+        assert float((part[:, 0].double().sum(0) - a).abs().max()) < 1e-5 * sc
+        assert float((part[:, 1].double().sum(0) - b).abs().max()) < 1e-5 * sc
+        dx1, dg1, db1 = torch.empty_like(x), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        dx2, dg2, db2 = torch.empty_like(x), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        _n.check(lib.wsis_bn_bwd_from_partials(_n.ptr(part), n_part, _n.ptr(x), _n.ptr(out), _n.ptr(mean), _n.ptr(var),
+                                               _n.ptr(gamma), _n.ptr(beta), eps, relu, _n.ptr(dx1), _n.ptr(dg1), _n.ptr(db1),
+                                               _n.ptr(addend), M, C, _n.ptr(ws), ws.numel(), _n.stream_ptr()), "bn_bwd_from_partials")
+        wb = torch.empty(lib.wsis_bn_workspace_bytes(M, C), dtype=torch.uint8, device=DEV)
+        _n.check(lib.wsis_bn_bwd(_n.ptr(x), _n.ptr(out), _n.ptr(mean), _n.ptr(var), _n.ptr(gamma), _n.ptr(beta), eps, relu, 1,
+                                 _n.ptr(dx2), _n.ptr(dg2), _n.ptr(db2), _n.ptr(addend), M, C, _n.ptr(wb), wb.numel(),
+                                 _n.stream_ptr()), "bn_bwd")
+        for u, v in ((dg1, dg2), (db1, db2), (dx1, dx2)):
+            assert float((u - v).abs().max()) <= 1e-5 * max(float(v.abs().max()), 1.0)
