@@ -1082,7 +1082,8 @@ int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_orde
   WSIS_REQUIRE(M_in * Cin * 4 < ((int64_t)1 << 32) && M_out * Cout * 4 < ((int64_t)1 << 32),
                "dW addresses features as 32-bit byte offsets: a feature matrix must stay below 4 GiB");
   WSIS_REQUIRE(ws_bytes >= wsis_spconv_dw_workspace_bytes(M_out, K, Cin, Cout), "workspace too small");
-  if (dw2_supported(K, Cin, Cout) && dw2_fits(M_in, M_out, K, Cin, Cout) && d_nbr && d_order && ((reinterpret_cast<uintptr_t>(d_X) | reinterpret_cast<uintptr_t>(d_dY) |
+  if (dw2_supported(K, Cin, Cout) && dw2_fits(M_in, M_out, K, Cin, Cout) &&
+      ((d_nbr && d_order) || (!d_nbr && K == 1 && M_in == M_out)) && ((reinterpret_cast<uintptr_t>(d_X) | reinterpret_cast<uintptr_t>(d_dY) |
                                        reinterpret_cast<uintptr_t>(d_dW) | reinterpret_cast<uintptr_t>(d_ws)) & 15) == 0)
     return dw2_launch(d_X, d_nbr, d_order, d_dY, d_dW, M_in, M_out, K, Cin, Cout, d_ws, st);
   DwPlan plan;

@@ -121,7 +121,16 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
   // header of a slice: table entries of this worker's offsets nb[slot][row] and the slice's output rows, 5 DMA
   // instructions of 4 bytes per lane (no alignment requirement on M_out); rows past M_out read row M_out - 1 and are
   // overwritten with -1 by fix_tail before the header is used, slots past K re-read slot 0 and are masked
+  const bool dense = nbrS == nullptr;          // 1x1 layer without a table: row t pairs with itself (K = 1)
+  const int NH = dense ? 0 : 5;                // DMA instructions of a header
   auto issueH = [&](int64_t s, int32_t* hb) {
+    if (dense) {                               // written, not loaded: slot 0 and the row list are the identity
+      const int64_t tt = s * 32 + r31;
+      const int32_t v = tt < M_out ? (int32_t)tt : -1;
+      hb[r31] = v;
+      hb[GS * 32 + r31] = v;
+      return;
+    }
     uint32_t t = (uint32_t)s * 32u + (uint32_t)r31;
     t = t < m_last ? t : m_last;
 #pragma unroll
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
         if (g_has_next) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           issueH(slice_of(g_pos + stride), hb);                       // into the header the generator just left
-          n = 13;
+          n = 8 + NH;
         }
         issueB(hn, Bt);
         p = hn + __builtin_ctz(m) * 32 + d_row;
@@ -492,7 +501,8 @@ int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, c
 extern "C" int wsis_debug_dw2_diag(const void* d_X, const void* d_nbr, const void* d_order, const void* d_dY,
                                    int64_t M_in, int64_t M_out, int K, int Cin, int Cout, void* d_ws, void* d_dbg, int64_t dbg_bytes,
                                    int64_t* n_waves, void* stream) {
-  WSIS_REQUIRE(wsis::dw2_supported(K, Cin, Cout) && wsis::dw2_fits(M_in, M_out, K, Cin, Cout) && d_nbr && d_order,
+  WSIS_REQUIRE(wsis::dw2_supported(K, Cin, Cout) && wsis::dw2_fits(M_in, M_out, K, Cin, Cout) &&
+                   ((d_nbr && d_order) || (!d_nbr && K == 1)),
                "shape not supported by the dw2 kernel");
   const int NOG = (K + GS - 1) / GS;
   const int P = dw2_P(M_out, K, Cin, Cout);

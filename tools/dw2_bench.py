@@ -49,6 +49,14 @@ def run():
             t = timeit(lambda: ops._dw(X, rb.nbr_p, rb.order, dY, 27, X.shape[1], dY.shape[1]))
             print(f"L{l} subm {cin:3d}->{cout:3d} x{cnt}: {t:6.1f}us  rel err {err:.1e}  repeat-identical {bool(torch.equal(dW, dW2))}", flush=True)
             tot += cnt * t
+        if l < 4:      # the 1x1 projection of the decoder blocks (no table: row t pairs with itself)
+            X = torch.randn(M, 2 * C, device=dev, generator=g); dY = torch.randn(M, C, device=dev, generator=g)
+            dW = ops._dw(X, None, None, dY, 1, 2 * C, C)
+            want = (X.double().t() @ dY.double())[None]
+            err = float((dW.double() - want).abs().max()) / float(want.abs().max())
+            t = timeit(lambda: ops._dw(X, None, None, dY, 1, 2 * C, C))
+            print(f"L{l} 1x1  {2 * C:3d}->{C:3d} x1: {t:6.1f}us  rel err {err:.1e}", flush=True)
+            tot += t
         if l < 4:
             rd = ops.build_down_rulebook(cur_idx, cur_shape, [2] * 3, [2] * 3, [0] * 3)
             Mo = rd.out_indices.shape[0]; cin, cout = C, planes[l + 1]
