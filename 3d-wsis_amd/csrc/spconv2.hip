@@ -653,6 +653,382 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent form of the multi-wave work item (the mid pyramid levels: enough slices for a few per workgroup, too few
+// for one wave per slice).  spconv_fwd2_kernel pays per slice a workgroup launch, two dependent memory latencies (gather
+// table, then the first gathered rows: ~5.8 us) and an epilogue, and all resident workgroups go through these phases
+// together, so the MFMA pipe idles for more than half of the launch.  Here a workgroup of NW waves stays resident and
+// walks slices blockIdx.x, + gridDim.x, ...; every wave keeps the offsets fwd2 gives it (k % ZS == z,
+// (k / ZS) % NW == wave: identical order of additions, bit-identical output) and runs its own generator one step
+// ahead of its MFMA chain ACROSS slice boundaries: header of the next slice (its <= 8 table rows + the row list) by
+// LDS-DMA one slice ahead, gathered rows of the next step by buffer LDS-DMA (32-bit offsets, missing pair = out of
+// range = zeros), weights of the next step straight to registers; every wait is a counted vmcnt.  Per slice the waves
+// meet twice (accumulators -> LDS in the ring slot just consumed, sum in wave order, store / statistics).
+constexpr int P3_GS = 8;                               // offsets per wave
+constexpr int P3_HDR_INTS = P3_GS * 32 + 64;           // nb[8][32] + rows[32] (+ 32 written by the upper half wave)
+constexpr int P3_HDR = P3_HDR_INTS * 4;
+constexpr int P3_WAVE = 2 * P3_HDR + 2 * A_BYTES;      // two headers, two-slot ring of gathered rows
+constexpr int P3_WG = 64;                              // ring parities of the waves
+
+template <int NW, bool DIAG>
+__global__ __launch_bounds__(64 * NW, 12 / NW) void spconv_fwd3_kernel(
+    const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
+    const float* __restrict__ WT, const float* __restrict__ bias, const float* __restrict__ residual,
+    float* __restrict__ out, float* __restrict__ partial, int64_t M_out, int K, int Cin, int Cout, int flip,
+    uint32_t x_bytes, float* __restrict__ stats, BnEpi epi, unsigned long long* __restrict__ dbg = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r31 = lane & 31, half = lane >> 5;
+  int32_t* const par = reinterpret_cast<int32_t*>(lds);
+  unsigned char* const my = lds + P3_WG + wave * P3_WAVE;
+  int32_t* const hdr0 = reinterpret_cast<int32_t*>(my);
+  unsigned char* const At = my + 2 * P3_HDR;
+
+  const int ZS = gridDim.z, z = blockIdx.z;
+  const int col0 = blockIdx.y * 32;
+  const int nchunk = Cin >> 5;
+  const int64_t n_slices = (M_out + 31) >> 5;
+  const int64_t stride = gridDim.x;
+  // offset slot j of this wave: k = z + ZS * (wave + NW * j)
+  const int k0 = z + ZS * wave, kstep = ZS * NW;
+
+  const uint32_t a_pitch = (uint32_t)Cin * 4u;
+  const rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), (short)0, (int)x_bytes, 0x00020000);
+  const rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(nbrS), (short)0,
+                                                       (int)((int64_t)K * M_out * 4), 0x00020000);
+  const rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(order), (short)0, (int)(M_out * 4), 0x00020000);
+  const int d_row = lane >> 3, d_piece = lane & 7;
+  uint32_t a_po[4];                      // swizzled 16-byte piece of this lane in DMA instruction i
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a_po[i] = (uint32_t)((d_piece ^ swz(i * 8 + d_row)) << 4);
+  const uint32_t m_last = (uint32_t)(M_out - 1);
+  const char* const Wb = reinterpret_cast<const char*>(WT);
+  const uint32_t b_voff = (uint32_t)(r31 * Cin + half * 16) * 4u;
+
+  auto issueH = [&](int64_t s, int32_t* hb) {          // 5 DMA instructions
+    uint32_t t = (uint32_t)s * 32u + (uint32_t)r31;
+    t = t < m_last ? t : m_last;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int k = k0 + (2 * q + half) * kstep;
+      k = k < K ? k : k0 % K;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsN, (__attribute__((address_space(3))) void*)(hb + q * 64), 4,
+                                               (int)(((uint32_t)k * (uint32_t)M_out + t) * 4u), 0, 0, 0);
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, (__attribute__((address_space(3))) void*)(hb + P3_GS * 32), 4,
+                                             (int)(t * 4u), 0, 0, 0);
+  };
+  auto fix_tail = [&](int32_t* hb, int64_t s) {        // the last slice only: rows past M_out are missing
+    if (s * 32 + 32 <= M_out) return;
+    const int64_t t0 = s * 32 + (lane & 7) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (t0 + e >= M_out) hb[lane * 4 + e] = -1;
+    if (lane < 32 && s * 32 + lane >= M_out) hb[P3_GS * 32 + lane] = -1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  auto readmask = [&](const int32_t* hb) -> uint32_t {
+    const int4 v = *reinterpret_cast<const int4*>(hb + lane * 4);      // slot lane >> 3, rows (lane & 7) * 4 ..
+    const bool any = (k0 + (lane >> 3) * kstep < K) & ((v.x & v.y & v.z & v.w) >= 0);
+    unsigned long long b = __ballot(any);
+    b |= b >> 4;
+    b |= b >> 2;
+    b |= b >> 1;
+    uint32_t m = 0u;
+#pragma unroll
+    for (int j = 0; j < P3_GS; ++j) m |= (uint32_t)((b >> (8 * j)) & 1ull) << j;
+    return m;
+  };
+  // gathered rows of (offset slot j, chunk c) -> ring slot; 4 DMA instructions
+  auto issueA = [&](const int32_t* hb, int j, int c, unsigned char* dst) {
+    const int32_t* p = hb + j * 32 + d_row;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      bdma16(rsX, (uint32_t)p[i * 8] * a_pitch + a_po[i], (uint32_t)c * 128u, dst + i * 1024);
+  };
+  // weights of (offset slot j, chunk c): the lane's 16 values of output column col0 + r31; 4 plain loads.  (Every
+  // step top waits vmcnt(0) anyway -- one step of lookahead -- so the compiler's own wait at the first use costs
+  // nothing; inline-asm loads with the wait "by hand" let hipcc copy the destination registers at control-flow merges
+  // before the data had landed.)
+  auto loadB = [&](int j, int c, f32x4 (&b)[4]) {
+    const int k = k0 + j * kstep;
+    const int kk = flip ? K - 1 - k : k;
+    const char* base = Wb + (((int64_t)kk * Cout + col0) * Cin + c * 32) * 4 + b_voff;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const f32x4*>(base + q * 16);
+  };
+  auto tie = [&](f32x4 (&b)[4]) {};
+  auto readfragA = [&](const unsigned char* img, f32x4 (&a)[4]) {
+    const unsigned char* arow = img + r31 * 128;
+    const int sw = swz(r31);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4*>(arow + (((half * 4 + q) ^ sw) << 4));
+  };
+
+  f32x16 acc;
+  const bool final_pass = ZS == 1;
+  float* const dst = final_pass ? out : partial + (int64_t)z * M_out * Cout;
+  if (!final_pass) {
+    bias = nullptr;
+    residual = nullptr;
+  }
+
+  // ---- generator state (wave-uniform): position (slice, remaining offset slots, slot, chunk) of the NEXT step to issue
+  int64_t g_slice = blockIdx.x;          // gridDim.x <= n_slices
+  int g_hb = 0;
+  uint32_t g_rem = 0u;                   // offset slots of g_slice after g_j
+  int g_j = 0, g_c = 0;
+  bool g_live = false;                   // (g_j, g_c) is a step not yet issued
+  bool g_has_next = g_slice + stride < n_slices;
+  int gi = 0, ci = 0;                    // slices entered by the generator / the compute side
+  uint32_t mask_next = 0u;
+  int F = 0;                             // steps issued and not consumed (0 / 1)
+  int c_rd = 0;                          // ring slot of the next step to consume
+  bool parity = false;                   // which weight register set the next step to consume uses
+  f32x4 bA[4], bB[4], afr[4];
+
+  // first header, synchronously; the second one in flight
+  issueH(g_slice, hdr0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  fix_tail(hdr0, g_slice);
+  uint32_t c_mask = readmask(hdr0);
+  bool h_pending = false;                // a header DMA issued and no vmcnt(0) since
+  if (g_has_next) {
+    issueH(g_slice + stride, hdr0 + P3_HDR_INTS);
+    h_pending = true;
+  }
+  g_rem = c_mask;
+  if (g_rem) {
+    g_j = __builtin_ctz(g_rem);
+    g_rem &= g_rem - 1u;
+    g_c = 0;
+    g_live = true;
+  }
+  // one advance of the generator: everything of the next step (and, at a slice change, header / bookkeeping of the
+  // slice behind it).  Returns false when there is nothing it may issue now.
+  auto advance = [&](f32x4 (&bdst)[4], int slot, int& n) -> bool {
+    n = 8;
+    if (!g_live) {
+      // enter the next slice?  only once the compute side is in the slice before it (one spare header)
+      if (gi != ci || !g_has_next) return false;
+      // the next header was issued one slice ago; a wave without any step since then has not waited for it yet
+      if (h_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      h_pending = false;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      int32_t* const hb = hdr0 + g_hb * P3_HDR_INTS;
+      int32_t* const hn = hdr0 + (g_hb ^ 1) * P3_HDR_INTS;
+      g_slice += stride;
+      fix_tail(hn, g_slice);
+      const uint32_t m = readmask(hn);
+      g_hb ^= 1;
+      ++gi;
+      mask_next = m;
+      g_has_next = g_slice + stride < n_slices;
+      int nh = 0;
+      if (g_has_next) {
+        issueH(g_slice + stride, hb);            // into the header just left (its rows are in registers: my_rows)
+        h_pending = true;
+        nh = 5;
+      }
+      g_rem = m;
+      if (!g_rem) return false;                  // no pair for this wave in that slice: nothing but the header
+      g_j = __builtin_ctz(g_rem);
+      g_rem &= g_rem - 1u;
+      g_c = 0;
+      g_live = true;
+      n = 8 + nh;
+    }
+    const int32_t* hbq = hdr0 + g_hb * P3_HDR_INTS;
+    loadB(g_j, g_c, bdst);
+    issueA(hbq, g_j, g_c, At + slot * A_BYTES);
+    if (++g_c == nchunk) {
+      g_c = 0;
+      if (g_rem) {
+        g_j = __builtin_ctz(g_rem);
+        g_rem &= g_rem - 1u;
+      } else {
+        g_live = false;
+      }
+    }
+    return true;
+  };
+
+  const int PER = (32 * 32) / (64 * NW);
+  int32_t my_rows[(32 * 32) / (64 * NW)];
+  auto load_rows = [&](const int32_t* hb) {
+#pragma unroll
+    for (int it = 0; it < PER; ++it) my_rows[it] = hb[P3_GS * 32 + (int)(threadIdx.x + it * 64 * NW) / 32];
+  };
+  load_rows(hdr0);
+  int c_hb = 0;
+
+  // first step of the wave (if its first slice has one)
+  {
+    int n;
+    if (advance(bA, 0, n)) F = 1;
+  }
+  // one step on weight set `bc`, prefetching into `bn`
+  auto step = [&](f32x4 (&bc)[4], f32x4 (&bn)[4]) {
+    // the step's gathered rows and weights are the youngest loads in flight (one step of lookahead)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    h_pending = false;
+    tie(bc);
+    readfragA(At + c_rd * A_BYTES, afr);
+    int n = 0;
+    // the next step's loads are issued from inside the chain
+#define WSIS_M3(s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[(s_) >> 2][(s_) & 3], bc[(s_) >> 2][(s_) & 3], acc, 0, 0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    WSIS_M3(0); WSIS_M3(1); WSIS_M3(2); WSIS_M3(3);
+    __builtin_amdgcn_sched_barrier(0);
+    const bool issued = advance(bn, c_rd ^ 1, n);
+    __builtin_amdgcn_sched_barrier(0);
+    WSIS_M3(4); WSIS_M3(5); WSIS_M3(6); WSIS_M3(7);
+    WSIS_M3(8); WSIS_M3(9); WSIS_M3(10); WSIS_M3(11);
+    WSIS_M3(12); WSIS_M3(13); WSIS_M3(14); WSIS_M3(15);
+    __builtin_amdgcn_sched_barrier(0);
+#undef WSIS_M3
+    F = issued ? 1 : 0;
+    c_rd ^= 1;
+    parity = !parity;
+  };
+
+  for (int64_t cs = blockIdx.x; cs < n_slices; cs += stride) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    int T = __builtin_popcount(c_mask) * nchunk;
+    while (T > 0) {
+      if (F == 0) {        // nothing in flight for this step: issue it now (after an empty slice)
+        int n;
+        const bool ok = parity ? advance(bB, c_rd, n) : advance(bA, c_rd, n);
+        (void)ok;
+        F = 1;
+      }
+      if (!parity)
+        step(bA, bB);
+      else
+        step(bB, bA);
+      --T;
+    }
+    // the generator may still have to enter the next slice (this wave had no step in the current one, or its steps
+    // ended before the advance could cross): the next slice's first step must be in flight before the epilogue
+    if (F == 0) {
+      int n;
+      const bool ok = parity ? advance(bB, c_rd, n) : advance(bA, c_rd, n);
+      if (ok) F = 1;
+    }
+    // everything this wave has in flight lands before the epilogue: from here to the next step only the epilogue's own
+    // loads and stores are issued (they are older than anything the next chain issues, so no count has to know them)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    h_pending = false;
+
+    // ---- epilogue of slice cs.  C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * half
+    const int64_t t0 = cs * 32;
+    float* red = reinterpret_cast<float*>(At + (c_rd ^ 1) * A_BYTES);       // the ring slot just consumed
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+      red[rr * 32 + r31] = acc[reg];
+    }
+    if (lane == 0) par[wave] = c_rd ^ 1;
+    __syncthreads();
+    {
+      float keep[PER];
+      bool live[PER];
+      float sa = 0.0f, sq = 0.0f;
+      const bool bn_mode = stats && final_pass && epi.x;
+      BnCoef kc = {0.0f, 0.0f, 0.0f, 0.0f};
+      const int cc = (int)(threadIdx.x & 31), c = col0 + cc;
+      if (bn_mode) kc = bn_coef(epi, c);
+      const float bv = bias ? bias[c] : 0.0f;
+      int64_t off[PER];
+      float rv[PER], xv[PER];
+#pragma unroll
+      for (int it = 0; it < PER; ++it) {
+        const int32_t r = my_rows[it];
+        live[it] = r >= 0;
+        off[it] = (int64_t)(r >= 0 ? r : 0) * Cout + c;
+      }
+#pragma unroll
+      for (int it = 0; it < PER; ++it) rv[it] = residual ? residual[off[it]] : 0.0f;
+#pragma unroll
+      for (int it = 0; it < PER; ++it) xv[it] = bn_mode ? epi.x[off[it]] : 0.0f;
+#pragma unroll
+      for (int it = 0; it < PER; ++it) {
+        const int e = threadIdx.x + it * 64 * NW;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+          v += reinterpret_cast<const float*>(lds + P3_WG + w * P3_WAVE + 2 * P3_HDR + par[w] * A_BYTES)[e];
+        if (bias) v += bv;
+        if (residual) v += rv[it];
+        keep[it] = live[it] ? v : 0.0f;
+        if (live[it]) dst[off[it]] = v;
+        if (bn_mode) {
+          float dz, dzx;
+          bn_terms(kc, epi.relu, v, xv[it], dz, dzx);
+          sa += live[it] ? dz : 0.0f;
+          sq += live[it] ? dzx : 0.0f;
+        } else {
+          sa += live[it] ? v : 0.0f;
+        }
+      }
+      __syncthreads();                 // the accumulator copies are no longer needed
+      if (stats && final_pass) {
+        float* sred = reinterpret_cast<float*>(At + (c_rd ^ 1) * A_BYTES);      // this wave's free slot: 64 floats x 2
+        float* sall = reinterpret_cast<float*>(lds + P3_WG);
+        // per-wave staging at a fixed place in every wave's free slot
+        sred[lane] = sa;
+        sred[64 + lane] = sq;
+        __syncthreads();
+        // threads of one column: t, t + 32, ... (the order of spconv_fwd2_kernel: thread id ascending)
+        auto col_sum = [&](int which) -> float {
+          float tsum = 0.0f;
+          for (int j = cc; j < 64 * NW; j += 32) {
+            const int w = j >> 6, l = j & 63;
+            tsum += reinterpret_cast<const float*>(lds + P3_WG + w * P3_WAVE + 2 * P3_HDR + par[w] * A_BYTES)[which * 64 + l];
+          }
+          return tsum;
+        };
+        (void)sall;
+        if (bn_mode) {
+          if (threadIdx.x < 32) {
+            stats[((int64_t)cs * 2 + 0) * Cout + c] = col_sum(0);
+            stats[((int64_t)cs * 2 + 1) * Cout + c] = col_sum(1);
+          }
+          __syncthreads();
+        } else {
+          const float ta = col_sum(0);
+          const int64_t left = M_out - t0;
+          const float mean_s = ta / (float)(left < SL ? left : SL);
+          float sb = 0.0f;
+#pragma unroll
+          for (int it = 0; it < PER; ++it) {
+            const float d = live[it] ? keep[it] - mean_s : 0.0f;
+            sb += d * d;
+          }
+          __syncthreads();
+          sred[64 + lane] = sb;
+          __syncthreads();
+          if (threadIdx.x < 32) {
+            stats[((int64_t)cs * 2 + 0) * Cout + c] = ta;
+            stats[((int64_t)cs * 2 + 1) * Cout + c] = col_sum(1);
+          }
+          __syncthreads();
+        }
+      }
+    }
+    // next slice of the compute side
+    if (cs + stride < n_slices) {
+      c_hb ^= 1;
+      ++ci;
+      c_mask = mask_next;
+      // (the generator entered it: gi == ci now, its header is current and intact until the generator leaves it)
+      load_rows(hdr0 + c_hb * P3_HDR_INTS);
+    }
+  }
+}
+
 // out = sum_z partial[z] (+ bias, + residual), four channels per thread, z order fixed
 __global__ void spconv2_reduce_kernel(const float4* __restrict__ partial, const float4* __restrict__ bias,
                                       const float4* __restrict__ residual, float4* __restrict__ out, int64_t total4,
@@ -890,6 +1266,37 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
   hipStream_t st = as_stream(stream);
   const dim3 grid((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32 / p.NB), (unsigned)p.ZS);
   ProfScope prof(0, st);
+  // the persistent form pays where a launch is split into offset slabs (deep levels: 15 % faster at level 3 of the
+  // C2 scene); at level 1 (ZS = 1, 2.2 slices per workgroup) the slice-count quantisation eats the gain
+  // (50 us against 48): WSIS_FWD3=2 forces it wherever it applies, 0 disables it
+  static int fwd3_on = -1, fwd3_wgs = 768, fwd3_min = 2;
+  if (fwd3_on < 0) {
+    fwd3_on = env_int("WSIS_FWD3", 1);
+    fwd3_wgs = env_int("WSIS_FWD3_WGS", 768);        // resident 4-wave workgroups of the whole chip (3 per CU)
+    fwd3_min = env_int("WSIS_FWD3_MIN_SLICES", 2);   // slices per workgroup below which the one-shot kernel is kept
+  }
+  if (fwd3_on && (p.ZS > 1 || fwd3_on >= 2) && p.NB == 1 && p.NW == 4 && d_nbr && d_order &&
+      ceil_div(K, 4 * p.ZS) <= P3_GS &&
+      (int64_t)K * M_out * 4 < ((int64_t)1 << 31)) {
+    const int64_t n_slices = ceil_div(M_out, SL);
+    int64_t P = fwd3_wgs / ((Cout / 32) * p.ZS);
+    if (P < 1) P = 1;
+    if (P > n_slices) P = n_slices;
+    if (n_slices >= fwd3_min * P) {
+      const dim3 g3((unsigned)P, (unsigned)(Cout / 32), (unsigned)p.ZS);
+      const size_t ldsb = (size_t)P3_WG + (size_t)P3_WAVE * 4;
+      static bool attr3 = false;
+      if (!attr3) {
+        WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_fwd3_kernel<4, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        attr3 = true;
+      }
+      hipLaunchKernelGGL((spconv_fwd3_kernel<4, false>), g3, dim3(256), ldsb, st, d_X, d_nbr, d_order, d_WT, d_bias,
+                         d_residual, d_out, partial, M_out, K, Cin, Cout, flip, x_bytes, d_stats, epi,
+                         (unsigned long long*)nullptr);
+      goto launched;
+    }
+  }
 #define WSIS_F2X(nb, nw, da, bd)                                                                                 \
   do {                                                                                                           \
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<nb, da, bd>::WAVE_BYTES * nw;                         \
@@ -908,6 +1315,7 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
     WSIS_F2X(nb, nw, da, true);  \
   else                           \
     WSIS_F2X(nb, nw, da, false)
+  {
   const int key = p.NB * 100 + p.NW * 10 + p.DA;
   switch (key) {
     case 113: WSIS_F2(1, 1, 3); break;
@@ -924,8 +1332,10 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
     default:
       return fail(WSIS_ERR_ARG, "spconv_fwd_t: unsupported plan NB=%d NW=%d DA=%d", p.NB, p.NW, p.DA);
   }
+  }
 #undef WSIS_F2
 #undef WSIS_F2X
+launched:
   prof.stop();
   WSIS_LAUNCH_CHECK();
   if (p.ZS > 1 && d_stats) {
