@@ -11,9 +11,10 @@ rank, no data-path collective, weak scaling.  `python bench.py --gpus N` without
 (a torch.distributed.run child, before anything touches the GPU) and fails non-zero if the RCCL world is not N.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      -- dominant kernel (spconv_fwd_kernel: every forward and dIn pass of the 49 sparse convs):
-                   algorithmic gather/scatter bytes (P*(Cin+Cout)*4 + P*8 per launch) / HIP-event
-                   time of those launches, against the 8 TB/s HBM peak.
+  roofline      -- dominant kernel family (the forward / dIn launches of the 49 sparse convs: spconv_fwd2_kernel,
+                   its persistent form spconv_fwd3_kernel on the slab-split levels, spconv_fwd_kernel for the
+                   6-channel input conv): algorithmic gather/scatter bytes (P*(Cin+Cout)*4 + P*8 per launch,
+                   SURVEY 8d) / HIP-event time of those launches, against the 8 TB/s HBM peak.
   cpu_baseline  -- the oracle (torch-CPU restatement mirroring upstream's gather -> mm -> scatter-add) timed on
                    this box's host cores on the same scene (rank 0, N = 1 only).
 """
@@ -263,41 +264,6 @@ def side_measurements(harness, optimizer, device, args):
     return out
 
 
-def alt_math_modes(step, sp_ops, args):
-    """The same step with the other arithmetic modes of spconv_fwd_kernel (WSIS_CONV_MATH) -- reported NEXT TO the
-    headline, which is always the exact-fp32 MFMA: 2 = three bf16 terms per operand / six products (fp32-equivalent,
-    passes every parity test at the fp32 tolerances), 1 = two terms / three products (4e-6 relative error per layer;
-    misses the 2e-2 end-to-end gradient tolerance on one BatchNorm weight: 3.5e-2)."""
-    out = {}
-    prev = os.environ.get("WSIS_CONV_MATH")
-    for mode, name in (("2", "bf16x3_terms_fp32_equivalent"), ("1", "bf16x2_terms")):
-        os.environ["WSIS_CONV_MATH"] = mode
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / args.steps * 1e3
-        os.environ["WSIS_DW_STREAM"] = "0"
-        sp_ops.PROFILER = sp_ops.KernelProfiler()
-        for _ in range(2):
-            step()
-        k = sp_ops.PROFILER.summary().get("spconv_fwd_kernel")
-        sp_ops.PROFILER = None
-        del os.environ["WSIS_DW_STREAM"]
-        gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
-        out[name] = {"ms_per_step": round(ms, 3), "scenes_per_s": round(1e3 / ms, 3),
-                     "roofline_frac": round(gbs / HBM_PEAK_GBS, 4),
-                     "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 2)}
-    if prev is None:
-        del os.environ["WSIS_CONV_MATH"]
-    else:
-        os.environ["WSIS_CONV_MATH"] = prev
-    return out
-
-
 def other_configs(harness, device, args):
     """C3: training step on a batch of 4 scenes (full loss); C4: eval-mode forward of a ~1 M-point room."""
     out = {}
@@ -501,7 +467,8 @@ def main():
         k = summ.get("spconv_fwd_kernel")
         if k and k["ms"] > 0:
             gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
-            roof = {"kernel": "spconv_fwd_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+            roof = {"kernel": "spconv_fwd2_kernel (+ spconv_fwd3_kernel on slab-split levels, spconv_fwd_kernel for the 6-channel input conv)",
+                    "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
                     "alg_bytes_per_launch": k["bytes"] // k["launches"],
                     "launches_per_step": k["launches"] // args.profile_steps,
@@ -522,7 +489,6 @@ def main():
             extra["conv_ms_per_step"] = round((k["ms"] + d["ms"]) / args.profile_steps, 3)
 
     if rank == 0 and world == 1 and not args.no_stages:
-        extra["alt_math"] = alt_math_modes(step, sp_ops, args)
         extra.update(side_measurements(harness, optimizer, device, args))
 
     cpu = None

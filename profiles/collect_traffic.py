@@ -27,7 +27,7 @@ def per_launch(d, counter, kernel):
 
 def main():
     fetch_dir, write_dir = sys.argv[1], sys.argv[2]
-    kernel = "spconv_fwd_kernel"
+    kernel = "spconv_fwd"        # spconv_fwd2_kernel, spconv_fwd3_kernel, spconv_fwd_kernel: the family bench.py times
     fetch, nf = per_launch(fetch_dir, "FETCH_SIZE", kernel)
     write, nw = per_launch(write_dir, "WRITE_SIZE", kernel)
     out = {"kernel": kernel, "launches_sampled": [nf, nw], "FETCH_SIZE_per_launch_raw": fetch,
