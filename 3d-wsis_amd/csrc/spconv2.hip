@@ -7,10 +7,10 @@
 // or NW waves of a workgroup split its (active offset, 32-channel chunk) steps round-robin and add their accumulators
 // through LDS in wave order at the end (small pyramid levels: parallelism from the offsets instead of a second
 // "partial slab + reduce" launch).  There is no workgroup barrier inside the walk and no register staging:
-//   * the gathered input rows (A, 32 rows x 128 B) and the weight rows (B^T, 32*NB columns x 128 B) of a step go
-//     global -> LDS by LDS-DMA (global_load_lds_dwordx4, per-lane source address = the gather), three steps (A) and two
-//     steps (B) ahead, into the wave's private rings; completion is tracked with a counted s_waitcnt vmcnt -- never 0
-//     inside the loop;
+//   * the gathered input rows (A, 32 rows x 128 B) of a step go global -> LDS by LDS-DMA through a raw buffer
+//     descriptor (per-lane 32-bit offset = the gather, missing pair = out of range = zeros) into the wave's private
+//     ring (DA slots); the weight rows (B^T) go straight to registers (BD, default) or through a second ring;
+//     completion is tracked with counted s_waitcnt vmcnt;
 //   * the MFMA fragments of step t+1 are read from LDS (conflict-free ds_read_b128: the 16-byte pieces of a row are
 //     XOR-swizzled on the SOURCE side, the LDS image stays lane-linear as the DMA requires) while the 16*NB
 //     v_mfma_f32_32x32x2_f32 of step t run from registers;
