@@ -5,6 +5,8 @@
 //   backward = reduce (dgamma, dbeta; reads x, dy)      + apply (reads x, dy; writes dx)
 // All reductions use per-workgroup partials combined in a fixed order (Chan's formula for mean/M2), so the
 // result is run-to-run deterministic.  HBM-bound: 2*M*C*4 bytes per pass.
+#include <cstdlib>
+
 #include "common.h"
 
 using namespace wsis;
@@ -137,6 +139,10 @@ __global__ __launch_bounds__(64) void bn_stats_final_kernel(const float* __restr
 // mean = sum S_i / M, var = (sum Q_i + sum S_i^2 / n_i - M mean^2) / M, all in fp64 (Chan's pairwise combination).
 // Two levels so that the 1.2 MB of partials of a 150k-row level is read by up to 64 workgroups per 32 channels instead of
 // one: chunk sums (fixed order inside a chunk) -> [G][3][C] doubles, then one thread per channel adds the chunks in order.
+// arrival tickets of the two-level reductions (zero between launches: the last workgroup resets its counter).  A row
+// per 16 possible workspaces in flight (two reductions can only overlap on different streams, and then they have
+// different workspaces: the row is picked from the workspace address), 16 channel groups per row.
+__device__ unsigned g_bn_ticket[2][16][16];
 constexpr int BN_FIN_CHUNKS = 64;      // <= 64: the finish kernels hold one chunk per lane
 
 __device__ __forceinline__ void bn_finish_centred(double S, double Q, double W, int64_t M, int c, float* mean, float* var,
@@ -159,7 +165,8 @@ __global__ __launch_bounds__(256) void bn_stats_chunk_centred_kernel(const float
                                                                      int64_t M, double* __restrict__ chunk,
                                                                      float* __restrict__ mean, float* __restrict__ var,
                                                                      float* __restrict__ running_mean,
-                                                                     float* __restrict__ running_var, float momentum) {
+                                                                     float* __restrict__ running_var, float momentum,
+                                                                     unsigned* __restrict__ ticket) {
   __shared__ double red[3][8][33];
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = blockIdx.y * 32 + cl;
@@ -199,6 +206,44 @@ __global__ __launch_bounds__(256) void bn_stats_chunk_centred_kernel(const float
       o[C + c] = Q;
       o[2 * C + c] = W;
     }
+  }
+  if (gridDim.x == 1 || !ticket) return;
+  // ---- the workgroup that arrives last (per channel group) adds the chunks, always in chunk order: one launch instead
+  // of two.  Release / acquire at agent scope around the ticket (the chunk rows come from other XCDs' L2s).
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(ticket + blockIdx.y, 1u);
+    s_last = t == gridDim.x - 1;
+    if (s_last) ticket[blockIdx.y] = 0u;          // self-cleaning: ready for the next launch on this stream
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int G = gridDim.x;
+  double s2 = 0.0, q2 = 0.0, w2 = 0.0;
+  if (c < C)
+    for (int g = pl; g < G; g += 8) {
+      const volatile double* o = chunk + (int64_t)g * 3 * C;
+      s2 += o[c];
+      q2 += o[C + c];
+      w2 += o[2 * C + c];
+    }
+  __syncthreads();
+  red[0][pl][cl] = s2;
+  red[1][pl][cl] = q2;
+  red[2][pl][cl] = w2;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    double S = 0.0, Q = 0.0, W = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      S += red[0][j][cl];
+      Q += red[1][j][cl];
+      W += red[2][j][cl];
+    }
+    bn_finish_centred(S, Q, W, M, c, mean, var, running_mean, running_var, momentum);
   }
 }
 
@@ -381,7 +426,7 @@ __global__ __launch_bounds__(64) void bn_bwd_final_kernel(const float* __restric
 // statistics.  grid (G, ceil(C / 32)), 256 threads = 32 channel lanes x 8 partial lanes; G == 1 writes the result.
 __global__ __launch_bounds__(256) void bn_sum_chunk_kernel(const float* __restrict__ partial, int nblk, int C,
                                                            double* __restrict__ chunk, float* __restrict__ dbeta,
-                                                           float* __restrict__ dgamma) {
+                                                           float* __restrict__ dgamma, unsigned* __restrict__ ticket) {
   __shared__ double red[2][8][33];
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = blockIdx.y * 32 + cl;
@@ -413,6 +458,41 @@ __global__ __launch_bounds__(256) void bn_sum_chunk_kernel(const float* __restri
       chunk[(int64_t)blockIdx.x * 2 * C + c] = A;
       chunk[(int64_t)blockIdx.x * 2 * C + C + c] = B;
     }
+  }
+  if (gridDim.x == 1 || !ticket) return;
+  // the last workgroup to arrive adds the chunks in chunk order (see bn_stats_chunk_centred_kernel)
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(ticket + blockIdx.y, 1u);
+    s_last = t == gridDim.x - 1;
+    if (s_last) ticket[blockIdx.y] = 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int G = gridDim.x;
+  double a2 = 0.0, b2 = 0.0;
+  if (c < C)
+    for (int g = pl; g < G; g += 8) {
+      const volatile double* o = chunk + (int64_t)g * 2 * C;
+      a2 += o[c];
+      b2 += o[C + c];
+    }
+  __syncthreads();
+  red[0][pl][cl] = a2;
+  red[1][pl][cl] = b2;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    double A = 0.0, B = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      A += red[0][j][cl];
+      B += red[1][j][cl];
+    }
+    dbeta[c] = (float)A;
+    dgamma[c] = (float)B;
   }
 }
 
@@ -712,6 +792,19 @@ int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* 
   return WSIS_OK;
 }
 
+// ticket row of a two-level reduction (nullptr: WSIS_BN_TICKET=0, the finish runs as a second launch)
+static unsigned* bn_tickets(int which, const void* chunk) {
+  static unsigned* base = nullptr;
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("WSIS_BN_TICKET");
+    on = e ? atoi(e) : 1;
+    if (on && hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_bn_ticket)) != hipSuccess) on = 0;
+  }
+  if (!on) return nullptr;
+  return base + (which * 16 + (int)((reinterpret_cast<uintptr_t>(chunk) >> 8) & 15)) * 16;
+}
+
 static int bn_fin_chunks(int64_t n_part) {
   int64_t g = n_part / 64;           // at least 64 partials per chunk
   if (g < 1) g = 1;
@@ -733,10 +826,12 @@ int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, i
   const int G = bn_fin_chunks(n_part);
   WSIS_REQUIRE(G == 1 || (d_ws && ws_bytes >= wsis_bn_stats_finalize_workspace_bytes(n_part, C)), "workspace too small");
   double* chunk = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(d_ws) + 255) & ~(uintptr_t)255);
+  WSIS_REQUIRE(C <= 512, "more than 512 channels");
+  unsigned* tickets = bn_tickets(0, chunk);
   hipLaunchKernelGGL(bn_stats_chunk_centred_kernel, dim3(G, (C + 31) / 32), dim3(256), 0, as_stream(stream), d_partials,
-                     (int)n_part, C, M, chunk, d_mean, d_var, d_running_mean, d_running_var, momentum);
+                     (int)n_part, C, M, chunk, d_mean, d_var, d_running_mean, d_running_var, momentum, tickets);
   WSIS_LAUNCH_CHECK();
-  if (G > 1) {
+  if (G > 1 && !tickets) {
     hipLaunchKernelGGL(bn_stats_final_centred_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), chunk, G, C, M,
                        d_mean, d_var, d_running_mean, d_running_var, momentum);
     WSIS_LAUNCH_CHECK();
@@ -770,10 +865,12 @@ int wsis_bn_bwd_from_partials(const float* d_partials, int64_t n_part, const flo
   WSIS_REQUIRE(G == 1 || (d_ws && ws_bytes >= wsis_bn_stats_finalize_workspace_bytes(n_part, C)), "workspace too small");
   double* chunk = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(d_ws) + 255) & ~(uintptr_t)255);
   hipStream_t st = as_stream(stream);
+  WSIS_REQUIRE(C <= 512, "more than 512 channels");
+  unsigned* tickets = bn_tickets(1, chunk);
   hipLaunchKernelGGL(bn_sum_chunk_kernel, dim3(G, (C + 31) / 32), dim3(256), 0, st, d_partials, (int)n_part, C, chunk,
-                     d_dbeta, d_dgamma);
+                     d_dbeta, d_dgamma, tickets);
   WSIS_LAUNCH_CHECK();
-  if (G > 1) {
+  if (G > 1 && !tickets) {
     hipLaunchKernelGGL(bn_sum_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, chunk, G, C, d_dbeta, d_dgamma);
     WSIS_LAUNCH_CHECK();
   }

@@ -1269,11 +1269,11 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
   // the persistent form pays where a launch is split into offset slabs (deep levels: 15 % faster at level 3 of the
   // C2 scene); at level 1 (ZS = 1, 2.2 slices per workgroup) the slice-count quantisation eats the gain
   // (50 us against 48): WSIS_FWD3=2 forces it wherever it applies, 0 disables it
-  static int fwd3_on = -1, fwd3_wgs = 768, fwd3_min = 2;
+  static int fwd3_on = -1, fwd3_wgs = 768, fwd3_min = 1;
   if (fwd3_on < 0) {
     fwd3_on = env_int("WSIS_FWD3", 1);
     fwd3_wgs = env_int("WSIS_FWD3_WGS", 768);        // resident 4-wave workgroups of the whole chip (3 per CU)
-    fwd3_min = env_int("WSIS_FWD3_MIN_SLICES", 2);   // slices per workgroup below which the one-shot kernel is kept
+    fwd3_min = env_int("WSIS_FWD3_MIN_SLICES", 1);   // slices per workgroup below which the one-shot kernel is kept
   }
   if (fwd3_on && (p.ZS > 1 || fwd3_on >= 2) && p.NB == 1 && p.NW == 4 && d_nbr && d_order &&
       ceil_div(K, 4 * p.ZS) <= P3_GS &&
