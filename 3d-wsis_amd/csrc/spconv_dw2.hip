@@ -79,7 +79,7 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
   int32_t* const negrow = reinterpret_cast<int32_t*>(At + DA * TILE);
   negrow[lane] = -1;
 
-  const int nchunk = Cin >> 5, nblk = Cout >> 5;
+  const int nchunk = Cin >> 5, nblk = (Cout + 31) >> 5;      // the last output block may be partial (Cout % 4 == 0)
   int combo = blockIdx.y;
   const int cb = combo % nblk;
   combo /= nblk;
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
   const int d_row = lane >> 3;
   const uint32_t d_po = (uint32_t)(lane & 7) * 16u;
   const uint32_t m_last = (uint32_t)(M_out - 1);
+  const bool y_piece_ok = (uint32_t)cb * 128u + d_po < y_pitch;
 
   // header of a slice: table entries of this worker's offsets nb[slot][row] and the slice's output rows, 5 DMA
   // instructions of 4 bytes per lane (no alignment requirement on M_out); rows past M_out read row M_out - 1 and are
@@ -167,7 +168,8 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
   auto issueB = [&](const int32_t* hb, unsigned char* dst) {
     const int32_t* p = hb + GS * 32 + d_row;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bdma16(rsY, (uint32_t)p[i * 8] * y_pitch + d_po, dst + i * 1024);
+    for (int i = 0; i < 4; ++i)      // pieces past the row's last column (partial last block) read as zero too
+      bdma16(rsY, y_piece_ok ? (uint32_t)p[i * 8] * y_pitch + d_po : 0xffffff00u, dst + i * 1024);
   };
   auto issueA = [&](const int32_t* hb, int j, unsigned char* dst) {
     const int32_t* p = hb + j * 32 + d_row;
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
 #pragma unroll
       for (int w = 1; w < WGW; ++w) v += red[w * (WAVE_LDS / 4) + e];
       const int ci = (e >> 5) & 31, co = e & 31;
-      slab[((int64_t)k * Cin + c * 32 + ci) * Cout + cb * 32 + co] = v;
+      if (cb * 32 + co < Cout) slab[((int64_t)k * Cin + c * 32 + ci) * Cout + cb * 32 + co] = v;
     }
     __syncthreads();
   };
@@ -429,7 +431,7 @@ int dw2_P(int64_t M_out, int K, int Cin, int Cout) {
   static int target = -1;
   if (target < 0) target = dw2_env("WSIS_DW2_WAVES", 2048);
   const int NOG = (K + GS - 1) / GS;
-  const int64_t combos = (int64_t)NOG * (Cin / 32) * (Cout / 32);
+  const int64_t combos = (int64_t)NOG * (Cin / 32) * ((Cout + 31) / 32);
   const int64_t n_slices = (M_out + 31) / 32;
   int64_t P = (target / WGW + combos - 1) / combos;
   const int64_t cap = (n_slices + WGW - 1) / WGW;
@@ -446,7 +448,7 @@ namespace wsis {
 bool dw2_supported(int K, int Cin, int Cout) {
   static int on = -1;
   if (on < 0) on = dw2_env("WSIS_DW2", 1);
-  return on && K >= 1 && K <= 32 && Cin >= 32 && Cin % 32 == 0 && Cout >= 32 && Cout % 32 == 0;
+  return on && K >= 1 && K <= 32 && Cin >= 32 && Cin % 32 == 0 && Cout >= 4 && Cout % 4 == 0;     // (16-byte dY pieces)
 }
 
 bool dw2_fits(int64_t M_in, int64_t M_out, int K, int Cin, int Cout) {
@@ -463,7 +465,7 @@ int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, c
   const int NOG = (K + GS - 1) / GS;
   const int P = dw2_P(M_out, K, Cin, Cout);
   float* partial = static_cast<float*>(d_ws);
-  const dim3 grid((unsigned)P, (unsigned)(NOG * (Cin / 32) * (Cout / 32)), 1);
+  const dim3 grid((unsigned)P, (unsigned)(NOG * (Cin / 32) * ((Cout + 31) / 32)), 1);
   const size_t ldsb = (size_t)WAVE_LDS * WGW;
   static bool attr_set = false;
   if (!attr_set) {
@@ -506,7 +508,7 @@ extern "C" int wsis_debug_dw2_diag(const void* d_X, const void* d_nbr, const voi
                "shape not supported by the dw2 kernel");
   const int NOG = (K + GS - 1) / GS;
   const int P = dw2_P(M_out, K, Cin, Cout);
-  const dim3 grid((unsigned)P, (unsigned)(NOG * (Cin / 32) * (Cout / 32)), 1);
+  const dim3 grid((unsigned)P, (unsigned)(NOG * (Cin / 32) * ((Cout + 31) / 32)), 1);
   *n_waves = (int64_t)grid.x * grid.y * WGW;
   WSIS_REQUIRE(dbg_bytes >= *n_waves * 80, "stamp buffer too small");
   WSIS_REQUIRE(P % 8 == 0, "diagnostic build is the XCD-aware variant");

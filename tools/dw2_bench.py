@@ -74,6 +74,14 @@ def run():
             print(f"L{l} down {cin:3d}->{cout:3d}: {t1:6.1f}us err {err:.1e} | up {cout:3d}->{cin:3d}: {t2:6.1f}us err {erru:.1e}", flush=True)
             tot += t1 + t2
             cur_idx, cur_shape = rd.out_indices, rd.out_shape
+    # point-level Linear(32 -> 20) weight gradient (semantic head): dense rows, partial output block
+    N = 199790
+    X = torch.randn(N, 32, device=dev, generator=g); dY = torch.randn(N, 20, device=dev, generator=g)
+    dW = ops._dw(X, None, None, dY, 1, 32, 20)
+    want = (X.double().t() @ dY.double())[None]
+    err = float((dW.double() - want).abs().max()) / float(want.abs().max())
+    t = timeit(lambda: ops._dw(X, None, None, dY, 1, 32, 20))
+    print(f"head Linear 32->20 dW over {N} points: {t:6.1f}us  rel err {err:.1e}", flush=True)
     print("WSIS_DW2=%s: estimated per-step dW: %.2f ms" % (os.environ.get("WSIS_DW2", "1"), tot / 1e3), flush=True)
 
 
