@@ -278,6 +278,24 @@ def other_configs(harness, device, args):
     out["c3_batch4_train"] = {"workload": "C3: 4 C2-sized scenes (seeds 1-4) per step, fwd+bwd+AdamW, full loss",
                               "active_voxels": int(b["voxel_locs"].shape[0]), "ms_per_step": round(ms, 3),
                               "scenes_per_s": round(4e3 / ms, 2)}
+    # the same roofline accounting as the headline, for the conv family at this batch size (side stream off, 2 steps)
+    from spconv import ops as sp_ops
+    prev = os.environ.get("WSIS_DW_STREAM")
+    os.environ["WSIS_DW_STREAM"] = "0"
+    sp_ops.PROFILER = sp_ops.KernelProfiler()
+    for _ in range(2):
+        harness.train_step(model, crit, opt, b, cfg)
+    k = sp_ops.PROFILER.summary().get("spconv_fwd_kernel")
+    sp_ops.PROFILER = None
+    if prev is None:
+        del os.environ["WSIS_DW_STREAM"]
+    else:
+        os.environ["WSIS_DW_STREAM"] = prev
+    if k and k["ms"] > 0:
+        gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+        out["c3_batch4_train"]["conv_roofline"] = {"achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                                   "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 2),
+                                                   "launches_per_step": k["launches"] // 2}
     del b
     cfg.batch_size = 1
     big = harness.to_device(harness.collate([harness.bench_scene(5, room=(13.0, 10.0, 3.0), n_box=36)]), device)
