@@ -665,6 +665,9 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
 // range = zeros), weights of the next step straight to registers; every wait is a counted vmcnt.  Per slice the waves
 // meet twice (accumulators -> LDS in the ring slot just consumed, sum in wave order, store / statistics).
 constexpr int P3_GS = 8;                               // offsets per wave
+// slice queue of a launch: one ticket counter per (output block, offset slab); zero between launches (the workgroup
+// that draws the last ticket of a launch resets it; launches of this kernel are issued on ONE stream)
+__device__ unsigned g_fwd3_ctr[64];
 constexpr int P3_HDR_INTS = P3_GS * 32 + 64;           // nb[8][32] + rows[32] (+ 32 written by the upper half wave)
 constexpr int P3_HDR = P3_HDR_INTS * 4;
 constexpr int P3_WAVE = 2 * P3_HDR + 2 * A_BYTES;      // two headers, two-slot ring of gathered rows
@@ -676,6 +679,9 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void spconv_fwd3_kernel(
     const float* __restrict__ WT, const float* __restrict__ bias, const float* __restrict__ residual,
     float* __restrict__ out, float* __restrict__ partial, int64_t M_out, int K, int Cin, int Cout, int flip,
     uint32_t x_bytes, float* __restrict__ stats, BnEpi epi, unsigned long long* __restrict__ dbg = nullptr) {
+  unsigned long long d_t0 = 0, d_pro = 0, d_steps = 0, d_wait = 0, d_epi = 0, d_tmp = 0;
+  unsigned d_nsteps = 0, d_nsl = 0;
+  if (DIAG) d_t0 = __builtin_readcyclecounter();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -689,7 +695,57 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void spconv_fwd3_kernel(
   const int col0 = blockIdx.y * 32;
   const int nchunk = Cin >> 5;
   const int64_t n_slices = (M_out + 31) >> 5;
-  const int64_t stride = gridDim.x;
+  // ---- slice queue: the workgroups of a (block, slab) draw slices from a ticket counter in tile order (heaviest
+  // first), so they finish together whatever the spread of steps per slice (static strided dealing: steps per wave
+  // 8 ... 30 around a mean of 12 at level 1 of the C2 scene).  A slice's result does not depend on who computes it, so
+  // the output stays bit-reproducible.  Inside the workgroup the wave that first needs the i-th slice id draws it and
+  // publishes it in LDS; the others read it (they all walk the same sequence).
+  unsigned* const ctr = g_fwd3_ctr + (blockIdx.z * gridDim.y + blockIdx.y);
+  volatile int* const q_pub = reinterpret_cast<volatile int*>(lds + 16);
+  int* const q_claim = reinterpret_cast<int*>(lds + 20);
+  volatile int* const q_val = reinterpret_cast<volatile int*>(lds + 24);      // ring of 8
+  if (threadIdx.x == 0) {
+    *q_pub = 2;
+    *q_claim = 2;
+  }
+  __syncthreads();
+  // the first two slices of a workgroup are dealt statically (blockIdx.x, + gridDim.x): 2 x gridDim.x draws of one
+  // counter at kernel start took 22 us (device-scope atomics on one address across 8 XCDs); from the third on the
+  // draws are spread over the launch.  Ticket t = slice 2 P + t.
+  const int64_t q_P = gridDim.x;
+  const int64_t q_real = n_slices > 2 * q_P ? n_slices - 2 * q_P : 0;                 // slices handed out by tickets
+  const int64_t q_draw = n_slices > q_P ? (n_slices - q_P < q_P ? n_slices - q_P : q_P) : 0;   // workgroups that draw
+  const unsigned q_last = (unsigned)(q_real + q_draw - 1);
+  auto q_get = [&](int i) -> int64_t {
+    if (i < 2) {
+      const int64_t sl = (int64_t)blockIdx.x + i * q_P;
+      return sl < n_slices ? sl : n_slices;
+    }
+    for (;;) {
+      if (__builtin_amdgcn_readfirstlane(*q_pub) > i) break;
+      int won = 0;
+      if (lane == 0) won = atomicCAS(q_claim, i, i + 1) == i;
+      won = __builtin_amdgcn_readfirstlane(won);
+      if (won) {
+        unsigned t = 0;
+        if (lane == 0) {
+          t = atomicAdd(ctr, 1u);
+          if (t == q_last) *ctr = 0u;                 // the last draw of the launch: ready for the next one
+          const int64_t sl = 2 * q_P + (int64_t)t;
+          q_val[i & 7] = (int)(sl < n_slices ? sl : n_slices);
+          __threadfence_block();
+          *q_pub = i + 1;
+        }
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    for (;;) {       // (the winner's own publication included)
+      if (__builtin_amdgcn_readfirstlane(*q_pub) > i) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    return (int64_t)__builtin_amdgcn_readfirstlane(q_val[i & 7]);
+  };
   // offset slot j of this wave: k = z + ZS * (wave + NW * j)
   const int k0 = z + ZS * wave, kstep = ZS * NW;
 
@@ -775,12 +831,16 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void spconv_fwd3_kernel(
   }
 
   // ---- generator state (wave-uniform): position (slice, remaining offset slots, slot, chunk) of the NEXT step to issue
-  int64_t g_slice = blockIdx.x;          // gridDim.x <= n_slices
+  int64_t g_slice = q_get(0);
+  if (g_slice >= n_slices) return;       // (uniform: every wave reads the same id)
+  const int64_t first_slice = g_slice;   // (the generator may enter the next slice before the compute loop starts)
+  int64_t g_nxt = q_get(1);              // the slice after it: its header is prefetched
+  int64_t slice_next = 0;
   int g_hb = 0;
   uint32_t g_rem = 0u;                   // offset slots of g_slice after g_j
   int g_j = 0, g_c = 0;
   bool g_live = false;                   // (g_j, g_c) is a step not yet issued
-  bool g_has_next = g_slice + stride < n_slices;
+  bool g_has_next = g_nxt < n_slices;
   int gi = 0, ci = 0;                    // slices entered by the generator / the compute side
   uint32_t mask_next = 0u;
   int F = 0;                             // steps issued and not consumed (0 / 1)
@@ -795,7 +855,7 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void spconv_fwd3_kernel(
   uint32_t c_mask = readmask(hdr0);
   bool h_pending = false;                // a header DMA issued and no vmcnt(0) since
   if (g_has_next) {
-    issueH(g_slice + stride, hdr0 + P3_HDR_INTS);
+    issueH(g_nxt, hdr0 + P3_HDR_INTS);
     h_pending = true;
   }
   g_rem = c_mask;
@@ -818,16 +878,18 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void spconv_fwd3_kernel(
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       int32_t* const hb = hdr0 + g_hb * P3_HDR_INTS;
       int32_t* const hn = hdr0 + (g_hb ^ 1) * P3_HDR_INTS;
-      g_slice += stride;
+      g_slice = g_nxt;
+      slice_next = g_slice;
       fix_tail(hn, g_slice);
       const uint32_t m = readmask(hn);
       g_hb ^= 1;
       ++gi;
       mask_next = m;
-      g_has_next = g_slice + stride < n_slices;
+      g_nxt = q_get(gi + 1);
+      g_has_next = g_nxt < n_slices;
       int nh = 0;
       if (g_has_next) {
-        issueH(g_slice + stride, hb);            // into the header just left (its rows are in registers: my_rows)
+        issueH(g_nxt, hb);                       // into the header just left (its rows are in registers: my_rows)
         h_pending = true;
         nh = 5;
       }
@@ -893,7 +955,9 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void spconv_fwd3_kernel(
     parity = !parity;
   };
 
-  for (int64_t cs = blockIdx.x; cs < n_slices; cs += stride) {
+  if (DIAG) d_pro = __builtin_readcyclecounter() - d_t0;
+  for (int64_t cs = first_slice;;) {
+    if (DIAG) d_tmp = __builtin_readcyclecounter();
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
     int T = __builtin_popcount(c_mask) * nchunk;
@@ -909,6 +973,7 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void spconv_fwd3_kernel(
       else
         step(bB, bA);
       --T;
+      if (DIAG) ++d_nsteps;
     }
     // the generator may still have to enter the next slice (this wave had no step in the current one, or its steps
     // ended before the advance could cross): the next slice's first step must be in flight before the epilogue
@@ -931,7 +996,9 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void spconv_fwd3_kernel(
       red[rr * 32 + r31] = acc[reg];
     }
     if (lane == 0) par[wave] = c_rd ^ 1;
+    if (DIAG) { const unsigned long long t = __builtin_readcyclecounter(); d_steps += t - d_tmp; d_tmp = t; }
     __syncthreads();
+    if (DIAG) { const unsigned long long t = __builtin_readcyclecounter(); d_wait += t - d_tmp; d_tmp = t; }
     {
       float keep[PER];
       bool live[PER];
@@ -1018,14 +1085,28 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void spconv_fwd3_kernel(
         }
       }
     }
+    if (DIAG) { d_epi += __builtin_readcyclecounter() - d_tmp; ++d_nsl; }
     // next slice of the compute side
-    if (cs + stride < n_slices) {
+    if (gi == ci) break;                 // the generator found no further slice: the queue is empty
+    {
+      cs = slice_next;
       c_hb ^= 1;
       ++ci;
       c_mask = mask_next;
       // (the generator entered it: gi == ci now, its header is current and intact until the generator leaves it)
       load_rows(hdr0 + c_hb * P3_HDR_INTS);
     }
+  }
+  if (DIAG && dbg && lane == 0) {
+    unsigned long long* d = dbg + (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW * 8 + wave * 8;
+    d[0] = __builtin_readcyclecounter() - d_t0;
+    d[1] = d_pro;
+    d[2] = d_steps;
+    d[3] = d_wait;
+    d[4] = d_epi;
+    d[5] = d_nsteps;
+    d[6] = d_nsl;
+    d[7] = 0;
   }
 }
 
@@ -1267,22 +1348,23 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
   const dim3 grid((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32 / p.NB), (unsigned)p.ZS);
   ProfScope prof(0, st);
   // the persistent form pays where a launch is split into offset slabs (deep levels: 15 % faster at level 3 of the
-  // C2 scene); at level 1 (ZS = 1, 2.2 slices per workgroup) the slice-count quantisation eats the gain
-  // (50 us against 48): WSIS_FWD3=2 forces it wherever it applies, 0 disables it
-  static int fwd3_on = -1, fwd3_wgs = 768, fwd3_min = 1;
+  // C2 scene); WSIS_FWD3=2 forces it wherever it applies, 0 disables it
+  static int fwd3_on = -1, fwd3_wgs = 768, fwd3_min = 2;
   if (fwd3_on < 0) {
     fwd3_on = env_int("WSIS_FWD3", 1);
     fwd3_wgs = env_int("WSIS_FWD3_WGS", 768);        // resident 4-wave workgroups of the whole chip (3 per CU)
-    fwd3_min = env_int("WSIS_FWD3_MIN_SLICES", 1);   // slices per workgroup below which the one-shot kernel is kept
+    fwd3_min = env_int("WSIS_FWD3_MIN_SLICES", 2);   // slices per workgroup below which the one-shot kernel is kept
   }
-  if (fwd3_on && (p.ZS > 1 || fwd3_on >= 2) && p.NB == 1 && p.NW == 4 && d_nbr && d_order &&
-      ceil_div(K, 4 * p.ZS) <= P3_GS &&
+  if (fwd3_on && p.NB == 1 && p.NW == 4 && d_nbr && d_order && ceil_div(K, 4 * p.ZS) <= P3_GS &&
       (int64_t)K * M_out * 4 < ((int64_t)1 << 31)) {
     const int64_t n_slices = ceil_div(M_out, SL);
     int64_t P = fwd3_wgs / ((Cout / 32) * p.ZS);
     if (P < 1) P = 1;
     if (P > n_slices) P = n_slices;
-    if (n_slices >= fwd3_min * P) {
+    // without slabs: in the per-layer benchmark level 1 of the C2 scene goes 48.0 -> 45.8 us with the slice queue, but
+    // inside the training step (epilogues with statistics / residuals, K = 8 tables) the launches of that class average
+    // slower than on the one-shot kernel (42.3 vs 40.6 us over the family), so only slab-split launches take this path
+    if (n_slices >= fwd3_min * P && (p.ZS > 1 || fwd3_on >= 2)) {
       const dim3 g3((unsigned)P, (unsigned)(Cout / 32), (unsigned)p.ZS);
       const size_t ldsb = (size_t)P3_WG + (size_t)P3_WAVE * 4;
       static bool attr3 = false;
@@ -1355,6 +1437,13 @@ launched:
   return WSIS_OK;
 }
 
+// diagnostic: the slice-queue counters of spconv_fwd3_kernel (all zero between launches)
+int wsis_debug_fwd3_counters(unsigned* h_out64) {
+  WSIS_HIP_CHECK(hipDeviceSynchronize());
+  WSIS_HIP_CHECK(hipMemcpyFromSymbol(h_out64, HIP_SYMBOL(g_fwd3_ctr), 64 * sizeof(unsigned)));
+  return WSIS_OK;
+}
+
 // diagnostic (not part of the ABI header): the NW = 1 kernel with per-workgroup stamps, dbg[ceil(M/32) * Cout/32 * 8];
 // variant 0: weights direct to registers, ring depth 2; 1: both operands through LDS rings, depth 3
 int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT,
@@ -1367,6 +1456,20 @@ int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 2, true, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, 0,
+                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, d_dbg);
+  } else if (variant >= 100) {    // persistent form (spconv_fwd3_kernel), variant - 100 offset slabs, 768 resident workgroups;
+                                  // stamps: 8 x u64 per wave {total, prologue, steps, barrier wait, epilogue, n steps, n slices}
+    const int zs = variant - 100;
+    int64_t P = 768 / ((Cout / 32) * zs);
+    const int64_t n_slices = ceil_div(M_out, SL);
+    if (P < 1) P = 1;
+    if (P > n_slices) P = n_slices;
+    const dim3 g3((unsigned)P, (unsigned)(Cout / 32), (unsigned)zs);
+    const size_t ldsb = (size_t)P3_WG + (size_t)P3_WAVE * 4;
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_fwd3_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)ldsb));
+    hipLaunchKernelGGL((spconv_fwd3_kernel<4, true>), g3, dim3(256), ldsb, st, d_X, d_nbr, d_order, d_WT,
+                       (const float*)nullptr, (const float*)nullptr, d_out, d_out, M_out, K, Cin, Cout, 0,
                        (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, d_dbg);
   } else if (variant >= 2) {      // the production small-level form: 4 waves per work item, `variant - 1` offset slabs
     const dim3 g4((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32), (unsigned)(variant - 1));
