@@ -221,6 +221,28 @@ def test_native_unet_executor_is_bit_identical_to_the_module_walk(monkeypatch, t
     assert [n for n in s0 if not torch.equal(s0[n], s1[n])] == []
 
 
+def test_graph_replay_of_the_op_list_equals_eager_launches(monkeypatch):
+    """WSIS_GRAPH=16: the executor records its launches (dW side stream included) into HIP graphs of ~16 ops and
+    replays them; loss and every gradient must be EQUAL to the eagerly launched pass, also for a second scene of a
+    different size that goes through hipGraphExecUpdate / re-instantiation."""
+    cfg = harness.default_cfg()
+    res = {}
+    for mode in ("0", "16"):
+        monkeypatch.setenv("WSIS_GRAPH", mode)
+        model, crit, opt = harness.build_model(cfg, "cuda")
+        out = []
+        for seed, room in ((21, (1.8, 1.4, 1.1)), (22, (1.5, 1.2, 1.0)), (21, (1.8, 1.4, 1.1))):
+            batch = harness.to_device(harness.collate([harness.make_scene(seed, room=room, n_box=2)]), "cuda")
+            model.zero_grad(set_to_none=True)
+            loss, _ = harness.forward_loss(model, crit, batch, cfg)
+            loss.backward()
+            out.append((loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+        res[mode] = out
+    for (l0, g0), (l1, g1) in zip(res["0"], res["16"]):
+        assert torch.equal(l0, l1)
+        assert [n for n in g0 if not torch.equal(g0[n], g1[n])] == []
+
+
 def test_rulebook_prefetcher_builds_the_same_pyramid_in_the_background():
     """spconv.ops.RulebookPrefetcher (helper thread + side stream) against the inline build: identical tables"""
     import spconv
