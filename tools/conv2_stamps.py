@@ -7,7 +7,7 @@ from spconv import ops
 level = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = 'cuda:0'
-b = harness.collate([harness.make_scene(1)])
+b = harness.collate([harness.make_scene(1 + i) for i in range(int(os.environ.get('CONV2_SCENES', '1')))])
 idx = b['voxel_locs'].int().to(dev).contiguous(); shape = [int(s) for s in b['spatial_shape']]
 for l in range(level):
     rd = ops.build_down_rulebook(idx, shape, [2]*3, [2]*3, [0]*3); idx, shape = rd.out_indices, rd.out_shape
