@@ -1,6 +1,7 @@
 // Weight gradient of the sparse convolutions, wave-autonomous form:
 //   dW[k][ci][co] = sum over rows r with nbr[k][r] >= 0 of  X[nbr[k][r]][ci] * dY[r][co]
-// for layers whose channel counts are multiples of 32 and K <= 32 (every UNet layer but the 6-channel input conv).
+// for layers with Cin % 32 == 0, Cout % 4 == 0 and K <= 32 (every UNet layer but the 6-channel input conv, plus the
+// point-level Linear layers as dense K = 1 products).
 //
 // One wave = one worker with a FIXED (offset group, 32-channel chunk of Cin, 32-channel block of Cout): it owns up to
 // 8 kernel offsets (k = og, og + NOG, ...) whose 32x32 accumulators stay in registers for the whole launch (8 x 16
@@ -9,9 +10,13 @@
 // LDS by LDS-DMA and kept as 16 fragment registers for all offsets of the slice; per active offset the X rows it pairs
 // with (the A operand) are gathered the same way (full 128-byte lines, 8 rows per instruction -- the round-1 kernel
 // fetched both operands with 4-byte loads, two rows per instruction) and read back transposed (lane = input channel)
-// with conflict-free ds_read_b32; 16 v_mfma_f32_32x32x2_f32 per (slice, offset).  The next step's gather flies while
-// the current step computes.  The 4 waves of a workgroup share a combination and add their accumulators through LDS in
-// wave order; workgroup slabs are added in workgroup order by dw2_reduce_kernel: no atomics, bit-reproducible.
+// with conflict-free ds_read_b32; 16 v_mfma_f32_32x32x2_f32 per (slice, offset).  All gathers go through raw buffer
+// descriptors (32-bit offsets, a missing pair is out of range and reads as zeros); the header of the next slice (table
+// rows of the wave's offsets + row list, 5 dword-DMA instructions) arrives a slice ahead, two X tiles fly behind the one
+// computing (counted s_waitcnt vmcnt), and the tile issue is interleaved by hand into the MFMA chain.  The 4 waves of a
+// workgroup share a combination and add their accumulators through LDS in wave order; workgroup slabs are added in
+// workgroup order by dw2_reduce_kernel: no atomics, bit-reproducible.  Dense 1x1 layers (no table) and a partial last
+// output block (Cout % 4 == 0) are covered too.  Measurements and what bounds it: DESIGN.md 4.1.
 #include <cstdlib>
 
 #include "common.h"
