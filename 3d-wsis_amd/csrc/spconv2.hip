@@ -538,16 +538,8 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
     else
       store_tile(std::false_type{});
   } else {
-    // accumulators -> this wave's ring memory as [row][NB*32 cols]; then every thread adds the NW copies in wave order
-    float* red = reinterpret_cast<float*>(Aring);
-#pragma unroll
-    for (int cb = 0; cb < NB; ++cb)
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-        red[rr * (NB * 32) + cb * 32 + r31] = acc[cb][reg];
-      }
-    __syncthreads();
+    // every global read of the epilogue is issued first (row 0 for the masked rows): they fly while the waves write
+    // their accumulators and wait for the slowest of them; inside the element loop each would expose its latency
     const int32_t* rowId0 = rowId;
     constexpr int PER = (32 * NB * 32) / (64 * NW);      // elements of this thread (its column is fixed: 64 NW is a
     float keep[PER];                                     // multiple of NB * 32)
@@ -558,8 +550,6 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
     const int cc = (int)(threadIdx.x % (NB * 32)), c = col0 + cc;
     if (bn_mode) kc = bn_coef(epi, c);
     const float bv = bias ? bias[c] : 0.0f;
-    // every global read of the epilogue in flight before the first use (row 0 for the masked rows): inside the
-    // element loop each one would expose its full latency
     int64_t off[PER];
     float rv[PER], xv[PER];
 #pragma unroll
@@ -573,6 +563,16 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
     for (int it = 0; it < PER; ++it) rv[it] = residual ? residual[off[it]] : 0.0f;
 #pragma unroll
     for (int it = 0; it < PER; ++it) xv[it] = bn_mode ? epi.x[off[it]] : 0.0f;
+    // accumulators -> this wave's ring memory as [row][NB*32 cols]; then every thread adds the NW copies in wave order
+    float* red = reinterpret_cast<float*>(Aring);
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        red[rr * (NB * 32) + cb * 32 + r31] = acc[cb][reg];
+      }
+    __syncthreads();
 #pragma unroll
     for (int it = 0; it < PER; ++it) {
       const int e = threadIdx.x + it * 64 * NW;
@@ -989,17 +989,8 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void spconv_fwd3_kernel(
 
     // ---- epilogue of slice cs.  C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * half
     const int64_t t0 = cs * 32;
-    float* red = reinterpret_cast<float*>(At + (c_rd ^ 1) * A_BYTES);       // the ring slot just consumed
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-      red[rr * 32 + r31] = acc[reg];
-    }
-    if (lane == 0) par[wave] = c_rd ^ 1;
-    if (DIAG) { const unsigned long long t = __builtin_readcyclecounter(); d_steps += t - d_tmp; d_tmp = t; }
-    __syncthreads();
-    if (DIAG) { const unsigned long long t = __builtin_readcyclecounter(); d_wait += t - d_tmp; d_tmp = t; }
     {
+      // the epilogue's global reads first: they fly while the waves meet
       float keep[PER];
       bool live[PER];
       float sa = 0.0f, sq = 0.0f;
@@ -1020,6 +1011,16 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void spconv_fwd3_kernel(
       for (int it = 0; it < PER; ++it) rv[it] = residual ? residual[off[it]] : 0.0f;
 #pragma unroll
       for (int it = 0; it < PER; ++it) xv[it] = bn_mode ? epi.x[off[it]] : 0.0f;
+      float* red = reinterpret_cast<float*>(At + (c_rd ^ 1) * A_BYTES);       // the ring slot just consumed
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int rr = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        red[rr * 32 + r31] = acc[reg];
+      }
+      if (lane == 0) par[wave] = c_rd ^ 1;
+      if (DIAG) { const unsigned long long t = __builtin_readcyclecounter(); d_steps += t - d_tmp; d_tmp = t; }
+      __syncthreads();
+      if (DIAG) { const unsigned long long t = __builtin_readcyclecounter(); d_wait += t - d_tmp; d_tmp = t; }
 #pragma unroll
       for (int it = 0; it < PER; ++it) {
         const int e = threadIdx.x + it * 64 * NW;
