@@ -1112,3 +1112,20 @@ def test_din_epilogue_writes_the_batchnorm_backward_partials(C, rooms):
                                  _n.stream_ptr()), "bn_bwd")
         for u, v in ((dg1, dg2), (db1, db2), (dx1, dx2)):
             assert float((u - v).abs().max()) <= 1e-5 * max(float(v.abs().max()), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,cin,cout", [(199790, 32, 20), (30011, 64, 32), (5000, 128, 64), (777, 32, 4)])
+def test_dense_weight_gradient_on_the_wave_autonomous_kernel(rows, cin, cout):
+    """wsis_spconv_dw without a table (K = 1: row t pairs with itself) is X^T dY -- the 1x1 projections of the decoder
+    blocks and the point-level Linear layers (tall_linear); a partial last output block (Cout % 4 == 0) is allowed.
+    Against fp64, and bit-identical when repeated."""
+    from spconv import ops
+    g = torch.Generator(device=DEV).manual_seed(rows)
+    X = torch.randn(rows, cin, device=DEV, generator=g)
+    dY = torch.randn(rows, cout, device=DEV, generator=g)
+    dW = ops._dw(X, None, None, dY, 1, cin, cout)
+    want = (X.double().t() @ dY.double())[None]
+    assert dW.shape == (1, cin, cout)
+    assert float((dW.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    assert torch.equal(dW, ops._dw(X, None, None, dY, 1, cin, cout))
