@@ -3,6 +3,8 @@ restatement on top of the HIP segmented mean, same parameter names as the refere
 (modules/model/graphnet.py:19-114, modules/model/spg_modules.py:61-121,128-185,207-253; state-dict grammar
 in SURVEY App. B: ``ecc.0._cell.*``, ``ecc.0._fnet.{0,2,4,5,7}``, ``ecc.1``, ``ecc.2``).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -144,6 +146,12 @@ class RNNGraphConvModule(nn.Module):
         Waug = torch.cat([last.weight.view(32, 32, 64).permute(0, 2, 1).reshape(32, 64 * 32),
                           last.bias.view(32, 32)], 1)
         csr, csr_dst = self._gci.csr(), self._gci.csr_dst()
+        cell = self._cell
+        if (os.environ.get("WSIS_GNN_LOOP", "1") != "0" and os.environ.get("WSIS_FUSE_GRU", "1") != "0"
+                and getattr(cell, "_ingate", False) and getattr(cell, "_layernorm", False) and cell.bias
+                and getattr(cell, "hidden_size", 0) == 32 and hx.shape[0] > 0 and h.shape[0] > 0):
+            # the whole recurrence as one autograd node (same kernels, same order)
+            return wsis_ops.ecc_gru_loop(hx, h, Waug, cell, csr, csr_dst, self._nrepeats, self._cat_all)
         hxs = [hx]
         for _ in range(self._nrepeats):
             U = hx @ Waug                                                  # [S, 65*32]

@@ -357,6 +357,93 @@ def gru_cell_ex(x, h, cell):
     return _GruCellEx.apply(x, h, ig.weight, ig.bias, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)
 
 
+# ---- the whole recurrent graph convolution as ONE autograd node -------------------------------------------------
+
+class _EccGruLoop(Function):
+    """R x { U = hx @ W' -> m_e = h_e . U_t (ecc_contract) -> mean over the out-edges -> GRUCellEx }
+    (spg_modules.py:152-185) recorded as one node: the same kernels in the same order as the per-op Functions above,
+    but the 4 R autograd nodes, their Python dispatch and the gradient-accumulation kernels of the shared parameters
+    (W', the edge features h, the six GRU tensors, all used R times) collapse into one forward and one backward call
+    with in-place accumulation.  Returns cat([hx_0 .. hx_R], 1) or hx_R."""
+
+    @staticmethod
+    def forward(ctx, hx, h, Waug, w_ig, b_ig, w_ih, w_hh, b_ih, b_hh, csr_src, csr_dst, repeats, cat_all):
+        _n.require_cuda(hx, h)
+        lib = _n.hip()
+        f = lambda t: t.contiguous().float()
+        hx, h, Waug = f(hx), f(h), f(Waug)
+        gp = [f(t) for t in (w_ig, b_ig, w_ih, w_hh, b_ih, b_hh)]
+        S, E = hx.shape[0], h.shape[0]
+        assert hx.shape[1] == 32 and h.shape[1] == 64 and Waug.shape == (32, 65 * 32) and csr_dst.S == S and csr_src.S == S
+        st = _n.stream_ptr()
+        hxs, inps, Us = [hx], [], []
+        for _ in range(repeats):
+            U = hxs[-1] @ Waug
+            m = torch.empty((E, 32), dtype=torch.float32, device=hx.device)
+            _n.check(lib.wsis_ecc_contract_fwd(_n.ptr(h), _n.ptr(U), _n.ptr(csr_dst.perm), _n.ptr(csr_dst.offsets),
+                                               _n.ptr(m), S, E, st), "ecc_contract_fwd")
+            inp = torch.empty((S, 32), dtype=torch.float32, device=hx.device)
+            _n.check(lib.wsis_segment_reduce_fwd(_n.ptr(m), _n.ptr(csr_src.perm), _n.ptr(csr_src.offsets), _n.ptr(inp),
+                                                 None, E, S, 32, 1, st), "segment_reduce_fwd")
+            hy = torch.empty_like(hxs[-1])
+            _n.check(lib.wsis_gru_cell_fwd(_n.ptr(inp), _n.ptr(hxs[-1]), *[_n.ptr(t) for t in gp], _n.ptr(hy), S, 32, st),
+                     "gru_cell_fwd")
+            Us.append(U)
+            inps.append(inp)
+            hxs.append(hy)
+        ctx.save_for_backward(h, Waug, *gp, *hxs, *inps, *Us)
+        ctx.meta = (csr_src, csr_dst, repeats, cat_all)
+        return torch.cat(hxs, 1) if cat_all else hxs[-1]
+
+    @staticmethod
+    def backward(ctx, dout):
+        csr_src, csr_dst, R, cat_all = ctx.meta
+        sv = ctx.saved_tensors
+        h, Waug, gp = sv[0], sv[1], list(sv[2:8])
+        hxs, inps, Us = sv[8:8 + R + 1], sv[8 + R + 1:8 + 2 * R + 1], sv[8 + 2 * R + 1:8 + 3 * R + 1]
+        lib = _n.hip()
+        st = _n.stream_ptr()
+        S, E = hxs[0].shape[0], h.shape[0]
+        dev = h.device
+        dout = dout.contiguous().float()
+        d_slices = [dout[:, 32 * i:32 * (i + 1)] for i in range(R + 1)] if cat_all else None
+        d_hx = d_slices[R].contiguous() if cat_all else dout
+        dWaug = torch.zeros_like(Waug)
+        dh = torch.zeros_like(h)
+        dgp = [torch.zeros_like(t) for t in gp]
+        tmp = [torch.empty_like(t) for t in gp]
+        ws_bytes = lib.wsis_gru_cell_workspace_bytes(S)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        for i in reversed(range(R)):
+            d_inp, d_hprev = torch.empty_like(d_hx), torch.empty_like(d_hx)
+            _n.check(lib.wsis_gru_cell_bwd(_n.ptr(inps[i]), _n.ptr(hxs[i]), *[_n.ptr(t) for t in gp], _n.ptr(d_hx),
+                                           _n.ptr(d_inp), _n.ptr(d_hprev), _n.ptr(tmp[0]), _n.ptr(tmp[1]), _n.ptr(tmp[2]),
+                                           _n.ptr(tmp[3]), _n.ptr(tmp[4]), _n.ptr(tmp[5]), S, 32, _n.ptr(ws), ws_bytes,
+                                           st), "gru_cell_bwd")
+            torch._foreach_add_(dgp, tmp)
+            d_m = torch.empty((E, 32), dtype=torch.float32, device=dev)
+            _n.check(lib.wsis_segment_reduce_bwd(_n.ptr(d_inp), _n.ptr(csr_src.index), _n.ptr(csr_src.offsets), None,
+                                                 _n.ptr(d_m), E, S, 32, 1, st), "segment_reduce_bwd")
+            dU, dh_i = torch.empty_like(Us[i]), torch.empty_like(h)
+            _n.check(lib.wsis_ecc_contract_bwd(_n.ptr(h), _n.ptr(Us[i]), _n.ptr(d_m), _n.ptr(csr_dst.perm),
+                                               _n.ptr(csr_dst.offsets), _n.ptr(dU), _n.ptr(dh_i), S, E, st),
+                     "ecc_contract_bwd")
+            dh += dh_i
+            dWaug.addmm_(hxs[i].t(), dU)
+            d_hx = torch.addmm(d_hprev, dU, Waug.t())
+            if cat_all:
+                d_hx += d_slices[i]
+        need = ctx.needs_input_grad
+        return (d_hx if need[0] else None, dh if need[1] else None, dWaug if need[2] else None,
+                *[g if need[3 + j] else None for j, g in enumerate(dgp)], None, None, None, None)
+
+
+def ecc_gru_loop(hx, h, Waug, cell, csr_src, csr_dst, repeats, cat_all):
+    ig = cell._modules["ig"]
+    return _EccGruLoop.apply(hx, h, Waug, ig.weight, ig.bias, cell.weight_ih, cell.weight_hh, cell.bias_ih,
+                             cell.bias_hh, csr_src, csr_dst, int(repeats), bool(cat_all))
+
+
 # ---- point-level Linear with a split-K weight gradient ----------------------------------------------------------
 
 class _TallLinear(Function):
