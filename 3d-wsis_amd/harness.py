@@ -229,6 +229,8 @@ def collate(scenes, mode=4):
         "superpoint": torch.cat(sps, 0).long(), "GIs": GIs,
         "sp_batch_offsets": torch.tensor(sp_batch_offsets, dtype=torch.int32),
         "edge_u_list": edges[:, 0].contiguous().long(), "edge_v_list": edges[:, 1].contiguous().long(),
+        # rows of scatter(..., edge_u): known here on the host, so the device step never has to read it back
+        "edge_src_rows": (int(edges[:, 0].max()) + 1) if edges.shape[0] else 0,
         "superpoint_semantic_labels": torch.cat(sp_sem, 0).long(),
         "superpoint_instance_labels": torch.cat(sp_ins, 0).long(),
         "superpoint_offset_vector": torch.cat(sp_off, 0).float(),
@@ -273,7 +275,8 @@ def build_batch_graphs(batch):
     S = int(batch["sp_batch_offsets"][-1])
     batch["superpoint_csr"] = SegmentCSR(batch["superpoint"], S)
     batch["p2v_csr"] = SegmentCSR(batch["p2v_map"], int(batch["voxel_locs"].shape[0]))
-    batch["edge_graph"] = wsis_ops.EdgeGraph(batch["edge_u_list"], batch["edge_v_list"], S)
+    batch["edge_graph"] = wsis_ops.EdgeGraph(batch["edge_u_list"], batch["edge_v_list"], S,
+                                             num_src=batch.get("edge_src_rows"))
     return batch
 
 
@@ -297,7 +300,7 @@ def forward_loss(model, criterion, batch, cfg, epoch=5):
     extra = {"superpoint": superpoint, "GIs": batch["GIs"], "edge_u_list": batch["edge_u_list"],
              "edge_v_list": batch["edge_v_list"], "superpoint_cenetr_xyz": centre,
              "superpoint_csr": batch.get("superpoint_csr"), "edge_graph": batch.get("edge_graph"),
-             "p2v_csr": batch.get("p2v_csr")}
+             "p2v_csr": batch.get("p2v_csr"), "edge_src_rows": batch.get("edge_src_rows")}
     feats = batch["feats"]
     if cfg.model.use_coords:
         feats = torch.cat((feats, coords_float), 1)

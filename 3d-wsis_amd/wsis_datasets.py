@@ -311,6 +311,7 @@ def collate_fn(batch, full_scale_min=128, mode=4):
         "offsets": torch.tensor(batch_offsets, dtype=torch.int), "spatial_shape": spatial_shape,
         "superpoint": superpoint, "GIs": GIs, "sp_batch_offsets": torch.tensor(sp_batch_offsets, dtype=torch.int),
         "edge_u_list": edges[:, 0].contiguous().long(), "edge_v_list": edges[:, 1].contiguous().long(),
+        "edge_src_rows": (int(edges[:, 0].max()) + 1) if edges.shape[0] else 0,   # rows of scatter(.., edge_u)
         "is1ins_labels": torch.cat(is1ins, 0),
         "superpoint_semantic_labels": torch.cat(sp_sem, 0).long(),
         "superpoint_instance_labels": torch.cat(sp_ins, 0).long(),

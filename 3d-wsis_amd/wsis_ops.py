@@ -16,13 +16,21 @@ from torch_scatter import SegmentCSR
 class EdgeGraph(object):
     """CSR over sources and over targets of a directed edge list (built once per batch)."""
 
-    def __init__(self, edge_u, edge_v, num_nodes):
+    def __init__(self, edge_u, edge_v, num_nodes, num_src=None):
+        """``num_src`` = edge_u.max() + 1, the row count of the reference's ``scatter(..., edge_u, dim=0)``
+        (backbone_3D_WSIS.py:232).  Read from the device when not given: that D2H copy waits for everything queued
+        on the stream (a whole training step when the host runs ahead), so loaders pass the value they know from
+        the host-side edge list."""
         _n.require_cuda(edge_u, edge_v)
         self.eu = edge_u.contiguous().long()
         self.ev = edge_v.contiguous().long()
         self.E = self.eu.numel()
         self.S = int(num_nodes)
-        self.Su = int(self.eu.max().item()) + 1 if self.E > 0 else 0
+        if num_src is not None:
+            self.Su = int(num_src) if self.E > 0 else 0
+            assert 0 <= self.Su <= self.S
+        else:
+            self.Su = int(self.eu.max().item()) + 1 if self.E > 0 else 0
         self.csr_u = SegmentCSR(self.eu, self.Su)
         self.csr_v = SegmentCSR(self.ev, self.S)
 
