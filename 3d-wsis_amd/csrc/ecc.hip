@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void ecc_contract_bwd_kernel(const float* __re
                                                                const float* __restrict__ dm,
                                                                const int32_t* __restrict__ perm_dst,
                                                                const int32_t* __restrict__ off_dst,
-                                                               float* __restrict__ dU, float* __restrict__ dh, int64_t S) {
+                                                               float* __restrict__ dU, float* __restrict__ dh, int64_t S,
+                                                               int accumulate) {
   __shared__ __attribute__((aligned(16))) float hs[4][EBATCH][EH];
   __shared__ __attribute__((aligned(16))) float ds[4][EBATCH][EC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -278,7 +279,8 @@ __global__ __launch_bounds__(256) void ecc_contract_bwd_kernel(const float* __re
             p += v.z * ur[q * 4 + 2];
             p += v.w * ur[q * 4 + 3];
           }
-          dh[(int64_t)eid[i] * EH + lane] = p;
+          float* o = dh + (int64_t)eid[i] * EH + lane;     // every edge row is written by exactly one wave
+          *o = accumulate ? *o + p : p;
         }
       }
     }
@@ -335,16 +337,28 @@ int wsis_ecc_contract_fwd(const float* d_h, const float* d_U, const int32_t* d_p
   return WSIS_OK;
 }
 
-int wsis_ecc_contract_bwd(const float* d_h, const float* d_U, const float* d_dm, const int32_t* d_perm_dst,
-                          const int32_t* d_off_dst, float* d_dU, float* d_dh, int64_t S, int64_t E, void* stream) {
+static int ecc_contract_bwd_impl(const float* d_h, const float* d_U, const float* d_dm, const int32_t* d_perm_dst,
+                                 const int32_t* d_off_dst, float* d_dU, float* d_dh, int64_t S, int64_t E,
+                                 int accumulate, void* stream) {
   WSIS_REQUIRE(S >= 0 && E >= 0, "bad sizes");
   if (S == 0) return WSIS_OK;
   WSIS_REQUIRE(d_U && d_off_dst && d_dU && (E == 0 || (d_h && d_dm && d_perm_dst && d_dh)), "null pointer");
   WSIS_REQUIRE(((reinterpret_cast<uintptr_t>(d_U) | reinterpret_cast<uintptr_t>(d_h)) & 15) == 0, "16-byte alignment");
   hipLaunchKernelGGL(ecc_contract_bwd_kernel, dim3(waves_grid(S)), dim3(256), 0, as_stream(stream), d_h, d_U, d_dm,
-                     d_perm_dst, d_off_dst, d_dU, d_dh, S);
+                     d_perm_dst, d_off_dst, d_dU, d_dh, S, accumulate);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
+}
+
+int wsis_ecc_contract_bwd(const float* d_h, const float* d_U, const float* d_dm, const int32_t* d_perm_dst,
+                          const int32_t* d_off_dst, float* d_dU, float* d_dh, int64_t S, int64_t E, void* stream) {
+  return ecc_contract_bwd_impl(d_h, d_U, d_dm, d_perm_dst, d_off_dst, d_dU, d_dh, S, E, 0, stream);
+}
+
+int wsis_ecc_contract_bwd_acc(const float* d_h, const float* d_U, const float* d_dm, const int32_t* d_perm_dst,
+                              const int32_t* d_off_dst, float* d_dU, float* d_dh, int64_t S, int64_t E,
+                              int32_t accumulate, void* stream) {
+  return ecc_contract_bwd_impl(d_h, d_U, d_dm, d_perm_dst, d_off_dst, d_dU, d_dh, S, E, accumulate ? 1 : 0, stream);
 }
 
 }  // extern "C"

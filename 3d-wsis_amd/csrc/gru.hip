@@ -335,6 +335,32 @@ int wsis_gru_cell_fwd(const float* d_x, const float* d_h, const float* d_Wig, co
   return WSIS_OK;
 }
 
+// one backward evaluation; slot >= 0 selects the slab region of a sequence (wsis_gru_cell_bwd_seq), n_reduce > 0
+// runs the fixed-order slab reduce over that many slabs
+static int gru_bwd_impl(const float* d_x, const float* d_h, const float* d_Wig, const float* d_big, const float* d_Wih,
+                        const float* d_Whh, const float* d_bih, const float* d_bhh, const float* d_dhy, float* d_dx,
+                        float* d_dh, float* d_dWig, float* d_dbig, float* d_dWih, float* d_dWhh, float* d_dbih,
+                        float* d_dbhh, int64_t S, int slot, int n_reduce, void* d_ws, hipStream_t st) {
+  const size_t lds = sizeof(GruLds);
+  const int nb = gru_blocks(S);
+  static bool attr_set = false;
+  if (!attr_set) {
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)gru_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  float* base = static_cast<float*>(d_ws);
+  float* partial = base + (int64_t)slot * nb * GRU_P;
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(nb), dim3(64 * GRU_WAVES), lds, st, d_x, d_h, d_Wig, d_big, d_Wih, d_Whh,
+                     d_bih, d_bhh, d_dhy, d_dx, d_dh, partial, S);
+  WSIS_LAUNCH_CHECK();
+  if (n_reduce > 0) {
+    hipLaunchKernelGGL(gru_reduce_kernel, dim3((GRU_P + RED_OUT - 1) / RED_OUT), dim3(RED_OUT * RED_LANES), 0, st, base,
+                       n_reduce, d_dWih, d_dWhh, d_dWig, d_dbih, d_dbhh, d_dbig);
+    WSIS_LAUNCH_CHECK();
+  }
+  return WSIS_OK;
+}
+
 int wsis_gru_cell_bwd(const float* d_x, const float* d_h, const float* d_Wig, const float* d_big,
                       const float* d_Wih, const float* d_Whh, const float* d_bih, const float* d_bhh,
                       const float* d_dhy, float* d_dx, float* d_dh, float* d_dWig, float* d_dbig, float* d_dWih,
@@ -345,18 +371,23 @@ int wsis_gru_cell_bwd(const float* d_x, const float* d_h, const float* d_Wig, co
                    d_dWig && d_dbig && d_dWih && d_dWhh && d_dbih && d_dbhh && d_ws,
                "null pointer");
   WSIS_REQUIRE(ws_bytes >= wsis_gru_cell_workspace_bytes(S), "workspace too small");
-  const size_t lds = sizeof(GruLds);
-  const int nb = gru_blocks(S);
-  hipStream_t st = as_stream(stream);
-  WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)gru_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  float* partial = static_cast<float*>(d_ws);
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(nb), dim3(64 * GRU_WAVES), lds, st, d_x, d_h, d_Wig, d_big, d_Wih, d_Whh,
-                     d_bih, d_bhh, d_dhy, d_dx, d_dh, partial, S);
-  WSIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gru_reduce_kernel, dim3((GRU_P + RED_OUT - 1) / RED_OUT), dim3(RED_OUT * RED_LANES), 0, st, partial,
-                     nb, d_dWih, d_dWhh, d_dWig, d_dbih, d_dbhh, d_dbig);
-  WSIS_LAUNCH_CHECK();
-  return WSIS_OK;
+  return gru_bwd_impl(d_x, d_h, d_Wig, d_big, d_Wih, d_Whh, d_bih, d_bhh, d_dhy, d_dx, d_dh, d_dWig, d_dbig, d_dWih,
+                      d_dWhh, d_dbih, d_dbhh, S, 0, gru_blocks(S), d_ws, as_stream(stream));
+}
+
+int wsis_gru_cell_bwd_seq(const float* d_x, const float* d_h, const float* d_Wig, const float* d_big,
+                          const float* d_Wih, const float* d_Whh, const float* d_bih, const float* d_bhh,
+                          const float* d_dhy, float* d_dx, float* d_dh, float* d_dWig, float* d_dbig, float* d_dWih,
+                          float* d_dWhh, float* d_dbih, float* d_dbhh, int64_t S, int32_t C, int32_t slot,
+                          int32_t n_slots, int32_t finish, void* d_ws, int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(S >= 1 && C == GC, "GRUCellEx kernel supports C == 32, S >= 1");
+  WSIS_REQUIRE(n_slots >= 1 && slot >= 0 && slot < n_slots, "bad slot");
+  WSIS_REQUIRE(d_x && d_h && d_Wig && d_big && d_Wih && d_Whh && d_bih && d_bhh && d_dhy && d_dx && d_dh && d_ws,
+               "null pointer");
+  WSIS_REQUIRE(!finish || (d_dWig && d_dbig && d_dWih && d_dWhh && d_dbih && d_dbhh), "null pointer");
+  WSIS_REQUIRE(ws_bytes >= (wsis_gru_cell_workspace_bytes(S) - 256) * n_slots + 256, "workspace too small");
+  return gru_bwd_impl(d_x, d_h, d_Wig, d_big, d_Wih, d_Whh, d_bih, d_bhh, d_dhy, d_dx, d_dh, d_dWig, d_dbig, d_dWih,
+                      d_dWhh, d_dbih, d_dbhh, S, slot, finish ? gru_blocks(S) * n_slots : 0, d_ws, as_stream(stream));
 }
 
 }  // extern "C"

@@ -141,7 +141,15 @@ class RNNGraphConvModule(nn.Module):
         edge_indexes = self._gci.get_pyg_buffers()
         src = edge_indexes[0]
         last = self._fnet[-1]
-        h = self._fnet[:-1](self._gci.get_buffers())                      # fnet hidden state [E, 64]
+        h = self._gci.get_buffers()
+        for mod in self._fnet[:-1]:                                       # fnet hidden state [E, 64]
+            # Linear over the E edge rows: the weight gradient is a [Cin x Cout] output reduced over E rows, one
+            # workgroup in hipBLASLt; tall_linear sends it through the row-split MFMA reduction where it applies
+            if (isinstance(mod, nn.Linear) and mod.in_features % 32 == 0 and mod.out_features % 4 == 0
+                    and os.environ.get("WSIS_FNET_TALL", "1") != "0"):
+                h = wsis_ops.tall_linear(h, mod)
+            else:
+                h = mod(h)
         # W'[a, c*32 + b] = Wl[a*32 + b, c];  W'[a, 64*32 + b] = bl[a*32 + b]
         Waug = torch.cat([last.weight.view(32, 32, 64).permute(0, 2, 1).reshape(32, 64 * 32),
                           last.bias.view(32, 32)], 1)

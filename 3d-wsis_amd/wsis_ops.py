@@ -384,65 +384,75 @@ class _EccGruLoop(Function):
         S, E = hx.shape[0], h.shape[0]
         assert hx.shape[1] == 32 and h.shape[1] == 64 and Waug.shape == (32, 65 * 32) and csr_dst.S == S and csr_src.S == S
         st = _n.stream_ptr()
-        hxs, inps, Us = [hx], [], []
-        for _ in range(repeats):
-            U = hxs[-1] @ Waug
+        # hx_0 .. hx_R stacked in one buffer: the backward reduces dW' over all R iterations in ONE launch
+        hx_all = torch.empty(((repeats + 1) * S, 32), dtype=torch.float32, device=hx.device)
+        hxs = [hx_all[i * S:(i + 1) * S] for i in range(repeats + 1)]
+        hxs[0].copy_(hx)
+        inps, Us = [], []
+        for i in range(repeats):
+            U = hxs[i] @ Waug
             m = torch.empty((E, 32), dtype=torch.float32, device=hx.device)
             _n.check(lib.wsis_ecc_contract_fwd(_n.ptr(h), _n.ptr(U), _n.ptr(csr_dst.perm), _n.ptr(csr_dst.offsets),
                                                _n.ptr(m), S, E, st), "ecc_contract_fwd")
             inp = torch.empty((S, 32), dtype=torch.float32, device=hx.device)
             _n.check(lib.wsis_segment_reduce_fwd(_n.ptr(m), _n.ptr(csr_src.perm), _n.ptr(csr_src.offsets), _n.ptr(inp),
                                                  None, E, S, 32, 1, st), "segment_reduce_fwd")
-            hy = torch.empty_like(hxs[-1])
-            _n.check(lib.wsis_gru_cell_fwd(_n.ptr(inp), _n.ptr(hxs[-1]), *[_n.ptr(t) for t in gp], _n.ptr(hy), S, 32, st),
-                     "gru_cell_fwd")
+            _n.check(lib.wsis_gru_cell_fwd(_n.ptr(inp), _n.ptr(hxs[i]), *[_n.ptr(t) for t in gp], _n.ptr(hxs[i + 1]), S,
+                                           32, st), "gru_cell_fwd")
             Us.append(U)
             inps.append(inp)
-            hxs.append(hy)
-        ctx.save_for_backward(h, Waug, *gp, *hxs, *inps, *Us)
+        ctx.save_for_backward(h, Waug, *gp, hx_all, *inps, *Us)
         ctx.meta = (csr_src, csr_dst, repeats, cat_all)
-        return torch.cat(hxs, 1) if cat_all else hxs[-1]
+        return torch.cat(hxs, 1) if cat_all else hxs[-1].clone()     # never a view of the saved buffer
 
     @staticmethod
     def backward(ctx, dout):
         csr_src, csr_dst, R, cat_all = ctx.meta
         sv = ctx.saved_tensors
         h, Waug, gp = sv[0], sv[1], list(sv[2:8])
-        hxs, inps, Us = sv[8:8 + R + 1], sv[8 + R + 1:8 + 2 * R + 1], sv[8 + 2 * R + 1:8 + 3 * R + 1]
+        hx_all, inps, Us = sv[8], sv[9:9 + R], sv[9 + R:9 + 2 * R]
         lib = _n.hip()
         st = _n.stream_ptr()
-        S, E = hxs[0].shape[0], h.shape[0]
+        E = h.shape[0]
+        S = hx_all.shape[0] // (R + 1)
+        hxs = [hx_all[i * S:(i + 1) * S] for i in range(R + 1)]
         dev = h.device
         dout = dout.contiguous().float()
         d_slices = [dout[:, 32 * i:32 * (i + 1)] for i in range(R + 1)] if cat_all else None
         d_hx = d_slices[R].contiguous() if cat_all else dout
-        dWaug = torch.zeros_like(Waug)
-        dh = torch.zeros_like(h)
-        dgp = [torch.zeros_like(t) for t in gp]
-        tmp = [torch.empty_like(t) for t in gp]
-        ws_bytes = lib.wsis_gru_cell_workspace_bytes(S)
+        dh = torch.empty_like(h) if R > 0 else torch.zeros_like(h)      # written by the first evaluated iteration
+        # the six GRU parameter gradients: every iteration leaves its slabs in its own region, ONE reduce at the end
+        dgp = [torch.empty_like(t) for t in gp] if R > 0 else [torch.zeros_like(t) for t in gp]
+        ws_bytes = (lib.wsis_gru_cell_workspace_bytes(S) - 256) * max(R, 1) + 256
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        # dU of every iteration kept: dW' = sum_i hx_i^T dU_i = [hx_0; ..; hx_{R-1}]^T [dU_0; ..; dU_{R-1}] is one
+        # row-split MFMA reduction (the sparse-conv dW kernel, K = 1, dense rows) instead of R one-workgroup GEMMs
+        dU_all = torch.empty((R * S, Waug.shape[1]), dtype=torch.float32, device=dev)
+        WaugT = Waug.t()
         for i in reversed(range(R)):
             d_inp, d_hprev = torch.empty_like(d_hx), torch.empty_like(d_hx)
-            _n.check(lib.wsis_gru_cell_bwd(_n.ptr(inps[i]), _n.ptr(hxs[i]), *[_n.ptr(t) for t in gp], _n.ptr(d_hx),
-                                           _n.ptr(d_inp), _n.ptr(d_hprev), _n.ptr(tmp[0]), _n.ptr(tmp[1]), _n.ptr(tmp[2]),
-                                           _n.ptr(tmp[3]), _n.ptr(tmp[4]), _n.ptr(tmp[5]), S, 32, _n.ptr(ws), ws_bytes,
-                                           st), "gru_cell_bwd")
-            torch._foreach_add_(dgp, tmp)
+            _n.check(lib.wsis_gru_cell_bwd_seq(_n.ptr(inps[i]), _n.ptr(hxs[i]), *[_n.ptr(t) for t in gp], _n.ptr(d_hx),
+                                               _n.ptr(d_inp), _n.ptr(d_hprev), *[_n.ptr(t) for t in dgp], S, 32,
+                                               R - 1 - i, R, 1 if i == 0 else 0, _n.ptr(ws), ws_bytes, st),
+                     "gru_cell_bwd_seq")
             d_m = torch.empty((E, 32), dtype=torch.float32, device=dev)
             _n.check(lib.wsis_segment_reduce_bwd(_n.ptr(d_inp), _n.ptr(csr_src.index), _n.ptr(csr_src.offsets), None,
                                                  _n.ptr(d_m), E, S, 32, 1, st), "segment_reduce_bwd")
-            dU, dh_i = torch.empty_like(Us[i]), torch.empty_like(h)
-            _n.check(lib.wsis_ecc_contract_bwd(_n.ptr(h), _n.ptr(Us[i]), _n.ptr(d_m), _n.ptr(csr_dst.perm),
-                                               _n.ptr(csr_dst.offsets), _n.ptr(dU), _n.ptr(dh_i), S, E, st),
-                     "ecc_contract_bwd")
-            dh += dh_i
-            dWaug.addmm_(hxs[i].t(), dU)
-            d_hx = torch.addmm(d_hprev, dU, Waug.t())
+            dU = dU_all[i * S:(i + 1) * S]
+            _n.check(lib.wsis_ecc_contract_bwd_acc(_n.ptr(h), _n.ptr(Us[i]), _n.ptr(d_m), _n.ptr(csr_dst.perm),
+                                                   _n.ptr(csr_dst.offsets), _n.ptr(dU), _n.ptr(dh), S, E,
+                                                   0 if i == R - 1 else 1, st), "ecc_contract_bwd")
+            d_hx = torch.addmm(d_hprev, dU, WaugT)
             if cat_all:
                 d_hx += d_slices[i]
+        dWaug = None
+        if ctx.needs_input_grad[2] and R == 0:
+            dWaug = torch.zeros_like(Waug)
+        elif ctx.needs_input_grad[2]:
+            from spconv import ops as sp_ops
+            dWaug = sp_ops._dw(hx_all[:R * S], None, None, dU_all, 1, 32, Waug.shape[1]).view(32, Waug.shape[1])
         need = ctx.needs_input_grad
-        return (d_hx if need[0] else None, dh if need[1] else None, dWaug if need[2] else None,
+        return (d_hx if need[0] else None, dh if need[1] else None, dWaug,
                 *[g if need[3 + j] else None for j, g in enumerate(dgp)], None, None, None, None)
 
 

@@ -327,6 +327,11 @@ int wsis_ecc_contract_fwd(const float* d_h, const float* d_U, const int32_t* d_p
                           float* d_m, int64_t S, int64_t E, void* stream);
 int wsis_ecc_contract_bwd(const float* d_h, const float* d_U, const float* d_dm, const int32_t* d_perm_dst,
                           const int32_t* d_off_dst, float* d_dU, float* d_dh, int64_t S, int64_t E, void* stream);
+/* accumulate != 0: dh += (every edge row is owned by one wavefront: still fixed order); the R repeats of the
+ * recurrence share h, so its gradient is summed in place instead of by R - 1 extra launches */
+int wsis_ecc_contract_bwd_acc(const float* d_h, const float* d_U, const float* d_dm, const int32_t* d_perm_dst,
+                              const int32_t* d_off_dst, float* d_dU, float* d_dh, int64_t S, int64_t E,
+                              int32_t accumulate, void* stream);
 int wsis_ecc_message_fwd(const float* d_x, const float* d_w, const int64_t* d_dst, const int32_t* d_perm_src,
                          const int32_t* d_off_src, float* d_out, int64_t S, int64_t E, int32_t C, void* stream);
 int wsis_ecc_message_bwd(const float* d_x, const float* d_w, const float* d_dout, const int64_t* d_src,
@@ -345,6 +350,15 @@ int wsis_gru_cell_bwd(const float* d_x, const float* d_h, const float* d_Wig, co
                       const float* d_dhy, float* d_dx, float* d_dh, float* d_dWig, float* d_dbig, float* d_dWih,
                       float* d_dWhh, float* d_dbih, float* d_dbhh, int64_t S, int32_t C, void* d_ws,
                       int64_t ws_bytes, void* stream);
+/* The same backward as evaluation `slot` of a sequence of `n_slots` evaluations that share the six parameter
+ * tensors (the R repeats of spg_modules.py:152-185): every evaluation leaves its parameter-gradient slabs in its own
+ * region of d_ws (n_slots x the single-call workspace); the call with finish != 0 reduces ALL regions in one
+ * fixed-order launch into d_dW* / d_db* (= the sum over the sequence; may be NULL on the other calls). */
+int wsis_gru_cell_bwd_seq(const float* d_x, const float* d_h, const float* d_Wig, const float* d_big,
+                          const float* d_Wih, const float* d_Whh, const float* d_bih, const float* d_bhh,
+                          const float* d_dhy, float* d_dx, float* d_dh, float* d_dWig, float* d_dbig, float* d_dWih,
+                          float* d_dWhh, float* d_dbih, float* d_dbhh, int64_t S, int32_t C, int32_t slot,
+                          int32_t n_slots, int32_t finish, void* d_ws, int64_t ws_bytes, void* stream);
 
 /* ---- a17: dense inter-superpoint affinity + label propagation -------------------------------
  * train_scannetv2.py:562-570, modules/datasets/scannetv2_dataset.py:664-721 (fp64, host numpy).

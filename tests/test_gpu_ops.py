@@ -989,11 +989,13 @@ def test_rulebooks_wait_for_coordinates_produced_late_on_the_main_stream():
 
 # ---------------------------------------------------------------- ECC without the [E, 1024] filter tensor (8f-1)
 @pytest.mark.gpu
-@pytest.mark.parametrize("S,deg", [(60, 4), (700, 9)])
+@pytest.mark.parametrize("S,deg", [(60, 4), (700, 9), (1500, 9)])
 def test_ecc_contraction_matches_oracle_and_never_forms_the_filter_tensor(S, deg, monkeypatch):
     """graphnet.RNNGraphConvModule with the filter-free evaluation (m_e = h_e . U_t, U = x @ W') against the oracle's
     RefRNNGraphConv in fp64 (which forms W_e = fnet(f_e) like spg_modules.py:168-183): outputs and every gradient at
-    1e-4 of the tensor scale; while it runs no tensor of E * 1024 elements is allocated."""
+    1e-4 of the tensor scale; while it runs no per-edge tensor of E * 1024 elements is allocated (the per-node
+    U / dU buffers [R*S, 65*32] are not per-edge).  The largest case has E >= 4096: the filter net's Linear layers
+    take the row-split weight-gradient path."""
     import graphnet
     from oracle import network_ref
     eu, ev = _graph(S + 3, S, deg)
@@ -1018,7 +1020,8 @@ def test_ecc_contraction_matches_oracle_and_never_forms_the_filter_tensor(S, deg
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
             out = func(*args, **(kwargs or {}))
             for t in (out if isinstance(out, (tuple, list)) else (out,)):
-                if isinstance(t, torch.Tensor) and t.is_floating_point() and t.numel() >= E * 1024:
+                if (isinstance(t, torch.Tensor) and t.is_floating_point() and t.numel() >= E * 1024
+                        and t.shape[0] % E == 0):
                     big.append((str(func), tuple(t.shape)))
             return out
 
@@ -1028,6 +1031,7 @@ def test_ecc_contraction_matches_oracle_and_never_forms_the_filter_tensor(S, deg
         out = mod(xg)
         out.backward(go.to(DEV))
     assert not big, big
+    assert E >= 4096 or S < 1500
     xr = x.clone().double().requires_grad_(True)
     want = ref(xr, edge_indexes, feats.double())
     want.backward(go.double())
