@@ -146,7 +146,8 @@ class Network(nn.Module):
 
         # ---- affinity between adjacent superpoints (backbone_3D_WSIS.py:207-253) ----
         centre = extra_data["superpoint_cenetr_xyz"]
-        q, k, v = self.w_qs(ecc_outputs), self.w_ks(ecc_outputs), self.w_vs(ecc_outputs)
+        q, k, v = (wsis_ops.tall_linear(ecc_outputs, m) if ecc_outputs.is_cuda else m(ecc_outputs)
+                   for m in (self.w_qs, self.w_ks, self.w_vs))
         edge_u, edge_v = extra_data["edge_u_list"], extra_data["edge_v_list"]
         graph = extra_data.get("edge_graph")
         if graph is None:

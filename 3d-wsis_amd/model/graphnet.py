@@ -245,5 +245,9 @@ class GraphNetwork(nn.Module):
 
     def forward(self, input):
         for module in self._modules.values():
-            input = module(input)
+            if isinstance(module, nn.Linear) and input.is_cuda:
+                import wsis_ops
+                input = wsis_ops.tall_linear(input, module)      # row-split weight gradient where it applies
+            else:
+                input = module(input)
         return input

@@ -147,20 +147,22 @@ class MultiTaskLoss(nn.Module):
                 loss_out["occupancy_loss"] = (occupancy_loss, n_valid)
                 loss_out["instance_size_loss"] = (instance_size_loss, n_valid)
 
-        loss = 0.0
-        loss = loss + 1.0 * semantic_loss
+        # losses_3D_WSIS.py:130-151: loss = 0.0 + 1.0 * term + ...  All weights are 1.0 there, and 0.0 + x and 1.0 * x are
+        # exact in floating point: the same sum in the same order without the seven scalar multiplications (each one a
+        # launch forward and one backward)
+        loss = semantic_loss
         self._log("point semantic loss", semantic_loss)
         if joint:
-            loss = loss + 1.0 * superpoint_semantic_loss
+            loss = loss + superpoint_semantic_loss
             self._log("sp semantic loss", superpoint_semantic_loss)
             if self.supervise_sp_offset:
-                loss = loss + (1.0 * offset_norm_loss + 1.0 * offset_dir_loss)
+                loss = loss + (offset_norm_loss + offset_dir_loss)
                 self._log("sp offset norm loss", offset_norm_loss)
                 self._log("sp offset dir loss", offset_dir_loss)
-            loss = loss + 1.0 * sp_d_loss
+            loss = loss + sp_d_loss
             self._log("sp discriminative loss", sp_d_loss)
             if self.supervise_instance_size:
-                loss = loss + 1.0 * occupancy_loss + 1.0 * instance_size_loss
+                loss = loss + occupancy_loss + instance_size_loss
                 self._log("sp occupancy loss", occupancy_loss)
                 self._log("sp instance size loss", instance_size_loss)
         return loss, loss_out

@@ -442,7 +442,7 @@ class _EccGruLoop(Function):
             _n.check(lib.wsis_ecc_contract_bwd_acc(_n.ptr(h), _n.ptr(Us[i]), _n.ptr(d_m), _n.ptr(csr_dst.perm),
                                                    _n.ptr(csr_dst.offsets), _n.ptr(dU), _n.ptr(dh), S, E,
                                                    0 if i == R - 1 else 1, st), "ecc_contract_bwd")
-            d_hx = torch.addmm(d_hprev, dU, WaugT)
+            d_hx = d_hprev.addmm_(dU, WaugT)          # in place: no copy of d_hprev into a new output first
             if cat_all:
                 d_hx += d_slices[i]
         dWaug = None
@@ -463,6 +463,9 @@ def ecc_gru_loop(hx, h, Waug, cell, csr_src, csr_dst, repeats, cat_all):
 
 
 # ---- point-level Linear with a split-K weight gradient ----------------------------------------------------------
+
+_TALL_MIN_ROWS = int(__import__("os").environ.get("WSIS_TALL_MIN_ROWS", "1024"))
+
 
 class _TallLinear(Function):
     """y = x @ W^T + b for x [N, Cin] with N ~ 2*10^5 points (backbone_3D_WSIS.py:59-64, 182).  hipBLASLt runs
@@ -490,7 +493,9 @@ class _TallLinear(Function):
 
 
 def tall_linear(x, linear):
-    if not x.is_cuda or x.shape[0] < 4096:
+    # rows from which the row-split dW reduction beats the one-workgroup GEMM (measured at 2.3 k rows: 15 -> 7 us);
+    # shapes the conv dW kernel takes: Cin a multiple of 32, Cout a multiple of 4
+    if (not x.is_cuda or x.shape[0] < _TALL_MIN_ROWS or linear.in_features % 32 != 0 or linear.out_features % 4 != 0):
         return linear(x)
     return _TallLinear.apply(x, linear.weight, linear.bias)
 
