@@ -792,6 +792,68 @@ int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* 
   return WSIS_OK;
 }
 
+// ---- column sums of x [M, C] (bias gradient of a Linear layer over M rows): two levels in ONE launch, fixed order.
+// 256 threads = (C/4 float4 column lanes) x (row lanes); every workgroup sums a block of rows, the one that arrives
+// last adds the block results in block order.
+__device__ unsigned g_colsum_ticket[64];
+
+__device__ __forceinline__ void colsum_block(const float* __restrict__ x, int64_t lo, int64_t hi, int C4, float4* red,
+                                             float* __restrict__ out) {
+  const int RL = 256 / C4;
+  const int cl = threadIdx.x % C4, rl = threadIdx.x / C4;
+  float4 a = {0.f, 0.f, 0.f, 0.f};
+  if (rl < RL) {
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+#pragma unroll 4
+    for (int64_t r = lo + rl; r < hi; r += RL) {
+      const float4 v = x4[r * C4 + cl];
+      a.x += v.x;
+      a.y += v.y;
+      a.z += v.z;
+      a.w += v.w;
+    }
+    red[rl * C4 + cl] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < C4) {
+    float4 s = red[threadIdx.x];
+    for (int j = 1; j < RL; ++j) {      // fixed order
+      const float4 v = red[j * C4 + threadIdx.x];
+      s.x += v.x;
+      s.y += v.y;
+      s.z += v.z;
+      s.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[threadIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t M, int C, int64_t per,
+                                                     float* __restrict__ chunk, float* __restrict__ out,
+                                                     unsigned* __restrict__ ticket) {
+  __shared__ float4 red[256];
+  __shared__ int s_last;
+  const int C4 = C >> 2;
+  const int64_t lo = (int64_t)blockIdx.x * per;
+  const int64_t hi = lo + per < M ? lo + per : M;
+  if (gridDim.x == 1) {
+    colsum_block(x, lo, hi, C4, red, out);
+    return;
+  }
+  colsum_block(x, lo, hi, C4, red, chunk + (int64_t)blockIdx.x * C);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(ticket, 1u);
+    s_last = t == gridDim.x - 1;
+    if (s_last) *ticket = 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  colsum_block(chunk, 0, gridDim.x, C4, red, out);
+}
+
 // ticket row of a two-level reduction (nullptr: WSIS_BN_TICKET=0, the finish runs as a second launch)
 static unsigned* bn_tickets(int which, const void* chunk) {
   static unsigned* base = nullptr;
@@ -918,6 +980,40 @@ int wsis_bn_bwd(const float* d_x, const float* d_dy, const float* d_mean, const 
                        d_dgamma, d_dbeta, d_addend, eps, relu, training, d_dx, M, C);
     WSIS_LAUNCH_CHECK();
   }
+  return WSIS_OK;
+}
+
+int64_t wsis_colsum_workspace_bytes(int64_t M, int32_t C) {
+  if (M < 0 || C < 4) return -1;
+  int64_t per = (M + 1023) / 1024;
+  if (per < 256) per = 256;
+  const int64_t G = (M + per - 1) / per;
+  return (G > 1 ? G : 1) * (int64_t)C * (int64_t)sizeof(float) + 256;
+}
+
+int wsis_colsum(const float* d_x, int64_t M, int32_t C, float* d_out, void* d_ws, int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(M >= 0 && C >= 4 && C % 4 == 0 && C <= 1024 && d_out, "colsum: C must be a multiple of 4, <= 1024");
+  hipStream_t st = as_stream(stream);
+  if (M == 0) {
+    WSIS_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(float) * (size_t)C, st));
+    return WSIS_OK;
+  }
+  WSIS_REQUIRE(d_x && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0,
+               "colsum: 16-byte alignment");
+  int64_t per = (M + 1023) / 1024;
+  if (per < 256) per = 256;
+  const int64_t G = (M + per - 1) / per;
+  float* chunk = nullptr;
+  unsigned* ticket = nullptr;
+  if (G > 1) {
+    WSIS_REQUIRE(d_ws && ws_bytes >= wsis_colsum_workspace_bytes(M, C), "workspace too small");
+    chunk = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(d_ws) + 255) & ~(uintptr_t)255);
+    static unsigned* base = nullptr;
+    if (!base) WSIS_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_colsum_ticket)));
+    ticket = base + ((reinterpret_cast<uintptr_t>(chunk) >> 8) & 63);   // concurrent launches use different workspaces
+  }
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)G), dim3(256), 0, st, d_x, M, (int)C, per, chunk, d_out, ticket);
+  WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }
 

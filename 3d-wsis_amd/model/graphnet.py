@@ -65,6 +65,34 @@ def create_fnet(widths, orthoinit, llbias, bnidx=-1):
     return nn.Sequential(*mods)
 
 
+def _run_modules(mods, x):
+    """nn.Sequential semantics over ``mods`` with the device forms of the plain layers: Linear over many rows through
+    ``tall_linear`` (weight gradient = a [Cin x Cout] output reduced over the rows: one workgroup in hipBLASLt, the
+    row-split MFMA reduction here), BatchNorm1d (+ a following ReLU) as the fused two-kernel form instead of four
+    torch launches each way.  WSIS_FNET_TALL=0 / WSIS_FUSE_BN=0: the modules as they are."""
+    if not x.is_cuda:
+        for m in mods:
+            x = m(x)
+        return x
+    import wsis_ops
+    tall = os.environ.get("WSIS_FNET_TALL", "1") != "0"
+    fuse_bn = os.environ.get("WSIS_FUSE_BN", "1") != "0"
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if tall and type(m) is nn.Linear and x.dim() == 2:
+            x = wsis_ops.tall_linear(x, m)
+        elif (fuse_bn and type(m) is nn.BatchNorm1d and x.dim() == 2 and m.affine and x.shape[0] > 1
+              and x.dtype == torch.float32):
+            relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+            x = wsis_ops.batch_norm_relu(x, m, relu=relu)
+            i += 1 if relu else 0
+        else:
+            x = m(x)
+        i += 1
+    return x
+
+
 class GRUCellEx(nn.GRUCell):
     """GRU cell with per-row normalisation of the gate pre-activations and an input gate
     (spg_modules.py:207-253).  The reference's InstanceNorm1d(1) over [S,1,3H] is a per-row
@@ -141,15 +169,7 @@ class RNNGraphConvModule(nn.Module):
         edge_indexes = self._gci.get_pyg_buffers()
         src = edge_indexes[0]
         last = self._fnet[-1]
-        h = self._gci.get_buffers()
-        for mod in self._fnet[:-1]:                                       # fnet hidden state [E, 64]
-            # Linear over the E edge rows: the weight gradient is a [Cin x Cout] output reduced over E rows, one
-            # workgroup in hipBLASLt; tall_linear sends it through the row-split MFMA reduction where it applies
-            if (isinstance(mod, nn.Linear) and mod.in_features % 32 == 0 and mod.out_features % 4 == 0
-                    and os.environ.get("WSIS_FNET_TALL", "1") != "0"):
-                h = wsis_ops.tall_linear(h, mod)
-            else:
-                h = mod(h)
+        h = _run_modules(list(self._fnet[:-1]), self._gci.get_buffers())     # fnet hidden state [E, 64]
         # W'[a, c*32 + b] = Wl[a*32 + b, c];  W'[a, 64*32 + b] = bl[a*32 + b]
         Waug = torch.cat([last.weight.view(32, 32, 64).permute(0, 2, 1).reshape(32, 64 * 32),
                           last.bias.view(32, 32)], 1)
@@ -244,10 +264,4 @@ class GraphNetwork(nn.Module):
             gc.set_info(gc_infos[i])
 
     def forward(self, input):
-        for module in self._modules.values():
-            if isinstance(module, nn.Linear) and input.is_cuda:
-                import wsis_ops
-                input = wsis_ops.tall_linear(input, module)      # row-split weight gradient where it applies
-            else:
-                input = module(input)
-        return input
+        return _run_modules(list(self._modules.values()), input)

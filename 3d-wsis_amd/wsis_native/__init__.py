@@ -107,6 +107,8 @@ _HIP_SIGS = {
     "wsis_gru_cell_workspace_bytes": (I64, [I64]),
     "wsis_gru_cell_fwd": (I32, [P] * 9 + [I64, I32, P]),
     "wsis_gru_cell_bwd": (I32, [P] * 17 + [I64, I32, P, I64, P]),
+    "wsis_colsum_workspace_bytes": (I64, [I64, I32]),
+    "wsis_colsum": (I32, [P, I64, I32, P, P, I64, P]),
     "wsis_gru_cell_bwd_seq": (I32, [P] * 17 + [I64, I32, I32, I32, I32, P, I64, P]),
     "wsis_affinity_dense_build": (I32, [P, P, P, I64, P, I64, P]),
     "wsis_affinity_transition": (I32, [P, P, P, P, P, I32, F32, P, I64, P]),

@@ -467,6 +467,19 @@ def ecc_gru_loop(hx, h, Waug, cell, csr_src, csr_dst, repeats, cat_all):
 _TALL_MIN_ROWS = int(__import__("os").environ.get("WSIS_TALL_MIN_ROWS", "1024"))
 
 
+def colsum(x):
+    """x.sum(0) of a contiguous fp32 [M, C] device tensor in one fixed-order launch (C % 4 == 0, C <= 1024)"""
+    M, C = x.shape
+    if not x.is_cuda or C % 4 != 0 or C > 1024 or C < 4 or x.dtype != torch.float32 or not x.is_contiguous():
+        return x.sum(0)
+    lib = _n.hip()
+    ws_bytes = lib.wsis_colsum_workspace_bytes(M, C)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    _n.check(lib.wsis_colsum(_n.ptr(x), M, C, _n.ptr(out), _n.ptr(ws), ws_bytes, _n.stream_ptr()), "colsum")
+    return out
+
+
 class _TallLinear(Function):
     """y = x @ W^T + b for x [N, Cin] with N ~ 2*10^5 points (backbone_3D_WSIS.py:59-64, 182).  hipBLASLt runs
     the weight gradient X^T dY (a [Cin x Cout] output reduced over N rows) as ONE workgroup (~0.4 ms); here it
@@ -488,7 +501,9 @@ class _TallLinear(Function):
         if ctx.needs_input_grad[1]:
             cout, cin = weight.shape
             dw = sp_ops._dw(x.contiguous(), None, None, dy, 1, cin, cout).view(cin, cout).t()
-        db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy)
         return dx, dw, db
 
 

@@ -338,6 +338,13 @@ int wsis_ecc_message_bwd(const float* d_x, const float* d_w, const float* d_dout
                          const int32_t* d_perm_dst, const int32_t* d_off_dst, const int32_t* d_off_src,
                          float* d_dx, float* d_dw, int64_t S, int64_t E, int32_t C, void* stream);
 
+/* Column sums out[c] = sum_r x[r, c] of x [M, C] (C % 4 == 0, C <= 1024): the bias gradient of the point-level
+ * Linear layers (backbone_3D_WSIS.py:59-64, `dy.sum(0)` in torch's AddmmBackward).  One launch, two levels, fixed
+ * summation order (run-to-run identical).  Launches that may run concurrently (different streams) must use different
+ * workspaces: the arrival counter is picked from the workspace address. */
+int64_t wsis_colsum_workspace_bytes(int64_t M, int32_t C);
+int wsis_colsum(const float* d_x, int64_t M, int32_t C, float* d_out, void* d_ws, int64_t ws_bytes, void* stream);
+
 /* GRUCellEx of the superpoint GNN (modules/model/spg_modules.py:207-253: GRU cell + input gate + per-row
  * normalisation of the gate pre-activations), C == 32: one kernel forward, one backward + a fixed-order reduce of
  * the parameter gradients.  Weights in torch.nn.GRUCell layout: Wih/Whh [3C,C] (r,z,n blocks), Wig [C,C]. */

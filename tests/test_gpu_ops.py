@@ -1133,3 +1133,21 @@ def test_dense_weight_gradient_on_the_wave_autonomous_kernel(rows, cin, cout):
     assert dW.shape == (1, cin, cout)
     assert float((dW.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
     assert torch.equal(dW, ops._dw(X, None, None, dY, 1, cin, cout))
+
+
+# ---------------------------------------------------------------- column sums (Linear bias gradient)
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,C", [(1, 4), (255, 20), (2289, 64), (4097, 128), (199790, 32), (300000, 1024), (0, 8)])
+def test_colsum_matches_fp64_and_is_run_to_run_identical(M, C):
+    """wsis_colsum: out[c] = sum_r x[r, c] against an fp64 sum (1e-6 of sum |x|), bit-identical between two launches
+    (fixed summation order), shapes it does not take fall back to torch.sum."""
+    g = torch.Generator(device=DEV).manual_seed(M + C)
+    x = torch.randn(M, C, device=DEV, generator=g)
+    a = wsis_ops.colsum(x)
+    b = wsis_ops.colsum(x)
+    assert a.shape == (C,) and torch.equal(a, b)
+    want = x.double().sum(0)
+    bound = 1e-6 * max(float(x.double().abs().sum(0).max()) if M else 0.0, 1e-30)
+    assert float((a.double() - want).abs().max()) <= bound if M else float(a.abs().max()) == 0.0
+    odd = torch.randn(17, 7, device=DEV, generator=g)
+    assert torch.allclose(wsis_ops.colsum(odd), odd.sum(0))
