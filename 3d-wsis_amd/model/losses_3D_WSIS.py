@@ -77,8 +77,15 @@ class MultiTaskLoss(nn.Module):
         joint = epoch > self.joint_training_epoch
         if joint:
             sp_sem_labels, sp_ins_labels = loss_inp["superpoint_labels"]
-            sp_valid = (sp_ins_labels != self.ignore_label) & (sp_sem_labels != self.ignore_label)
-            n_valid = sp_valid.sum()
+            # the validity mask and its count: only the unfused branches read them (the fused kernels take the two label
+            # tensors), so they are formed on first use -- four launches the default device path never needs
+            _mask = []
+
+            def _valid():
+                if not _mask:
+                    m = (sp_ins_labels != self.ignore_label) & (sp_sem_labels != self.ignore_label)
+                    _mask.extend([m, m.sum()])
+                return _mask
 
             sp_semantic_scores = loss_inp["sp_semantic"]
             superpoint_semantic_loss = self.superpoint_semantic_criterion(sp_semantic_scores, sp_sem_labels)
@@ -101,6 +108,7 @@ class MultiTaskLoss(nn.Module):
             if self.supervise_sp_offset and not fused_reg:
                 pred_off, gt_off = loss_inp["sp_offset_vector"]
                 pt_dist = torch.sum(torch.abs(pred_off - gt_off), dim=-1)
+                sp_valid, n_valid = _valid()
                 offset_norm_loss = torch.sum(pt_dist * sp_valid) / (n_valid + 1e-6)
                 gt_dir = gt_off / (torch.norm(gt_off, p=2, dim=1).unsqueeze(-1) + 1e-8)
                 pt_dir = pred_off / (torch.norm(pred_off, p=2, dim=1).unsqueeze(-1) + 1e-8)
@@ -115,8 +123,8 @@ class MultiTaskLoss(nn.Module):
             d_losses = []
             for i in range(1, len(offs)):
                 b, e = offs[i - 1], offs[i]
-                valid = sp_valid[b:e]
                 if indexed:
+                    valid = _valid()[0][b:e]
                     d_loss, _, _, _ = self.discriminative_loss(feats[b:e][valid], sp_ins_labels[b:e][valid])
                 elif (slots is not None and feats.is_cuda and 1 <= int(slots[i - 1]) <= 64 and 1 <= e - b <= 4096
                       and self.discriminative_feature_dim == 7 and os.environ.get("WSIS_FUSE_DISC_LOSS", "1") != "0"):
@@ -125,11 +133,13 @@ class MultiTaskLoss(nn.Module):
                                                           int(slots[i - 1]), self.ignore_label, self.delta_v,
                                                           self.delta_d, self.param_var, self.param_dist, self.param_reg)
                 elif slots is not None and 1 <= int(slots[i - 1]) <= 512:
-                    d_loss = self.discriminative_loss_slots(feats[b:e], sp_ins_labels[b:e], valid, int(slots[i - 1]))
+                    d_loss = self.discriminative_loss_slots(feats[b:e], sp_ins_labels[b:e], _valid()[0][b:e],
+                                                            int(slots[i - 1]))
                 else:
-                    d_loss = self.discriminative_loss_masked(feats[b:e], sp_ins_labels[b:e], valid)
+                    d_loss = self.discriminative_loss_masked(feats[b:e], sp_ins_labels[b:e], _valid()[0][b:e])
                 d_losses.append(d_loss.view(-1))
-            sp_d_loss = torch.mean(torch.cat(d_losses))
+            # mean over the scenes; one scene: the mean of one value is that value (x / 1 is exact)
+            sp_d_loss = torch.mean(torch.cat(d_losses)) if len(d_losses) != 1 else d_losses[0].reshape(())
             loss_out["superpoint_discriminative_loss"] = (sp_d_loss, feats.shape[0])
 
             if fused_reg:
@@ -138,6 +148,7 @@ class MultiTaskLoss(nn.Module):
             elif self.supervise_instance_size:
                 pred_occ, gt_occ = loss_inp["sp_occupancy"]
                 pred_size, gt_size = loss_inp["sp_instance_size"]
+                sp_valid, n_valid = _valid()
                 if indexed:
                     occupancy_loss = self.occupany_L1loss(pred_occ[sp_valid], gt_occ[sp_valid])
                     instance_size_loss = self.instance_size_L1loss(pred_size[sp_valid], gt_size[sp_valid])
