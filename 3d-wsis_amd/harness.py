@@ -253,10 +253,10 @@ def to_device(batch, device):
     for k in _DEVICE_KEYS:
         out[k] = batch[k].to(device)
     out["voxel_coords_int"] = out["voxel_locs"].int().contiguous()
-    ev = torch.cuda.Event()
+    out["GIs"][0].cuda()
+    ev = torch.cuda.Event()                # every index tensor of the batch is on the device behind this point
     ev.record()
     out["coords_ready_event"] = ev
-    out["GIs"][0].cuda()
     build_batch_graphs(out)
     # bound of the superpoint instance ids per scene, read while the labels are still host tensors: lets the loss
     # place the instances in fixed slots instead of torch.unique (sync) or an [S, S] same-instance matrix
@@ -265,18 +265,46 @@ def to_device(batch, device):
     return out
 
 
-def build_batch_graphs(batch):
+def build_batch_graphs(batch, side_stream=None):
     """per-batch device structures of the segmented reductions: CSR of the superpoint ids and of the point->voxel
-    map, both edge directions of the superpoint graph.  Part of this build's ``scatter`` cost for every NEW batch
-    (upstream torch_scatter pays it as atomics inside every call), so ``bench.py`` rebuilds them inside the timed
-    step."""
+    map, both edge directions of the superpoint graph and of the ECC graph (``GIs``).  Part of this build's ``scatter``
+    cost for every NEW batch (upstream torch_scatter pays it as atomics inside every call), so ``bench.py`` rebuilds
+    them inside the timed step.
+
+    They only depend on the batch's index tensors, so -- like the rulebooks -- they are built on the side stream
+    (``WSIS_GRAPH_STREAM=0`` / ``side_stream=False``: on the current stream): the ~50 small sort launches run next to
+    whatever the main stream still has queued (the previous iteration's backward pass) instead of in front of the
+    forward pass; the main stream joins before its first use."""
     from torch_scatter import SegmentCSR
     import wsis_ops
+    import spconv
     S = int(batch["sp_batch_offsets"][-1])
-    batch["superpoint_csr"] = SegmentCSR(batch["superpoint"], S)
-    batch["p2v_csr"] = SegmentCSR(batch["p2v_map"], int(batch["voxel_locs"].shape[0]))
-    batch["edge_graph"] = wsis_ops.EdgeGraph(batch["edge_u_list"], batch["edge_v_list"], S,
-                                             num_src=batch.get("edge_src_rows"))
+    dev = batch["superpoint"].device
+    if side_stream is None:
+        side_stream = os.environ.get("WSIS_GRAPH_STREAM", "1") != "0"
+    side = spconv.ops._side_stream(dev) if (side_stream and dev.type == "cuda") else None
+    main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+    if side is not None:
+        ev = batch.get("coords_ready_event")       # recorded after the H2D copies of the index tensors
+        if ev is not None:
+            side.wait_event(ev)
+        else:
+            side.wait_stream(main)
+    with (torch.cuda.stream(side) if side is not None else spconv.ops._NullCtx()):
+        batch["superpoint_csr"] = SegmentCSR(batch["superpoint"], S)
+        batch["p2v_csr"] = SegmentCSR(batch["p2v_map"], int(batch["voxel_locs"].shape[0]))
+        batch["edge_graph"] = wsis_ops.EdgeGraph(batch["edge_u_list"], batch["edge_v_list"], S,
+                                                 num_src=batch.get("edge_src_rows"))
+        csrs = [batch["superpoint_csr"], batch["p2v_csr"], batch["edge_graph"].csr_u, batch["edge_graph"].csr_v]
+        for gi in batch.get("GIs", []):            # a new batch has a new GraphConvInfo: its two CSRs are per-batch too
+            if getattr(gi, "_edge_indexes", None) is not None and gi._edge_indexes.is_cuda:
+                gi._csr = gi._csr_dst = None
+                csrs += [gi.csr(), gi.csr_dst()]
+    if side is not None:
+        main.wait_stream(side)
+        for c in csrs:                             # allocated on the side stream, consumed on the main stream
+            for t in (c.perm, c.offsets, c.index):
+                t.record_stream(main)
     return batch
 
 
