@@ -1151,3 +1151,41 @@ def test_colsum_matches_fp64_and_is_run_to_run_identical(M, C):
     assert float((a.double() - want).abs().max()) <= bound if M else float(a.abs().max()) == 0.0
     odd = torch.randn(17, 7, device=DEV, generator=g)
     assert torch.allclose(wsis_ops.colsum(odd), odd.sum(0))
+
+
+@pytest.mark.gpu
+def test_edge_graph_row_count_from_the_loader_equals_the_device_read_back():
+    """EdgeGraph(num_src=...) (the loader's host-side edge_u.max() + 1, no device read-back) gives the tensors of the
+    default constructor, which mirrors the reference's scatter(..., edge_u) row count."""
+    S, D = 300, 64
+    eu, ev = _graph(S, S, 12)
+    g = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn(S, D, generator=g).to(DEV) for _ in range(3))
+    pos = torch.randn(len(eu), generator=g).to(DEV)
+    tu, tv = torch.from_numpy(eu).to(DEV), torch.from_numpy(ev).to(DEV)
+    a = wsis_ops.EdgeGraph(tu, tv, S)
+    b = wsis_ops.EdgeGraph(tu, tv, S, num_src=int(eu.max()) + 1)
+    assert a.Su == b.Su == int(eu.max()) + 1 < S
+    ra, rb = (wsis_ops.edge_affinity(q, k, v, pos, gr, 0.125) for gr in (a, b))
+    assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1])
+
+
+@pytest.mark.gpu
+def test_batch_graphs_built_on_the_side_stream_equal_the_in_stream_build(monkeypatch):
+    """harness.build_batch_graphs: the CSRs of a batch built on the side stream (default) are the tensors of the
+    in-stream build, and a step that uses them right away sees them complete (stream join)."""
+    import harness
+    bt = harness.to_device(harness.collate([harness.make_scene(11, room=(1.6, 1.3, 1.0), n_box=2)]), DEV)
+
+    def snap():
+        cs = [bt["superpoint_csr"], bt["p2v_csr"], bt["edge_graph"].csr_u, bt["edge_graph"].csr_v,
+              bt["GIs"][0].csr(), bt["GIs"][0].csr_dst()]
+        return [(c.perm.clone(), c.offsets.clone()) for c in cs]
+
+    harness.build_batch_graphs(bt, side_stream=True)
+    side = snap()
+    torch.cuda.synchronize()
+    harness.build_batch_graphs(bt, side_stream=False)
+    main = snap()
+    for (p0, o0), (p1, o1) in zip(side, main):
+        assert torch.equal(p0, p1) and torch.equal(o0, o1)
