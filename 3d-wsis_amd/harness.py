@@ -178,9 +178,11 @@ def synthetic_predictions(scene, seed=0, noise=0.02):
 
 
 # -------------------------------------------------------------------------------------------------------------
-def collate(scenes, mode=4):
-    """Batch dict with the schema of scannetv2_dataset.py:460-474; host tensors."""
+def collate(scenes, mode=4, n_levels=5):
+    """Batch dict with the schema of scannetv2_dataset.py:460-474; host tensors.
+    ``n_levels``: UNet depth the host-side ``level_counts`` are computed for (config ``blocks``)."""
     import pointgroup_ops
+    import spconv
     from graphnet import GraphConvInfo
     locs, locs_float, feats, sem, ins, sps = [], [], [], [], [], []
     sp_sem, sp_ins, sp_off, sp_vox, sp_size = [], [], [], [], []
@@ -231,6 +233,8 @@ def collate(scenes, mode=4):
         "edge_u_list": edges[:, 0].contiguous().long(), "edge_v_list": edges[:, 1].contiguous().long(),
         # rows of scatter(..., edge_u): known here on the host, so the device step never has to read it back
         "edge_src_rows": (int(edges[:, 0].max()) + 1) if edges.shape[0] else 0,
+        # active voxels of the UNet's strided levels, from the host-side coordinates (spconv.ops.level_voxel_counts)
+        "level_counts": spconv.ops.level_voxel_counts(voxel_locs.numpy(), spatial_shape, n_levels),
         "superpoint_semantic_labels": torch.cat(sp_sem, 0).long(),
         "superpoint_instance_labels": torch.cat(sp_ins, 0).long(),
         "superpoint_offset_vector": torch.cat(sp_off, 0).float(),
@@ -335,6 +339,9 @@ def forward_loss(model, criterion, batch, cfg, epoch=5):
     voxel_feats = pointgroup_ops.voxelization(feats, batch["v2p_map"], cfg.mode)
     input_ = spconv.SparseConvTensor(voxel_feats, batch["voxel_coords_int"], batch["spatial_shape"], cfg.batch_size)
     input_._ready_event = batch.get("coords_ready_event")
+    counts = batch.get("level_counts")
+    if counts is not None and len(counts) == model.blocks - 1:
+        input_._level_counts = counts
     rulebooks = batch.get("rulebooks")        # built ahead by a spconv.ops.RulebookPrefetcher (loader stage)
     if rulebooks is not None:
         rulebooks.attach(input_)

@@ -243,9 +243,73 @@ def build_down_rulebook(indices, spatial_shape, ksize, stride, padding):
         return done.value
 
 
-def _down_rulebook_gen(indices, spatial_shape, ksize, stride, padding, deferred=None):
+_PENDING_COUNTS = []     # (device count, host value it was assumed to have): verified at the next pyramid build
+
+
+_CHECK_STREAMS = {}
+
+
+def verify_pending_counts():
+    """compare the output row counts the device found with the host values the rulebooks were sized by
+    (``level_voxel_counts``); one small D2H copy for all levels of the previous build, on a stream of its own (the
+    counts were written a whole step ago: the copy does not queue behind the builds now in flight on the side stream).
+    A mismatch means the hint did not belong to the coordinates: the tables built from it are invalid."""
+    if not _PENDING_COUNTS:
+        return
+    pend = list(_PENDING_COUNTS)
+    del _PENDING_COUNTS[:]
+    dev = pend[0][0].device
+    key = (dev.type, dev.index)
+    chk = _CHECK_STREAMS.get(key)
+    if chk is None:
+        chk = _CHECK_STREAMS[key] = torch.cuda.Stream(device=dev)
+    chk.wait_event(pend[-1][2])          # recorded on the building stream behind the last count (stream order)
+    with torch.cuda.stream(chk):
+        both = torch.cat([c for c, _, _ in pend])
+        got = both.tolist()
+    for c, _, _ in pend:
+        c.record_stream(chk)
+    for g, (_, want, _) in zip(got, pend):
+        if int(g) != int(want):
+            raise _n.WsisError("strided rulebook: the device found %d output voxels, the batch's level_counts said %d"
+                               % (int(g), int(want)))
+
+
+def level_voxel_counts(voxel_locs, spatial_shape, n_levels, ksize=2, stride=2):
+    """Active voxels of levels 1 .. n_levels-1 of a UBlock pyramid (SparseConv3d k2 s2 p0 between levels) from the
+    level-0 coordinates [M, 4] (batch, x, y, z), on the HOST: output voxel = floor(coordinate / 2) where that lies
+    inside the output shape (sparse_unet3d.py:170-172 with spconv's output-size rule).  A loader has the coordinates
+    on the host anyway (``voxelization_idx`` runs in ``collate_fn``); with these counts in the batch the device
+    rulebook build sizes its tables without reading the counts back, i.e. without stopping the host four times per
+    forward pass."""
+    assert ksize == 2 and stride == 2
+    idx = np.asarray(voxel_locs, dtype=np.int64).reshape(-1, 4)
+    shape = [int(v) for v in spatial_shape]
+    counts = []
+    for _ in range(int(n_levels) - 1):
+        out_shape = get_conv_output_size(shape, [2] * 3, [2] * 3, [0] * 3, [1] * 3)
+        oa = np.asarray(out_shape, dtype=np.int64)
+        o = idx[:, 1:] >> 1
+        ok = np.all(o < oa, axis=1)
+        b, o = idx[ok, 0], o[ok]
+        lin = np.unique(((b * oa[0] + o[:, 0]) * oa[1] + o[:, 1]) * oa[2] + o[:, 2])
+        counts.append(int(lin.shape[0]))
+        nxt = np.empty((lin.shape[0], 4), dtype=np.int64)
+        nxt[:, 3] = lin % oa[2]
+        lin = lin // oa[2]
+        nxt[:, 2] = lin % oa[1]
+        lin = lin // oa[1]
+        nxt[:, 1] = lin % oa[0]
+        nxt[:, 0] = lin // oa[0]
+        idx, shape = nxt, out_shape
+    return counts
+
+
+def _down_rulebook_gen(indices, spatial_shape, ksize, stride, padding, deferred=None, m_out=None):
     """generator form: yields once, right before the host reads the output row count (the one sync of the level),
-    so that a caller can do other work while the candidate / sort / unique kernels run (RulebookPipeline)"""
+    so that a caller can do other work while the candidate / sort / unique kernels run (RulebookPipeline).
+    ``m_out``: the count known on the host (level_voxel_counts): no read, no yield; the device count is kept for
+    ``verify_pending_counts``."""
     _n.require_cuda(indices)
     _check_indices(indices)
     lib = _n.hip()
@@ -267,8 +331,14 @@ def _down_rulebook_gen(indices, spatial_shape, ksize, stride, padding, deferred=
     _n.check(lib.wsis_rulebook_down_keys(_n.ptr(indices), M_in, in3, out3, k3, s3, p3, _n.ptr(cand),
                                          _n.ptr(out_keys), _n.ptr(count), _n.ptr(ws), ws_bytes, st),
              "rulebook_down_keys")
-    yield
-    M_out = int(count.item())   # the one host sync per level (upstream has the same one)
+    if m_out is not None:
+        M_out = int(m_out)
+        ev = torch.cuda.Event()
+        ev.record()                      # behind the kernel that wrote ``count`` on the building stream
+        _PENDING_COUNTS.append((count, M_out, ev))
+    else:
+        yield
+        M_out = int(count.item())   # the one host sync per level (upstream has the same one)
     out_indices = torch.empty((M_out, 4), dtype=torch.int32, device=dev)
     cap = _pow2_cap(M_out)
     keys = torch.empty(cap, dtype=torch.int64, device=dev)
@@ -526,6 +596,9 @@ def _build_pyramid_gen(tensor, n_levels, subm_key, down_key, first_id):
     batch_size = int(getattr(tensor, "batch_size", 0) or 0)
     deferred = [] if _tile_batch_enabled(batch_size) else None
     new_rbs = []
+    hints = getattr(tensor, "_level_counts", None)
+    if hints is not None and (len(hints) != n_levels - 1 or os.environ.get("WSIS_LEVEL_COUNTS", "1") == "0"):
+        hints = None
     for lvl in range(n_levels):
         kid = first_id + lvl
         key = subm_key.format(kid)
@@ -542,7 +615,8 @@ def _build_pyramid_gen(tensor, n_levels, subm_key, down_key, first_id):
             dkey = down_key.format(kid)
             rb = tensor.indice_dict.get(dkey)
             if rb is None:
-                rb = yield from _down_rulebook_gen(indices, shape, [2, 2, 2], [2, 2, 2], [0, 0, 0], deferred=deferred)
+                rb = yield from _down_rulebook_gen(indices, shape, [2, 2, 2], [2, 2, 2], [0, 0, 0], deferred=deferred,
+                                                   m_out=hints[lvl] if hints is not None else None)
                 tensor.indice_dict[dkey] = rb
                 new_rbs.append(rb)
             indices, shape, hash_tab = rb.out_indices, rb.out_shape, rb.out_hash
@@ -583,6 +657,7 @@ def prebuild_unet_rulebooks(tensor, n_levels, subm_key="subm{}", down_key="spcon
         else:
             side.wait_stream(main)
     with ctx:
+        verify_pending_counts()      # counts of the PREVIOUS build that was sized from host values (long finished)
         built = _build_pyramid(tensor, n_levels, subm_key, down_key, first_id)
     if side is not None:
         main.wait_stream(side)

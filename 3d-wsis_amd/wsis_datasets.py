@@ -253,6 +253,13 @@ class ScenePrep(object):
                 torch.from_numpy(infos["instance_info"]), infos["instance_pointnum"])
 
 
+def _level_counts(voxel_locs, spatial_shape, n_levels=5):
+    """host-side voxel counts of the UNet's strided levels (config ``blocks`` = 5); the device rulebook build sizes
+    its tables from them instead of reading the counts back (spconv.ops.level_voxel_counts)"""
+    import spconv
+    return spconv.ops.level_voxel_counts(voxel_locs.numpy(), spatial_shape, n_levels)
+
+
 def collate_fn(batch, full_scale_min=128, mode=4):
     """``collate_fn`` (:343-474): list of ``ScenePrep`` 12-tuples -> batch dict."""
     import pointgroup_ops
@@ -312,6 +319,7 @@ def collate_fn(batch, full_scale_min=128, mode=4):
         "superpoint": superpoint, "GIs": GIs, "sp_batch_offsets": torch.tensor(sp_batch_offsets, dtype=torch.int),
         "edge_u_list": edges[:, 0].contiguous().long(), "edge_v_list": edges[:, 1].contiguous().long(),
         "edge_src_rows": (int(edges[:, 0].max()) + 1) if edges.shape[0] else 0,   # rows of scatter(.., edge_u)
+        "level_counts": _level_counts(voxel_locs, spatial_shape),      # active voxels of the strided UNet levels
         "is1ins_labels": torch.cat(is1ins, 0),
         "superpoint_semantic_labels": torch.cat(sp_sem, 0).long(),
         "superpoint_instance_labels": torch.cat(sp_ins, 0).long(),

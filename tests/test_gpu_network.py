@@ -482,3 +482,44 @@ def test_batched_tile_order_equals_the_per_table_orders(monkeypatch, n_scenes):
         for o in (rb.order, rb.order_up):
             if o is not None:
                 assert torch.equal(torch.sort(o.long())[0], torch.arange(o.numel(), device="cuda"))
+
+
+@pytest.mark.gpu
+def test_rulebooks_sized_from_host_counts_equal_the_read_back_build(monkeypatch):
+    """prebuild_unet_rulebooks with the batch's host-side ``level_counts`` (no device read-back, no host stop) builds the
+    tables of the default path bit for bit; the device counts are verified at the next build, and a wrong hint is
+    reported there."""
+    import spconv
+    from spconv import ops
+    import wsis_native as _n
+    bt = harness.to_device(harness.collate([harness.make_scene(17, room=(2.0, 1.7, 1.2), n_box=3),
+                                            harness.make_scene(18, room=(1.6, 1.3, 1.0), n_box=2)]), "cuda")
+    shape, idx = bt["spatial_shape"], bt["voxel_coords_int"]
+    feats = torch.zeros(idx.shape[0], 1, device="cuda")
+
+    def build(counts):
+        t = spconv.SparseConvTensor(feats, idx, shape, 2)
+        if counts is not None:
+            t._level_counts = counts
+        ops.prebuild_unet_rulebooks(t, 5)
+        torch.cuda.synchronize()
+        return t.indice_dict
+
+    ref = build(None)
+    assert len(bt["level_counts"]) == 4
+    hinted = build(bt["level_counts"])
+    assert len(ops._PENDING_COUNTS) == 4
+    for key, rb in ref.items():
+        other = hinted[key]
+        for name in ("nbr", "nbr_up", "order", "order_up", "nbr_p", "nbr_up_p", "out_indices"):
+            a, b = getattr(rb, name, None), getattr(other, name, None)
+            assert (a is None) == (b is None), (key, name)
+            if a is not None:
+                assert torch.equal(a, b), (key, name)
+    ops.verify_pending_counts()
+    assert not ops._PENDING_COUNTS
+    wrong = list(bt["level_counts"])
+    wrong[2] -= 1
+    build(wrong)
+    with pytest.raises(_n.WsisError):
+        ops.verify_pending_counts()

@@ -93,3 +93,23 @@ def test_pair_table_roundtrip():
     for k in range(K):
         o = np.nonzero(nbr[k] >= 0)[0]
         assert np.array_equal(nbr[K - 1 - k][nbr[k][o]], o)
+
+
+# ---------------------------------------------------------------- host-side voxel counts of the strided levels
+@pytest.mark.parametrize("shape,seed", [((9, 8, 7), 0), ((16, 16, 16), 1), ((13, 21, 6), 2), ((33, 5, 17), 3)])
+def test_level_voxel_counts_equal_the_oracle_pyramid(shape, seed):
+    """spconv.ops.level_voxel_counts (what a loader puts in the batch so that the device rulebook build does not read
+    the counts back) against the oracle's SparseConv3d k2 s2 p0 chain, incl. odd extents (the last plane has no
+    output voxel) and several batch items."""
+    import importlib
+    importlib.import_module("3d-wsis_amd")
+    import spconv
+    idx = random_sparse_coords(seed, batch=3, shape=shape, density=0.25)
+    levels = 4
+    got = spconv.ops.level_voxel_counts(idx, shape, levels)
+    want, cur, cur_shape = [], idx.astype(np.int64), list(shape)
+    for _ in range(levels - 1):
+        out_idx, out_shape, _ = ref.down_pairs_fast(cur, cur_shape, 2, 2, 0)
+        want.append(len(out_idx))
+        cur, cur_shape = out_idx, list(out_shape)
+    assert got == want and len(got) == levels - 1
