@@ -201,7 +201,8 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void gru_bwd_kernel(
     }
     // dxin[j] = sum_o Wih[o][j] dgi[o],  dh[j] += sum_o Whh[o][j] dgh[o]    (lane j = c; halves split o)
     float dxin = 0.f, dhh = 0.f;
-#pragma unroll 8
+#pragma unroll     // fully: aWih / aWhh must be indexed by constants to stay in registers (a partial unroll put the 96
+                   // accumulators into scratch memory: 400 bytes per thread, a load + store per accumulate)
     for (int t = 0; t < 48; ++t) {
       const int o = hi + 2 * t;
       const float gi_o = dgi[o], gh_o = dgh[o];
