@@ -160,18 +160,18 @@ __device__ __forceinline__ void bn_finish_centred(double S, double Q, double W, 
   }
 }
 
-// grid (G, ceil(C / 32)), 256 threads = 32 channel lanes x 8 partial lanes; G == 1 finishes in place
-__global__ __launch_bounds__(256) void bn_stats_chunk_centred_kernel(const float* __restrict__ partial, int nblk, int C,
-                                                                     int64_t M, double* __restrict__ chunk,
-                                                                     float* __restrict__ mean, float* __restrict__ var,
-                                                                     float* __restrict__ running_mean,
-                                                                     float* __restrict__ running_var, float momentum,
-                                                                     unsigned* __restrict__ ticket) {
-  __shared__ double red[3][8][33];
+// chunk g of G for channel group cgi: 256 threads = 32 channel lanes x 8 partial lanes; G == 1 finishes in place.
+// Returns true in the workgroup that wrote the final mean / var of the channel group (G == 1, or the last arrival).
+__device__ __forceinline__ bool bn_chunk_centred_stage(const float* __restrict__ partial, int nblk, int C, int64_t M,
+                                                       double* __restrict__ chunk, float* __restrict__ mean,
+                                                       float* __restrict__ var, float* __restrict__ running_mean,
+                                                       float* __restrict__ running_var, float momentum,
+                                                       unsigned* __restrict__ ticket, int g0, int G, int cgi,
+                                                       double (&red)[3][8][33], int& s_last) {
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-  const int c = blockIdx.y * 32 + cl;
-  const int per = (nblk + gridDim.x - 1) / gridDim.x;
-  const int lo = blockIdx.x * per;
+  const int c = cgi * 32 + cl;
+  const int per = (nblk + G - 1) / G;
+  const int lo = g0 * per;
   const int hi = lo + per < nblk ? lo + per : nblk;
   double s = 0.0, q = 0.0, w = 0.0;
   if (c < C) {
@@ -198,30 +198,29 @@ __global__ __launch_bounds__(256) void bn_stats_chunk_centred_kernel(const float
       Q += red[1][j][cl];
       W += red[2][j][cl];
     }
-    if (gridDim.x == 1) {
+    if (G == 1) {
       bn_finish_centred(S, Q, W, M, c, mean, var, running_mean, running_var, momentum);
     } else {
-      double* o = chunk + (int64_t)blockIdx.x * 3 * C;
+      double* o = chunk + (int64_t)g0 * 3 * C;
       o[c] = S;
       o[C + c] = Q;
       o[2 * C + c] = W;
     }
   }
-  if (gridDim.x == 1 || !ticket) return;
+  if (G == 1) return true;
+  if (!ticket) return false;
   // ---- the workgroup that arrives last (per channel group) adds the chunks, always in chunk order: one launch instead
   // of two.  Release / acquire at agent scope around the ticket (the chunk rows come from other XCDs' L2s).
-  __shared__ int s_last;
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(ticket + blockIdx.y, 1u);
-    s_last = t == gridDim.x - 1;
-    if (s_last) ticket[blockIdx.y] = 0u;          // self-cleaning: ready for the next launch on this stream
+    const unsigned t = atomicAdd(ticket + cgi, 1u);
+    s_last = t == (unsigned)G - 1;
+    if (s_last) ticket[cgi] = 0u;          // self-cleaning: ready for the next launch on this stream
   }
   __syncthreads();
-  if (!s_last) return;
+  if (!s_last) return false;
   __threadfence();
-  const int G = gridDim.x;
   double s2 = 0.0, q2 = 0.0, w2 = 0.0;
   if (c < C)
     for (int g = pl; g < G; g += 8) {
@@ -245,6 +244,20 @@ __global__ __launch_bounds__(256) void bn_stats_chunk_centred_kernel(const float
     }
     bn_finish_centred(S, Q, W, M, c, mean, var, running_mean, running_var, momentum);
   }
+  return true;
+}
+
+// grid (G, ceil(C / 32))
+__global__ __launch_bounds__(256) void bn_stats_chunk_centred_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                                     int64_t M, double* __restrict__ chunk,
+                                                                     float* __restrict__ mean, float* __restrict__ var,
+                                                                     float* __restrict__ running_mean,
+                                                                     float* __restrict__ running_var, float momentum,
+                                                                     unsigned* __restrict__ ticket) {
+  __shared__ double red[3][8][33];
+  __shared__ int s_last;
+  bn_chunk_centred_stage(partial, nblk, C, M, chunk, mean, var, running_mean, running_var, momentum, ticket,
+                         (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, red, s_last);
 }
 
 // one wavefront per channel: lane g holds chunk g (G <= 64), fixed butterfly
@@ -263,10 +276,20 @@ __global__ __launch_bounds__(256) void bn_stats_final_centred_kernel(const doubl
   if (lane == 0) bn_finish_centred(S, Q, W, M, c, mean, var, running_mean, running_var, momentum);
 }
 
-__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
-                                const float* __restrict__ var, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, float eps, int relu, float* __restrict__ y,
-                                int64_t M, int C) {
+// COHERENT: mean / var were written by other workgroups of THIS launch (bn_finalize_apply_kernel): they are read with
+// agent-scope loads, which do not hit stale lines of this XCD's L2 -- cheaper than an acquire fence, whose L2 invalidate
+// is serialised over the waiting workgroups of an XCD (measured: + 50 ns per waiting workgroup)
+template <bool COHERENT>
+__device__ __forceinline__ float bn_ld_stat(const float* p) {
+  if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+
+template <bool COHERENT>
+__device__ __forceinline__ void bn_apply_body(const float* __restrict__ x, const float* mean,
+                                              const float* var, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, float eps, int relu,
+                                              float* __restrict__ y, int64_t M, int C) {
   const int64_t total = M * C;
   if ((C & 3) == 0) {
     const int64_t total4 = total >> 2;
@@ -280,8 +303,8 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int c = (int)g * 4 + e;
-        sc[e] = (gamma ? gamma[c] : 1.0f) * rsqrtf(var[c] + eps);
-        mu[e] = mean[c];
+        sc[e] = (gamma ? gamma[c] : 1.0f) * rsqrtf(bn_ld_stat<COHERENT>(var + c) + eps);
+        mu[e] = bn_ld_stat<COHERENT>(mean + c);
         bt[e] = beta ? beta[c] : 0.0f;
       }
     };
@@ -316,12 +339,60 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * blockDim.x) {
       const int c = (int)(t % C);
-      const float sc = (gamma ? gamma[c] : 1.0f) * rsqrtf(var[c] + eps);
-      float z = (x[t] - mean[c]) * sc + (beta ? beta[c] : 0.0f);
+      const float sc = (gamma ? gamma[c] : 1.0f) * rsqrtf(bn_ld_stat<COHERENT>(var + c) + eps);
+      float z = (x[t] - bn_ld_stat<COHERENT>(mean + c)) * sc + (beta ? beta[c] : 0.0f);
       if (relu) z = fmaxf(z, 0.0f);
       y[t] = z;
     }
   }
+}
+
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                const float* __restrict__ var, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float eps, int relu, float* __restrict__ y,
+                                int64_t M, int C) {
+  bn_apply_body<false>(x, mean, var, gamma, beta, eps, relu, y, M, C);
+}
+
+// ---- statistics finish + apply in ONE launch.  The first G * ceil(C/32) workgroups run the chunk stage of
+// bn_stats_chunk_centred_kernel (tickets included); the workgroup that completes the last channel group publishes the
+// launch's epoch in `flag`; every workgroup waits for it and then applies.  The grid is at most 512 workgroups of 256
+// threads (two per CU): all of them are resident, the waiting ones cannot keep the working ones off the machine.
+// Same arithmetic as the two launches (bn_stats_chunk_centred_kernel, bn_apply_kernel): identical results.
+constexpr int BN_POLL_SLEEP = 12;      // x 64 cycles
+__device__ unsigned g_bn_flag[16];
+__device__ unsigned g_bn_done[16];
+
+__global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
+    const float* __restrict__ partial, int nblk, int C, int64_t M, double* __restrict__ chunk, int G,
+    float* mean, float* var, float* __restrict__ running_mean,
+    float* __restrict__ running_var, float momentum, unsigned* __restrict__ ticket, unsigned* __restrict__ done,
+    unsigned* __restrict__ flag, unsigned epoch, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, int relu, float* __restrict__ y) {
+  __shared__ double red[3][8][33];
+  __shared__ int s_last;
+  const int CG = (C + 31) / 32;
+  if ((int)blockIdx.x < G * CG) {
+    const bool fin = bn_chunk_centred_stage(partial, nblk, C, M, chunk, mean, var, running_mean, running_var, momentum,
+                                            ticket, (int)blockIdx.x % G, G, (int)blockIdx.x / G, red, s_last);
+    if (fin) {               // this workgroup wrote mean / var of one channel group; the last such group publishes
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const unsigned d = atomicAdd(done, 1u);
+        if (d == (unsigned)CG - 1) {
+          *done = 0u;
+          __threadfence();
+          __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+  if (threadIdx.x == 0) {     // relaxed polls a few hundred ns apart (hundreds of pollers on one word), ONE acquire at the end
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(BN_POLL_SLEEP);
+  }
+  __syncthreads();
+  bn_apply_body<true>(x, mean, var, gamma, beta, eps, relu, y, M, C);
 }
 
 // backward pass 1: per-workgroup partial (sum dz, sum dz*xhat) per channel.  partial [nblk][2][Cp]
@@ -898,6 +969,76 @@ int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, i
                        d_mean, d_var, d_running_mean, d_running_var, momentum);
     WSIS_LAUNCH_CHECK();
   }
+  return WSIS_OK;
+}
+
+int wsis_bn_stats_finalize_apply(const float* d_partials, int64_t n_part, int64_t M, int32_t C, float* d_mean,
+                                 float* d_var, float* d_running_mean, float* d_running_var, float momentum,
+                                 const float* d_x, const float* d_gamma, const float* d_beta, float eps, int32_t relu,
+                                 float* d_y, void* d_ws, int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(n_part >= 1 && M >= 1 && C >= 1 && d_partials && d_mean && d_var && d_x && d_y, "bad args");
+  WSIS_REQUIRE(n_part == (M + 31) / 32 && n_part < ((int64_t)1 << 31), "one partial per 32-row slice");
+  WSIS_REQUIRE(C <= 512, "more than 512 channels");
+  hipStream_t st = as_stream(stream);
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("WSIS_BN_FUSED_APPLY");
+    on = e ? atoi(e) : 1;
+  }
+  const int G = bn_fin_chunks(n_part);
+  const int CG = (C + 31) / 32;
+  WSIS_REQUIRE(G == 1 || (d_ws && ws_bytes >= wsis_bn_stats_finalize_workspace_bytes(n_part, C)), "workspace too small");
+  double* chunk = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(d_ws) + 255) & ~(uintptr_t)255);
+  unsigned* tickets = bn_tickets(0, chunk);
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+  // the one-launch form needs: the ticket path (G > 1), every workgroup resident (<= 512), vector rows, and eager
+  // launches (its epoch is a launch argument: a replayed graph would carry a stale one)
+  const int cw = C >> 2;
+  static int gmax = -1;
+  if (gmax < 0) {
+    const char* e = getenv("WSIS_BN_FUSED_GRID");
+    gmax = e ? atoi(e) : 256;
+    if (gmax < 64 || gmax > 512) gmax = 256;
+  }
+  const int64_t work = (M * C) >> 2;
+  static int n_cu = -1;
+  if (n_cu < 0) {      // every workgroup of the launch must be resident: at most two per CU of THIS device / partition
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+  }
+  int gcap = (work > 600000 && gmax == 256) ? 512 : gmax;     // level 0: two workgroups per CU for the apply pass
+  if (gcap > 2 * n_cu) gcap = 2 * n_cu;
+  if (gcap < 1) gcap = 1;
+  int grid = gcap - (gcap % (cw > 0 ? cw : 1));
+  const int need = grid_for(work, 256);
+  if (need < grid) {
+    grid = need;
+    if (grid > cw) grid -= grid % cw;
+  }
+  const bool fused = on && (C & 3) == 0 && (G == 1 || tickets) && cap == hipStreamCaptureStatusNone &&
+                     grid >= G * CG && grid >= 1;
+  if (!fused) {
+    const int rc = wsis_bn_stats_finalize(d_partials, n_part, M, C, d_mean, d_var, d_running_mean, d_running_var, momentum,
+                                          d_ws, ws_bytes, stream);
+    if (rc != WSIS_OK) return rc;
+    return wsis_bn_apply(d_x, d_mean, d_var, d_gamma, d_beta, eps, relu, d_y, M, C, stream);
+  }
+  static unsigned* flag_base = nullptr;
+  static unsigned* done_base = nullptr;
+  static unsigned epochs[16] = {0};
+  if (!flag_base) {
+    WSIS_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&flag_base), HIP_SYMBOL(g_bn_flag)));
+    WSIS_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&done_base), HIP_SYMBOL(g_bn_done)));
+  }
+  const int slot = (int)((reinterpret_cast<uintptr_t>(chunk) >> 8) & 15);
+  unsigned epoch = ++epochs[slot];
+  if (epoch == 0) epoch = ++epochs[slot];       // 0 is the flag's initial value
+  hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(grid), dim3(256), 0, st, d_partials, (int)n_part, (int)C, M, chunk, G,
+                     d_mean, d_var, d_running_mean, d_running_var, momentum, tickets ? tickets : done_base + slot,
+                     done_base + slot, flag_base + slot, epoch, d_x, d_gamma, d_beta, eps, (int)relu, d_y);
+  WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }
 

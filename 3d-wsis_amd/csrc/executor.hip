@@ -400,6 +400,14 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
             // the producers' epilogues left (sum, sum of squares) partials per 32-row slice: no pass over x
             const int64_t n_part = (op.M_in + 31) / 32;
             const int C0 = op.in[6] ? op.K : op.Cin;
+            if (!op.in[6]) {     // one producer: statistics finish and apply pass in one launch (falls back by itself)
+              rc = wsis_bn_stats_finalize_apply((const float*)op.in[5], n_part, op.M_in, op.Cin, (float*)op.out[1],
+                                                (float*)op.out[2], rm, rv, op.momentum, (const float*)op.in[0],
+                                                (const float*)op.in[1], (const float*)op.in[2], op.eps,
+                                                (op.flags & WSIS_OPF_RELU) ? 1 : 0, (float*)op.out[0], ws, ws_bytes,
+                                                stream);
+              break;
+            }
             rc = wsis_bn_stats_finalize((const float*)op.in[5], n_part, op.M_in, C0, (float*)op.out[1],
                                         (float*)op.out[2], rm, rv, op.momentum, ws, ws_bytes, stream);
             if (rc == WSIS_OK && op.in[6])

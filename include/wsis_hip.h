@@ -254,6 +254,14 @@ int64_t wsis_bn_stats_finalize_workspace_bytes(int64_t n_part, int32_t C);
 int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, int32_t C, float* d_mean, float* d_var,
                            float* d_running_mean, float* d_running_var, float momentum, void* d_ws, int64_t ws_bytes,
                            void* stream);
+/* wsis_bn_stats_finalize followed by wsis_bn_apply (y = relu?((x - mean) * gamma / sqrt(var + eps) + beta)) as ONE
+ * launch where that is possible (eager launch, C % 4 == 0, a grid of <= 512 resident workgroups): the workgroups that
+ * finish the statistics publish them, all wait for that and apply.  Identical results to the two calls, which it makes
+ * itself otherwise (WSIS_BN_FUSED_APPLY=0, stream capture, odd shapes).  Same workspace as wsis_bn_stats_finalize. */
+int wsis_bn_stats_finalize_apply(const float* d_partials, int64_t n_part, int64_t M, int32_t C, float* d_mean,
+                                 float* d_var, float* d_running_mean, float* d_running_var, float momentum,
+                                 const float* d_x, const float* d_gamma, const float* d_beta, float eps, int32_t relu,
+                                 float* d_y, void* d_ws, int64_t ws_bytes, void* stream);
 /* backward of the fused BN(+ReLU) when dy was produced by wsis_spconv_fwd_t_bn: d_partials holds the n_part =
  * ceil(M / 32) rows of (sum dz, sum dz * xhat) slice partials (pitch 2*C floats) that the convolution's epilogue wrote,
  * so the reduction pass over x and dy of wsis_bn_bwd is replaced by an fp64 sum of the partials (fixed order, chunk

@@ -1189,3 +1189,54 @@ def test_batch_graphs_built_on_the_side_stream_equal_the_in_stream_build(monkeyp
     main = snap()
     for (p0, o0), (p1, o1) in zip(side, main):
         assert torch.equal(p0, p1) and torch.equal(o0, o1)
+
+
+# ---------------------------------------------------------------- BatchNorm: statistics finish + apply in one launch
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,C", [(153685, 32), (40003, 64), (12011, 96), (3300, 128), (1100, 160), (70, 32), (200000, 256)])
+def test_bn_finalize_apply_in_one_launch_equals_the_two_calls(M, C):
+    """wsis_bn_stats_finalize_apply (chunk stage + tickets, epoch flag, apply by the waiting workgroups) against
+    wsis_bn_stats_finalize followed by wsis_bn_apply on the same slice partials: mean, var, running statistics and y bit
+    for bit, twice in a row (the flag / ticket / done counters are ready for the next launch), and y against torch."""
+    import wsis_native as _n
+    lib = _n.hip()
+    g = torch.Generator(device=DEV).manual_seed(M + C)
+    x = torch.randn(M, C, device=DEV, generator=g) * 1.7 + 0.3
+    gamma, beta = torch.rand(C, device=DEV, generator=g) + 0.5, torch.randn(C, device=DEV, generator=g)
+    n_part = (M + 31) // 32
+    pad = n_part * 32 - M
+    xp = torch.cat([x, torch.zeros(pad, C, device=DEV)]) if pad else x
+    blocks = xp.view(n_part, 32, C)
+    cnt = torch.full((n_part, 1), 32.0, device=DEV)
+    cnt[-1] = 32 - pad
+    s = blocks.sum(1)
+    mask = (torch.arange(n_part * 32, device=DEV) < M).view(n_part, 32, 1).float()
+    q = (((blocks - (s / cnt).unsqueeze(1)) * mask) ** 2).sum(1)
+    partial = torch.stack([s, q], 1).contiguous()                     # [n_part, 2, C]
+    ws_bytes = lib.wsis_bn_stats_finalize_workspace_bytes(n_part, C)
+    st = _n.stream_ptr()
+
+    def run(fused):
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+        mean, var = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        y = torch.empty_like(x)
+        if fused:
+            _n.check(lib.wsis_bn_stats_finalize_apply(_n.ptr(partial), n_part, M, C, _n.ptr(mean), _n.ptr(var), _n.ptr(rm),
+                                                      _n.ptr(rv), 0.1, _n.ptr(x), _n.ptr(gamma), _n.ptr(beta), 1e-4, 1,
+                                                      _n.ptr(y), _n.ptr(ws), ws_bytes, st), "fused")
+        else:
+            _n.check(lib.wsis_bn_stats_finalize(_n.ptr(partial), n_part, M, C, _n.ptr(mean), _n.ptr(var), _n.ptr(rm),
+                                                _n.ptr(rv), 0.1, _n.ptr(ws), ws_bytes, st), "finalize")
+            _n.check(lib.wsis_bn_apply(_n.ptr(x), _n.ptr(mean), _n.ptr(var), _n.ptr(gamma), _n.ptr(beta), 1e-4, 1,
+                                       _n.ptr(y), M, C, st), "apply")
+        torch.cuda.synchronize()
+        return mean, var, rm, rv, y
+
+    ref = run(False)
+    for _ in range(3):
+        got = run(True)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
+    want = torch.relu(torch.nn.functional.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-4))
+    assert torch.allclose(ref[4], want, rtol=1e-4, atol=1e-4)
