@@ -360,8 +360,8 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 // threads (two per CU): all of them are resident, the waiting ones cannot keep the working ones off the machine.
 // Same arithmetic as the two launches (bn_stats_chunk_centred_kernel, bn_apply_kernel): identical results.
 constexpr int BN_POLL_SLEEP = 12;      // x 64 cycles
-__device__ unsigned g_bn_flag[16];
-__device__ unsigned g_bn_done[16];
+__device__ unsigned g_bn_flag[2][16];      // [forward, backward][slot]
+__device__ unsigned g_bn_done[2][16];
 
 __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
     const float* __restrict__ partial, int nblk, int C, int64_t M, double* __restrict__ chunk, int G,
@@ -495,14 +495,14 @@ __global__ __launch_bounds__(64) void bn_bwd_final_kernel(const float* __restric
 // the reduction of the backward pass from per-slice partials (sum dz, sum dz * xhat) written by the epilogue of the
 // dIn convolution that produced dy (wsis_spconv_fwd_t_bn): fp64 sums in a fixed order, two levels like the forward
 // statistics.  grid (G, ceil(C / 32)), 256 threads = 32 channel lanes x 8 partial lanes; G == 1 writes the result.
-__global__ __launch_bounds__(256) void bn_sum_chunk_kernel(const float* __restrict__ partial, int nblk, int C,
-                                                           double* __restrict__ chunk, float* __restrict__ dbeta,
-                                                           float* __restrict__ dgamma, unsigned* __restrict__ ticket) {
-  __shared__ double red[2][8][33];
+__device__ __forceinline__ bool bn_sum_chunk_stage(const float* __restrict__ partial, int nblk, int C,
+                                                   double* __restrict__ chunk, float* dbeta, float* dgamma,
+                                                   unsigned* __restrict__ ticket, int g0, int G, int cgi,
+                                                   double (&red)[2][8][33], int& s_last) {
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
-  const int c = blockIdx.y * 32 + cl;
-  const int per = (nblk + gridDim.x - 1) / gridDim.x;
-  const int lo = blockIdx.x * per;
+  const int c = cgi * 32 + cl;
+  const int per = (nblk + G - 1) / G;
+  const int lo = g0 * per;
   const int hi = lo + per < nblk ? lo + per : nblk;
   double a = 0.0, b = 0.0;
   if (c < C) {
@@ -522,28 +522,27 @@ __global__ __launch_bounds__(256) void bn_sum_chunk_kernel(const float* __restri
       A += red[0][j][cl];
       B += red[1][j][cl];
     }
-    if (gridDim.x == 1) {
+    if (G == 1) {
       dbeta[c] = (float)A;
       dgamma[c] = (float)B;
     } else {
-      chunk[(int64_t)blockIdx.x * 2 * C + c] = A;
-      chunk[(int64_t)blockIdx.x * 2 * C + C + c] = B;
+      chunk[(int64_t)g0 * 2 * C + c] = A;
+      chunk[(int64_t)g0 * 2 * C + C + c] = B;
     }
   }
-  if (gridDim.x == 1 || !ticket) return;
-  // the last workgroup to arrive adds the chunks in chunk order (see bn_stats_chunk_centred_kernel)
-  __shared__ int s_last;
+  if (G == 1) return true;
+  if (!ticket) return false;
+  // the last workgroup to arrive adds the chunks in chunk order (see bn_chunk_centred_stage)
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(ticket + blockIdx.y, 1u);
-    s_last = t == gridDim.x - 1;
-    if (s_last) ticket[blockIdx.y] = 0u;
+    const unsigned t = atomicAdd(ticket + cgi, 1u);
+    s_last = t == (unsigned)G - 1;
+    if (s_last) ticket[cgi] = 0u;
   }
   __syncthreads();
-  if (!s_last) return;
+  if (!s_last) return false;
   __threadfence();
-  const int G = gridDim.x;
   double a2 = 0.0, b2 = 0.0;
   if (c < C)
     for (int g = pl; g < G; g += 8) {
@@ -565,6 +564,16 @@ __global__ __launch_bounds__(256) void bn_sum_chunk_kernel(const float* __restri
     dbeta[c] = (float)A;
     dgamma[c] = (float)B;
   }
+  return true;
+}
+
+__global__ __launch_bounds__(256) void bn_sum_chunk_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                           double* __restrict__ chunk, float* __restrict__ dbeta,
+                                                           float* __restrict__ dgamma, unsigned* __restrict__ ticket) {
+  __shared__ double red[2][8][33];
+  __shared__ int s_last;
+  bn_sum_chunk_stage(partial, nblk, C, chunk, dbeta, dgamma, ticket, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, red,
+                     s_last);
 }
 
 __global__ __launch_bounds__(256) void bn_sum_final_kernel(const double* __restrict__ chunk, int G, int C,
@@ -582,12 +591,13 @@ __global__ __launch_bounds__(256) void bn_sum_final_kernel(const double* __restr
 }
 
 // backward pass 2: dx = gamma*rstd*(dz - dbeta/M - xhat*dgamma/M)  (training);  gamma*rstd*dz (eval)
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                    const float* __restrict__ mean, const float* __restrict__ var,
-                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                    const float* __restrict__ addend, float eps, int relu, int training,
-                                    float* __restrict__ dx, int64_t M, int C) {
+template <bool COHERENT>     // COHERENT: dgamma / dbeta come from other workgroups of this launch (see bn_apply_body)
+__device__ __forceinline__ void bn_bwd_apply_body(const float* __restrict__ x, const float* __restrict__ dy,
+                                                  const float* __restrict__ mean, const float* __restrict__ var,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  const float* dgamma, const float* dbeta,
+                                                  const float* __restrict__ addend, float eps, int relu, int training,
+                                                  float* __restrict__ dx, int64_t M, int C) {
   const int64_t total = M * C;
   const float inv_m = 1.0f / (float)M;
   const bool vec = (C & 3) == 0;
@@ -609,8 +619,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
         rstd[e] = rsqrtf(var[c] + eps);
         gm[e] = gamma ? gamma[c] : 1.0f;
         bt[e] = beta ? beta[c] : 0.0f;
-        k1[e] = training ? dbeta[c] * inv_m : 0.0f;
-        k2[e] = training ? dgamma[c] * inv_m : 0.0f;
+        k1[e] = training ? bn_ld_stat<COHERENT>(dbeta + c) * inv_m : 0.0f;
+        k2[e] = training ? bn_ld_stat<COHERENT>(dgamma + c) * inv_m : 0.0f;
       }
     }
   };
@@ -674,6 +684,49 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
     else
       dx[t] = ov[0];
   }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                    const float* __restrict__ mean, const float* __restrict__ var,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                    const float* __restrict__ addend, float eps, int relu, int training,
+                                    float* __restrict__ dx, int64_t M, int C) {
+  bn_bwd_apply_body<false>(x, dy, mean, var, gamma, beta, dgamma, dbeta, addend, eps, relu, training, dx, M, C);
+}
+
+// reduction finish + apply of the backward pass in ONE launch: the form of bn_finalize_apply_kernel (chunk stage and
+// tickets in the first G * ceil(C/32) workgroups, epoch flag, every workgroup waits and applies)
+__global__ __launch_bounds__(256) void bn_bwd_finish_apply_kernel(
+    const float* __restrict__ partial, int nblk, int C, double* __restrict__ chunk, int G, float* dbeta, float* dgamma,
+    unsigned* __restrict__ ticket, unsigned* __restrict__ done, unsigned* __restrict__ flag, unsigned epoch,
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ addend, float eps, int relu, float* __restrict__ dx, int64_t M) {
+  __shared__ double red[2][8][33];
+  __shared__ int s_last;
+  const int CG = (C + 31) / 32;
+  if ((int)blockIdx.x < G * CG) {
+    const bool fin = bn_sum_chunk_stage(partial, nblk, C, chunk, dbeta, dgamma, ticket, (int)blockIdx.x % G, G,
+                                        (int)blockIdx.x / G, red, s_last);
+    if (fin) {
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const unsigned d = atomicAdd(done, 1u);
+        if (d == (unsigned)CG - 1) {
+          *done = 0u;
+          __threadfence();
+          __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(BN_POLL_SLEEP);
+  }
+  __syncthreads();
+  bn_bwd_apply_body<true>(x, dy, mean, var, gamma, beta, dgamma, dbeta, addend, eps, relu, 1, dx, M, C);
 }
 
 // ---- small inputs (M <= bn_small_rows): the whole reduction in ONE launch, one workgroup per channel group of 4.
@@ -972,6 +1025,61 @@ int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, i
   return WSIS_OK;
 }
 
+// flag / done words and the epoch of one producer-consumer launch (which: 0 forward, 1 backward; the slot follows the
+// workspace address like the ticket rows).  Epochs of a slot only grow, 0 is the words' initial value.
+struct BnSync {
+  unsigned* flag;
+  unsigned* done;
+  unsigned epoch;
+};
+static bool bn_sync_for(int which, const void* chunk, BnSync* out) {
+  static unsigned* flag_base = nullptr;
+  static unsigned* done_base = nullptr;
+  static unsigned epochs[2][16] = {{0}};
+  if (!flag_base) {
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&flag_base), HIP_SYMBOL(g_bn_flag)) != hipSuccess) return false;
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&done_base), HIP_SYMBOL(g_bn_done)) != hipSuccess) return false;
+  }
+  const int slot = (int)((reinterpret_cast<uintptr_t>(chunk) >> 8) & 15);
+  unsigned e = ++epochs[which][slot];
+  if (e == 0) e = ++epochs[which][slot];
+  out->flag = flag_base + which * 16 + slot;
+  out->done = done_base + which * 16 + slot;
+  out->epoch = e;
+  return true;
+}
+
+// grid of a producer-consumer launch over M x C elements: every workgroup resident (<= 2 per CU of this device),
+// a multiple of the channel groups; 0 when the one-launch form does not apply
+static int bn_fused_grid(int64_t M, int C, int need_chunk_wgs, hipStream_t st) {
+  static int on = -1, gmax = -1, n_cu = -1;
+  if (on < 0) {
+    const char* e = getenv("WSIS_BN_FUSED_APPLY");
+    on = e ? atoi(e) : 1;
+    const char* g = getenv("WSIS_BN_FUSED_GRID");
+    gmax = g ? atoi(g) : 256;
+    if (gmax < 64 || gmax > 512) gmax = 256;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+  }
+  if (!on || (C & 3) != 0) return 0;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 0;   // epoch = launch argument
+  const int cw = C >> 2;
+  const int64_t work = (M * C) >> 2;
+  int gcap = (work > 600000 && gmax == 256) ? 512 : gmax;     // level 0: two workgroups per CU for the apply pass
+  if (gcap > 2 * n_cu) gcap = 2 * n_cu;
+  if (gcap < 1) return 0;
+  int grid = gcap - (gcap % cw);
+  const int need = grid_for(work, 256);
+  if (need < grid) {
+    grid = need;
+    if (grid > cw) grid -= grid % cw;
+  }
+  return (grid >= need_chunk_wgs && grid >= 1) ? grid : 0;
+}
+
 int wsis_bn_stats_finalize_apply(const float* d_partials, int64_t n_part, int64_t M, int32_t C, float* d_mean,
                                  float* d_var, float* d_running_mean, float* d_running_var, float momentum,
                                  const float* d_x, const float* d_gamma, const float* d_beta, float eps, int32_t relu,
@@ -980,64 +1088,25 @@ int wsis_bn_stats_finalize_apply(const float* d_partials, int64_t n_part, int64_
   WSIS_REQUIRE(n_part == (M + 31) / 32 && n_part < ((int64_t)1 << 31), "one partial per 32-row slice");
   WSIS_REQUIRE(C <= 512, "more than 512 channels");
   hipStream_t st = as_stream(stream);
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("WSIS_BN_FUSED_APPLY");
-    on = e ? atoi(e) : 1;
-  }
   const int G = bn_fin_chunks(n_part);
   const int CG = (C + 31) / 32;
   WSIS_REQUIRE(G == 1 || (d_ws && ws_bytes >= wsis_bn_stats_finalize_workspace_bytes(n_part, C)), "workspace too small");
   double* chunk = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(d_ws) + 255) & ~(uintptr_t)255);
   unsigned* tickets = bn_tickets(0, chunk);
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
-  // the one-launch form needs: the ticket path (G > 1), every workgroup resident (<= 512), vector rows, and eager
-  // launches (its epoch is a launch argument: a replayed graph would carry a stale one)
-  const int cw = C >> 2;
-  static int gmax = -1;
-  if (gmax < 0) {
-    const char* e = getenv("WSIS_BN_FUSED_GRID");
-    gmax = e ? atoi(e) : 256;
-    if (gmax < 64 || gmax > 512) gmax = 256;
-  }
-  const int64_t work = (M * C) >> 2;
-  static int n_cu = -1;
-  if (n_cu < 0) {      // every workgroup of the launch must be resident: at most two per CU of THIS device / partition
-    int dev = 0;
-    hipDeviceProp_t prop;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
-  }
-  int gcap = (work > 600000 && gmax == 256) ? 512 : gmax;     // level 0: two workgroups per CU for the apply pass
-  if (gcap > 2 * n_cu) gcap = 2 * n_cu;
-  if (gcap < 1) gcap = 1;
-  int grid = gcap - (gcap % (cw > 0 ? cw : 1));
-  const int need = grid_for(work, 256);
-  if (need < grid) {
-    grid = need;
-    if (grid > cw) grid -= grid % cw;
-  }
-  const bool fused = on && (C & 3) == 0 && (G == 1 || tickets) && cap == hipStreamCaptureStatusNone &&
-                     grid >= G * CG && grid >= 1;
+  // the one-launch form needs: the ticket path (G > 1), every workgroup resident, vector rows, and eager launches
+  const int grid = (G == 1 || tickets) ? bn_fused_grid(M, C, G * CG, st) : 0;
+  const bool fused = grid > 0;
   if (!fused) {
     const int rc = wsis_bn_stats_finalize(d_partials, n_part, M, C, d_mean, d_var, d_running_mean, d_running_var, momentum,
                                           d_ws, ws_bytes, stream);
     if (rc != WSIS_OK) return rc;
     return wsis_bn_apply(d_x, d_mean, d_var, d_gamma, d_beta, eps, relu, d_y, M, C, stream);
   }
-  static unsigned* flag_base = nullptr;
-  static unsigned* done_base = nullptr;
-  static unsigned epochs[16] = {0};
-  if (!flag_base) {
-    WSIS_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&flag_base), HIP_SYMBOL(g_bn_flag)));
-    WSIS_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&done_base), HIP_SYMBOL(g_bn_done)));
-  }
-  const int slot = (int)((reinterpret_cast<uintptr_t>(chunk) >> 8) & 15);
-  unsigned epoch = ++epochs[slot];
-  if (epoch == 0) epoch = ++epochs[slot];       // 0 is the flag's initial value
+  BnSync sy;
+  if (!bn_sync_for(0, chunk, &sy)) return fail(WSIS_ERR_HIP, "bn: sync words not found");
   hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(grid), dim3(256), 0, st, d_partials, (int)n_part, (int)C, M, chunk, G,
-                     d_mean, d_var, d_running_mean, d_running_var, momentum, tickets ? tickets : done_base + slot,
-                     done_base + slot, flag_base + slot, epoch, d_x, d_gamma, d_beta, eps, (int)relu, d_y);
+                     d_mean, d_var, d_running_mean, d_running_var, momentum, tickets ? tickets : sy.done, sy.done, sy.flag,
+                     sy.epoch, d_x, d_gamma, d_beta, eps, (int)relu, d_y);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }
@@ -1070,6 +1139,18 @@ int wsis_bn_bwd_from_partials(const float* d_partials, int64_t n_part, const flo
   hipStream_t st = as_stream(stream);
   WSIS_REQUIRE(C <= 512, "more than 512 channels");
   unsigned* tickets = bn_tickets(1, chunk);
+  if (d_dx) {     // reduction finish + apply in one launch (the form of wsis_bn_stats_finalize_apply)
+    const int CG = (C + 31) / 32;
+    const int fgrid = (G == 1 || tickets) ? bn_fused_grid(M, C, G * CG, st) : 0;
+    BnSync sy;
+    if (fgrid > 0 && bn_sync_for(1, chunk, &sy)) {
+      hipLaunchKernelGGL(bn_bwd_finish_apply_kernel, dim3(fgrid), dim3(256), 0, st, d_partials, (int)n_part, (int)C, chunk, G,
+                         d_dbeta, d_dgamma, tickets ? tickets : sy.done, sy.done, sy.flag, sy.epoch, d_x, d_dy, d_mean,
+                         d_var, d_gamma, d_beta, d_addend, eps, (int)relu, d_dx, M);
+      WSIS_LAUNCH_CHECK();
+      return WSIS_OK;
+    }
+  }
   hipLaunchKernelGGL(bn_sum_chunk_kernel, dim3(G, (C + 31) / 32), dim3(256), 0, st, d_partials, (int)n_part, C, chunk,
                      d_dbeta, d_dgamma, tickets);
   WSIS_LAUNCH_CHECK();
