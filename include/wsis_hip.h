@@ -270,6 +270,8 @@ int wsis_bn_bwd_from_partials(const float* d_partials, int64_t n_part, const flo
                               const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta,
                               float eps, int32_t relu, float* d_dx, float* d_dgamma, float* d_dbeta,
                               const float* d_addend, int64_t M, int32_t C, void* d_ws, int64_t ws_bytes, void* stream);
+/* (with d_dx the reduction finish and the apply pass are one launch where wsis_bn_stats_finalize_apply's conditions
+ * hold; identical results) */
 /* y = relu?( (x-mean)*rsqrt(var+eps)*gamma + beta )   (gamma/beta may be NULL = 1/0) */
 int wsis_bn_apply(const float* d_x, const float* d_mean, const float* d_var, const float* d_gamma,
                   const float* d_beta, float eps, int32_t relu, float* d_y, int64_t M, int32_t C, void* stream);
