@@ -139,10 +139,8 @@ __global__ __launch_bounds__(64) void bn_stats_final_kernel(const float* __restr
 // mean = sum S_i / M, var = (sum Q_i + sum S_i^2 / n_i - M mean^2) / M, all in fp64 (Chan's pairwise combination).
 // Two levels so that the 1.2 MB of partials of a 150k-row level is read by up to 64 workgroups per 32 channels instead of
 // one: chunk sums (fixed order inside a chunk) -> [G][3][C] doubles, then one thread per channel adds the chunks in order.
-// arrival tickets of the two-level reductions (zero between launches: the last workgroup resets its counter).  A row
-// per 16 possible workspaces in flight (two reductions can only overlap on different streams, and then they have
-// different workspaces: the row is picked from the workspace address), 16 channel groups per row.
-__device__ unsigned g_bn_ticket[2][16][16];
+// arrival tickets of the two-level reductions: one counter per channel group in the caller's sync slot (common.h
+// SyncSlot; zero between launches: the last workgroup resets its counter).
 constexpr int BN_FIN_CHUNKS = 64;      // <= 64: the finish kernels hold one chunk per lane
 
 __device__ __forceinline__ void bn_finish_centred(double S, double Q, double W, int64_t M, int c, float* mean, float* var,
@@ -360,38 +358,56 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 // threads (two per CU): all of them are resident, the waiting ones cannot keep the working ones off the machine.
 // Same arithmetic as the two launches (bn_stats_chunk_centred_kernel, bn_apply_kernel): identical results.
 constexpr int BN_POLL_SLEEP = 12;      // x 64 cycles
-__device__ unsigned g_bn_flag[2][16];      // [forward, backward][slot]
-__device__ unsigned g_bn_done[2][16];
+constexpr unsigned long long BN_SPIN_LIMIT = 200000000ull;      // s_memrealtime ticks (100 MHz): 2 s
+
+// every workgroup of a producer / consumer launch: wait until the producers have published (flag != 0), bounded -- a
+// launch whose producers never become resident sets `err` and goes on instead of hanging the device --, then the
+// workgroup that leaves the wait last puts flag and counter back to zero for the next launch on this slot
+__device__ __forceinline__ void bn_wait_published(SyncSlot* s) {
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(&s->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      __builtin_amdgcn_s_sleep(BN_POLL_SLEEP);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > BN_SPIN_LIMIT) {
+        __hip_atomic_store(&s->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    const unsigned l = atomicAdd(&s->left, 1u);
+    if (l == gridDim.x - 1) {
+      __hip_atomic_store(&s->left, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&s->flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void bn_publish(SyncSlot* s, int CG) {      // by thread 0 of a workgroup that finished a group
+  const unsigned d = atomicAdd(&s->done, 1u);
+  if (d == (unsigned)CG - 1) {
+    __hip_atomic_store(&s->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    __hip_atomic_store(&s->flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 
 __global__ __launch_bounds__(256) void bn_finalize_apply_kernel(
     const float* __restrict__ partial, int nblk, int C, int64_t M, double* __restrict__ chunk, int G,
     float* mean, float* var, float* __restrict__ running_mean,
-    float* __restrict__ running_var, float momentum, unsigned* __restrict__ ticket, unsigned* __restrict__ done,
-    unsigned* __restrict__ flag, unsigned epoch, const float* __restrict__ x, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float eps, int relu, float* __restrict__ y) {
+    float* __restrict__ running_var, float momentum, SyncSlot* __restrict__ sync, const float* __restrict__ x,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu, float* __restrict__ y) {
   __shared__ double red[3][8][33];
   __shared__ int s_last;
   const int CG = (C + 31) / 32;
   if ((int)blockIdx.x < G * CG) {
     const bool fin = bn_chunk_centred_stage(partial, nblk, C, M, chunk, mean, var, running_mean, running_var, momentum,
-                                            ticket, (int)blockIdx.x % G, G, (int)blockIdx.x / G, red, s_last);
+                                            sync->ticket, (int)blockIdx.x % G, G, (int)blockIdx.x / G, red, s_last);
     if (fin) {               // this workgroup wrote mean / var of one channel group; the last such group publishes
       __threadfence();
       __syncthreads();
-      if (threadIdx.x == 0) {
-        const unsigned d = atomicAdd(done, 1u);
-        if (d == (unsigned)CG - 1) {
-          *done = 0u;
-          __threadfence();
-          __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
+      if (threadIdx.x == 0) bn_publish(sync, CG);
     }
   }
-  if (threadIdx.x == 0) {     // relaxed polls a few hundred ns apart (hundreds of pollers on one word), ONE acquire at the end
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(BN_POLL_SLEEP);
-  }
-  __syncthreads();
+  bn_wait_published(sync);    // relaxed polls a few hundred ns apart (hundreds of pollers on one word)
   bn_apply_body<true>(x, mean, var, gamma, beta, eps, relu, y, M, C);
 }
 
@@ -699,33 +715,22 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
 // tickets in the first G * ceil(C/32) workgroups, epoch flag, every workgroup waits and applies)
 __global__ __launch_bounds__(256) void bn_bwd_finish_apply_kernel(
     const float* __restrict__ partial, int nblk, int C, double* __restrict__ chunk, int G, float* dbeta, float* dgamma,
-    unsigned* __restrict__ ticket, unsigned* __restrict__ done, unsigned* __restrict__ flag, unsigned epoch,
-    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    SyncSlot* __restrict__ sync, const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
     const float* __restrict__ var, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ addend, float eps, int relu, float* __restrict__ dx, int64_t M) {
   __shared__ double red[2][8][33];
   __shared__ int s_last;
   const int CG = (C + 31) / 32;
   if ((int)blockIdx.x < G * CG) {
-    const bool fin = bn_sum_chunk_stage(partial, nblk, C, chunk, dbeta, dgamma, ticket, (int)blockIdx.x % G, G,
+    const bool fin = bn_sum_chunk_stage(partial, nblk, C, chunk, dbeta, dgamma, sync->ticket, (int)blockIdx.x % G, G,
                                         (int)blockIdx.x / G, red, s_last);
     if (fin) {
       __threadfence();
       __syncthreads();
-      if (threadIdx.x == 0) {
-        const unsigned d = atomicAdd(done, 1u);
-        if (d == (unsigned)CG - 1) {
-          *done = 0u;
-          __threadfence();
-          __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
+      if (threadIdx.x == 0) bn_publish(sync, CG);
     }
   }
-  if (threadIdx.x == 0) {
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(BN_POLL_SLEEP);
-  }
-  __syncthreads();
+  bn_wait_published(sync);
   bn_bwd_apply_body<true>(x, dy, mean, var, gamma, beta, dgamma, dbeta, addend, eps, relu, 1, dx, M, C);
 }
 
@@ -919,7 +924,6 @@ int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* 
 // ---- column sums of x [M, C] (bias gradient of a Linear layer over M rows): two levels in ONE launch, fixed order.
 // 256 threads = (C/4 float4 column lanes) x (row lanes); every workgroup sums a block of rows, the one that arrives
 // last adds the block results in block order.
-__device__ unsigned g_colsum_ticket[64];
 
 __device__ __forceinline__ void colsum_block(const float* __restrict__ x, int64_t lo, int64_t hi, int C4, float4* red,
                                              float* __restrict__ out) {
@@ -978,17 +982,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   colsum_block(chunk, 0, gridDim.x, C4, red, out);
 }
 
-// ticket row of a two-level reduction (nullptr: WSIS_BN_TICKET=0, the finish runs as a second launch)
-static unsigned* bn_tickets(int which, const void* chunk) {
-  static unsigned* base = nullptr;
+// ticket row of a two-level reduction: the caller's sync slot (nullptr without one, or with WSIS_BN_TICKET=0: the finish
+// runs as a second launch)
+static unsigned* bn_tickets(void* d_sync) {
   static int on = -1;
   if (on < 0) {
     const char* e = getenv("WSIS_BN_TICKET");
     on = e ? atoi(e) : 1;
-    if (on && hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_bn_ticket)) != hipSuccess) on = 0;
   }
-  if (!on) return nullptr;
-  return base + (which * 16 + (int)((reinterpret_cast<uintptr_t>(chunk) >> 8) & 15)) * 16;
+  if (!on || !d_sync) return nullptr;
+  return static_cast<SyncSlot*>(d_sync)->ticket;
 }
 
 static int bn_fin_chunks(int64_t n_part) {
@@ -1004,7 +1007,7 @@ int64_t wsis_bn_stats_finalize_workspace_bytes(int64_t n_part, int32_t C) {
 
 int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, int32_t C, float* d_mean, float* d_var,
                            float* d_running_mean, float* d_running_var, float momentum, void* d_ws, int64_t ws_bytes,
-                           void* stream) {
+                           void* d_sync, void* stream) {
   WSIS_REQUIRE(n_part >= 1 && M >= 1 && C >= 1 && d_partials && d_mean && d_var, "bad args");
   WSIS_REQUIRE(n_part < ((int64_t)1 << 31), "too many partials");
   WSIS_REQUIRE((d_running_mean == nullptr) == (d_running_var == nullptr), "running stats come in pairs");
@@ -1013,7 +1016,7 @@ int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, i
   WSIS_REQUIRE(G == 1 || (d_ws && ws_bytes >= wsis_bn_stats_finalize_workspace_bytes(n_part, C)), "workspace too small");
   double* chunk = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(d_ws) + 255) & ~(uintptr_t)255);
   WSIS_REQUIRE(C <= 512, "more than 512 channels");
-  unsigned* tickets = bn_tickets(0, chunk);
+  unsigned* tickets = bn_tickets(d_sync);
   hipLaunchKernelGGL(bn_stats_chunk_centred_kernel, dim3(G, (C + 31) / 32), dim3(256), 0, as_stream(stream), d_partials,
                      (int)n_part, C, M, chunk, d_mean, d_var, d_running_mean, d_running_var, momentum, tickets);
   WSIS_LAUNCH_CHECK();
@@ -1025,33 +1028,9 @@ int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, i
   return WSIS_OK;
 }
 
-// flag / done words and the epoch of one producer-consumer launch (which: 0 forward, 1 backward; the slot follows the
-// workspace address like the ticket rows).  Epochs of a slot only grow, 0 is the words' initial value.
-struct BnSync {
-  unsigned* flag;
-  unsigned* done;
-  unsigned epoch;
-};
-static bool bn_sync_for(int which, const void* chunk, BnSync* out) {
-  static unsigned* flag_base = nullptr;
-  static unsigned* done_base = nullptr;
-  static unsigned epochs[2][16] = {{0}};
-  if (!flag_base) {
-    if (hipGetSymbolAddress(reinterpret_cast<void**>(&flag_base), HIP_SYMBOL(g_bn_flag)) != hipSuccess) return false;
-    if (hipGetSymbolAddress(reinterpret_cast<void**>(&done_base), HIP_SYMBOL(g_bn_done)) != hipSuccess) return false;
-  }
-  const int slot = (int)((reinterpret_cast<uintptr_t>(chunk) >> 8) & 15);
-  unsigned e = ++epochs[which][slot];
-  if (e == 0) e = ++epochs[which][slot];
-  out->flag = flag_base + which * 16 + slot;
-  out->done = done_base + which * 16 + slot;
-  out->epoch = e;
-  return true;
-}
-
 // grid of a producer-consumer launch over M x C elements: every workgroup resident (<= 2 per CU of this device),
 // a multiple of the channel groups; 0 when the one-launch form does not apply
-static int bn_fused_grid(int64_t M, int C, int need_chunk_wgs, hipStream_t st) {
+static int bn_fused_grid(int64_t M, int C, int need_chunk_wgs) {
   static int on = -1, gmax = -1, n_cu = -1;
   if (on < 0) {
     const char* e = getenv("WSIS_BN_FUSED_APPLY");
@@ -1059,13 +1038,13 @@ static int bn_fused_grid(int64_t M, int C, int need_chunk_wgs, hipStream_t st) {
     const char* g = getenv("WSIS_BN_FUSED_GRID");
     gmax = g ? atoi(g) : 256;
     if (gmax < 64 || gmax > 512) gmax = 256;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+  }
+  {   // per call: the CU count of the CURRENT device (cheap attribute query, no cache shared between devices)
+    int dev = 0, v = 0;
+    n_cu = (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? v : 0;
   }
   if (!on || (C & 3) != 0) return 0;
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 0;   // epoch = launch argument
   const int cw = C >> 2;
   const int64_t work = (M * C) >> 2;
   int gcap = (work > 600000 && gmax == 256) ? 512 : gmax;     // level 0: two workgroups per CU for the apply pass
@@ -1083,7 +1062,7 @@ static int bn_fused_grid(int64_t M, int C, int need_chunk_wgs, hipStream_t st) {
 int wsis_bn_stats_finalize_apply(const float* d_partials, int64_t n_part, int64_t M, int32_t C, float* d_mean,
                                  float* d_var, float* d_running_mean, float* d_running_var, float momentum,
                                  const float* d_x, const float* d_gamma, const float* d_beta, float eps, int32_t relu,
-                                 float* d_y, void* d_ws, int64_t ws_bytes, void* stream) {
+                                 float* d_y, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream) {
   WSIS_REQUIRE(n_part >= 1 && M >= 1 && C >= 1 && d_partials && d_mean && d_var && d_x && d_y, "bad args");
   WSIS_REQUIRE(n_part == (M + 31) / 32 && n_part < ((int64_t)1 << 31), "one partial per 32-row slice");
   WSIS_REQUIRE(C <= 512, "more than 512 channels");
@@ -1092,21 +1071,19 @@ int wsis_bn_stats_finalize_apply(const float* d_partials, int64_t n_part, int64_
   const int CG = (C + 31) / 32;
   WSIS_REQUIRE(G == 1 || (d_ws && ws_bytes >= wsis_bn_stats_finalize_workspace_bytes(n_part, C)), "workspace too small");
   double* chunk = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(d_ws) + 255) & ~(uintptr_t)255);
-  unsigned* tickets = bn_tickets(0, chunk);
-  // the one-launch form needs: the ticket path (G > 1), every workgroup resident, vector rows, and eager launches
-  const int grid = (G == 1 || tickets) ? bn_fused_grid(M, C, G * CG, st) : 0;
+  unsigned* tickets = bn_tickets(d_sync);
+  // the one-launch form needs: a sync slot (tickets + flag), every workgroup resident, vector rows
+  const int grid = tickets ? bn_fused_grid(M, C, G * CG) : 0;
   const bool fused = grid > 0;
   if (!fused) {
     const int rc = wsis_bn_stats_finalize(d_partials, n_part, M, C, d_mean, d_var, d_running_mean, d_running_var, momentum,
-                                          d_ws, ws_bytes, stream);
+                                          d_ws, ws_bytes, d_sync, stream);
     if (rc != WSIS_OK) return rc;
     return wsis_bn_apply(d_x, d_mean, d_var, d_gamma, d_beta, eps, relu, d_y, M, C, stream);
   }
-  BnSync sy;
-  if (!bn_sync_for(0, chunk, &sy)) return fail(WSIS_ERR_HIP, "bn: sync words not found");
   hipLaunchKernelGGL(bn_finalize_apply_kernel, dim3(grid), dim3(256), 0, st, d_partials, (int)n_part, (int)C, M, chunk, G,
-                     d_mean, d_var, d_running_mean, d_running_var, momentum, tickets ? tickets : sy.done, sy.done, sy.flag,
-                     sy.epoch, d_x, d_gamma, d_beta, eps, (int)relu, d_y);
+                     d_mean, d_var, d_running_mean, d_running_var, momentum, static_cast<SyncSlot*>(d_sync), d_x, d_gamma,
+                     d_beta, eps, (int)relu, d_y);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }
@@ -1130,7 +1107,8 @@ int wsis_bn_apply(const float* d_x, const float* d_mean, const float* d_var, con
 int wsis_bn_bwd_from_partials(const float* d_partials, int64_t n_part, const float* d_x, const float* d_dy,
                               const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta,
                               float eps, int32_t relu, float* d_dx, float* d_dgamma, float* d_dbeta,
-                              const float* d_addend, int64_t M, int32_t C, void* d_ws, int64_t ws_bytes, void* stream) {
+                              const float* d_addend, int64_t M, int32_t C, void* d_ws, int64_t ws_bytes, void* d_sync,
+                              void* stream) {
   WSIS_REQUIRE(M >= 1 && C >= 1 && d_partials && d_x && d_dy && d_mean && d_var && d_dgamma && d_dbeta, "bad args");
   WSIS_REQUIRE(n_part == (M + 31) / 32 && n_part < ((int64_t)1 << 31), "one partial per 32-row slice");
   const int G = bn_fin_chunks(n_part);
@@ -1138,14 +1116,13 @@ int wsis_bn_bwd_from_partials(const float* d_partials, int64_t n_part, const flo
   double* chunk = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(d_ws) + 255) & ~(uintptr_t)255);
   hipStream_t st = as_stream(stream);
   WSIS_REQUIRE(C <= 512, "more than 512 channels");
-  unsigned* tickets = bn_tickets(1, chunk);
+  unsigned* tickets = bn_tickets(d_sync);
   if (d_dx) {     // reduction finish + apply in one launch (the form of wsis_bn_stats_finalize_apply)
     const int CG = (C + 31) / 32;
-    const int fgrid = (G == 1 || tickets) ? bn_fused_grid(M, C, G * CG, st) : 0;
-    BnSync sy;
-    if (fgrid > 0 && bn_sync_for(1, chunk, &sy)) {
+    const int fgrid = tickets ? bn_fused_grid(M, C, G * CG) : 0;
+    if (fgrid > 0) {
       hipLaunchKernelGGL(bn_bwd_finish_apply_kernel, dim3(fgrid), dim3(256), 0, st, d_partials, (int)n_part, (int)C, chunk, G,
-                         d_dbeta, d_dgamma, tickets ? tickets : sy.done, sy.done, sy.flag, sy.epoch, d_x, d_dy, d_mean,
+                         d_dbeta, d_dgamma, static_cast<SyncSlot*>(d_sync), d_x, d_dy, d_mean,
                          d_var, d_gamma, d_beta, d_addend, eps, (int)relu, d_dx, M);
       WSIS_LAUNCH_CHECK();
       return WSIS_OK;
@@ -1205,6 +1182,8 @@ int wsis_bn_bwd(const float* d_x, const float* d_dy, const float* d_mean, const 
   return WSIS_OK;
 }
 
+int64_t wsis_sync_bytes(void) { return (int64_t)kSyncSlots * (int64_t)sizeof(SyncSlot); }
+
 int64_t wsis_colsum_workspace_bytes(int64_t M, int32_t C) {
   if (M < 0 || C < 4) return -1;
   int64_t per = (M + 1023) / 1024;
@@ -1213,7 +1192,8 @@ int64_t wsis_colsum_workspace_bytes(int64_t M, int32_t C) {
   return (G > 1 ? G : 1) * (int64_t)C * (int64_t)sizeof(float) + 256;
 }
 
-int wsis_colsum(const float* d_x, int64_t M, int32_t C, float* d_out, void* d_ws, int64_t ws_bytes, void* stream) {
+int wsis_colsum(const float* d_x, int64_t M, int32_t C, float* d_out, void* d_ws, int64_t ws_bytes, void* d_sync,
+                void* stream) {
   WSIS_REQUIRE(M >= 0 && C >= 4 && C % 4 == 0 && C <= 1024 && d_out, "colsum: C must be a multiple of 4, <= 1024");
   hipStream_t st = as_stream(stream);
   if (M == 0) {
@@ -1230,9 +1210,8 @@ int wsis_colsum(const float* d_x, int64_t M, int32_t C, float* d_out, void* d_ws
   if (G > 1) {
     WSIS_REQUIRE(d_ws && ws_bytes >= wsis_colsum_workspace_bytes(M, C), "workspace too small");
     chunk = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(d_ws) + 255) & ~(uintptr_t)255);
-    static unsigned* base = nullptr;
-    if (!base) WSIS_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_colsum_ticket)));
-    ticket = base + ((reinterpret_cast<uintptr_t>(chunk) >> 8) & 63);   // concurrent launches use different workspaces
+    WSIS_REQUIRE(d_sync, "colsum over more than one chunk needs a sync slot");
+    ticket = static_cast<SyncSlot*>(d_sync)->ticket;
   }
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)G), dim3(256), 0, st, d_x, M, (int)C, per, chunk, d_out, ticket);
   WSIS_LAUNCH_CHECK();

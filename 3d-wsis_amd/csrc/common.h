@@ -44,7 +44,7 @@ inline int grid_for(int64_t work_items, int block) {
 // ---- live kernel timing for bench.py's roofline: HIP events recorded on the launch stream directly around the
 // dominant kernels (not around the host wrapper), enabled by wsis_prof_enable().
 struct ProfRec {
-  hipEvent_t a, b;
+  hipEvent_t a, b, c;      // a -> b: the main kernel; b -> c: the fixed-order slab sum that finishes it (c == nullptr: none)
 };
 inline bool g_prof_on = false;
 inline std::vector<ProfRec> g_prof[2];   // 0 = spconv_fwd_kernel, 1 = spconv_dw_kernel
@@ -53,21 +53,42 @@ struct ProfScope {
   int which;
   hipStream_t st;
   ProfRec r{};
-  bool live = false;
+  int stage = 0;           // 1: a recorded, 2: b recorded
   ProfScope(int w, hipStream_t s) : which(w), st(s) {
     if (g_prof_on && hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess) {
-      live = hipEventRecord(r.a, st) == hipSuccess;
+      stage = hipEventRecord(r.a, st) == hipSuccess ? 1 : 0;
     }
   }
-  void stop() {
-    if (live) {
+  void stop() {             // behind the main kernel
+    if (stage == 1) {
       (void)hipEventRecord(r.b, st);
-      g_prof[which].push_back(r);
-      live = false;
+      stage = 2;
     }
+  }
+  void tail() {             // behind the launch(es) that finish the product (slab sums): counted with it
+    if (stage == 2 && hipEventCreate(&r.c) == hipSuccess) (void)hipEventRecord(r.c, st);
+  }
+  ~ProfScope() {
+    if (stage == 2) g_prof[which].push_back(r);
   }
 };
 
+
+// ---- cross-workgroup sync words of the one-launch reductions (no global mutable state).  The words live in
+// CALLER memory: a slot is 256 bytes, zero-filled once by the caller; every kernel that uses a slot leaves it zero
+// again (the last arrival of a ticket resets it, the last workgroup to leave a flag wait resets flag and counter), so
+// consecutive launches on one stream can share a slot; launches that may overlap (different streams) need different
+// slots.  A NULL slot selects the multi-launch form of the operator.
+struct SyncSlot {
+  unsigned ticket[16];     // one arrival counter per channel group
+  unsigned done, flag, left, err;
+  unsigned ctr[44];        // slice-queue counters of spconv_fwd3_kernel: one per (output block, offset slab)
+};
+static_assert(sizeof(SyncSlot) == 256, "sync slot layout");
+constexpr int kSyncSlots = 64;
+inline SyncSlot* sync_slot(void* d_sync, int i) {
+  return d_sync ? static_cast<SyncSlot*>(d_sync) + (i % kSyncSlots) : nullptr;
+}
 
 // wave-autonomous weight-gradient kernel (csrc/spconv_dw2.hip), dispatched from wsis_spconv_dw
 bool dw2_supported(int K, int Cin, int Cout);

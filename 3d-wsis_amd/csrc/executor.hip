@@ -222,12 +222,12 @@ int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n) {
   return wt + dw + need + ALIGN;
 }
 
-int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* stream) {
-  return wsis_run_ops_marked(ops, n, d_ws, ws_bytes, stream, -1, nullptr);
+int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream) {
+  return wsis_run_ops_marked(ops, n, d_ws, ws_bytes, d_sync, stream, -1, nullptr);
 }
 
-static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* stream, int32_t mark_op,
-                        void* waiter_stream);
+static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream,
+                        int32_t mark_op, void* waiter_stream);
 
 // WSIS_GRAPH=N (opt-in experiment, default 0): the launches of a pass are recorded into HIP graphs of ~N ops each
 // (N < 4: one graph per pass; the weight-gradient side stream joins the capture through its fork / join events) and
@@ -236,12 +236,12 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
 // identical, replay removes about 1 ms of dispatch gaps from the forward pass, but recording + patching costs the
 // host about 1 ms more than launching, and the GPU cannot start a chunk before its recording ends: 12.0 -> 13.0 ms
 // per step.  The way to make it pay is to patch node parameters without re-recording.
-int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* stream, int32_t mark_op,
-                        void* waiter_stream) {
+int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream,
+                        int32_t mark_op, void* waiter_stream) {
   const char* ge = getenv("WSIS_GRAPH");        // read per pass (a test switches it)
   const int graph_mode = ge ? atoi(ge) : 0;
   if (!graph_mode || mark_op >= 0 || g_prof_on || n == 0)
-    return run_ops_impl(ops, n, d_ws, ws_bytes, stream, mark_op, waiter_stream);
+    return run_ops_impl(ops, n, d_ws, ws_bytes, d_sync, stream, mark_op, waiter_stream);
   hipStream_t st = as_stream(stream);
   // chunks of ~graph_mode ops: the host records chunk k + 1 while chunk k runs (one graph for the whole pass would keep
   // the GPU idle for the whole recording time).  A chunk never separates a dIn pass from the BatchNorm backward that
@@ -261,7 +261,8 @@ int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
       if (i1 - i0 >= target && pending == 0) break;
     }
     WSIS_HIP_CHECK(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
-    const int rc = run_ops_impl(ops + i0, i1 - i0, d_ws, ws_bytes, cap, -1, nullptr);
+    // (the sync slots follow the op's index in its chunk: chunks run one after the other on the caller's stream)
+    const int rc = run_ops_impl(ops + i0, i1 - i0, d_ws, ws_bytes, d_sync, cap, -1, nullptr);
     hipGraph_t g = nullptr;
     const hipError_t ec = hipStreamEndCapture(cap, &g);
     if (ec != hipSuccess || !g) return fail(WSIS_ERR_HIP, "graph capture failed: %s", hipGetErrorString(ec));
@@ -299,8 +300,8 @@ int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   return WSIS_OK;
 }
 
-static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* stream, int32_t mark_op,
-                        void* waiter_stream) {
+static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream,
+                        int32_t mark_op, void* waiter_stream) {
   WSIS_REQUIRE(ops && n >= 0, "bad op list");
   WSIS_REQUIRE(mark_op < n && (mark_op < 0 || waiter_stream), "bad milestone");
   WSIS_REQUIRE(ws_bytes >= wsis_run_ops_workspace_bytes(ops, n) && (d_ws || n == 0), "workspace too small");
@@ -379,7 +380,7 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
                                  reinterpret_cast<const float*>(wt_base + wt_off[i]), 0, (const float*)op.in[4],
                                  (const float*)op.in[5], (float*)op.out[0],
                                  (op.flags & WSIS_OPF_STATS) ? (float*)op.out[1] : nullptr, op.M_in, op.M_out, op.K,
-                                 op.Cin, op.Cout, ws, ws_bytes, stream);
+                                 op.Cin, op.Cout, ws, ws_bytes, sync_slot(d_sync, i), stream);
         else if (op.flags & WSIS_OPF_STATS)
           // the program was recorded for the kernel that writes BatchNorm partials; this launch cannot use it (input
           // of 2 GiB or more, or WSIS_FWD2 changed between recording and running)
@@ -405,15 +406,15 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
                                                 (float*)op.out[2], rm, rv, op.momentum, (const float*)op.in[0],
                                                 (const float*)op.in[1], (const float*)op.in[2], op.eps,
                                                 (op.flags & WSIS_OPF_RELU) ? 1 : 0, (float*)op.out[0], ws, ws_bytes,
-                                                stream);
+                                                sync_slot(d_sync, i), stream);
               break;
             }
             rc = wsis_bn_stats_finalize((const float*)op.in[5], n_part, op.M_in, C0, (float*)op.out[1],
-                                        (float*)op.out[2], rm, rv, op.momentum, ws, ws_bytes, stream);
+                                        (float*)op.out[2], rm, rv, op.momentum, ws, ws_bytes, sync_slot(d_sync, i), stream);
             if (rc == WSIS_OK && op.in[6])
               rc = wsis_bn_stats_finalize((const float*)op.in[6], n_part, op.M_in, op.Cin - C0, (float*)op.out[1] + C0,
                                           (float*)op.out[2] + C0, rm ? rm + C0 : nullptr, rv ? rv + C0 : nullptr,
-                                          op.momentum, ws, ws_bytes, stream);
+                                          op.momentum, ws, ws_bytes, sync_slot(d_sync, i), stream);
           } else {
             rc = wsis_bn_stats((const float*)op.in[0], op.M_in, op.Cin, (float*)op.out[1], (float*)op.out[2], rm, rv,
                                op.momentum, ws, ws_bytes, stream);
@@ -491,7 +492,7 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
               rc = wsis_spconv_fwd_t((const float*)op.in[2], (const int32_t*)op.in[5], (const int32_t*)op.in[6],
                                      (const float*)op.in[1], (op.flags & WSIS_OPF_FLIP) ? 1 : 0, nullptr, nullptr,
                                      (float*)op.out[0], nullptr, op.M_out, op.M_in, op.K, op.Cout, op.Cin, rest,
-                                     rest_bytes, stream);
+                                     rest_bytes, sync_slot(d_sync, i), stream);
               if (rc != WSIS_OK) break;
               goto din_done;
             }
@@ -500,12 +501,12 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
                                       (float*)const_cast<void*>(bn->in[7]), (const float*)bn->in[0],
                                       (const float*)bn->in[2], (const float*)bn->in[3], (const float*)bn->in[4],
                                       (const float*)bn->in[5], bn->eps, (bn->flags & WSIS_OPF_RELU) ? 1 : 0, op.M_out,
-                                      op.M_in, op.K, op.Cout, op.Cin, rest, rest_bytes, stream);
+                                      op.M_in, op.K, op.Cout, op.Cin, rest, rest_bytes, sync_slot(d_sync, i), stream);
           } else {   // the weight [K, Cin, Cout] is the B^T operand of the dIn product as it stands
             rc = wsis_spconv_fwd_t((const float*)op.in[2], (const int32_t*)op.in[5], (const int32_t*)op.in[6],
                                    (const float*)op.in[1], (op.flags & WSIS_OPF_FLIP) ? 1 : 0, nullptr, nullptr,
                                    (float*)op.out[0], nullptr, op.M_out, op.M_in, op.K, op.Cout, op.Cin, rest, rest_bytes,
-                                   stream);
+                                   sync_slot(d_sync, i), stream);
           }
           if (rc != WSIS_OK) break;
         }
@@ -539,7 +540,8 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
                                          (const float*)op.in[1], (const float*)op.in[2], (const float*)op.in[3],
                                          (const float*)op.in[4], (const float*)op.in[5], op.eps,
                                          (op.flags & WSIS_OPF_RELU) ? 1 : 0, (float*)op.out[0], (float*)op.out[1],
-                                         (float*)op.out[2], (const float*)op.in[6], op.M_in, op.Cin, ws, ws_bytes, stream);
+                                         (float*)op.out[2], (const float*)op.in[6], op.M_in, op.Cin, ws, ws_bytes,
+                                         sync_slot(d_sync, i), stream);
           break;
         }
         rc = wsis_bn_bwd((const float*)op.in[0], (const float*)op.in[1], (const float*)op.in[2], (const float*)op.in[3],

@@ -281,6 +281,13 @@ __global__ void sp_reg_bwd_kernel(const float* __restrict__ p_off, const float* 
 // saved: mu [64][8] (column 7 = member count), k [S] = 2 max(t - dv, 0) / t per row, n.  The backward kernel is the
 // analytic gradient (checked against autograd in fp64 on the host before it was written).
 constexpr int DL_D = 7, DL_SLOTS = 64, DL_ROWS = 4096, DL_THREADS = 1024;
+// the whole scene is staged in LDS: xs (112 KB) + kk (16 KB) + slot (8 KB) + per-slot sums -- this needs gfx950's
+// 160 KB of LDS per CU (a 64 KB-LDS target would have to stream the rows instead)
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "csrc/loss.hip is written for gfx950 (160 KB LDS per CU)"
+#endif
+static_assert(DL_ROWS * DL_D * 4 + DL_ROWS * 4 + DL_ROWS * 2 + DL_SLOTS * 8 * 4 * 2 <= 160 * 1024,
+              "disc_loss kernels stage the scene in LDS: the bound follows the 160 KB of a gfx950 CU");
 
 // row chunks of the per-instance walks: as many as fit 1024 threads at I*8 threads per chunk (<= 16)
 __device__ __forceinline__ int dl_chunks(int I) {

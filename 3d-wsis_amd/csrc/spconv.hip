@@ -967,6 +967,7 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
       hipLaunchKernelGGL(spconv_reduce_kernel, dim3(grid_for(M_out * Cout, 256)), dim3(256), 0, st, partial, d_bias,
                          d_residual, d_out, M_out, Cout, kz);
     }
+    prof.tail();
     WSIS_LAUNCH_CHECK();
   }
   return WSIS_OK;
@@ -981,15 +982,39 @@ int wsis_prof_summary(int32_t which, double* total_ms, int64_t* launches) {
   WSIS_REQUIRE(which >= 0 && which < 2 && total_ms && launches, "bad args");
   double ms = 0.0;
   for (ProfRec& r : g_prof[which]) {
-    WSIS_HIP_CHECK(hipEventSynchronize(r.b));
+    hipEvent_t last = r.c ? r.c : r.b;
+    WSIS_HIP_CHECK(hipEventSynchronize(last));
     float t = 0.0f;
-    WSIS_HIP_CHECK(hipEventElapsedTime(&t, r.a, r.b));
+    WSIS_HIP_CHECK(hipEventElapsedTime(&t, r.a, last));
     ms += t;
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
+    if (r.c) (void)hipEventDestroy(r.c);
   }
   *total_ms = ms;
   *launches = (int64_t)g_prof[which].size();
+  g_prof[which].clear();
+  return WSIS_OK;
+}
+
+int wsis_prof_records(int32_t which, double* h_main_ms, double* h_total_ms, int64_t cap, int64_t* n) {
+  WSIS_REQUIRE(which >= 0 && which < 2 && h_main_ms && h_total_ms && n && cap >= 0, "bad args");
+  WSIS_REQUIRE((int64_t)g_prof[which].size() <= cap, "record buffer too small");
+  int64_t i = 0;
+  for (ProfRec& r : g_prof[which]) {
+    hipEvent_t last = r.c ? r.c : r.b;
+    WSIS_HIP_CHECK(hipEventSynchronize(last));
+    float t0 = 0.0f, t1 = 0.0f;
+    WSIS_HIP_CHECK(hipEventElapsedTime(&t0, r.a, r.b));
+    WSIS_HIP_CHECK(hipEventElapsedTime(&t1, r.a, last));
+    h_main_ms[i] = t0;
+    h_total_ms[i] = t1;
+    ++i;
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+    if (r.c) (void)hipEventDestroy(r.c);
+  }
+  *n = i;
   g_prof[which].clear();
   return WSIS_OK;
 }
@@ -1126,6 +1151,7 @@ int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_orde
     hipLaunchKernelGGL(dw_reduce_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, partial, d_dW, plan, K, Cin,
                        Cout, ci_pad);
   }
+  prof.tail();
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

@@ -675,9 +675,8 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
 // range = zeros), weights of the next step straight to registers; every wait is a counted vmcnt.  Per slice the waves
 // meet twice (accumulators -> LDS in the ring slot just consumed, sum in wave order, store / statistics).
 constexpr int P3_GS = 8;                               // offsets per wave
-// slice queue of a launch: one ticket counter per (output block, offset slab); zero between launches (the workgroup
-// that draws the last ticket of a launch resets it; launches of this kernel are issued on ONE stream)
-__device__ unsigned g_fwd3_ctr[64];
+// slice queue of a launch: one ticket counter per (output block, offset slab) in the caller's sync slot (SyncSlot::ctr;
+// zero between launches: the workgroup that draws the last ticket of a launch resets it)
 constexpr int P3_HDR_INTS = P3_GS * 32 + 64;           // nb[8][32] + rows[32] (+ 32 written by the upper half wave)
 constexpr int P3_HDR = P3_HDR_INTS * 4;
 constexpr int P3_WAVE = 2 * P3_HDR + 2 * A_BYTES;      // two headers, two-slot ring of gathered rows
@@ -688,7 +687,8 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void spconv_fwd3_kernel(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ WT, const float* __restrict__ bias, const float* __restrict__ residual,
     float* __restrict__ out, float* __restrict__ partial, int64_t M_out, int K, int Cin, int Cout, int flip,
-    uint32_t x_bytes, float* __restrict__ stats, BnEpi epi, unsigned long long* __restrict__ dbg = nullptr) {
+    uint32_t x_bytes, float* __restrict__ stats, BnEpi epi, unsigned* __restrict__ q_ctr,
+    unsigned long long* __restrict__ dbg = nullptr) {
   unsigned long long d_t0 = 0, d_pro = 0, d_steps = 0, d_wait = 0, d_epi = 0, d_tmp = 0;
   unsigned d_nsteps = 0, d_nsl = 0;
   if (DIAG) d_t0 = __builtin_readcyclecounter();
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(64 * NW, 12 / NW) void spconv_fwd3_kernel(
   // 8 ... 30 around a mean of 12 at level 1 of the C2 scene).  A slice's result does not depend on who computes it, so
   // the output stays bit-reproducible.  Inside the workgroup the wave that first needs the i-th slice id draws it and
   // publishes it in LDS; the others read it (they all walk the same sequence).
-  unsigned* const ctr = g_fwd3_ctr + (blockIdx.z * gridDim.y + blockIdx.y);
+  unsigned* const ctr = q_ctr + (blockIdx.z * gridDim.y + blockIdx.y);
   volatile int* const q_pub = reinterpret_cast<volatile int*>(lds + 16);
   int* const q_claim = reinterpret_cast<int*>(lds + 20);
   volatile int* const q_val = reinterpret_cast<volatile int*>(lds + 24);      // ring of 8
@@ -1307,21 +1307,21 @@ int64_t wsis_spconv_fwd_t_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin,
 static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT,
                              int32_t flip, const float* d_bias, const float* d_residual, float* d_out, float* d_stats,
                              const BnEpi& epi, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout,
-                             void* d_ws, int64_t ws_bytes, void* stream);
+                             void* d_ws, int64_t ws_bytes, void* d_sync, void* stream);
 
 int wsis_spconv_fwd_t(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT, int32_t flip,
                       const float* d_bias, const float* d_residual, float* d_out, float* d_stats, int64_t M_in,
                       int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
-                      void* stream) {
+                      void* d_sync, void* stream) {
   return spconv_fwd_t_impl(d_X, d_nbr, d_order, d_WT, flip, d_bias, d_residual, d_out, d_stats, BnEpi{}, M_in, M_out, K,
-                           Cin, Cout, d_ws, ws_bytes, stream);
+                           Cin, Cout, d_ws, ws_bytes, d_sync, stream);
 }
 
 int wsis_spconv_fwd_t_bn(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT, int32_t flip,
                          float* d_out, float* d_partials, const float* d_bn_x, const float* d_bn_mean,
                          const float* d_bn_var, const float* d_bn_gamma, const float* d_bn_beta, float eps, int32_t relu,
                          int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
-                         void* stream) {
+                         void* d_sync, void* stream) {
   WSIS_REQUIRE(d_partials && d_bn_x && d_bn_mean && d_bn_var, "null pointer");
   WSIS_REQUIRE((reinterpret_cast<uintptr_t>(d_bn_x) & 15) == 0, "bn_x must be 16-byte aligned");
   BnEpi epi;
@@ -1333,13 +1333,13 @@ int wsis_spconv_fwd_t_bn(const float* d_X, const int32_t* d_nbr, const int32_t* 
   epi.eps = eps;
   epi.relu = relu;
   return spconv_fwd_t_impl(d_X, d_nbr, d_order, d_WT, flip, nullptr, nullptr, d_out, d_partials, epi, M_in, M_out, K,
-                           Cin, Cout, d_ws, ws_bytes, stream);
+                           Cin, Cout, d_ws, ws_bytes, d_sync, stream);
 }
 
 static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT,
                              int32_t flip, const float* d_bias, const float* d_residual, float* d_out, float* d_stats,
                              const BnEpi& epi, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout,
-                             void* d_ws, int64_t ws_bytes, void* stream) {
+                             void* d_ws, int64_t ws_bytes, void* d_sync, void* stream) {
   WSIS_REQUIRE(M_in >= 0 && M_out >= 0, "bad sizes");
   WSIS_REQUIRE(wsis_spconv_fwd_t_supported(K, Cin, Cout), "needs K <= 32 and channel counts that are multiples of 32");
   if (M_out == 0) return WSIS_OK;
@@ -1368,8 +1368,9 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
     fwd3_wgs = env_int("WSIS_FWD3_WGS", 768);        // resident 4-wave workgroups of the whole chip (3 per CU)
     fwd3_min = env_int("WSIS_FWD3_MIN_SLICES", 2);   // slices per workgroup below which the one-shot kernel is kept
   }
-  if (fwd3_on && p.NB == 1 && p.NW == 4 && d_nbr && d_order && ceil_div(K, 4 * p.ZS) <= P3_GS &&
-      (int64_t)K * M_out * 4 < ((int64_t)1 << 31)) {
+  // (the slice queue needs a sync slot with one counter per (output block, offset slab))
+  if (fwd3_on && d_sync && (Cout / 32) * p.ZS <= (int)(sizeof(SyncSlot::ctr) / sizeof(unsigned)) && p.NB == 1 && p.NW == 4 &&
+      d_nbr && d_order && ceil_div(K, 4 * p.ZS) <= P3_GS && (int64_t)K * M_out * 4 < ((int64_t)1 << 31)) {
     const int64_t n_slices = ceil_div(M_out, SL);
     int64_t P = fwd3_wgs / ((Cout / 32) * p.ZS);
     if (P < 1) P = 1;
@@ -1388,7 +1389,7 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
       }
       hipLaunchKernelGGL((spconv_fwd3_kernel<4, false>), g3, dim3(256), ldsb, st, d_X, d_nbr, d_order, d_WT, d_bias,
                          d_residual, d_out, partial, M_out, K, Cin, Cout, flip, x_bytes, d_stats, epi,
-                         (unsigned long long*)nullptr);
+                         static_cast<SyncSlot*>(d_sync)->ctr, (unsigned long long*)nullptr);
       goto launched;
     }
   }
@@ -1438,6 +1439,7 @@ launched:
                        reinterpret_cast<const float4*>(partial), reinterpret_cast<const float4*>(d_bias),
                        reinterpret_cast<const float4*>(d_residual), reinterpret_cast<float4*>(d_out), M_out, Cout / 4,
                        p.ZS, d_stats, epi);
+    prof.tail();
     WSIS_LAUNCH_CHECK();
   } else if (p.ZS > 1) {
     const int64_t total4 = M_out * Cout / 4;
@@ -1445,15 +1447,9 @@ launched:
                        reinterpret_cast<const float4*>(partial), reinterpret_cast<const float4*>(d_bias),
                        reinterpret_cast<const float4*>(d_residual), reinterpret_cast<float4*>(d_out), total4, Cout / 4,
                        p.ZS);
+    prof.tail();
     WSIS_LAUNCH_CHECK();
   }
-  return WSIS_OK;
-}
-
-// diagnostic: the slice-queue counters of spconv_fwd3_kernel (all zero between launches)
-int wsis_debug_fwd3_counters(unsigned* h_out64) {
-  WSIS_HIP_CHECK(hipDeviceSynchronize());
-  WSIS_HIP_CHECK(hipMemcpyFromSymbol(h_out64, HIP_SYMBOL(g_fwd3_ctr), 64 * sizeof(unsigned)));
   return WSIS_OK;
 }
 
@@ -1461,7 +1457,7 @@ int wsis_debug_fwd3_counters(unsigned* h_out64) {
 // variant 0: weights direct to registers, ring depth 2; 1: both operands through LDS rings, depth 3
 int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT,
                             float* d_out, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, int32_t variant,
-                            unsigned long long* d_dbg, void* stream) {
+                            unsigned long long* d_dbg, void* d_sync, void* stream) {
   WSIS_REQUIRE(wsis_spconv_fwd_t_supported(K, Cin, Cout) && d_dbg, "bad args");
   const dim3 grid((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32), 1);
   hipStream_t st = as_stream(stream);
@@ -1470,6 +1466,8 @@ int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 2, true, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, 0,
                        (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, d_dbg);
+  } else if (variant >= 100 && !d_sync) {
+    return fail(WSIS_ERR_ARG, "the persistent form needs a sync slot");
   } else if (variant >= 100) {    // persistent form (spconv_fwd3_kernel), variant - 100 offset slabs, 768 resident workgroups;
                                   // stamps: 8 x u64 per wave {total, prologue, steps, barrier wait, epilogue, n steps, n slices}
     const int zs = variant - 100;
@@ -1483,7 +1481,7 @@ int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_
                                        (int)ldsb));
     hipLaunchKernelGGL((spconv_fwd3_kernel<4, true>), g3, dim3(256), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, d_out, M_out, K, Cin, Cout, 0,
-                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, d_dbg);
+                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, static_cast<SyncSlot*>(d_sync)->ctr, d_dbg);
   } else if (variant >= 2) {      // the production small-level form: 4 waves per work item, `variant - 1` offset slabs
     const dim3 g4((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32), (unsigned)(variant - 1));
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES * 4;

@@ -497,6 +497,7 @@ int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, c
   const int64_t total4 = (int64_t)K * Cin * Cout / 4;
   hipLaunchKernelGGL(dw2_reduce_kernel, dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, st,
                      reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(d_dW), total4, P);
+  prof.tail();
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

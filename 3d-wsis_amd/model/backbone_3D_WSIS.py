@@ -125,6 +125,8 @@ class Network(nn.Module):
             output = self.unet(output)
             output = self.output_layer(output)
             voxel_feats = output.features
+            if voxel_feats.is_cuda:
+                spconv.ops.verify_pending_counts()      # hint-sized rulebooks are checked inside the same pass
         if voxel_feats.is_cuda:                                       # [N, m] voxel -> point
             output_feats = wsis_ops.gather_rows(voxel_feats, input_map, extra_data.get("p2v_csr"))
         else:

@@ -407,7 +407,7 @@ class UNetProgram(object):
         for name, nbr, lvl, Cin, Cout in entries:
             t = tensors[nbr & _ID_MASK] if nbr else None
             P = prof.pairs(t, int(Mvec[lvl]))
-            prof.end(name, None, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout)
+            prof.end(name, None, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout, (int(Mvec[lvl]), Cin, Cout, P))
 
 
 def _arena_tensor(nbytes, device, zero=False):
@@ -442,6 +442,10 @@ class UNetFunction(Function):
         luts = {_FWD: fwd_lut, _TBL: table_lut, _EXT: np.array([x.data_ptr(), 0], dtype=np.uint64), _BWD: none,
                 _PAR: none}
         _run(_n.hip(), c.fwd.instantiate(Mvec, luts), x.device)
+        # tables sized from the batch's host-side level counts: the device's own counts are compared NOW, inside the
+        # same pass (they were written at the top of the rulebook chain on the side stream, long before the host got
+        # here: the read waits for that stream only), before any result or gradient of this pass is used
+        sp_ops.verify_pending_counts()
         prog.account(c.acc_f, Mvec, tensors)
         out = _view(arena, base, offs[c.out_id], (int(Mvec[0]), c.out_channels))
         ctx.prog, ctx.c, ctx.arena, ctx.fwd_lut, ctx.x = prog, c, arena, fwd_lut, x
@@ -500,10 +504,12 @@ def _run(lib, ops, device, mark_op=-1, waiter=None):
     if ws_bytes < 0:
         raise _n.WsisError("run_ops workspace query failed")
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    sync = _n.ptr(_n.sync_block(device))
     if mark_op >= 0:
-        _n.check(lib.wsis_run_ops_marked(p, n, _n.ptr(ws), ws_bytes, _n.stream_ptr(), int(mark_op), waiter), "run_ops")
+        _n.check(lib.wsis_run_ops_marked(p, n, _n.ptr(ws), ws_bytes, sync, _n.stream_ptr(), int(mark_op), waiter),
+                 "run_ops")
     else:
-        _n.check(lib.wsis_run_ops(p, n, _n.ptr(ws), ws_bytes, _n.stream_ptr()), "run_ops")
+        _n.check(lib.wsis_run_ops(p, n, _n.ptr(ws), ws_bytes, sync, _n.stream_ptr()), "run_ops")
 
 
 def run_unet(net, input_tensor):

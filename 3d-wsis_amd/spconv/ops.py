@@ -251,8 +251,10 @@ _CHECK_STREAMS = {}
 
 def verify_pending_counts():
     """compare the output row counts the device found with the host values the rulebooks were sized by
-    (``level_voxel_counts``); one small D2H copy for all levels of the previous build, on a stream of its own (the
-    counts were written a whole step ago: the copy does not queue behind the builds now in flight on the side stream).
+    (``level_voxel_counts``); one small D2H copy for all levels of the build, on a stream of its own that waits for the
+    event recorded behind the last count only (not for the convolutions queued since).  Called right after the UNet
+    forward pass has been issued -- the same pass that uses the tables, so a wrong hint raises before the loss, the
+    backward pass or an inference result is used -- and again at the next build (a no-op then).
     A mismatch means the hint did not belong to the coordinates: the tables built from it are invalid."""
     if not _PENDING_COUNTS:
         return
@@ -369,15 +371,18 @@ def _down_rulebook_gen(indices, spatial_shape, ksize, stride, padding, deferred=
 
 class KernelProfiler(object):
     """Live per-launch timing of the conv kernels for bench.py's roofline.  The durations come from HIP events
-    that libwsis_hip.so records on the launch stream directly around each spconv_fwd_kernel / spconv_dw_kernel
-    launch (wsis_prof_enable / wsis_prof_summary); the algorithmic bytes per launch follow SURVEY.md 8d:
+    that libwsis_hip.so records on the launch stream directly around each forward / dIn product and each
+    weight-gradient product -- the main kernel AND the fixed-order slab sum that finishes it where there is one
+    (wsis_prof_enable / wsis_prof_records); the algorithmic bytes per launch follow SURVEY.md 8d:
     P*(Cin+Cout)*4 + P*8, flops 2*P*Cin*Cout, with P = number of rulebook pairs of the launch (entries >= 0 of
-    its gather table; M rows for the dense 1x1 case)."""
+    its gather table; M rows for the dense 1x1 case).  ``summary()["..."]["per_launch"]`` lists every product in
+    issue order: (rows, Cin, Cout, K-table-or-dense, bytes, flops, main-kernel ms, ms with the finishing launch)."""
 
     NAMES = ("spconv_fwd_kernel", "spconv_dw_kernel")
 
     def __init__(self):
         self.acc = {n: [0, 0, 0] for n in self.NAMES}   # launches, bytes, flops
+        self.log = {n: [] for n in self.NAMES}          # per product: (rows, Cin, Cout, pairs, bytes, flops)
         self._pairs = {}
         _n.check(_n.hip().wsis_prof_enable(1), "prof_enable")
 
@@ -392,11 +397,12 @@ class KernelProfiler(object):
     def begin(self):
         return None
 
-    def end(self, name, start, nbytes, flops):
+    def end(self, name, start, nbytes, flops, shape=None):
         a = self.acc[name]
         a[0] += 1
         a[1] += nbytes
         a[2] += flops
+        self.log[name].append((shape or (0, 0, 0, 0)) + (nbytes, flops))
 
     def summary(self):
         import ctypes
@@ -405,12 +411,17 @@ class KernelProfiler(object):
         _n.check(lib.wsis_prof_enable(0), "prof_enable")
         out = {}
         for which, name in enumerate(self.NAMES):
-            ms = ctypes.c_double(0.0)
-            n = ctypes.c_int64(0)
-            _n.check(lib.wsis_prof_summary(which, ctypes.addressof(ms), ctypes.addressof(n)), "prof_summary")
             launches, nbytes, flops = self.acc[name]
+            main = (ctypes.c_double * max(launches, 1))()
+            total = (ctypes.c_double * max(launches, 1))()
+            n = ctypes.c_int64(0)
+            _n.check(lib.wsis_prof_records(which, ctypes.addressof(main), ctypes.addressof(total), max(launches, 1),
+                                           ctypes.addressof(n)), "prof_records")
             assert n.value == launches, (name, n.value, launches)
-            out[name] = {"launches": launches, "ms": ms.value, "bytes": nbytes, "flops": flops}
+            per = [rec + (main[i], total[i]) for i, rec in enumerate(self.log[name])]
+            out[name] = {"launches": launches, "ms": float(sum(total[i] for i in range(launches))),
+                         "ms_main": float(sum(main[i] for i in range(launches))), "bytes": nbytes, "flops": flops,
+                         "per_launch": per}
         return out
 
 
@@ -446,7 +457,7 @@ def _conv(X, nbr, order, W, bias, residual, M_out):
                                  _n.ptr(residual), _n.ptr(out), X.shape[0], M_out, K, Cin, Cout, _n.ptr(ws),
                                  ws_bytes, _n.stream_ptr()), "spconv_fwd")
     if prof is not None:
-        prof.end("spconv_fwd_kernel", t0, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout)
+        prof.end("spconv_fwd_kernel", t0, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout, (int(M_out), Cin, Cout, P))
     return out
 
 
@@ -479,9 +490,10 @@ def _conv_t(X, nbr, order, WT, flip, bias, residual, M_out, stats=None):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=X.device) if ws_bytes > 256 else None
     _n.check(lib.wsis_spconv_fwd_t(_n.ptr(X), _n.ptr(nbr), _n.ptr(order), _n.ptr(WT), int(flip), _n.ptr(bias),
                                    _n.ptr(residual), _n.ptr(out), _n.ptr(stats), X.shape[0], M_out, K, Cin, Cout, _n.ptr(ws),
-                                   ws_bytes, _n.stream_ptr()), "spconv_fwd_t")
+                                   ws_bytes, _n.ptr(_n.sync_block(X.device)), _n.stream_ptr()), "spconv_fwd_t")
     if prof is not None:
-        prof.end("spconv_fwd_kernel", None, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout)
+        prof.end("spconv_fwd_kernel", None, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout,
+                 (int(M_out), Cin, Cout, P))
     return out
 
 
@@ -506,7 +518,7 @@ def _dw(X, nbr, order, dY, K, Cin, Cout):
     _n.check(lib.wsis_spconv_dw(_n.ptr(X), _n.ptr(nbr), _n.ptr(order), _n.ptr(dY), _n.ptr(dW), X.shape[0], M_out,
                                 K, Cin, Cout, _n.ptr(ws), ws_bytes, _n.stream_ptr()), "spconv_dw")
     if prof is not None:
-        prof.end("spconv_dw_kernel", t0, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout)
+        prof.end("spconv_dw_kernel", t0, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout, (int(M_out), Cin, Cout, P))
     return dW
 
 

@@ -75,13 +75,14 @@ _HIP_SIGS = {
     "wsis_spconv_fwd": (I32, [P, P, P, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
     "wsis_spconv_fwd_t_supported": (I32, [I32, I32, I32]),
     "wsis_spconv_fwd_t_workspace_bytes": (I64, [I64, I32, I32, I32]),
-    "wsis_spconv_fwd_t": (I32, [P, P, P, P, I32, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
+    "wsis_spconv_fwd_t": (I32, [P, P, P, P, I32, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P, P]),
     "wsis_spconv_fwd_t_slabs": (I32, [I64, I32, I32, I32]),
-    "wsis_bn_bwd_from_partials": (I32, [P, I64, P, P, P, P, P, P, F32, I32, P, P, P, P, I64, I32, P, I64, P]),
-    "wsis_spconv_fwd_t_bn": (I32, [P, P, P, P, I32, P, P, P, P, P, P, P, F32, I32, I64, I64, I32, I32, I32, P, I64, P]),
+    "wsis_bn_bwd_from_partials": (I32, [P, I64, P, P, P, P, P, P, F32, I32, P, P, P, P, I64, I32, P, I64, P, P]),
+    "wsis_sync_bytes": (I64, []),
+    "wsis_spconv_fwd_t_bn": (I32, [P, P, P, P, I32, P, P, P, P, P, P, P, F32, I32, I64, I64, I32, I32, I32, P, I64, P, P]),
     "wsis_bn_stats_finalize_workspace_bytes": (I64, [I64, I32]),
-    "wsis_bn_stats_finalize": (I32, [P, I64, I64, I32, P, P, P, P, F32, P, I64, P]),
-    "wsis_bn_stats_finalize_apply": (I32, [P, I64, I64, I32, P, P, P, P, F32, P, P, P, F32, I32, P, P, I64, P]),
+    "wsis_bn_stats_finalize": (I32, [P, I64, I64, I32, P, P, P, P, F32, P, I64, P, P]),
+    "wsis_bn_stats_finalize_apply": (I32, [P, I64, I64, I32, P, P, P, P, F32, P, P, P, F32, I32, P, P, I64, P, P]),
     "wsis_weight_transpose": (I32, [P, P, I32, I32, I32, I32, P]),
     "wsis_spconv_dw_workspace_bytes": (I64, [I64, I32, I32, I32]),
     "wsis_spconv_dw": (I32, [P, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
@@ -89,6 +90,7 @@ _HIP_SIGS = {
     "wsis_rulebook_pack_batch": (I32, [I32, P, P, P, P, P, P]),
     "wsis_prof_enable": (I32, [I32]),
     "wsis_prof_summary": (I32, [I32, P, P]),
+    "wsis_prof_records": (I32, [I32, P, P, I64, P]),
     "wsis_bn_workspace_bytes": (I64, [I64, I32]),
     "wsis_bn_stats": (I32, [P, I64, I32, P, P, P, P, F32, P, I64, P]),
     "wsis_bn_apply": (I32, [P, P, P, P, P, F32, I32, P, I64, I32, P]),
@@ -109,7 +111,7 @@ _HIP_SIGS = {
     "wsis_gru_cell_fwd": (I32, [P] * 9 + [I64, I32, P]),
     "wsis_gru_cell_bwd": (I32, [P] * 17 + [I64, I32, P, I64, P]),
     "wsis_colsum_workspace_bytes": (I64, [I64, I32]),
-    "wsis_colsum": (I32, [P, I64, I32, P, P, I64, P]),
+    "wsis_colsum": (I32, [P, I64, I32, P, P, I64, P, P]),
     "wsis_gru_cell_bwd_seq": (I32, [P] * 17 + [I64, I32, I32, I32, I32, P, I64, P]),
     "wsis_affinity_dense_build": (I32, [P, P, P, I64, P, I64, P]),
     "wsis_affinity_transition": (I32, [P, P, P, P, P, I32, F32, P, I64, P]),
@@ -132,8 +134,8 @@ _HIP_SIGS = {
     "wsis_adamw_chunk": (I32, []),
     "wsis_adamw_step": (I32, [P, P, I64, F64, F64, F64, F64, F64, P]),
     "wsis_run_ops_workspace_bytes": (I64, [P, I32]),
-    "wsis_run_ops": (I32, [P, I32, P, I64, P]),
-    "wsis_run_ops_marked": (I32, [P, I32, P, I64, P, I32, P]),
+    "wsis_run_ops": (I32, [P, I32, P, I64, P, P]),
+    "wsis_run_ops_marked": (I32, [P, I32, P, I64, P, P, I32, P]),
 }
 
 
@@ -189,6 +191,34 @@ def stream_ptr():
     """raw hipStream_t of torch's current stream on the current device"""
     import torch
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+
+_SYNC = {}
+
+
+def sync_block(device=None):
+    """zero-filled sync block (wsis_sync_bytes: 64 slots of 256 bytes) of (device, current stream): the cross-workgroup
+    words of the one-launch reductions live in caller memory; every launch leaves its slot zero again, launches of one
+    stream share the block, another stream gets its own (include/wsis_hip.h)"""
+    import torch
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev is None:
+        dev = torch.cuda.current_device()
+    key = (dev, torch._C._cuda_getCurrentRawStream(dev))
+    t = _SYNC.get(key)
+    if t is None:
+        t = _SYNC[key] = torch.zeros(int(hip().wsis_sync_bytes()), dtype=torch.uint8, device=torch.device("cuda", dev))
+    return t
+
+
+def sync_errors():
+    """slots whose bounded wait ran out (word 19 of a slot): a list of (device, stream, slot); reads the device"""
+    bad = []
+    for (dev, st), t in _SYNC.items():
+        w = t.view(__import__("torch").int32).view(-1, 64)[:, 19]
+        for i in w.nonzero().flatten().tolist():
+            bad.append((dev, st, int(i)))
+    return bad
 
 
 def require_cuda(*tensors):

@@ -476,7 +476,8 @@ def colsum(x):
     ws_bytes = lib.wsis_colsum_workspace_bytes(M, C)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     out = torch.empty(C, dtype=torch.float32, device=x.device)
-    _n.check(lib.wsis_colsum(_n.ptr(x), M, C, _n.ptr(out), _n.ptr(ws), ws_bytes, _n.stream_ptr()), "colsum")
+    _n.check(lib.wsis_colsum(_n.ptr(x), M, C, _n.ptr(out), _n.ptr(ws), ws_bytes, _n.ptr(_n.sync_block(x.device)),
+                             _n.stream_ptr()), "colsum")
     return out
 
 

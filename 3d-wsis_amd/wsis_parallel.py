@@ -24,7 +24,11 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        # WSIS_DIST_TIMEOUT (seconds): a rank that dies or raises must not leave its peers blocked in a collective for
+        # the backend's default of 10-30 minutes
+        timeout = datetime.timedelta(seconds=int(os.environ.get("WSIS_DIST_TIMEOUT", "1800")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, local_rank, world
 
 
@@ -209,3 +213,7 @@ class GradSync(object):
                 for p, g in zip(rest, grads):
                     if p.grad is None:
                         p.grad = g
+        if self._comm_stream is None and model is not None and self._agree_calls >= self.AGREE_CALLS:
+            # plan frozen: from the next backward pass on, the first half of the flat buffer is exchanged from inside
+            # the pass (no-op without a native UNet program, on CPU, or with WSIS_SYNC_OVERLAP=0)
+            self.enable_overlap(model)

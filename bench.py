@@ -67,9 +67,10 @@ def parse():
                     help="build the next step's rulebooks from a helper thread (measured slower: GIL contention)")
     ap.add_argument("--profile-steps", type=int, default=2, help="extra event-instrumented steps for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--cpu-warmup", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=8)
-    ap.add_argument("--cpu-timeout", type=int, default=150)
+    ap.add_argument("--cpu-timeout", type=int, default=240)
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--setup-steps", type=int, default=300,
                     help="untimed initialisation passes before the W warm-up steps: lazy code-object loads, allocator "
@@ -104,13 +105,11 @@ def self_launch(args):
             sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}\n")
             sys.exit(2)
         return
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    # --standalone: the launcher binds its own rendezvous port (a port probed here and closed again could be taken by
+    # another job before the launcher binds it)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--standalone", "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.exit(subprocess.run(cmd, env=env).returncode)
@@ -138,11 +137,16 @@ def cpu_worker(args):
         loss.backward()
 
     t0 = time.time()
-    one()                       # warm-up (first-touch page faults dominate it)
+    one()                       # first warm-up pass (first-touch page faults dominate it)
     warm = time.time() - t0
-    out = {"c1": c1, "warm": warm, "iters": 0, "dt": warm, "voxels": int(batch_host["voxel_locs"].shape[0]),
-           "threads": threads}
+    out = {"c1": c1, "warm": warm, "warm_passes": 1, "iters": 0, "dt": warm,
+           "voxels": int(batch_host["voxel_locs"].shape[0]), "threads": threads}
     print(json.dumps(out), flush=True)
+    for w in range(1, max(args.cpu_warmup, 1)):
+        t1 = time.time()
+        one()
+        out.update(warm_passes=w + 1, dt=time.time() - t1)
+        print(json.dumps(out), flush=True)
     t0 = time.time()
     for it in range(args.cpu_iters):
         one()
@@ -313,6 +317,24 @@ def other_configs(harness, device, args):
     return out
 
 
+def per_level(records, steps):
+    """roofline.per_level: the forward / dIn products of a step grouped by the pyramid level of their OUTPUT rows
+    (level = rank of the row count, 0 = finest): launches, time with the finishing slab sums, algorithmic GB/s"""
+    rows = sorted({r[0] for r in records}, reverse=True)
+    out = []
+    for lvl, m in enumerate(rows):
+        sel = [r for r in records if r[0] == m]
+        nbytes, flops = sum(r[4] for r in sel), sum(r[5] for r in sel)
+        ms_main, ms = sum(r[6] for r in sel), sum(r[7] for r in sel)
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out.append({"level": lvl, "rows": int(m), "launches": len(sel) // steps, "us": round(ms * 1e3 / steps, 1),
+                    "us_main_kernel_only": round(ms_main * 1e3 / steps, 1),
+                    "alg_MB": round(nbytes / steps / 1e6, 1), "alg_GBs": round(gbs, 1),
+                    "frac": round(gbs / HBM_PEAK_GBS, 4),
+                    "mfma_frac_fp32": round(flops / (ms * 1e-3) / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4) if ms > 0 else 0.0})
+    return out
+
+
 def cpu_baseline(full_voxels, args):
     """The oracle (torch-CPU port of the upstream gather -> mm -> scatter-add algorithm, oracle/network_ref.py)
     timed on this box's host cores in a child process with a hard time limit, on the SAME C2 scene the GPU leg
@@ -320,9 +342,10 @@ def cpu_baseline(full_voxels, args):
     keeps the passes that finished); the C1 leg (10 k-pt room, host plumbing) runs first in the same child."""
     import subprocess
     cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 32))
+    threads = cores                      # SURVEY 8d: torch.set_num_threads(os.cpu_count())
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-threads", str(threads),
-           "--cpu-iters", str(args.cpu_iters), "--scene-seed", str(args.scene_seed)]
+           "--cpu-iters", str(args.cpu_iters), "--cpu-warmup", str(args.cpu_warmup), "--scene-seed",
+           str(args.scene_seed)]
     env = dict(os.environ)
     env["HIP_VISIBLE_DEVICES"] = ""      # the child must not open the GPU
     env["OMP_NUM_THREADS"] = str(threads)
@@ -355,9 +378,10 @@ def cpu_baseline(full_voxels, args):
     timed = r["iters"] > 0
     return {"value": round(1.0 / r["dt"], 5), "unit": "scenes/s", "cores": r["threads"], "kind": "port",
             "c1": r.get("c1"),
-            "sample": (f"{r['iters']} timed fwd+bwd pass(es)" if timed else "the warm-up pass only") +
+            "sample": (f"{r['iters']} timed fwd+bwd pass(es)" if timed else "warm-up passes only") +
                       f" of the {r['voxels']}-voxel C2 scene itself (the scene of the GPU leg; {full_voxels} voxels) "
-                      f"after a {r['warm']:.1f} s warm-up pass, {r['dt']:.2f} s per pass{note}; torch-CPU oracle, "
+                      f"after {r.get('warm_passes', 1)} warm-up pass(es) (first one {r['warm']:.1f} s), "
+                      f"{r['dt']:.2f} s per pass{note}; torch-CPU oracle, "
                       f"{r['threads']} threads of {cores} logical cores, {model_name}"}
 
 
@@ -485,18 +509,23 @@ def main():
         k = summ.get("spconv_fwd_kernel")
         if k and k["ms"] > 0:
             gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
-            roof = {"kernel": "spconv_fwd2_kernel (+ spconv_fwd3_kernel on slab-split levels, spconv_fwd_kernel for the 6-channel input conv)",
+            roof = {"kernel": "spconv_fwd2_kernel (+ spconv_fwd3_kernel on slab-split levels, spconv_fwd_kernel for the "
+                              "6-channel input conv) INCLUDING the fixed-order slab sums that finish a product "
+                              "(spconv2_reduce_kernel / spconv2_reduce_stats_kernel)",
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
                     "alg_bytes_per_launch": k["bytes"] // k["launches"],
                     "launches_per_step": k["launches"] // args.profile_steps,
                     "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 2),
+                    "avg_launch_us_main_kernel_only": round(k["ms_main"] * 1e3 / k["launches"], 2),
+                    "frac_main_kernel_only": round(k["bytes"] / (k["ms_main"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "alg_bytes_per_step": k["bytes"] // args.profile_steps,
                     "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2),
                     "mfma_frac_fp32": round(k["flops"] / (k["ms"] * 1e-3) / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4),
-                    "measured": "HIP events around every launch in %d extra steps with the dW side stream off "
-                                "(kernel alone on the GPU); rocprofv3 of WSIS_DW_STREAM=0 agrees, see profiles/"
-                                % args.profile_steps}
+                    "per_level": per_level(k["per_launch"], args.profile_steps),
+                    "measured": "HIP events around every product (main kernel + its slab sum where there is one) in "
+                                "%d extra steps with the dW side stream off (kernel alone on the GPU); rocprofv3 of "
+                                "WSIS_DW_STREAM=0 agrees, see profiles/" % args.profile_steps}
         d = summ.get("spconv_dw_kernel")
         if d and d["ms"] > 0:
             extra["dw_kernel"] = {"achieved_GBs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
@@ -508,6 +537,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_stages:
         extra.update(side_measurements(harness, optimizer, device, args))
+        if roof and extra.get("measured_copy_GBs"):       # the same bytes against what a device copy reaches here
+            roof["frac_vs_measured_copy"] = round(roof["achieved"] / extra["measured_copy_GBs"], 4)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -529,8 +560,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("C2: 1 synthetic ScanNet-shaped scene on 1 GPU" if (world == 1 and spg == 1) else
                                     f"C5-shaped: {spg} synthetic ScanNet-shaped scene(s) per GPU x {world} GPU(s) = "
-                                    f"batch {spg * world}, scenes sharded by rank, one RCCL gradient all-reduce per "
-                                    f"step") + ", 2 cm voxels, fwd+bwd+AdamW step (SubMConv3d UNet 32..160 + ECC GNN "
+                                    f"batch {spg * world}, scenes sharded by rank, gradient all-reduce per step over "
+                                    f"{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend() + ' (control-flow run, ranks may share a GPU)'}") + ", 2 cm voxels, fwd+bwd+AdamW step (SubMConv3d UNet 32..160 + ECC GNN "
                                     "+ edge affinity + MultiTaskLoss); per-batch segment CSRs / edge graph and all "
                                     "rulebooks are rebuilt inside every step" +
                                     (" EXCEPT the segment CSRs / edge graph (--hoist-graphs)" if args.hoist_graphs

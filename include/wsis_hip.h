@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define WSIS_ABI_VERSION 1
+#define WSIS_ABI_VERSION 2
 
 /* error codes */
 #define WSIS_OK 0
@@ -201,7 +201,9 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
  *                                            output channels), flip = 1 for submanifold tables (offset k uses
  *                                            slice K-1-k), 0 for the coupled strided / inverse tables
  * with NW = 1 bit-identical to wsis_spconv_fwd; small levels split the offsets over the waves of a workgroup (added
- * through LDS in wave order) and, below that, over blockIdx.z into partial slabs in d_ws (fixed order). */
+ * through LDS in wave order) and, below that, over blockIdx.z into partial slabs in d_ws (fixed order).  d_sync: a
+ * sync slot (wsis_sync_bytes; may be NULL): with one, slab-split launches run as the persistent kernel whose
+ * workgroups draw their slices from a counter in the slot -- the same results bit for bit. */
 int32_t wsis_spconv_fwd_t_supported(int32_t K, int32_t Cin, int32_t Cout);
 /* number of offset slabs the launch plan of wsis_spconv_fwd_t uses for this shape (1 = one kernel, no second pass) */
 int32_t wsis_spconv_fwd_t_slabs(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout);
@@ -213,7 +215,7 @@ int64_t wsis_spconv_fwd_t_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin,
 int wsis_spconv_fwd_t(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT, int32_t flip,
                       const float* d_bias, const float* d_residual, float* d_out, float* d_stats, int64_t M_in,
                       int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
-                      void* stream);
+                      void* d_sync, void* stream);
 /* the same product for a dIn pass whose output dy [M_out, Cout] feeds the backward of a BatchNorm(+ReLU) with input
  * d_bn_x [M_out, Cout] (reference: spconv's dIn followed by torch's batch_norm backward, sparse_unet3d.py:128-137):
  * besides d_out the epilogue writes, per 32-row slice, (sum dz, sum dz * xhat) with xhat = (x - mean) rsqrt(var + eps)
@@ -223,7 +225,7 @@ int wsis_spconv_fwd_t_bn(const float* d_X, const int32_t* d_nbr, const int32_t* 
                          float* d_out, float* d_partials, const float* d_bn_x, const float* d_bn_mean,
                          const float* d_bn_var, const float* d_bn_gamma, const float* d_bn_beta, float eps, int32_t relu,
                          int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
-                         void* stream);
+                         void* d_sync, void* stream);
 /* WT[k'] = W[k]^T with k' = (flip ? K-1-k : k); W [K,Cin,Cout] -> WT [K,Cout,Cin]. */
 int wsis_weight_transpose(const float* d_W, float* d_WT, int32_t K, int32_t Cin, int32_t Cout,
                           int32_t flip, void* stream);
@@ -234,11 +236,24 @@ int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_orde
                    float* d_dW, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws,
                    int64_t ws_bytes, void* stream);
 
-/* Live timing of the dominant kernels (bench.py roofline): with profiling enabled every spconv_fwd_kernel
- * (which = 0) and spconv_dw_kernel (which = 1) launch is bracketed by HIP events on its launch stream;
- * wsis_prof_summary synchronises them, returns the summed duration and the launch count, and clears the list. */
+/* Live timing of the dominant kernels (bench.py roofline): with profiling enabled every forward / dIn convolution
+ * (which = 0) and every weight-gradient product (which = 1) is bracketed by HIP events on its launch stream: one in
+ * front of the main kernel, one behind it, and -- where the product is finished by a second launch (the fixed-order sum
+ * of offset slabs / workgroup slabs) -- one behind that launch.  wsis_prof_summary synchronises them, returns the
+ * summed duration INCLUDING the finishing launches and the count, and clears the list; wsis_prof_records returns the
+ * per-product durations in issue order instead (h_main_ms: main kernel only, h_total_ms: with the finishing launch). */
 int wsis_prof_enable(int32_t on);
 int wsis_prof_summary(int32_t which, double* total_ms, int64_t* launches);
+int wsis_prof_records(int32_t which, double* h_main_ms, double* h_total_ms, int64_t cap, int64_t* n);
+
+/* ---- sync slots of the one-launch reductions ------------------------------------------------------------------
+ * Operators that finish a two-level reduction in the SAME launch (last-arrival tickets; published flag for the
+ * finish + apply forms) keep their cross-workgroup words in CALLER memory: d_sync points at a 256-byte slot that the
+ * caller zero-fills ONCE (e.g. torch.zeros); every launch leaves its slot zero again, so consecutive launches on one
+ * stream may share a slot, launches that may overlap on different streams need different slots.  d_sync == NULL selects
+ * the multi-launch form of the operator.  wsis_run_ops takes a block of wsis_sync_bytes() bytes (64 slots, one per op
+ * index modulo 64).  A wait that does not see its producers within 2 s sets word 19 of the slot (nothing hangs). */
+int64_t wsis_sync_bytes(void);
 
 /* ---- a12: BatchNorm1d(+ReLU) over the active voxels  sparse_unet3d.py:128-137, backbone_3D_WSIS.py:47,52-55 ---
  * Training statistics with a fixed reduction tree (deterministic).  d_ws from wsis_bn_workspace_bytes.
@@ -253,15 +268,16 @@ int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* 
 int64_t wsis_bn_stats_finalize_workspace_bytes(int64_t n_part, int32_t C);
 int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, int32_t C, float* d_mean, float* d_var,
                            float* d_running_mean, float* d_running_var, float momentum, void* d_ws, int64_t ws_bytes,
-                           void* stream);
+                           void* d_sync, void* stream);
 /* wsis_bn_stats_finalize followed by wsis_bn_apply (y = relu?((x - mean) * gamma / sqrt(var + eps) + beta)) as ONE
- * launch where that is possible (eager launch, C % 4 == 0, a grid of <= 512 resident workgroups): the workgroups that
- * finish the statistics publish them, all wait for that and apply.  Identical results to the two calls, which it makes
- * itself otherwise (WSIS_BN_FUSED_APPLY=0, stream capture, odd shapes).  Same workspace as wsis_bn_stats_finalize. */
+ * launch where that is possible (a sync slot, C % 4 == 0, a grid of <= 512 resident workgroups): the workgroups that
+ * finish the statistics publish them, all wait for that (bounded) and apply.  Identical results to the two calls, which
+ * it makes itself otherwise (d_sync == NULL, WSIS_BN_FUSED_APPLY=0, odd shapes).  Same workspace as
+ * wsis_bn_stats_finalize. */
 int wsis_bn_stats_finalize_apply(const float* d_partials, int64_t n_part, int64_t M, int32_t C, float* d_mean,
                                  float* d_var, float* d_running_mean, float* d_running_var, float momentum,
                                  const float* d_x, const float* d_gamma, const float* d_beta, float eps, int32_t relu,
-                                 float* d_y, void* d_ws, int64_t ws_bytes, void* stream);
+                                 float* d_y, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream);
 /* backward of the fused BN(+ReLU) when dy was produced by wsis_spconv_fwd_t_bn: d_partials holds the n_part =
  * ceil(M / 32) rows of (sum dz, sum dz * xhat) slice partials (pitch 2*C floats) that the convolution's epilogue wrote,
  * so the reduction pass over x and dy of wsis_bn_bwd is replaced by an fp64 sum of the partials (fixed order, chunk
@@ -269,7 +285,8 @@ int wsis_bn_stats_finalize_apply(const float* d_partials, int64_t n_part, int64_
 int wsis_bn_bwd_from_partials(const float* d_partials, int64_t n_part, const float* d_x, const float* d_dy,
                               const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta,
                               float eps, int32_t relu, float* d_dx, float* d_dgamma, float* d_dbeta,
-                              const float* d_addend, int64_t M, int32_t C, void* d_ws, int64_t ws_bytes, void* stream);
+                              const float* d_addend, int64_t M, int32_t C, void* d_ws, int64_t ws_bytes, void* d_sync,
+                              void* stream);
 /* (with d_dx the reduction finish and the apply pass are one launch where wsis_bn_stats_finalize_apply's conditions
  * hold; identical results) */
 /* y = relu?( (x-mean)*rsqrt(var+eps)*gamma + beta )   (gamma/beta may be NULL = 1/0) */
@@ -350,10 +367,11 @@ int wsis_ecc_message_bwd(const float* d_x, const float* d_w, const float* d_dout
 
 /* Column sums out[c] = sum_r x[r, c] of x [M, C] (C % 4 == 0, C <= 1024): the bias gradient of the point-level
  * Linear layers (backbone_3D_WSIS.py:59-64, `dy.sum(0)` in torch's AddmmBackward).  One launch, two levels, fixed
- * summation order (run-to-run identical).  Launches that may run concurrently (different streams) must use different
- * workspaces: the arrival counter is picked from the workspace address. */
+ * summation order (run-to-run identical); inputs of more than one chunk need a sync slot (d_sync, see
+ * wsis_sync_bytes). */
 int64_t wsis_colsum_workspace_bytes(int64_t M, int32_t C);
-int wsis_colsum(const float* d_x, int64_t M, int32_t C, float* d_out, void* d_ws, int64_t ws_bytes, void* stream);
+int wsis_colsum(const float* d_x, int64_t M, int32_t C, float* d_out, void* d_ws, int64_t ws_bytes, void* d_sync,
+                void* stream);
 
 /* GRUCellEx of the superpoint GNN (modules/model/spg_modules.py:207-253: GRU cell + input gate + per-row
  * normalisation of the gate pre-activations), C == 32: one kernel forward, one backward + a fixed-order reduce of
@@ -485,7 +503,8 @@ int wsis_adamw_step(const void* d_segments, const int32_t* d_blocks, int64_t n_b
  *   CONV_BWD     in: X, W, dY, nbr_f, order_f, nbr_b, order_b  out: dX (may be NULL), dW (may be NULL)
  *                M_in = rows of X / dX, M_out = rows of dY     (weight_transpose + wsis_spconv_fwd + wsis_spconv_dw)
  *   BN_RELU_BWD  in: x, dy, mean, var, gamma, beta, addend     out: dx, dgamma, dbeta      (wsis_bn_bwd)
- * BN ops use M_in rows and Cin channels.  d_ws from wsis_run_ops_workspace_bytes (max over the ops). */
+ * BN ops use M_in rows and Cin channels.  d_ws from wsis_run_ops_workspace_bytes (max over the ops); d_sync: a
+ * zero-filled block of wsis_sync_bytes() bytes (may be NULL: multi-launch forms). */
 enum {
   WSIS_OP_CONV = 1, WSIS_OP_BN_RELU = 2, WSIS_OP_CAT = 3, WSIS_OP_SPLIT = 4, WSIS_OP_ADD = 5, WSIS_OP_CONV_BWD = 6,
   WSIS_OP_BN_RELU_BWD = 7
@@ -504,13 +523,13 @@ typedef struct wsis_op {
   void* out[4];
 } wsis_op;
 int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n);
-int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* stream);
+int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream);
 /* The same with a milestone: once op `mark_op` (0-based) has been issued, `waiter_stream` is made to wait for
  * everything issued so far on `stream` and on the library's weight-gradient side stream.  The data-parallel step uses
  * it to start the RCCL all-reduce of the finished first part of the flat gradient buffer while the rest of the backward
  * pass still runs (the reference's DDP buckets, train_scannetv2.py:738).  mark_op < 0: no milestone. */
-int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* stream, int32_t mark_op,
-                        void* waiter_stream);
+int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream,
+                        int32_t mark_op, void* waiter_stream);
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ def bn_case(name, Xg, nbr, order, W, flip, rows, K, Cin, Cout):
     ws = torch.empty(max(lib.wsis_spconv_fwd_t_workspace_bytes(rows, K, Cin, Cout), 256), dtype=torch.uint8, device=dev)
     _n.check(lib.wsis_spconv_fwd_t_bn(_n.ptr(Xg), _n.ptr(nbr), _n.ptr(order), _n.ptr(W), flip, _n.ptr(out), _n.ptr(part), _n.ptr(x),
                                       _n.ptr(mean), _n.ptr(var), _n.ptr(gamma), _n.ptr(beta), 1e-4, 1, Xg.shape[0], rows, K, Cin, Cout,
-                                      _n.ptr(ws), ws.numel(), _n.stream_ptr()), name)
+                                      _n.ptr(ws), ws.numel(), _n.ptr(_n.sync_block()), _n.stream_ptr()), name)
     xh = (x - mean) * torch.rsqrt(var + 1e-4)
     dz = torch.where(xh * gamma + beta <= 0, torch.zeros_like(out), out)
     res[name + "_out"] = out.cpu().numpy(); res[name + "_part"] = part.cpu().numpy()

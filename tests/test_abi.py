@@ -30,8 +30,9 @@ def test_binding_table_matches_header():
 
 
 def test_libraries_load_and_report_version():
-    assert wsis_native.host().wsis_host_version() == 1
-    assert wsis_native.hip().wsis_version() == 1
+    abi = int(re.search(r"#define WSIS_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "wsis_hip.h")).read()).group(1))
+    assert wsis_native.host().wsis_host_version() == abi
+    assert wsis_native.hip().wsis_version() == abi
     assert wsis_native.hip().wsis_device_count() >= 0
 
 

@@ -341,7 +341,8 @@ def test_gradsync_allreduces_the_flat_unet_gradient_buffer_in_place():
             loss.backward()
             gs(model)
         want = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
-        assert gs.enable_overlap(model) and gs.ready()
+        assert gs.enable_overlap(model) and gs.ready()      # (GradSync switches it on by itself once the plan is frozen)
+        early0 = getattr(gs, "early_count", 0)
         for _ in range(2):
             opt.zero_grad(set_to_none=True)
             loss, _ = harness.forward_loss(model, crit, batch, cfg)
@@ -352,7 +353,7 @@ def test_gradsync_allreduces_the_flat_unet_gradient_buffer_in_place():
             for n, p in model.named_parameters():
                 if p.grad is not None:
                     assert torch.equal(p.grad, want[n]), n
-        assert gs.early_count == 2
+        assert gs.early_count - early0 == 2
     finally:
         dist.destroy_process_group()
 

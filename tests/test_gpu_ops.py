@@ -1095,7 +1095,8 @@ def test_din_epilogue_writes_the_batchnorm_backward_partials(C, rooms):
     for relu in (1, 0):
         _n.check(lib.wsis_spconv_fwd_t_bn(_n.ptr(dY), _n.ptr(rb.nbr_p), _n.ptr(rb.order), _n.ptr(W), 1, _n.ptr(out),
                                           _n.ptr(part), _n.ptr(x), _n.ptr(mean), _n.ptr(var), _n.ptr(gamma), _n.ptr(beta),
-                                          eps, relu, M, M, 27, C, C, _n.ptr(ws), ws.numel(), _n.stream_ptr()), "fwd_t_bn")
+                                          eps, relu, M, M, 27, C, C, _n.ptr(ws), ws.numel(), _n.ptr(_n.sync_block()),
+                                          _n.stream_ptr()), "fwd_t_bn")
         assert torch.equal(out, want_dx_in)
         xh = (x - mean) * torch.rsqrt(var + eps)
         dz = torch.where((xh * gamma + beta <= 0) if relu else torch.zeros_like(xh, dtype=torch.bool), torch.zeros_like(out), out)
@@ -1109,7 +1110,8 @@ def test_din_epilogue_writes_the_batchnorm_backward_partials(C, rooms):
         dx2, dg2, db2 = torch.empty_like(x), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
         _n.check(lib.wsis_bn_bwd_from_partials(_n.ptr(part), n_part, _n.ptr(x), _n.ptr(out), _n.ptr(mean), _n.ptr(var),
                                                _n.ptr(gamma), _n.ptr(beta), eps, relu, _n.ptr(dx1), _n.ptr(dg1), _n.ptr(db1),
-                                               _n.ptr(addend), M, C, _n.ptr(ws), ws.numel(), _n.stream_ptr()), "bn_bwd_from_partials")
+                                               _n.ptr(addend), M, C, _n.ptr(ws), ws.numel(), _n.ptr(_n.sync_block()),
+                                               _n.stream_ptr()), "bn_bwd_from_partials")
         wb = torch.empty(lib.wsis_bn_workspace_bytes(M, C), dtype=torch.uint8, device=DEV)
         _n.check(lib.wsis_bn_bwd(_n.ptr(x), _n.ptr(out), _n.ptr(mean), _n.ptr(var), _n.ptr(gamma), _n.ptr(beta), eps, relu, 1,
                                  _n.ptr(dx2), _n.ptr(dg2), _n.ptr(db2), _n.ptr(addend), M, C, _n.ptr(wb), wb.numel(),
@@ -1224,10 +1226,10 @@ def test_bn_finalize_apply_in_one_launch_equals_the_two_calls(M, C):
         if fused:
             _n.check(lib.wsis_bn_stats_finalize_apply(_n.ptr(partial), n_part, M, C, _n.ptr(mean), _n.ptr(var), _n.ptr(rm),
                                                       _n.ptr(rv), 0.1, _n.ptr(x), _n.ptr(gamma), _n.ptr(beta), 1e-4, 1,
-                                                      _n.ptr(y), _n.ptr(ws), ws_bytes, st), "fused")
+                                                      _n.ptr(y), _n.ptr(ws), ws_bytes, _n.ptr(_n.sync_block()), st), "fused")
         else:
             _n.check(lib.wsis_bn_stats_finalize(_n.ptr(partial), n_part, M, C, _n.ptr(mean), _n.ptr(var), _n.ptr(rm),
-                                                _n.ptr(rv), 0.1, _n.ptr(ws), ws_bytes, st), "finalize")
+                                                _n.ptr(rv), 0.1, _n.ptr(ws), ws_bytes, None, st), "finalize")
             _n.check(lib.wsis_bn_apply(_n.ptr(x), _n.ptr(mean), _n.ptr(var), _n.ptr(gamma), _n.ptr(beta), 1e-4, 1,
                                        _n.ptr(y), M, C, st), "apply")
         torch.cuda.synchronize()
@@ -1240,3 +1242,58 @@ def test_bn_finalize_apply_in_one_launch_equals_the_two_calls(M, C):
             assert torch.equal(a, b)
     want = torch.relu(torch.nn.functional.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-4))
     assert torch.allclose(ref[4], want, rtol=1e-4, atol=1e-4)
+    assert not _n.sync_block().any(), "every launch must leave its sync slot zero"
+    assert _n.sync_errors() == []
+
+
+@pytest.mark.gpu
+def test_fused_batchnorm_launches_on_two_streams_concurrently_do_not_interfere():
+    """the sync words of the one-launch BatchNorm forms live in the caller's slots (no device globals): 1,000 launches on
+    each of two streams at the same time, each stream with its own sync block, every result bit-identical to the
+    two-launch form; no bounded wait runs out (SURVEY 8b: re-entrant, no global mutable state)"""
+    import wsis_native as _n
+    lib = _n.hip()
+    cases = []
+    for M, C in ((12011, 96), (40003, 64)):
+        g = torch.Generator(device=DEV).manual_seed(M)
+        x = torch.randn(M, C, device=DEV, generator=g)
+        gamma, beta = torch.rand(C, device=DEV, generator=g) + 0.5, torch.randn(C, device=DEV, generator=g)
+        n_part = (M + 31) // 32
+        pad = n_part * 32 - M
+        blocks = torch.cat([x, torch.zeros(pad, C, device=DEV)]).view(n_part, 32, C)
+        cnt = torch.full((n_part, 1), 32.0, device=DEV)
+        cnt[-1] = 32 - pad
+        s = blocks.sum(1)
+        mask = (torch.arange(n_part * 32, device=DEV) < M).view(n_part, 32, 1).float()
+        q = (((blocks - (s / cnt).unsqueeze(1)) * mask) ** 2).sum(1)
+        partial = torch.stack([s, q], 1).contiguous()
+        wsb = lib.wsis_bn_stats_finalize_workspace_bytes(n_part, C)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+        mean, var, y = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty_like(x)
+        _n.check(lib.wsis_bn_stats_finalize(_n.ptr(partial), n_part, M, C, _n.ptr(mean), _n.ptr(var), None, None, 0.1,
+                                            _n.ptr(ws), wsb, None, _n.stream_ptr()), "finalize")
+        _n.check(lib.wsis_bn_apply(_n.ptr(x), _n.ptr(mean), _n.ptr(var), _n.ptr(gamma), _n.ptr(beta), 1e-4, 1, _n.ptr(y),
+                                   M, C, _n.stream_ptr()), "apply")
+        cases.append(dict(M=M, C=C, x=x, gamma=gamma, beta=beta, partial=partial, n_part=n_part, wsb=wsb, want=y,
+                          ws=torch.empty(wsb, dtype=torch.uint8, device=DEV), mean=torch.empty(C, device=DEV),
+                          var=torch.empty(C, device=DEV), y=torch.empty_like(x), stream=torch.cuda.Stream()))
+    torch.cuda.synchronize()
+    for c in cases:
+        with torch.cuda.stream(c["stream"]):
+            c["sync"] = _n.sync_block()            # one block per (device, stream)
+    assert cases[0]["sync"].data_ptr() != cases[1]["sync"].data_ptr()
+    for it in range(1000):
+        for c in cases:                            # alternate: both streams always have launches queued
+            with torch.cuda.stream(c["stream"]):
+                _n.check(lib.wsis_bn_stats_finalize_apply(
+                    _n.ptr(c["partial"]), c["n_part"], c["M"], c["C"], _n.ptr(c["mean"]), _n.ptr(c["var"]), None, None, 0.1,
+                    _n.ptr(c["x"]), _n.ptr(c["gamma"]), _n.ptr(c["beta"]), 1e-4, 1, _n.ptr(c["y"]), _n.ptr(c["ws"]),
+                    c["wsb"], _n.ptr(c["sync"]), _n.stream_ptr()), "fused")
+        if it % 250 == 249:
+            torch.cuda.synchronize()
+            for c in cases:
+                assert torch.equal(c["y"], c["want"])
+    torch.cuda.synchronize()
+    assert _n.sync_errors() == []
+    for c in cases:
+        assert not c["sync"].any()

@@ -1,4 +1,6 @@
 #!/bin/bash
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root (gpurun exports it; derived from the script path otherwise)
+export GRAFT_REPO_ROOT
 # per-kernel BN durations at several one-launch thresholds (rocprofv3 kernel stats of tools/bn_bench.py)
 cd /tmp && export TMPDIR=/tmp
 for r in "$@"; do

@@ -21,10 +21,10 @@ dbg = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
 lib = _n.hip()
 fn = lib.wsis_debug_spconv2_diag
 fn.restype = ctypes.c_int32
-fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int64] + [ctypes.c_int32] * 4 + [ctypes.c_void_p, ctypes.c_void_p]
+fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int64] + [ctypes.c_int32] * 4 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 for _ in range(3):
     _n.check(fn(X.data_ptr(), rb.nbr_p.data_ptr(), rb.order.data_ptr(), WT.data_ptr(), out.data_ptr(), M, 27, C, C,
-                variant, dbg.data_ptr(), _n.stream_ptr()), "diag")
+                variant, dbg.data_ptr(), _n.sync_block().data_ptr(), _n.stream_ptr()), "diag")
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().reshape(-1, 8).astype(np.float64)
 r0, r1 = d[:, 0], d[:, 1]

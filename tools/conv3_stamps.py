@@ -20,12 +20,12 @@ dbg = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
 lib = _n.hip()
 fn = lib.wsis_debug_spconv2_diag
 fn.restype = ctypes.c_int32
-fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int64] + [ctypes.c_int32] * 4 + [ctypes.c_void_p, ctypes.c_void_p]
+fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int64] + [ctypes.c_int32] * 4 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
 for it in range(3):
     if it == 2: s.record()
     _n.check(fn(X.data_ptr(), rb.nbr_p.data_ptr(), rb.order.data_ptr(), WT.data_ptr(), out.data_ptr(), M, 27, C, C,
-                100 + zs, dbg.data_ptr(), _n.stream_ptr()), "diag")
+                100 + zs, dbg.data_ptr(), _n.sync_block().data_ptr(), _n.stream_ptr()), "diag")
 e.record(); torch.cuda.synchronize()
 n_sl = (M + 31) // 32
 P = max(1, min(n_sl, 768 // ((C // 32) * zs)))

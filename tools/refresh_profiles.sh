@@ -1,3 +1,5 @@
+: "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root (gpurun exports it; derived from the script path otherwise)
+export GRAFT_REPO_ROOT
 # Regenerates the evidence under profiles/ for round $R (default r02) on the GPU box:
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh'
 # then copy gpurun_out/${R}_* into profiles/ (see profiles/README.md).
@@ -10,13 +12,13 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/st0 /tmp/st1 /tmp/pmc_fetch /tmp/pmc_write
 B="$GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --setup-steps 3 --no-cpu-baseline --no-stages"
 WSIS_DW_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st0 -- python3 $B > $GRAFT_REPO_ROOT/gpurun_out/${R}_bench_under_rocprof.json 2>/dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st1 -- python3 $B > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st1 -- python3 $B > /tmp/$(basename $0).log 2>&1 || tail -20 /tmp/$(basename $0).log
 cp $(find /tmp/st0 -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/gpurun_out/${R}_bench_kernel_stats.csv
 cp $(find /tmp/st1 -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/gpurun_out/${R}_bench_kernel_stats_overlap.csv
 python3 $GRAFT_REPO_ROOT/tools/timeline.py $(find /tmp/st1 -name "*kernel_trace.csv" | head -1) $GRAFT_REPO_ROOT/gpurun_out/${R}_step_timeline.txt
 # HBM traffic of the dominant kernel family: separate counter passes (no trace domains besides --kernel-trace)
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch -- python3 $B --profile-steps 0 > /dev/null 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write -- python3 $B --profile-steps 0 > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pmc_fetch -- python3 $B --profile-steps 0 > /tmp/$(basename $0).log 2>&1 || tail -20 /tmp/$(basename $0).log
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pmc_write -- python3 $B --profile-steps 0 > /tmp/$(basename $0).log 2>&1 || tail -20 /tmp/$(basename $0).log
 python3 $GRAFT_REPO_ROOT/profiles/collect_traffic.py /tmp/pmc_fetch /tmp/pmc_write > $GRAFT_REPO_ROOT/gpurun_out/${R}_conv_traffic.json
 cp $GRAFT_REPO_ROOT/profiles/conv_traffic.json $GRAFT_REPO_ROOT/gpurun_out/${R}_conv_traffic_file.json
 head -4 $GRAFT_REPO_ROOT/gpurun_out/${R}_bench_kernel_stats.csv | cut -c1-200
