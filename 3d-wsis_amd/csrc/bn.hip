@@ -141,22 +141,7 @@ __global__ __launch_bounds__(64) void bn_stats_final_kernel(const float* __restr
 // one: chunk sums (fixed order inside a chunk) -> [G][3][C] doubles, then one thread per channel adds the chunks in order.
 // arrival tickets of the two-level reductions: one counter per channel group in the caller's sync slot (common.h
 // SyncSlot; zero between launches: the last workgroup resets its counter).
-constexpr int BN_FIN_CHUNKS = 64;      // <= 64: the finish kernels hold one chunk per lane
-
-__device__ __forceinline__ void bn_finish_centred(double S, double Q, double W, int64_t M, int c, float* mean, float* var,
-                                                  float* running_mean, float* running_var, float momentum) {
-  const double n = (double)M;
-  const double mu = S / n;
-  double v = (Q + (W - n * mu * mu)) / n;
-  if (v < 0.0) v = 0.0;
-  mean[c] = (float)mu;
-  var[c] = (float)v;
-  if (running_mean) {
-    const double unb = n > 1 ? v * n / (n - 1) : v;
-    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
-    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
-  }
-}
+constexpr int BN_FIN_CHUNKS = kBnFinChunks;      // <= 64: the finish kernels hold one chunk per lane
 
 // chunk g of G for channel group cgi: 256 threads = 32 channel lanes x 8 partial lanes; G == 1 finishes in place.
 // Returns true in the workgroup that wrote the final mean / var of the channel group (G == 1, or the last arrival).
@@ -307,12 +292,14 @@ __device__ __forceinline__ void bn_apply_body(const float* __restrict__ x, const
       }
     };
     coef(cg);
-    // (x - mean)*sc + beta, written as x*sc + (beta - mean*sc) would change rounding: keep the torch order
+    // fma(x - mean, sc, beta): x - mean first (x*sc + (beta - mean*sc) cancels when |mean| >> sigma), one rounding for
+    // the scale-and-shift; the convolutions that apply the BatchNorm while they read their input (csrc/spconv2.hip
+    // bnfrag, csrc/spconv_dw2.hip) use the same expression, so fused and unfused passes agree bit for bit
     auto body = [&](const float4 v) {
       float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float z = (o[e] - mu[e]) * sc[e] + bt[e];
+        float z = __builtin_fmaf(o[e] - mu[e], sc[e], bt[e]);
         if (relu) z = fmaxf(z, 0.0f);
         o[e] = z;
       }
@@ -338,7 +325,7 @@ __device__ __forceinline__ void bn_apply_body(const float* __restrict__ x, const
          t += (int64_t)gridDim.x * blockDim.x) {
       const int c = (int)(t % C);
       const float sc = (gamma ? gamma[c] : 1.0f) * rsqrtf(bn_ld_stat<COHERENT>(var + c) + eps);
-      float z = (x[t] - bn_ld_stat<COHERENT>(mean + c)) * sc + (beta ? beta[c] : 0.0f);
+      float z = __builtin_fmaf(x[t] - bn_ld_stat<COHERENT>(mean + c), sc, beta ? beta[c] : 0.0f);
       if (relu) z = fmaxf(z, 0.0f);
       y[t] = z;
     }
@@ -994,12 +981,6 @@ static unsigned* bn_tickets(void* d_sync) {
   return static_cast<SyncSlot*>(d_sync)->ticket;
 }
 
-static int bn_fin_chunks(int64_t n_part) {
-  int64_t g = n_part / 64;           // at least 64 partials per chunk
-  if (g < 1) g = 1;
-  if (g > BN_FIN_CHUNKS) g = BN_FIN_CHUNKS;
-  return (int)g;
-}
 
 int64_t wsis_bn_stats_finalize_workspace_bytes(int64_t n_part, int32_t C) {
   return (int64_t)bn_fin_chunks(n_part) * 3 * C * (int64_t)sizeof(double) + 256;

@@ -75,7 +75,7 @@ struct ProfScope {
 
 
 // ---- cross-workgroup sync words of the one-launch reductions (no global mutable state).  The words live in
-// CALLER memory: a slot is 256 bytes, zero-filled once by the caller; every kernel that uses a slot leaves it zero
+// CALLER memory: a slot is 4 KiB, zero-filled once by the caller; every kernel that uses a slot leaves it zero
 // again (the last arrival of a ticket resets it, the last workgroup to leave a flag wait resets flag and counter), so
 // consecutive launches on one stream can share a slot; launches that may overlap (different streams) need different
 // slots.  A NULL slot selects the multi-launch form of the operator.
@@ -83,11 +83,39 @@ struct SyncSlot {
   unsigned ticket[16];     // one arrival counter per channel group
   unsigned done, flag, left, err;
   unsigned ctr[44];        // slice-queue counters of spconv_fwd3_kernel: one per (output block, offset slab)
+  unsigned fin[960];       // chunk / final tickets of the in-launch statistics finish of spconv_fwd2_kernel
 };
-static_assert(sizeof(SyncSlot) == 256, "sync slot layout");
+static_assert(sizeof(SyncSlot) == 4096, "sync slot layout");
 constexpr int kSyncSlots = 64;
 inline SyncSlot* sync_slot(void* d_sync, int i) {
   return d_sync ? static_cast<SyncSlot*>(d_sync) + (i % kSyncSlots) : nullptr;
+}
+
+// mean / biased variance (+ running statistics) of one channel from the fp64 totals of the centred slice partials:
+// S = sum of slice sums, Q = sum of the slices' centred sums of squares, W = sum S_i^2 / n_i (Chan's combination)
+__device__ __forceinline__ void bn_finish_centred(double S, double Q, double W, int64_t M, int c, float* mean, float* var,
+                                                  float* running_mean, float* running_var, float momentum) {
+  const double n = (double)M;
+  const double mu = S / n;
+  double v = (Q + (W - n * mu * mu)) / n;
+  if (v < 0.0) v = 0.0;
+  mean[c] = (float)mu;
+  var[c] = (float)v;
+  if (running_mean) {
+    const double unb = n > 1 ? v * n / (n - 1) : v;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+  }
+}
+
+// number of chunks / partial rows per chunk of the two-level statistics finish (bn.hip and the in-launch finish of
+// spconv2.hip must agree: identical order of additions)
+constexpr int kBnFinChunks = 64;
+inline int bn_fin_chunks(int64_t n_part) {
+  int64_t g = n_part / 64;           // at least 64 partials per chunk
+  if (g < 1) g = 1;
+  if (g > kBnFinChunks) g = kBnFinChunks;
+  return (int)g;
 }
 
 // wave-autonomous weight-gradient kernel (csrc/spconv_dw2.hip), dispatched from wsis_spconv_dw
@@ -96,6 +124,9 @@ bool dw2_fits(int64_t M_in, int64_t M_out, int K, int Cin, int Cout);   // 32-bi
 int64_t dw2_workspace_bytes(int64_t M_out, int K, int Cin, int Cout);
 int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY, float* d_dW,
                int64_t M_in, int64_t M_out, int K, int Cin, int Cout, void* d_ws, hipStream_t st);
+int dw2_launch_swapped(const float* d_X, const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta,
+                       float eps, int relu, const int32_t* d_nbr_b, const int32_t* d_order_b, int flip, const float* d_dY,
+                       float* d_dW, int64_t M_in, int64_t M_out, int K, int Cin, int Cout, void* d_ws, hipStream_t st);
 
 // ---- device-side hash (linear-index keys) --------------------------------------------------
 constexpr int64_t kEmptyKey = -1;

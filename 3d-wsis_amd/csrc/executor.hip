@@ -180,9 +180,18 @@ inline bool needs_wt(const wsis_op& op, bool on) {
   return false;
 }
 
+// slab workspace of an op's weight-gradient product (the own-rows form when its input BatchNorm is applied on the fly)
+inline int64_t dw_ws_of(const wsis_op& op) {
+  if (op.flags & WSIS_OPF_BN_IN) return up(wsis_spconv_dw_bn_workspace_bytes(op.M_in, op.K, op.Cin, op.Cout));
+  return up(wsis_spconv_dw_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout));
+}
+
 int64_t op_ws_bytes(const wsis_op& op, bool on) {
   switch (op.kind) {
     case WSIS_OP_CONV:
+      if (op.flags & (WSIS_OPF_BN_IN | WSIS_OPF_STAT_FIN))
+        return up(std::max(wsis_spconv_fwd_f_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout),
+                           wsis_spconv_fwd_t_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout)));
       if (use_fwd2(op, on)) return up(wsis_spconv_fwd_t_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout));
       return up(wsis_spconv_fwd_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout));
     case WSIS_OP_BN_RELU:
@@ -215,7 +224,8 @@ int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n) {
     if (b > need) need = b;
     if (needs_wt(ops[i], on)) wt += wt_bytes_of(ops[i]);
     if (ops[i].kind == WSIS_OP_CONV_BWD && ops[i].out[1]) {
-      const int64_t d = up(wsis_spconv_dw_workspace_bytes(ops[i].M_out, ops[i].K, ops[i].Cin, ops[i].Cout));
+      const int64_t d = dw_ws_of(ops[i]);
+      if (d < 0) return -1;
       if (d > dw) dw = d;
     }
   }
@@ -353,7 +363,7 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   int64_t dw_bytes = 0;
   for (int i = 0; i < n; ++i)
     if (ops[i].kind == WSIS_OP_CONV_BWD && ops[i].out[1]) {
-      const int64_t d = up(wsis_spconv_dw_workspace_bytes(ops[i].M_out, ops[i].K, ops[i].Cin, ops[i].Cout));
+      const int64_t d = dw_ws_of(ops[i]);
       if (d > dw_bytes) dw_bytes = d;
     }
   char* const dw_ws = ws;
@@ -375,6 +385,45 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
     int rc = WSIS_OK;
     switch (op.kind) {
       case WSIS_OP_CONV:
+        if (op.flags & (WSIS_OPF_BN_IN | WSIS_OPF_STAT_FIN)) {
+          if (wt_off[i] < 0) {
+            rc = fail(WSIS_ERR_ARG, "op %d: fused BatchNorm requested from a convolution that is not on wsis_spconv_fwd_t", i);
+            break;
+          }
+          wsis_bn_in bi;
+          bi.mean = (const float*)op.in[6];
+          bi.var = (const float*)op.in[7];
+          bi.gamma = (const float*)op.in[8];
+          bi.beta = (const float*)op.in[9];
+          bi.eps = op.eps;
+          bi.relu = (op.flags & WSIS_OPF_RELU) ? 1 : 0;
+          wsis_stat_target tg[2];
+          int nt = 0;
+          if (op.flags & WSIS_OPF_STAT_FIN) {
+            tg[0].mean = (float*)op.out[2];
+            tg[0].var = (float*)op.out[3];
+            tg[0].running_mean = (float*)const_cast<void*>(op.in[10]);
+            tg[0].running_var = (float*)const_cast<void*>(op.in[11]);
+            tg[0].momentum = op.momentum;
+            tg[0].reserved = 0;
+            nt = 1;
+            if (op.out[4]) {
+              tg[1].mean = (float*)op.out[4];
+              tg[1].var = (float*)op.out[5];
+              tg[1].running_mean = (float*)op.out[6];
+              tg[1].running_var = (float*)op.out[7];
+              tg[1].momentum = op.momentum2;
+              tg[1].reserved = 0;
+              nt = 2;
+            }
+          }
+          rc = wsis_spconv_fwd_f((const float*)op.in[0], (op.flags & WSIS_OPF_BN_IN) ? &bi : nullptr, (const int32_t*)op.in[1],
+                                 (const int32_t*)op.in[2], reinterpret_cast<const float*>(wt_base + wt_off[i]), 0,
+                                 (const float*)op.in[4], (const float*)op.in[5], (float*)op.out[0],
+                                 (op.flags & WSIS_OPF_STATS) ? (float*)op.out[1] : nullptr, tg, nt, op.M_in, op.M_out, op.K,
+                                 op.Cin, op.Cout, ws, ws_bytes, sync_slot(d_sync, i), stream);
+          break;
+        }
         if (wt_off[i] >= 0)
           rc = wsis_spconv_fwd_t((const float*)op.in[0], (const int32_t*)op.in[1], (const int32_t*)op.in[2],
                                  reinterpret_cast<const float*>(wt_base + wt_off[i]), 0, (const float*)op.in[4],
@@ -401,7 +450,7 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
             // the producers' epilogues left (sum, sum of squares) partials per 32-row slice: no pass over x
             const int64_t n_part = (op.M_in + 31) / 32;
             const int C0 = op.in[6] ? op.K : op.Cin;
-            if (!op.in[6]) {     // one producer: statistics finish and apply pass in one launch (falls back by itself)
+            if (!op.in[6] && op.out[0]) {     // one producer: statistics finish and apply pass in one launch (falls back by itself)
               rc = wsis_bn_stats_finalize_apply((const float*)op.in[5], n_part, op.M_in, op.Cin, (float*)op.out[1],
                                                 (float*)op.out[2], rm, rv, op.momentum, (const float*)op.in[0],
                                                 (const float*)op.in[1], (const float*)op.in[2], op.eps,
@@ -424,6 +473,7 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
           mean = (const float*)op.in[3];
           var = (const float*)op.in[4];
         }
+        if (!op.out[0]) break;      // statistics only: the consuming convolution applies the BatchNorm as it reads
         rc = wsis_bn_apply((const float*)op.in[0], mean, var, (const float*)op.in[1], (const float*)op.in[2], op.eps,
                            (op.flags & WSIS_OPF_RELU) ? 1 : 0, (float*)op.out[0], op.M_in, op.Cin, stream);
         break;
@@ -524,9 +574,16 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
             dw_stream = side->stream;
             forked = true;
           }
-          rc = wsis_spconv_dw((const float*)op.in[0], (const int32_t*)op.in[3], (const int32_t*)op.in[4],
-                              (const float*)op.in[2], (float*)op.out[1], op.M_in, op.M_out, op.K, op.Cin, op.Cout, dw_ws,
-                              dw_bytes, dw_stream);
+          if (op.flags & WSIS_OPF_BN_IN)     // the forward input was relu(bn(in[0])) applied on the fly: own-rows form
+            rc = wsis_spconv_dw_bn((const float*)op.in[0], (const float*)op.in[7], (const float*)op.in[8],
+                                   (const float*)op.in[9], (const float*)op.in[10], op.eps,
+                                   (op.flags & WSIS_OPF_RELU) ? 1 : 0, (const int32_t*)op.in[5], (const int32_t*)op.in[6],
+                                   (op.flags & WSIS_OPF_FLIP) ? 1 : 0, (const float*)op.in[2], (float*)op.out[1], op.M_in,
+                                   op.M_out, op.K, op.Cin, op.Cout, dw_ws, dw_bytes, dw_stream);
+          else
+            rc = wsis_spconv_dw((const float*)op.in[0], (const int32_t*)op.in[3], (const int32_t*)op.in[4],
+                                (const float*)op.in[2], (float*)op.out[1], op.M_in, op.M_out, op.K, op.Cin, op.Cout, dw_ws,
+                                dw_bytes, dw_stream);
         }
         break;
       }

@@ -1092,6 +1092,36 @@ int64_t wsis_spconv_dw_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, in
   return old_bytes;
 }
 
+int32_t wsis_spconv_dw_bn_supported(int32_t K, int32_t Cin, int32_t Cout) {
+  return (dw2_supported(K, Cout, Cin) && Cin % 32 == 0 && Cout % 32 == 0) ? 1 : 0;
+}
+
+int64_t wsis_spconv_dw_bn_workspace_bytes(int64_t M_in, int32_t K, int32_t Cin, int32_t Cout) {
+  if (M_in < 0 || !wsis_spconv_dw_bn_supported(K, Cin, Cout)) return -1;
+  return dw2_workspace_bytes(M_in, K, Cout, Cin);
+}
+
+int wsis_spconv_dw_bn(const float* d_X, const float* d_mean, const float* d_var, const float* d_gamma,
+                      const float* d_beta, float eps, int32_t relu, const int32_t* d_nbr_b, const int32_t* d_order_b,
+                      int32_t flip, const float* d_dY, float* d_dW, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin,
+                      int32_t Cout, void* d_ws, int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(M_in >= 0 && M_out >= 0 && d_dW, "bad args");
+  WSIS_REQUIRE(wsis_spconv_dw_bn_supported(K, Cin, Cout), "needs K <= 32 and channel counts that are multiples of 32");
+  hipStream_t st = as_stream(stream);
+  if (M_in == 0 || M_out == 0) {
+    WSIS_HIP_CHECK(hipMemsetAsync(d_dW, 0, sizeof(float) * (size_t)K * Cin * Cout, st));
+    return WSIS_OK;
+  }
+  WSIS_REQUIRE(d_X && d_dY && d_ws && d_nbr_b && d_order_b, "null pointer");
+  WSIS_REQUIRE((d_mean == nullptr) == (d_var == nullptr), "mean and var come in pairs");
+  WSIS_REQUIRE(dw2_fits(M_out, M_in, K, Cout, Cin), "tensor too large for 32-bit gather offsets");
+  WSIS_REQUIRE(ws_bytes >= wsis_spconv_dw_bn_workspace_bytes(M_in, K, Cin, Cout), "workspace too small");
+  WSIS_REQUIRE(((reinterpret_cast<uintptr_t>(d_X) | reinterpret_cast<uintptr_t>(d_dY) | reinterpret_cast<uintptr_t>(d_dW) |
+                 reinterpret_cast<uintptr_t>(d_ws)) & 15) == 0, "16-byte alignment");
+  return dw2_launch_swapped(d_X, d_mean, d_var, d_gamma, d_beta, eps, (int)relu, d_nbr_b, d_order_b, (int)flip, d_dY, d_dW,
+                            M_in, M_out, K, Cin, Cout, d_ws, st);
+}
+
 int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY,
                    float* d_dW, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws,
                    int64_t ws_bytes, void* stream) {

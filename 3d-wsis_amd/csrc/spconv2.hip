@@ -70,6 +70,32 @@ struct BnEpi {
 struct BnCoef {
   float mu, rstd, gm, bt;
 };
+// BatchNorm(+ReLU) of the convolution's INPUT, applied while the gathered rows are read as MFMA fragments (FB kernels):
+// the activation relu(bn(x)) of sparse_unet3d.py:128-137 is never written to memory.  mean / var: batch statistics
+// (training) or the running statistics (evaluation).
+struct BnIn {
+  const float* mean;         // nullptr: off
+  const float* var;
+  const float* gamma;        // may be nullptr (1)
+  const float* beta;         // may be nullptr (0)
+  float eps;
+  int relu;
+};
+// Finish of the output statistics inside the launch (training): the (slice, block) workgroups of a chunk of slices
+// draw tickets; the last one adds the chunk's partials in the order of bn_chunk_centred_stage (bit-identical to
+// wsis_bn_stats_finalize), the last chunk adds the chunk rows and writes mean / var / running statistics of up to two
+// BatchNorm layers that normalise this tensor (a skip connection feeds a second one).
+struct StatFin {
+  double* chunk;             // [G][Cout / 32][3][32] fp64 chunk rows; nullptr: off
+  unsigned* tickets;         // [G * Cout / 32] chunk tickets + [Cout / 32] final tickets, zero between launches
+  int G, per;                // chunks, partial rows per chunk
+  float* mean[2];
+  float* var[2];
+  float* rmean[2];
+  float* rvar[2];
+  float momentum[2];
+  int n_targets;
+};
 __device__ __forceinline__ BnCoef bn_coef(const BnEpi& e, int c) {
   BnCoef k;
   k.mu = e.mean[c];
@@ -94,12 +120,140 @@ __device__ __forceinline__ void dma16(const void* src, void* lds_dst) {
 // ds_read_b128 (rows 0-3,12-15,20-27 / 4-11,16-19,28-31 of one half) then covers 16 distinct 16-byte bank groups
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
-template <int NB, int NW, int DA, bool BD, bool DIAG = false>
+// sc1 (write-through) stores / loads of the words that another workgroup of the SAME launch reads (statistics partials,
+// chunk rows): no release fence, no acquire -- cdna_hip_programming.md Guideline 16, counter form
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float* p) {
+  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double* p) {
+  return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// In-launch finish of the BatchNorm statistics of the tensor this launch writes (StatFin), called by ONE wave of the
+// workgroup that has just stored the partials of slice `slice`, channels col0 .. col0 + 31 (block cbk of CB).
+// Level 1: the last workgroup of a chunk of slices to arrive adds the chunk's partial rows; level 2: the last chunk adds
+// the chunk rows.  Both in exactly the order of bn_chunk_centred_stage (thread (channel, partial lane pl of 8) walks
+// rows lo + pl, + 8, ...; the eight lane sums are added in lane order), so mean / var / running statistics come out
+// bit-identical to wsis_bn_stats_finalize -- whichever workgroup happens to be last.  `red`: 6 KB of LDS scratch.
+__device__ __forceinline__ void stat_finish(const StatFin& fin, const float* __restrict__ stats, int64_t M_out, int Cout,
+                                            int64_t slice, int col0, int CB, int cbk, double* red) {
+  const int lane = threadIdx.x & 63;
+  const int cl = lane & 31, ph = lane >> 5;
+  const int c = col0 + cl;
+  const int64_t n_part = (M_out + 31) >> 5;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's partial stores have left
+  const int g0 = (int)(slice / fin.per);
+  int last = 0;
+  if (lane == 0) {
+    const int64_t lo = (int64_t)g0 * fin.per;
+    const int64_t cnt = (lo + fin.per < n_part ? lo + fin.per : n_part) - lo;
+    unsigned* tk = fin.tickets + g0 * CB + cbk;
+    const unsigned t = atomicAdd(tk, 1u);
+    last = t == (unsigned)cnt - 1u;
+    if (last) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+  }
+  last = __builtin_amdgcn_readfirstlane(last);
+  if (!last) return;
+  double S = 0.0, Q = 0.0, W = 0.0;
+  {
+    const int64_t lo = (int64_t)g0 * fin.per;
+    const int64_t hi = lo + fin.per < n_part ? lo + fin.per : n_part;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0}, w[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t b0 = lo; b0 < hi; b0 += 8) {
+      float sf[4], qf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {            // partial lanes pl = ph * 4 + i; all eight loads in flight
+        const int64_t b = b0 + ph * 4 + i;
+        const int64_t bb = b < hi ? b : lo;
+        sf[i] = ld_sc1(stats + (bb * 2 + 0) * Cout + c);
+        qf[i] = ld_sc1(stats + (bb * 2 + 1) * Cout + c);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t b = b0 + ph * 4 + i;
+        if (b < hi) {
+          const int64_t left = M_out - b * 32;
+          const double si = sf[i];
+          s[i] += si;
+          q[i] += qf[i];
+          w[i] += si * si * (left < 32 ? 1.0 / (double)left : 0.03125);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      red[(0 * 8 + ph * 4 + i) * 32 + cl] = s[i];
+      red[(1 * 8 + ph * 4 + i) * 32 + cl] = q[i];
+      red[(2 * 8 + ph * 4 + i) * 32 + cl] = w[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {              // fixed order
+      S += red[(0 * 8 + j) * 32 + cl];
+      Q += red[(1 * 8 + j) * 32 + cl];
+      W += red[(2 * 8 + j) * 32 + cl];
+    }
+  }
+  const int G = fin.G;
+  if (G > 1) {
+    double* o = fin.chunk + ((int64_t)g0 * CB + cbk) * 96;
+    if (ph == 0) {
+      st_sc1(o + cl, S);
+      st_sc1(o + 32 + cl, Q);
+      st_sc1(o + 64 + cl, W);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int last2 = 0;
+    if (lane == 0) {
+      unsigned* tk = fin.tickets + G * CB + cbk;
+      const unsigned t = atomicAdd(tk, 1u);
+      last2 = t == (unsigned)G - 1u;
+      if (last2) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    last2 = __builtin_amdgcn_readfirstlane(last2);
+    if (!last2) return;
+    double s2[4] = {0.0, 0.0, 0.0, 0.0}, q2[4] = {0.0, 0.0, 0.0, 0.0}, w2[4] = {0.0, 0.0, 0.0, 0.0};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      for (int g = ph * 4 + i; g < G; g += 8) {
+        const double* oc = fin.chunk + ((int64_t)g * CB + cbk) * 96;
+        s2[i] += ld_sc1(oc + cl);
+        q2[i] += ld_sc1(oc + 32 + cl);
+        w2[i] += ld_sc1(oc + 64 + cl);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      red[(0 * 8 + ph * 4 + i) * 32 + cl] = s2[i];
+      red[(1 * 8 + ph * 4 + i) * 32 + cl] = q2[i];
+      red[(2 * 8 + ph * 4 + i) * 32 + cl] = w2[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    S = Q = W = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      S += red[(0 * 8 + j) * 32 + cl];
+      Q += red[(1 * 8 + j) * 32 + cl];
+      W += red[(2 * 8 + j) * 32 + cl];
+    }
+  }
+  if (ph == 0 && c < Cout) {
+    for (int tg = 0; tg < fin.n_targets; ++tg)
+      bn_finish_centred(S, Q, W, M_out, c, fin.mean[tg], fin.var[tg], fin.rmean[tg], fin.rvar[tg], fin.momentum[tg]);
+  }
+}
+
+template <int NB, int NW, int DA, bool BD, bool DIAG = false, bool FB = false>
 __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ WT, const float* __restrict__ bias, const float* __restrict__ residual,
     float* __restrict__ out, float* __restrict__ partial, int64_t M_out, int K, int Cin, int Cout, int flip,
-    uint32_t x_bytes, float* __restrict__ stats, BnEpi epi, unsigned long long* __restrict__ dbg = nullptr) {
+    uint32_t x_bytes, float* __restrict__ stats, BnEpi epi, BnIn bin, StatFin fin,
+    unsigned long long* __restrict__ dbg = nullptr) {
+  static_assert(!FB || (BD && NB == 1), "the fused input BatchNorm is built for the weights-to-registers form");
   // stats (optional, final pass only): per-slice BatchNorm partials of the FINISHED output rows (bias and residual
   // included), stats[(slice * 2 + {0: sum, 1: sum of squared deviations from the SLICE mean}) * Cout + channel] -- the
   // statistics pass of the BatchNorm that consumes this tensor (sparse_unet3d.py:128-137) without re-reading it.
@@ -121,6 +275,16 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
   int32_t* const klist = rowId + 32;
   unsigned char* const Aring = lds + HDR_BYTES + wave * L::WAVE_BYTES;
   unsigned char* const Bring = Aring + DA * A_BYTES;
+  // FB: per-channel (mean, scale, shift) of the input BatchNorm behind the rings, 3 x Cin floats; every wave writes
+  // the identical values itself (like the header: no workgroup barrier in the prologue)
+  float* const coef = reinterpret_cast<float*>(lds + HDR_BYTES + NW * L::WAVE_BYTES);
+  if (FB) {
+    for (int c = lane; c < Cin; c += 64) {
+      coef[c] = bin.mean[c];
+      coef[Cin + c] = (bin.gamma ? bin.gamma[c] : 1.0f) * rsqrtf(bin.var[c] + bin.eps);
+      coef[2 * Cin + c] = bin.beta ? bin.beta[c] : 0.0f;
+    }
+  }
 
   const int64_t t0 = (int64_t)blockIdx.x * SL;
   const int col0 = blockIdx.y * (NB * 32);
@@ -316,6 +480,26 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
       gen_next(gA);
       aS = aS + 1 == DA ? 0 : aS + 1;
     };
+    // FB: relu(bn(x)) of the fragment just read -- lane (row r31, half) holds channels half*16 .. +15 of chunk g.c of
+    // its row under offset g.k; a missing pair (zeros from the out-of-range DMA) must stay zero
+    Gen gR;
+    gen_init(gR);
+    auto bnhalf = [&](f32x4 (&a)[4], const Gen& g, int h) {       // pieces q = 2h, 2h + 1
+      const bool ok = nbT[g.k * 32 + r31] != (int32_t)NO_ROW;
+      const float* cm = coef + g.c * 32 + half * 16;
+#pragma unroll
+      for (int q = 2 * h; q < 2 * h + 2; ++q) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(cm + q * 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(cm + Cin + q * 4);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(cm + 2 * Cin + q * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float z = __builtin_fmaf(a[q][e] - mu[e], sc[e], bt[e]);      // the arithmetic of bn_apply_kernel
+          z = bin.relu ? fmaxf(z, 0.0f) : z;
+          a[q][e] = ok ? z : 0.0f;
+        }
+      }
+    };
     f32x4 a0[4], a1[4], b0[NB][4], b1[NB][4];
     issueA_all();                                   // A0
     loadB(gB, b0);                                  // B0
@@ -333,6 +517,12 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
     }
     tie(b0);
     readfrag(0, 0, a0, b0);
+    if (FB) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the coefficient stores of this wave)
+      bnhalf(a0, gR, 0);
+      bnhalf(a0, gR, 1);
+      gen_next(gR);
+    }
     arS = 1 == DA ? 0 : 1;
     int t = 0;
     auto iter = [&](const f32x4 (&ac)[4], f32x4 (&bc)[NB][4], f32x4 (&an)[4], f32x4 (&bn)[NB][4]) {
@@ -369,7 +559,23 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
         gen_next(gA);
         aS = aS + 1 == DA ? 0 : aS + 1;
       }
-      mfma(ac, bc, 12, 16);
+      if (FB) {
+        // the next step's fragments (read behind MFMA 3) through the BatchNorm, in two halves inside the tail of the
+        // chain: the VALU work runs in the shadow of this wave's own MFMAs and of the other waves of the SIMD
+        const bool nxt = t + 1 < T;
+        if (nxt) bnhalf(an, gR, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(ac, bc, 12, 14);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nxt) {
+          bnhalf(an, gR, 1);
+          gen_next(gR);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(ac, bc, 14, 16);
+      } else {
+        mfma(ac, bc, 12, 16);
+      }
       ++t;
     };
     while (t < T) {
@@ -537,9 +743,12 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
           }
           sb += __shfl_xor(sb, 32, 64);
           if (half == 0) {
-            stats[((int64_t)blockIdx.x * 2 + 0) * Cout + c] = sa;
-            stats[((int64_t)blockIdx.x * 2 + 1) * Cout + c] = sb;
+            st_sc1(stats + ((int64_t)blockIdx.x * 2 + 0) * Cout + c, sa);
+            st_sc1(stats + ((int64_t)blockIdx.x * 2 + 1) * Cout + c, sb);
           }
+          if (NB == 1 && fin.chunk)
+            stat_finish(fin, stats, M_out, Cout, (int64_t)blockIdx.x, col0, (int)gridDim.y, (int)blockIdx.y,
+                        reinterpret_cast<double*>(Aring));
         }
       }
     };
@@ -643,9 +852,12 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
         float tb = 0.0f;
         for (int j = threadIdx.x; j < 64 * NW; j += colw) tb += sred[j];
         const int c = col0 + threadIdx.x;
-        stats[((int64_t)blockIdx.x * 2 + 0) * Cout + c] = ta;
-        stats[((int64_t)blockIdx.x * 2 + 1) * Cout + c] = tb;
+        st_sc1(stats + ((int64_t)blockIdx.x * 2 + 0) * Cout + c, ta);
+        st_sc1(stats + ((int64_t)blockIdx.x * 2 + 1) * Cout + c, tb);
       }
+      if (NB == 1 && fin.chunk && wave == 0)      // (the partials of a 32-channel block are stored by lanes 0-31 of wave 0)
+        stat_finish(fin, stats, M_out, Cout, (int64_t)blockIdx.x, col0, (int)gridDim.y, (int)blockIdx.y,
+                    reinterpret_cast<double*>(lds + HDR_BYTES));
     }
   }
   if (DIAG && dbg && threadIdx.x == 0) {
@@ -1253,8 +1465,17 @@ struct Plan2 {
   int NB, NW, ZS, DA, BD;
 };
 
-Plan2 plan2(int64_t M_out, int K, int Cin, int Cout) {
+// noslab: the product is finished by ONE launch whatever the level -- up to 16 waves of a workgroup split the offsets of
+// a work item and add through LDS, no offset slabs and no second (reduce) launch; the form of the fused-BatchNorm
+// convolutions (wsis_spconv_fwd_f) and, with WSIS_FWD2_NOSLAB=1 (default), of every launch
+Plan2 plan2(int64_t M_out, int K, int Cin, int Cout, bool noslab = false) {
   static int nb_pref = -1, target = -1, nw_force = -1, zs_force = -1, da_pref = -1, nw_max = -1, bd_pref = -1;
+  static int noslab_all = -1, nw_max_noslab = 16;
+  if (noslab_all < 0) {
+    noslab_all = env_int("WSIS_FWD2_NOSLAB", 1);
+    nw_max_noslab = env_int("WSIS_FWD2_NW_MAX_NOSLAB", 16);
+  }
+  noslab = noslab || noslab_all != 0;
   if (nb_pref < 0) {
     bd_pref = env_int("WSIS_FWD2_BD", 1);
     nb_pref = env_int("WSIS_FWD2_NB", 1);
@@ -1270,14 +1491,16 @@ Plan2 plan2(int64_t M_out, int K, int Cin, int Cout) {
   const int64_t items = ceil_div(M_out, SL) * (nblk / p.NB);
   const int steps = K * (Cin / 32);     // steps of a dense work item
   int nw = 1;
-  // (eight waves per work item for the K = 8 strided / inverse tables measured 15-30 % faster per launch, but the
-  // fp64-oracle gradient error of the whole network rose from a median of 7.5e-5 to 2.9e-4 with it: not taken)
-  while (nw < nw_max && items * nw * 2 <= target && nw * 2 <= steps) nw *= 2;
+  const int nwm = noslab ? nw_max_noslab : nw_max;
+  while (nw < nwm && items * nw * 2 <= target && nw * 2 <= steps) nw *= 2;
   if (nw_force > 0) nw = nw_force;
   int zs = 1;
-  while (zs < 8 && items * nw * zs * 2 <= target && zs * 2 <= K && steps / (nw * zs * 2) >= 2) zs *= 2;
-  if (zs_force > 0) zs = zs_force;
-  if (zs > K) zs = K;
+  if (!noslab) {
+    while (zs < 8 && items * nw * zs * 2 <= target && zs * 2 <= K && steps / (nw * zs * 2) >= 2) zs *= 2;
+    if (zs_force > 0) zs = zs_force;
+    if (zs > K) zs = K;
+  }
+  if (noslab) p.NB = 1;
   p.NW = nw;
   p.ZS = zs;
   p.DA = (da_pref == 2 || nw >= 4) ? 2 : 3;     // 4+ waves per workgroup: two workgroups per CU need the short ring
@@ -1307,7 +1530,25 @@ int64_t wsis_spconv_fwd_t_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin,
 static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT,
                              int32_t flip, const float* d_bias, const float* d_residual, float* d_out, float* d_stats,
                              const BnEpi& epi, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout,
-                             void* d_ws, int64_t ws_bytes, void* d_sync, void* stream);
+                             void* d_ws, int64_t ws_bytes, void* d_sync, void* stream, const wsis_bn_in* bn_in = nullptr,
+                             const wsis_stat_target* targets = nullptr, int32_t n_targets = 0, bool fused = false);
+
+int64_t wsis_spconv_fwd_f_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout) {
+  if (M_out < 0 || !wsis_spconv_fwd_t_supported(K, Cin, Cout)) return -1;
+  const int64_t n_part = (M_out + 31) / 32;
+  return (int64_t)bn_fin_chunks(n_part) * (Cout / 32) * 96 * (int64_t)sizeof(double) + 256;
+}
+
+int wsis_spconv_fwd_f(const float* d_X, const wsis_bn_in* bn_in, const int32_t* d_nbr, const int32_t* d_order,
+                      const float* d_WT, int32_t flip, const float* d_bias, const float* d_residual, float* d_out,
+                      float* d_stats, const wsis_stat_target* targets, int32_t n_targets, int64_t M_in, int64_t M_out,
+                      int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream) {
+  WSIS_REQUIRE(n_targets >= 0 && n_targets <= 2 && (n_targets == 0 || (targets && d_stats && d_sync)),
+               "statistics targets need the partial buffer and a sync slot");
+  WSIS_REQUIRE(!bn_in || (bn_in->mean && bn_in->var), "input BatchNorm without statistics");
+  return spconv_fwd_t_impl(d_X, d_nbr, d_order, d_WT, flip, d_bias, d_residual, d_out, d_stats, BnEpi{}, M_in, M_out, K,
+                           Cin, Cout, d_ws, ws_bytes, d_sync, stream, bn_in, targets, n_targets, true);
+}
 
 int wsis_spconv_fwd_t(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT, int32_t flip,
                       const float* d_bias, const float* d_residual, float* d_out, float* d_stats, int64_t M_in,
@@ -1339,7 +1580,8 @@ int wsis_spconv_fwd_t_bn(const float* d_X, const int32_t* d_nbr, const int32_t* 
 static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT,
                              int32_t flip, const float* d_bias, const float* d_residual, float* d_out, float* d_stats,
                              const BnEpi& epi, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout,
-                             void* d_ws, int64_t ws_bytes, void* d_sync, void* stream) {
+                             void* d_ws, int64_t ws_bytes, void* d_sync, void* stream, const wsis_bn_in* bn_in,
+                             const wsis_stat_target* targets, int32_t n_targets, bool fused) {
   WSIS_REQUIRE(M_in >= 0 && M_out >= 0, "bad sizes");
   WSIS_REQUIRE(wsis_spconv_fwd_t_supported(K, Cin, Cout), "needs K <= 32 and channel counts that are multiples of 32");
   if (M_out == 0) return WSIS_OK;
@@ -1350,12 +1592,43 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
   const uint32_t x_bytes = (uint32_t)(M_in * Cin * 4);
   WSIS_REQUIRE(((reinterpret_cast<uintptr_t>(d_X) | reinterpret_cast<uintptr_t>(d_WT)) & 15) == 0,
                "X and WT must be 16-byte aligned");
-  const Plan2 p = plan2(M_out, K, Cin, Cout);
+  const Plan2 p = plan2(M_out, K, Cin, Cout, fused);
   float* partial = nullptr;
   if (p.ZS > 1) {
     WSIS_REQUIRE(d_ws && ws_bytes >= (int64_t)p.ZS * M_out * Cout * (int64_t)sizeof(float), "workspace too small");
     WSIS_REQUIRE((reinterpret_cast<uintptr_t>(d_ws) & 15) == 0, "workspace must be 16-byte aligned");
     partial = static_cast<float*>(d_ws);
+  }
+  BnIn bin{};
+  if (bn_in) {
+    bin.mean = bn_in->mean;
+    bin.var = bn_in->var;
+    bin.gamma = bn_in->gamma;
+    bin.beta = bn_in->beta;
+    bin.eps = bn_in->eps;
+    bin.relu = bn_in->relu;
+    WSIS_REQUIRE(p.NB == 1 && p.BD && p.ZS == 1, "fused input BatchNorm: plan without slabs expected");
+  }
+  StatFin fin{};
+  if (n_targets > 0) {
+    const int64_t n_part = ceil_div(M_out, SL);
+    WSIS_REQUIRE(p.NB == 1 && p.ZS == 1, "in-launch statistics finish: plan without slabs expected");
+    WSIS_REQUIRE(d_ws && ws_bytes >= wsis_spconv_fwd_f_workspace_bytes(M_out, K, Cin, Cout), "workspace too small");
+    fin.G = bn_fin_chunks(n_part);
+    fin.per = (int)ceil_div(n_part, fin.G);
+    WSIS_REQUIRE((int64_t)(fin.G + 1) * (Cout / 32) <= (int64_t)(sizeof(SyncSlot::fin) / sizeof(unsigned)), "too many tickets");
+    fin.chunk = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(d_ws) + 255) & ~(uintptr_t)255);
+    fin.tickets = static_cast<SyncSlot*>(d_sync)->fin;
+    fin.n_targets = n_targets;
+    for (int i = 0; i < n_targets; ++i) {
+      WSIS_REQUIRE(targets[i].mean && targets[i].var, "statistics target without mean / var");
+      WSIS_REQUIRE((targets[i].running_mean == nullptr) == (targets[i].running_var == nullptr), "running stats come in pairs");
+      fin.mean[i] = targets[i].mean;
+      fin.var[i] = targets[i].var;
+      fin.rmean[i] = targets[i].running_mean;
+      fin.rvar[i] = targets[i].running_var;
+      fin.momentum[i] = targets[i].momentum;
+    }
   }
   hipStream_t st = as_stream(stream);
   const dim3 grid((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32 / p.NB), (unsigned)p.ZS);
@@ -1369,7 +1642,7 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
     fwd3_min = env_int("WSIS_FWD3_MIN_SLICES", 2);   // slices per workgroup below which the one-shot kernel is kept
   }
   // (the slice queue needs a sync slot with one counter per (output block, offset slab))
-  if (fwd3_on && d_sync && (Cout / 32) * p.ZS <= (int)(sizeof(SyncSlot::ctr) / sizeof(unsigned)) && p.NB == 1 && p.NW == 4 &&
+  if (fwd3_on && !bn_in && n_targets == 0 && d_sync && (Cout / 32) * p.ZS <= (int)(sizeof(SyncSlot::ctr) / sizeof(unsigned)) && p.NB == 1 && p.NW == 4 &&
       d_nbr && d_order && ceil_div(K, 4 * p.ZS) <= P3_GS && (int64_t)K * M_out * 4 < ((int64_t)1 << 31)) {
     const int64_t n_slices = ceil_div(M_out, SL);
     int64_t P = fwd3_wgs / ((Cout / 32) * p.ZS);
@@ -1393,25 +1666,40 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
       goto launched;
     }
   }
-#define WSIS_F2X(nb, nw, da, bd)                                                                                 \
+#define WSIS_F2X(nb, nw, da, bd, fb)                                                                             \
   do {                                                                                                           \
-    const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<nb, da, bd>::WAVE_BYTES * nw;                         \
-    static bool attr_set = false;                                                                                \
-    if (!attr_set) {                                                                                             \
-      WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_fwd2_kernel<nb, nw, da, bd>,                        \
+    const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<nb, da, bd>::WAVE_BYTES * nw + (fb ? (size_t)Cin * 12 : 0); \
+    static size_t attr_set = 0;                                                                                  \
+    if (attr_set < ldsb) {                                                                                       \
+      WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_fwd2_kernel<nb, nw, da, bd, false, fb>,             \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));               \
-      attr_set = true;                                                                                           \
+      attr_set = ldsb;                                                                                           \
     }                                                                                                            \
-    hipLaunchKernelGGL((spconv_fwd2_kernel<nb, nw, da, bd>), grid, dim3(64 * nw), ldsb, st, d_X, d_nbr, d_order, \
-                       d_WT, d_bias, d_residual, d_out, partial, M_out, K, Cin, Cout, flip, x_bytes, d_stats, \
-                       epi);                                                                                     \
+    hipLaunchKernelGGL((spconv_fwd2_kernel<nb, nw, da, bd, false, fb>), grid, dim3(64 * nw), ldsb, st, d_X, d_nbr, \
+                       d_order, d_WT, d_bias, d_residual, d_out, partial, M_out, K, Cin, Cout, flip, x_bytes, d_stats, \
+                       epi, bin, fin);                                                                           \
   } while (0)
-#define WSIS_F2(nb, nw, da)      \
-  if (p.BD)                      \
-    WSIS_F2X(nb, nw, da, true);  \
-  else                           \
-    WSIS_F2X(nb, nw, da, false)
-  {
+#define WSIS_F2(nb, nw, da)             \
+  if (p.BD)                             \
+    WSIS_F2X(nb, nw, da, true, false);  \
+  else                                  \
+    WSIS_F2X(nb, nw, da, false, false)
+#define WSIS_F2B(nw) /* NB = 1, DA = 2, weights to registers: with or without the fused input BatchNorm */ \
+  if (bn_in)                                                                                               \
+    WSIS_F2X(1, nw, 2, true, true);                                                                        \
+  else                                                                                                     \
+    WSIS_F2X(1, nw, 2, true, false)
+  if (p.NB == 1 && p.DA == 2 && p.BD && (bn_in || p.NW == 16)) {
+    switch (p.NW) {
+      case 1: WSIS_F2B(1); break;
+      case 2: WSIS_F2B(2); break;
+      case 4: WSIS_F2B(4); break;
+      case 8: WSIS_F2B(8); break;
+      case 16: WSIS_F2B(16); break;
+      default: return fail(WSIS_ERR_ARG, "spconv_fwd_f: unsupported plan NW=%d", p.NW);
+    }
+  } else {
+  WSIS_REQUIRE(!bn_in, "fused input BatchNorm: unsupported plan");
   const int key = p.NB * 100 + p.NW * 10 + p.DA;
   switch (key) {
     case 113: WSIS_F2(1, 1, 3); break;
@@ -1429,6 +1717,7 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
       return fail(WSIS_ERR_ARG, "spconv_fwd_t: unsupported plan NB=%d NW=%d DA=%d", p.NB, p.NW, p.DA);
   }
   }
+#undef WSIS_F2B
 #undef WSIS_F2
 #undef WSIS_F2X
 launched:
@@ -1465,7 +1754,7 @@ int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 2, true, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, 0,
-                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, d_dbg);
+                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, d_dbg);
   } else if (variant >= 100 && !d_sync) {
     return fail(WSIS_ERR_ARG, "the persistent form needs a sync slot");
   } else if (variant >= 100) {    // persistent form (spconv_fwd3_kernel), variant - 100 offset slabs, 768 resident workgroups;
@@ -1487,12 +1776,12 @@ int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES * 4;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 4, 2, true, true>), g4, dim3(256), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, d_out, M_out, K, Cin, Cout, 0,
-                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, d_dbg);
+                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, d_dbg);
   } else {
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 3, false>::WAVE_BYTES;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 3, false, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, 0,
-                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, d_dbg);
+                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, d_dbg);
   }
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;

@@ -63,12 +63,29 @@ __device__ __forceinline__ void wait_after(int after) {
   }
 }
 
-template <bool DIAG, bool XCD>
+// SWAP: the same product with the roles of the two tensors exchanged (the "own rows" form used when the convolution's
+// input is a BatchNorm(+ReLU) applied on the fly): the rows of a slice are the convolution's INPUT rows (table =
+// the dIn table, rows = inputs), `dY` is the convolution's raw input x [M_out = conv M_in rows, Cout = conv Cin channels]
+// -- normalised ONCE per slice as its fragments are read (lane = channel: two per-lane constants, no pair mask: a
+// missing pair gathers zeros on the other side) --, `X` is the gathered conv dY [M_in = conv M_out rows, Cin = conv
+// Cout channels].  The accumulators then hold dW^T per dIn offset: the slab store transposes them and maps the offset
+// back (flip: forward offset = K - 1 - k for submanifold tables).
+struct DwBn {
+  const float* mean;         // nullptr: the own rows are used as they are
+  const float* var;
+  const float* gamma;        // may be nullptr (1)
+  const float* beta;         // may be nullptr (0)
+  float eps;
+  int relu;
+  int flip;
+};
+
+template <bool DIAG, bool XCD, bool SWAP = false>
 __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const float* __restrict__ X, const int32_t* __restrict__ nbrS,
                                                             const int32_t* __restrict__ order,
                                                             const float* __restrict__ dY, float* __restrict__ partial, int64_t M_in,
                                                             int64_t M_out, int K, int Cin, int Cout, int NOG, int XSH,
-                                                            unsigned long long* dbg) {
+                                                            unsigned long long* dbg, DwBn bn = DwBn{}) {
   unsigned long long t_start = 0, t_loop = 0, t_end_loop = 0;
   unsigned n_steps = 0, n_slices_done = 0;
   unsigned long long d_wait = 0, d_top = 0, d_chain = 0, d_bot = 0, t_prev = 0;
@@ -90,6 +107,17 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
   combo /= nblk;
   const int c = combo % nchunk;
   const int og = combo / nchunk;
+  // SWAP with a BatchNorm on the own rows: this lane's channel is cb * 32 + r31 for every fragment it reads
+  float bn_mu = 0.0f, bn_sc = 1.0f, bn_bt = 0.0f;
+  const bool bn_on = SWAP && bn.mean != nullptr;
+  if (bn_on) {
+    const int ch = cb * 32 + (threadIdx.x & 31);
+    if (ch < Cout) {
+      bn_mu = bn.mean[ch];
+      bn_sc = (bn.gamma ? bn.gamma[ch] : 1.0f) * rsqrtf(bn.var[ch] + bn.eps);
+      bn_bt = bn.beta ? bn.beta[ch] : 0.0f;
+    }
+  }
   // Slice -> worker map, XCD-aware: workgroup id % 8 picks the XCD (gridDim.x is a multiple of 8, so blockIdx.x % 8
   // does); the slices are dealt to the XCDs in chunks of 2^XSH (a spatial brick of the tile order whose gathered X rows
   // are shared by its offsets and neighbouring slices, so they stay in that XCD's L2), and inside an XCD its waves take
@@ -289,6 +317,13 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
         if (DIAG) tb = __builtin_readcyclecounter();
         if (new_slice) {
           readfrag(Bt, bfr);
+          if (bn_on) {       // the arithmetic of bn_apply_kernel: fma(x - mean, sc, beta), then ReLU
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+              float z = __builtin_fmaf(bfr[s] - bn_mu, bn_sc, bn_bt);
+              bfr[s] = bn.relu ? fmaxf(z, 0.0f) : z;
+            }
+          }
           new_slice = false;
         }
         readfrag(At + c_rd * TILE, afr);
@@ -381,6 +416,18 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
     for (int e = threadIdx.x; e < 4096; e += WGW * 64) {
       const int k = og + (jbase + (e >> 10)) * NOG;
       if (k >= K) break;                             // e ascends through the slots
+      if (SWAP) {
+        // accumulator row = gathered channel (conv Cout side, chunk c), column = own channel (conv Cin side, block
+        // cb): read transposed so that consecutive threads write consecutive conv-Cout elements of dW[kf][ci][co]
+        const int a = (e >> 5) & 31, b = e & 31;              // a: own channel, b: gathered channel
+        const int et = (e & ~1023) + b * 32 + a;
+        float v = red[et];
+#pragma unroll
+        for (int w = 1; w < WGW; ++w) v += red[w * (WAVE_LDS / 4) + et];
+        const int kf = bn.flip ? K - 1 - k : k;
+        if (cb * 32 + a < Cout) slab[((int64_t)kf * Cout + cb * 32 + a) * Cin + c * 32 + b] = v;
+        continue;
+      }
       float v = red[e];
 #pragma unroll
       for (int w = 1; w < WGW; ++w) v += red[w * (WAVE_LDS / 4) + e];
@@ -463,6 +510,44 @@ bool dw2_fits(int64_t M_in, int64_t M_out, int K, int Cin, int Cout) {
 
 int64_t dw2_workspace_bytes(int64_t M_out, int K, int Cin, int Cout) {
   return (int64_t)dw2_P(M_out, K, Cin, Cout) * K * Cin * Cout * (int64_t)sizeof(float) + 256;
+}
+
+// the own-rows form (kernel SWAP): conv input x [M_in, Cin] normalised on the fly, gathered conv dY [M_out, Cout] through
+// the dIn table (rows = conv inputs); writes dW [K, Cin, Cout] exactly like dw2_launch
+int dw2_launch_swapped(const float* d_X, const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta,
+                       float eps, int relu, const int32_t* d_nbr_b, const int32_t* d_order_b, int flip, const float* d_dY,
+                       float* d_dW, int64_t M_in, int64_t M_out, int K, int Cin, int Cout, void* d_ws, hipStream_t st) {
+  // kernel roles: gathered = conv dY (rows M_out, channels Cout), own = conv x (rows M_in, channels Cin)
+  const int NOG = (K + GS - 1) / GS;
+  const int P = dw2_P(M_in, K, Cout, Cin);
+  float* partial = static_cast<float*>(d_ws);
+  const dim3 grid((unsigned)P, (unsigned)(NOG * (Cout / 32) * ((Cin + 31) / 32)), 1);
+  const size_t ldsb = (size_t)WAVE_LDS * WGW;
+  static bool attr_set = false;
+  if (!attr_set) {
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_dw2_kernel<false, false, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    attr_set = true;
+  }
+  DwBn bn;
+  bn.mean = d_mean;
+  bn.var = d_var;
+  bn.gamma = d_gamma;
+  bn.beta = d_beta;
+  bn.eps = eps;
+  bn.relu = relu;
+  bn.flip = flip;
+  ProfScope prof(1, st);
+  hipLaunchKernelGGL((spconv_dw2_kernel<false, false, true>), grid, dim3(WGW * 64), ldsb, st, d_dY, d_nbr_b, d_order_b, d_X,
+                     partial, M_out, M_in, K, Cout, Cin, NOG, XSH_DEFAULT, (unsigned long long*)nullptr, bn);
+  prof.stop();
+  WSIS_LAUNCH_CHECK();
+  const int64_t total4 = (int64_t)K * Cin * Cout / 4;
+  hipLaunchKernelGGL(dw2_reduce_kernel, dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(d_dW), total4, P);
+  prof.tail();
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
 }
 
 int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY, float* d_dW,

@@ -26,12 +26,13 @@ import wsis_ops
 from spconv import ops as sp_ops
 
 OP_CONV, OP_BN_RELU, OP_CAT, OP_SPLIT, OP_ADD, OP_CONV_BWD, OP_BN_RELU_BWD = 1, 2, 3, 4, 5, 6, 7
-F_RELU, F_TRAINING, F_UPDATE, F_FLIP, F_STATS = 1, 2, 4, 8, 16
+F_RELU, F_TRAINING, F_UPDATE, F_FLIP, F_STATS, F_BN_IN, F_STAT_FIN = 1, 2, 4, 8, 16, 32, 64
+N_IN, N_OUT = 12, 8
 
 OP_DTYPE = np.dtype([("kind", "<i4"), ("flags", "<i4"), ("M_in", "<i8"), ("M_out", "<i8"), ("K", "<i4"),
                      ("Cin", "<i4"), ("Cout", "<i4"), ("reserved", "<i4"), ("eps", "<f4"), ("momentum", "<f4"),
-                     ("inp", "<u8", (8,)), ("out", "<u8", (4,))])
-assert OP_DTYPE.itemsize == 144          # sizeof(wsis_op)
+                     ("momentum2", "<f4"), ("reserved2", "<f4"), ("inp", "<u8", (N_IN,)), ("out", "<u8", (N_OUT,))])
+assert OP_DTYPE.itemsize == 216          # sizeof(wsis_op)
 
 # symbolic pointer = tag | id; plain device pointers (parameters, BN buffers) carry no tag
 _FWD = 1 << 62      # allocation id in the FORWARD arena
@@ -40,7 +41,24 @@ _PAR = 1 << 60      # allocation id in the flat PARAMETER-GRADIENT buffer
 _TBL = 1 << 59      # gather-table slot: level*6 + {0 subm.nbr, 1 subm.order, 2 down.nbr, 3 down.order, 4 up.nbr, 5 up.order}
 _EXT = 1 << 58      # external tensor: 0 = input features, 1 = gradient of the output
 _TAGS = (_FWD, _BWD, _PAR, _TBL, _EXT)
-_ID_MASK = (1 << 58) - 1
+_ID_MASK = (1 << 32) - 1       # allocation id / slot
+_OFF_SHIFT = 32                # bits 32..57: offset into the allocation, in floats (a channel range of a statistics vector)
+_OFF_MASK = (1 << 26) - 1
+
+
+def _at(handle, floats):
+    """symbolic pointer ``floats`` floats into an allocation; a plain device pointer is simply advanced"""
+    if floats == 0 or handle == 0:
+        return handle
+    if any(handle & t for t in _TAGS):
+        return handle + (int(floats) << _OFF_SHIFT)
+    return handle + 4 * int(floats)
+
+
+def _fuse_apply_enabled():
+    """BatchNorm(+ReLU) applied by the consuming convolution as it reads its input, statistics finished inside the
+    producing convolution's launch (WSIS_FUSE_BN_APPLY=0: the BatchNorm stays an op of its own)"""
+    return os.environ.get("WSIS_FUSE_BN_APPLY", "1") != "0"
 
 
 def _fuse_stats_enabled():
@@ -71,7 +89,12 @@ class _Recorder(object):
         return self.tag | (len(self.alloc_level) - 1)
 
     def op(self, kind, flags=0, M_in=0, M_out=0, K=0, Cin=0, Cout=0, eps=0.0, momentum=0.0, inp=(), out=()):
-        self.rows.append((kind, flags, M_in, M_out, K, Cin, Cout, eps, momentum, inp, out))
+        """appends an op; rows are lists (later ops patch earlier ones: statistics targets, epilogue reductions):
+        [kind, flags, M_in, M_out, K, Cin, Cout, eps, momentum, inp[N_IN], out[N_OUT], momentum2]"""
+        inp = list(inp) + [0] * (N_IN - len(inp))
+        out = list(out) + [0] * (N_OUT - len(out))
+        self.rows.append([kind, flags, M_in, M_out, K, Cin, Cout, eps, momentum, inp, out, 0.0])
+        return len(self.rows) - 1
 
 
 class _Arena(object):
@@ -99,16 +122,14 @@ class _Template(object):
     def __init__(self, rec):
         n = len(rec.rows)
         self.arr = np.zeros(n, dtype=OP_DTYPE)
-        ptr = np.zeros((n, 12), dtype=np.uint64)          # inp[0..7] | out[0..3]
+        ptr = np.zeros((n, N_IN + N_OUT), dtype=np.uint64)          # inp | out
         m_in = np.zeros(n, dtype=np.int64)
         m_out = np.zeros(n, dtype=np.int64)
         for i, r in enumerate(rec.rows):
-            self.arr[i] = (r[0], r[1], 0, 0, r[4], r[5], r[6], 0, r[7], r[8], 0, 0)
+            self.arr[i] = (r[0], r[1], 0, 0, r[4], r[5], r[6], 0, r[7], r[8], r[11], 0, 0, 0)
             m_in[i], m_out[i] = r[2], r[3]
-            if r[9]:
-                ptr[i, :len(r[9])] = r[9]
-            if r[10]:
-                ptr[i, 8:8 + len(r[10])] = r[10]
+            ptr[i, :N_IN] = r[9]
+            ptr[i, N_IN:] = r[10]
         self.m_in_lit, self.m_out_lit = np.maximum(m_in, 0), np.maximum(m_out, 0)
         self.m_in_lvl, self.m_out_lvl = np.maximum(-m_in - 1, 0), np.maximum(-m_out - 1, 0)
         self.m_in_sym, self.m_out_sym = m_in < 0, m_out < 0
@@ -117,7 +138,8 @@ class _Template(object):
         self.patch = {}
         for tag in _TAGS:
             pos = np.nonzero((flat & np.uint64(tag)) != 0)[0]
-            self.patch[tag] = (pos, (flat[pos] & np.uint64(_ID_MASK)).astype(np.int64))
+            off = ((flat[pos] >> np.uint64(_OFF_SHIFT)) & np.uint64(_OFF_MASK)) * np.uint64(4)      # bytes
+            self.patch[tag] = (pos, (flat[pos] & np.uint64(_ID_MASK)).astype(np.int64), off)
             self.static[pos] = 0
 
     def instantiate(self, Mvec, luts):
@@ -125,12 +147,12 @@ class _Template(object):
         arr["M_in"] = np.where(self.m_in_sym, Mvec[self.m_in_lvl], self.m_in_lit)
         arr["M_out"] = np.where(self.m_out_sym, Mvec[self.m_out_lvl], self.m_out_lit)
         flat = self.static.copy()
-        for tag, (pos, idx) in self.patch.items():
+        for tag, (pos, idx, off) in self.patch.items():
             if len(pos):
-                flat[pos] = luts[tag][idx]
-        ptr = flat.reshape(-1, 12)
-        arr["inp"] = ptr[:, :8]
-        arr["out"] = ptr[:, 8:]
+                flat[pos] = luts[tag][idx] + off
+        ptr = flat.reshape(-1, N_IN + N_OUT)
+        arr["inp"] = ptr[:, :N_IN]
+        arr["out"] = ptr[:, N_IN:]
         return arr
 
 
@@ -188,23 +210,37 @@ class UNetProgram(object):
         part = 0
         if stats and self._fuse_stats and sp_ops._use_fwd2(K, Cin, Cout):
             part = rec.alloc(lvl_out, 2 * Cout, per_slice=True)
-            self._stats_src[y] = [(part, Cout)]
-        rec.op(OP_CONV, F_STATS if part else 0, _lvl(lvl_in), _lvl(lvl_out), K, Cin, Cout,
-               inp=(x, t.nbr_f, t.order_f, W.data_ptr(), 0, residual), out=(y, part))
+        # the input may be a BatchNorm(+ReLU) that is applied while this convolution reads it (see _bn_relu)
+        v = self._virt.get(x)
+        flags, eps, bn_in = (F_STATS if part else 0), 0.0, (0, 0, 0, 0)
+        if v is not None:
+            assert sp_ops._use_fwd2(K, Cin, Cout) and v["C"] == Cin
+            x = v["x"]
+            flags |= F_BN_IN | (F_RELU if v["relu"] else 0)
+            eps, bn_in = v["eps"], (v["mean"], v["var"], v["gamma"], v["beta"])
+        row = rec.op(OP_CONV, flags, _lvl(lvl_in), _lvl(lvl_out), K, Cin, Cout, eps=eps,
+                     inp=(x, t.nbr_f, t.order_f, W.data_ptr(), 0, residual) + bn_in, out=(y, part))
+        if part:
+            self._stats_src[y] = [(part, Cout, row)]
         self._acc_f.append(("spconv_fwd_kernel", t.nbr_f, lvl_out, Cin, Cout))
 
         def bwd(recb, dy, need_dx=True):
             dx = recb.alloc(lvl_in, Cin) if need_dx else 0
             dW = self._grad_handle(W)
-            recb.op(OP_CONV_BWD, F_FLIP if t.flip else 0, _lvl(lvl_in), _lvl(lvl_out), K, Cin, Cout,
-                    inp=(x, W.data_ptr(), dy, t.nbr_f, t.order_f, t.nbr_b, t.order_b), out=(dx, dW))
+            bflags = (F_FLIP if t.flip else 0) | ((F_BN_IN | (F_RELU if v["relu"] else 0)) if v is not None else 0)
+            recb.op(OP_CONV_BWD, bflags, _lvl(lvl_in), _lvl(lvl_out), K, Cin, Cout, eps=eps,
+                    inp=(x, W.data_ptr(), dy, t.nbr_f, t.order_f, t.nbr_b, t.order_b) + bn_in, out=(dx, dW))
             if need_dx:
                 self._acc_b.append(("spconv_fwd_kernel", t.nbr_b, lvl_in, Cout, Cin))
             self._acc_b.append(("spconv_dw_kernel", t.nbr_f, lvl_out, Cin, Cout))
             return dx
         return y, bwd
 
-    def _bn_relu(self, rec, x, bn, lvl, relu=True):
+    def _bn_relu(self, rec, x, bn, lvl, relu=True, fuse=False):
+        """BatchNorm1d(+ReLU).  ``fuse``: the only consumer is a convolution on the wave-autonomous kernel, which applies
+        the BatchNorm while it reads its input (the returned handle is virtual: nothing is written).  Training
+        statistics come from the producing convolutions' epilogue partials where they exist -- finished inside those
+        launches (F_STAT_FIN) or by a finalize op -- otherwise from a pass over x."""
         C = bn.num_features
         training = bn.training or not bn.track_running_stats
         update = bn.training and bn.track_running_stats
@@ -212,18 +248,47 @@ class UNetProgram(object):
         if update and bn.num_batches_tracked is not None:
             assert bn.momentum is not None, "cumulative-average BatchNorm is not used by 3D-WSIS"
             self._count.append(bn)
-        y = rec.alloc(lvl, C)
+        fuse = fuse and self._fuse_apply and C % 32 == 0
+        momentum = bn.momentum if bn.momentum is not None else 0.1
         mean = rec.alloc(-1, C) if training else bn.running_mean.data_ptr()
         var = rec.alloc(-1, C) if training else bn.running_var.data_ptr()
         src = self._stats_src.get(x) if training else None
-        K0, parts = 0, (0, 0)
-        if src is not None and sum(c for _, c in src) == C and len(src) <= 2:
-            flags |= F_STATS             # the producers' epilogues wrote the partials: no statistics pass over x
-            K0 = src[0][1]
-            parts = (src[0][0], src[1][0] if len(src) == 2 else 0)
-        rec.op(OP_BN_RELU, flags, _lvl(lvl), _lvl(lvl), K0, C, C, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
-               inp=(x, _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var), parts[0], parts[1]),
-               out=(y, mean if training else 0, var if training else 0))
+        have_parts = src is not None and sum(c for _, c, _ in src) == C and len(src) <= 2
+        stats_done = False
+        if have_parts and self._fuse_apply and all(rec.rows[r][10][4] == 0 for _, _, r in src):
+            # every producer finishes its channel range of this BatchNorm's statistics inside its own launch
+            c0 = 0
+            rm = _ptr(bn.running_mean) if update else 0
+            rv = _ptr(bn.running_var) if update else 0
+            for _, c, r in src:
+                row = rec.rows[r]
+                tgt = (_at(mean, c0), _at(var, c0), _at(rm, c0), _at(rv, c0))
+                if not (row[1] & F_STAT_FIN):
+                    row[1] |= F_STAT_FIN
+                    row[10][2], row[10][3], row[9][10], row[9][11] = tgt
+                    row[8] = momentum
+                else:
+                    row[10][4:8] = tgt
+                    row[11] = momentum
+                c0 += c
+            stats_done = True
+        y = rec.alloc(lvl, 0 if fuse else C)
+        if fuse:
+            self._virt[y] = dict(x=x, C=C, mean=mean, var=var, gamma=_ptr(bn.weight), beta=_ptr(bn.bias), eps=bn.eps,
+                                 relu=relu)
+        if training and not stats_done:
+            K0, parts, sflags = 0, (0, 0), flags
+            if have_parts:
+                sflags |= F_STATS            # the producers' epilogues wrote the partials: no statistics pass over x
+                K0 = src[0][1]
+                parts = (src[0][0], src[1][0] if len(src) == 2 else 0)
+            rec.op(OP_BN_RELU, sflags, _lvl(lvl), _lvl(lvl), K0, C, C, bn.eps, momentum,
+                   inp=(x, _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var), parts[0], parts[1]),
+                   out=(0 if fuse else y, mean, var))
+        elif not fuse:
+            # statistics known (finished by the producers, or evaluation mode): apply pass only
+            rec.op(OP_BN_RELU, flags & ~(F_TRAINING | F_UPDATE), _lvl(lvl), _lvl(lvl), 0, C, C, bn.eps, momentum,
+                   inp=(x, _ptr(bn.weight), _ptr(bn.bias), mean, var), out=(y,))
 
         def bwd(recb, dy, addend=0):
             # ``addend``: gradient arriving at x over a second path (residual skip / UNet skip connection), added
@@ -244,7 +309,7 @@ class UNetProgram(object):
             return
         rows = recb.rows
         for i, r in enumerate(rows):
-            if r[0] != OP_CONV_BWD or not r[10] or not r[10][0]:
+            if r[0] != OP_CONV_BWD or not r[10][0]:
                 continue
             K, Cin, Cout = r[4], r[5], r[6]
             if not sp_ops._use_fwd2(K, Cout, Cin):          # the dIn product gathers dY: roles of the channels swap
@@ -252,22 +317,20 @@ class UNetProgram(object):
             dx = r[10][0]
             for j in range(i + 1, min(i + 5, len(rows))):
                 b = rows[j]
-                if b[0] == OP_BN_RELU_BWD and len(b[9]) >= 2 and b[9][1] == dx and (b[1] & F_TRAINING) and b[5] == Cin \
-                        and b[2] == r[2]:
+                if b[0] == OP_BN_RELU_BWD and b[9][1] == dx and (b[1] & F_TRAINING) and b[5] == Cin and b[2] == r[2]:
                     lvl = -b[2] - 1
-                    part = recb.alloc(lvl, 2 * Cin, per_slice=True)
-                    inp = tuple(b[9]) + (0,) * (7 - len(b[9])) + (part,)
-                    rows[j] = b[:1] + (b[1] | F_STATS,) + b[2:9] + (inp, b[10])
-                    rows[i] = r[:1] + (r[1] | F_STATS,) + r[2:]
+                    b[9][7] = recb.alloc(lvl, 2 * Cin, per_slice=True)
+                    b[1] |= F_STATS
+                    r[1] |= F_STATS
                     break
 
     def _residual_block(self, rec, x, blk, lvl):
         seq = blk.conv_branch
         bn1, conv1, bn2, conv2 = seq[0], seq[2], seq[3], seq[5]
         table = _subm(lvl)
-        a1, b_bn1 = self._bn_relu(rec, x, bn1, lvl)
+        a1, b_bn1 = self._bn_relu(rec, x, bn1, lvl, fuse=True)
         z1, b_c1 = self._conv(rec, a1, conv1, table, lvl, lvl)
-        a2, b_bn2 = self._bn_relu(rec, z1, bn2, lvl)
+        a2, b_bn2 = self._bn_relu(rec, z1, bn2, lvl, fuse=True)
         first = blk.i_branch[0]
         if isinstance(first, nn.Identity):
             res, b_i = x, None
@@ -296,10 +359,10 @@ class UNetProgram(object):
             return x, bwd_leaf
         C0 = ub.nPlanes[0]
         identity = x
-        a, b_bn = self._bn_relu(rec, x, ub.conv[0], lvl)
+        a, b_bn = self._bn_relu(rec, x, ub.conv[0], lvl, fuse=True)
         d, b_down = self._conv(rec, a, ub.conv[2], _down(lvl), lvl, lvl + 1)
         u, b_u = self._ublock(rec, d, ub.u, lvl + 1)
-        a2, b_bn2 = self._bn_relu(rec, u, ub.deconv[0], lvl + 1)
+        a2, b_bn2 = self._bn_relu(rec, u, ub.deconv[0], lvl + 1, fuse=True)
         up, b_up = self._conv(rec, a2, ub.deconv[2], _up(lvl), lvl + 1, lvl)
         cat = rec.alloc(lvl, 2 * C0)
         rec.op(OP_CAT, 0, _lvl(lvl), _lvl(lvl), 0, C0, C0, inp=(identity, up), out=(cat,))
@@ -337,7 +400,7 @@ class UNetProgram(object):
 
     # ---- compile (once per mode) / bind (per scene) ------------------------------------------------------------
     def _mode_key(self, need_dx):
-        return (need_dx, _fuse_stats_enabled(), os.environ.get("WSIS_FWD2", "1"),
+        return (need_dx, _fuse_stats_enabled(), _fuse_apply_enabled(), os.environ.get("WSIS_FWD2", "1"),
                 tuple(bn.training for bn in self.bns), tuple(p.data_ptr() for p in self.params),
                 tuple(bn.running_mean.data_ptr() if bn.running_mean is not None else 0 for bn in self.bns))
 
@@ -354,6 +417,7 @@ class UNetProgram(object):
         self._prec, self._grad = _Recorder(_PAR, align=16), {}
         self._acc_f, self._acc_b, self._count = [], [], []
         self._stats_src, self._fuse_stats = {}, _fuse_stats_enabled()
+        self._virt, self._fuse_apply = {}, _fuse_apply_enabled() and self._fuse_stats
         y, b_in = self._conv(rec, _EXT | 0, net.input_conv[0], _subm(0), 0, 0)
         y, b_u = self._ublock(rec, y, net.unet, 0)
         out, b_out = self._bn_relu(rec, y, net.output_layer[0], 0)

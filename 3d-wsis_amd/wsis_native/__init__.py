@@ -77,6 +77,8 @@ _HIP_SIGS = {
     "wsis_spconv_fwd_t_workspace_bytes": (I64, [I64, I32, I32, I32]),
     "wsis_spconv_fwd_t": (I32, [P, P, P, P, I32, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P, P]),
     "wsis_spconv_fwd_t_slabs": (I32, [I64, I32, I32, I32]),
+    "wsis_spconv_fwd_f_workspace_bytes": (I64, [I64, I32, I32, I32]),
+    "wsis_spconv_fwd_f": (I32, [P, P, P, P, P, I32, P, P, P, P, P, I32, I64, I64, I32, I32, I32, P, I64, P, P]),
     "wsis_bn_bwd_from_partials": (I32, [P, I64, P, P, P, P, P, P, F32, I32, P, P, P, P, I64, I32, P, I64, P, P]),
     "wsis_sync_bytes": (I64, []),
     "wsis_spconv_fwd_t_bn": (I32, [P, P, P, P, I32, P, P, P, P, P, P, P, F32, I32, I64, I64, I32, I32, I32, P, I64, P, P]),
@@ -86,6 +88,9 @@ _HIP_SIGS = {
     "wsis_weight_transpose": (I32, [P, P, I32, I32, I32, I32, P]),
     "wsis_spconv_dw_workspace_bytes": (I64, [I64, I32, I32, I32]),
     "wsis_spconv_dw": (I32, [P, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P]),
+    "wsis_spconv_dw_bn_supported": (I32, [I32, I32, I32]),
+    "wsis_spconv_dw_bn_workspace_bytes": (I64, [I64, I32, I32, I32]),
+    "wsis_spconv_dw_bn": (I32, [P, P, P, P, P, F32, I32, P, P, I32, P, P, I64, I64, I32, I32, I32, P, I64, P]),
     "wsis_rulebook_pack": (I32, [P, P, P, I64, I32, P]),
     "wsis_rulebook_pack_batch": (I32, [I32, P, P, P, P, P, P]),
     "wsis_prof_enable": (I32, [I32]),
@@ -197,7 +202,7 @@ _SYNC = {}
 
 
 def sync_block(device=None):
-    """zero-filled sync block (wsis_sync_bytes: 64 slots of 256 bytes) of (device, current stream): the cross-workgroup
+    """zero-filled sync block (wsis_sync_bytes: 64 slots of 4 KiB) of (device, current stream): the cross-workgroup
     words of the one-launch reductions live in caller memory; every launch leaves its slot zero again, launches of one
     stream share the block, another stream gets its own (include/wsis_hip.h)"""
     import torch
@@ -215,7 +220,7 @@ def sync_errors():
     """slots whose bounded wait ran out (word 19 of a slot): a list of (device, stream, slot); reads the device"""
     bad = []
     for (dev, st), t in _SYNC.items():
-        w = t.view(__import__("torch").int32).view(-1, 64)[:, 19]
+        w = t.view(__import__("torch").int32).view(-1, 1024)[:, 19]
         for i in w.nonzero().flatten().tolist():
             bad.append((dev, st, int(i)))
     return bad

@@ -226,6 +226,36 @@ int wsis_spconv_fwd_t_bn(const float* d_X, const int32_t* d_nbr, const int32_t* 
                          const float* d_bn_var, const float* d_bn_gamma, const float* d_bn_beta, float eps, int32_t relu,
                          int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
                          void* d_sync, void* stream);
+/* The fused form of wsis_spconv_fwd_t for one layer of `BatchNorm1d -> ReLU -> conv` chains (sparse_unet3d.py:127-143):
+ *   bn_in   (optional) BatchNorm(+ReLU) of the INPUT applied while the gathered rows are read: the activation
+ *           relu(bn(x)) is never written; mean / var are the batch statistics (training) or the running statistics;
+ *   targets (optional, needs d_stats and a sync slot) the statistics of the OUTPUT are FINISHED inside the launch: the
+ *           last workgroups to arrive add the slice partials (the order of wsis_bn_stats_finalize, bit-identical) and
+ *           write mean / var and update the running statistics of up to two BatchNorm layers that normalise this tensor
+ *           (the UNet's skip connection feeds a second one).
+ * One launch whatever the level: up to 16 waves of a workgroup split a work item's offsets, no slabs, no second kernel.
+ * With both NULL it is wsis_spconv_fwd_t without slabs.  Workspace: wsis_spconv_fwd_f_workspace_bytes. */
+typedef struct wsis_bn_in {
+  const float* mean;
+  const float* var;
+  const float* gamma; /* may be NULL (1) */
+  const float* beta;  /* may be NULL (0) */
+  float eps;
+  int32_t relu;
+} wsis_bn_in;
+typedef struct wsis_stat_target {
+  float* mean;
+  float* var;
+  float* running_mean; /* may be NULL (with running_var) */
+  float* running_var;
+  float momentum;
+  int32_t reserved;
+} wsis_stat_target;
+int64_t wsis_spconv_fwd_f_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout);
+int wsis_spconv_fwd_f(const float* d_X, const wsis_bn_in* bn_in, const int32_t* d_nbr, const int32_t* d_order,
+                      const float* d_WT, int32_t flip, const float* d_bias, const float* d_residual, float* d_out,
+                      float* d_stats, const wsis_stat_target* targets, int32_t n_targets, int64_t M_in, int64_t M_out,
+                      int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream);
 /* WT[k'] = W[k]^T with k' = (flip ? K-1-k : k); W [K,Cin,Cout] -> WT [K,Cout,Cin]. */
 int wsis_weight_transpose(const float* d_W, float* d_WT, int32_t K, int32_t Cin, int32_t Cout,
                           int32_t flip, void* stream);
@@ -235,6 +265,20 @@ int64_t wsis_spconv_dw_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, in
 int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY,
                    float* d_dW, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws,
                    int64_t ws_bytes, void* stream);
+
+/* The same weight gradient for a convolution whose INPUT is BatchNorm(+ReLU)(d_X) applied on the fly (the activation
+ * relu(bn(x)) of sparse_unet3d.py:128-137 is never materialised: the forward pass normalises the gathered rows as it
+ * reads them, wsis_spconv_fwd_f): dW[k] = sum_pairs relu(bn(X[i]))^T (x) dY[o].  "Own rows" form: the slices run over
+ * the convolution's INPUT rows, which are normalised once per slice (d_mean / d_var [Cin], optional d_gamma / d_beta;
+ * d_mean == NULL: X as it stands), and the paired dY rows are gathered through the dIn table d_nbr_b / d_order_b
+ * (packed, rows = inputs; flip = 1 for submanifold tables, whose dIn offset k pairs with forward offset K - 1 - k).
+ * Cin % 32 == 0, Cout % 32 == 0, K <= 32.  Fixed summation order, no atomics. */
+int32_t wsis_spconv_dw_bn_supported(int32_t K, int32_t Cin, int32_t Cout);
+int64_t wsis_spconv_dw_bn_workspace_bytes(int64_t M_in, int32_t K, int32_t Cin, int32_t Cout);
+int wsis_spconv_dw_bn(const float* d_X, const float* d_mean, const float* d_var, const float* d_gamma,
+                      const float* d_beta, float eps, int32_t relu, const int32_t* d_nbr_b, const int32_t* d_order_b,
+                      int32_t flip, const float* d_dY, float* d_dW, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin,
+                      int32_t Cout, void* d_ws, int64_t ws_bytes, void* stream);
 
 /* Live timing of the dominant kernels (bench.py roofline): with profiling enabled every forward / dIn convolution
  * (which = 0) and every weight-gradient product (which = 1) is bracketed by HIP events on its launch stream: one in
@@ -248,7 +292,7 @@ int wsis_prof_records(int32_t which, double* h_main_ms, double* h_total_ms, int6
 
 /* ---- sync slots of the one-launch reductions ------------------------------------------------------------------
  * Operators that finish a two-level reduction in the SAME launch (last-arrival tickets; published flag for the
- * finish + apply forms) keep their cross-workgroup words in CALLER memory: d_sync points at a 256-byte slot that the
+ * finish + apply forms) keep their cross-workgroup words in CALLER memory: d_sync points at a 4-KiB slot that the
  * caller zero-fills ONCE (e.g. torch.zeros); every launch leaves its slot zero again, so consecutive launches on one
  * stream may share a slot, launches that may overlap on different streams need different slots.  d_sync == NULL selects
  * the multi-launch form of the operator.  wsis_run_ops takes a block of wsis_sync_bytes() bytes (64 slots, one per op
@@ -513,14 +557,25 @@ enum {
  * WSIS_OPF_STATS on BN_RELU (training): the statistics come from partials instead of a pass over x: in[5] = partials
  * of channels [0, K), in[6] = partials of channels [K, Cin) (NULL when K == Cin; the input is a concatenation of two
  * producers' outputs), ceil(M_in / 32) rows each. */
-enum { WSIS_OPF_RELU = 1, WSIS_OPF_TRAINING = 2, WSIS_OPF_UPDATE_RUNNING = 4, WSIS_OPF_FLIP = 8, WSIS_OPF_STATS = 16 };
+/* WSIS_OPF_BN_IN on CONV: the input is BatchNorm(+ReLU, WSIS_OPF_RELU)(in[0]) applied on the fly (wsis_spconv_fwd_f):
+ * in[6] = mean, in[7] = var, in[8] = gamma, in[9] = beta, eps = op.eps -- the BN_RELU op in front of it is then not in the
+ * list at all (or only computes statistics: BN_RELU with out[0] == NULL).  On CONV_BWD: in[0] is that raw tensor and
+ * in[7..10] = mean, var, gamma, beta: the weight gradient runs as wsis_spconv_dw_bn.
+ * WSIS_OPF_STAT_FIN on CONV (with WSIS_OPF_STATS): the statistics of the output are finished inside the launch for
+ * n = 1 or 2 BatchNorm layers: target 0 = out[2] mean, out[3] var, in[10] running_mean, in[11] running_var, op.momentum;
+ * target 1 (when out[4] != NULL) = out[4], out[5], out[6], out[7], op.momentum2. */
+enum {
+  WSIS_OPF_RELU = 1, WSIS_OPF_TRAINING = 2, WSIS_OPF_UPDATE_RUNNING = 4, WSIS_OPF_FLIP = 8, WSIS_OPF_STATS = 16,
+  WSIS_OPF_BN_IN = 32, WSIS_OPF_STAT_FIN = 64
+};
 typedef struct wsis_op {
   int32_t kind, flags;
   int64_t M_in, M_out;
   int32_t K, Cin, Cout, reserved;
   float eps, momentum;
-  const void* in[8];
-  void* out[4];
+  float momentum2, reserved2;
+  const void* in[12];
+  void* out[8];
 } wsis_op;
 int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n);
 int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream);
