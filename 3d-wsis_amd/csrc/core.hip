@@ -135,3 +135,47 @@ int wsis_gather_rows(const float* d_src, const void* d_idx, int32_t idx_is_64, f
 }
 
 }  // extern "C"
+
+// ---- diagnostic (not part of the ABI header): what a dependent kernel boundary costs on this stream for kernels of
+// different shapes -- n back-to-back launches of an (almost) empty kernel; variant bits: 1 = 32 KB of dynamic LDS,
+// 2 = 64-thread workgroups x 4800 instead of 256 x 256, 4 = alternate LDS / no LDS, 8 = 40 bytes of LDS-free kernel
+// arguments replaced by a 160-byte struct.  tools/gap_probe.py times the chain with events.
+namespace {
+struct GapArgs {
+  float* p;
+  long long pad[19];
+};
+__global__ void gap_probe_kernel(float* p) {
+  extern __shared__ float sm[];
+  if (threadIdx.x == 0 && blockIdx.x == 0xffffff) p[0] = sm[0];
+}
+__global__ void gap_probe_big_kernel(GapArgs a) {
+  extern __shared__ float sm[];
+  if (threadIdx.x == 0 && blockIdx.x == 0xffffff) a.p[0] = sm[0] + (float)a.pad[3];
+}
+}  // namespace
+
+extern "C" int wsis_debug_gap_probe(int variant, int n, float* d_buf, void* stream) {
+  hipStream_t st = wsis::as_stream(stream);
+  const bool small = (variant & 2) != 0;
+  const dim3 grid(small ? 4800 : 256), block(small ? 64 : 256);
+  static bool attr = false;
+  if (!attr) {
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)gap_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)gap_probe_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    attr = true;
+  }
+  for (int i = 0; i < n; ++i) {
+    size_t lds = (variant & 1) ? 32768 : 0;
+    if ((variant & 4) && (i & 1)) lds = 0;
+    if (variant & 8) {
+      GapArgs a{};
+      a.p = d_buf;
+      hipLaunchKernelGGL(gap_probe_big_kernel, grid, block, lds, st, a);
+    } else {
+      hipLaunchKernelGGL(gap_probe_kernel, grid, block, lds, st, d_buf);
+    }
+  }
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}

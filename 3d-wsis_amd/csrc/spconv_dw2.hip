@@ -398,12 +398,14 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
   // C/D map: col (co) = lane & 31, row (ci) = (reg & 3) + 8 * (reg >> 2) + 4 * half
   float* const red = reinterpret_cast<float*>(lds);          // per wave [4 slots][32 ci][32 co] at stride WAVE_LDS
   float* const slab = partial + (int64_t)blockIdx.x * K * Cin * Cout;
+  // SWAP reads the image transposed: rows padded to 33 floats (a stride of 32 would put the 32 lanes of a read on one bank)
+  constexpr int RP = SWAP ? 33 : 32, QS = SWAP ? 1056 : 1024;
   auto put = [&](const f32x16& acc, int q) {
-    float* mine = red + wave * (WAVE_LDS / 4) + q * 1024;
+    float* mine = red + wave * (WAVE_LDS / 4) + q * QS;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-      mine[ci * 32 + r31] = acc[reg];
+      mine[ci * RP + r31] = acc[reg];
     }
   };
   auto flush4 = [&](const f32x16& a0, const f32x16& a1, const f32x16& a2, const f32x16& a3, int jbase) {
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
         // accumulator row = gathered channel (conv Cout side, chunk c), column = own channel (conv Cin side, block
         // cb): read transposed so that consecutive threads write consecutive conv-Cout elements of dW[kf][ci][co]
         const int a = (e >> 5) & 31, b = e & 31;              // a: own channel, b: gathered channel
-        const int et = (e & ~1023) + b * 32 + a;
+        const int et = (e >> 10) * QS + b * RP + a;
         float v = red[et];
 #pragma unroll
         for (int w = 1; w < WGW; ++w) v += red[w * (WAVE_LDS / 4) + et];

@@ -55,10 +55,23 @@ def _at(handle, floats):
     return handle + 4 * int(floats)
 
 
-def _fuse_apply_enabled():
-    """BatchNorm(+ReLU) applied by the consuming convolution as it reads its input, statistics finished inside the
-    producing convolution's launch (WSIS_FUSE_BN_APPLY=0: the BatchNorm stays an op of its own)"""
-    return os.environ.get("WSIS_FUSE_BN_APPLY", "1") != "0"
+def _fuse_fin_enabled():
+    """BatchNorm statistics finished inside the producing convolution's launch (last-arrival tickets,
+    WSIS_FUSE_BN_FIN=1; default off: finish + apply in one launch behind the convolution).  Measured on the C2 scene:
+    40 launches fewer, but every workgroup of the convolution then waits for its partial stores and a ticket before it
+    retires -- the level-0 layers run 59 -> 71 us, which is what the shorter apply pass (25 -> 10 us) gives back:
+    10.56 / 10.77 against 10.52 / 10.70 ms per step in alternating runs."""
+    return os.environ.get("WSIS_FUSE_BN_FIN", "0") != "0"
+
+
+def _fuse_apply_level():
+    """pyramid level from which the BatchNorm(+ReLU) in front of a convolution is applied by that convolution as it reads
+    its input (WSIS_FUSE_BN_APPLY=<level>; default off).  Measured on the C2 scene: the 64 VALU + 13 LDS instructions per
+    (offset, chunk) step are not hidden under the MFMAs -- the fused layers run 12-20 % longer (level 0: +11.5 us per
+    launch against a 10 us apply pass, level 3: +4 us against 3 us) and the own-rows weight gradient 30 % longer, so the
+    apply pass stays a launch of its own; the fused form remains for memory-tight runs (no activation copy)."""
+    v = os.environ.get("WSIS_FUSE_BN_APPLY", "")
+    return int(v) if v.lstrip("-").isdigit() else 99
 
 
 def _fuse_stats_enabled():
@@ -248,14 +261,14 @@ class UNetProgram(object):
         if update and bn.num_batches_tracked is not None:
             assert bn.momentum is not None, "cumulative-average BatchNorm is not used by 3D-WSIS"
             self._count.append(bn)
-        fuse = fuse and self._fuse_apply and C % 32 == 0
+        fuse = fuse and lvl >= self._fuse_apply_lvl and self._fuse_stats and C % 32 == 0
         momentum = bn.momentum if bn.momentum is not None else 0.1
         mean = rec.alloc(-1, C) if training else bn.running_mean.data_ptr()
         var = rec.alloc(-1, C) if training else bn.running_var.data_ptr()
         src = self._stats_src.get(x) if training else None
         have_parts = src is not None and sum(c for _, c, _ in src) == C and len(src) <= 2
         stats_done = False
-        if have_parts and self._fuse_apply and all(rec.rows[r][10][4] == 0 for _, _, r in src):
+        if have_parts and self._fuse_fin and all(rec.rows[r][10][4] == 0 for _, _, r in src):
             # every producer finishes its channel range of this BatchNorm's statistics inside its own launch
             c0 = 0
             rm = _ptr(bn.running_mean) if update else 0
@@ -400,7 +413,7 @@ class UNetProgram(object):
 
     # ---- compile (once per mode) / bind (per scene) ------------------------------------------------------------
     def _mode_key(self, need_dx):
-        return (need_dx, _fuse_stats_enabled(), _fuse_apply_enabled(), os.environ.get("WSIS_FWD2", "1"),
+        return (need_dx, _fuse_stats_enabled(), _fuse_fin_enabled(), _fuse_apply_level(), os.environ.get("WSIS_FWD2", "1"),
                 tuple(bn.training for bn in self.bns), tuple(p.data_ptr() for p in self.params),
                 tuple(bn.running_mean.data_ptr() if bn.running_mean is not None else 0 for bn in self.bns))
 
@@ -417,7 +430,8 @@ class UNetProgram(object):
         self._prec, self._grad = _Recorder(_PAR, align=16), {}
         self._acc_f, self._acc_b, self._count = [], [], []
         self._stats_src, self._fuse_stats = {}, _fuse_stats_enabled()
-        self._virt, self._fuse_apply = {}, _fuse_apply_enabled() and self._fuse_stats
+        self._virt, self._fuse_apply_lvl = {}, _fuse_apply_level()
+        self._fuse_fin = _fuse_fin_enabled() and self._fuse_stats
         y, b_in = self._conv(rec, _EXT | 0, net.input_conv[0], _subm(0), 0, 0)
         y, b_u = self._ublock(rec, y, net.unet, 0)
         out, b_out = self._bn_relu(rec, y, net.output_layer[0], 0)

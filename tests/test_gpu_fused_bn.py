@@ -231,17 +231,23 @@ print("OK")
 
 
 def test_network_with_and_without_the_batchnorm_fusion(tmp_path):
-    """WSIS_FUSE_BN_APPLY=1 (default) against =0: the forward pass is the same arithmetic in the same order -- loss,
-    scores and running statistics bit-identical --, the gradients differ only by the summation order of the
-    own-rows weight gradient (and what follows from it)"""
+    """every BatchNorm applied by its consuming convolution (WSIS_FUSE_BN_APPLY=0: from level 0 on) and the statistics
+    finished inside the producers' launches (WSIS_FUSE_BN_FIN=1) against the BatchNorm as launches of its own (the
+    default): the forward pass is the same arithmetic in the same order -- loss, scores and running statistics
+    bit-identical --, the gradients differ only by the summation order of the own-rows weight gradient (and what
+    follows from it); finish fused + apply pass separate ("default" below) is bit-identical throughout"""
     outs = {}
-    for tag, v in (("fused", "1"), ("plain", "0")):
+    for tag, env in (("fused", dict(WSIS_FUSE_BN_APPLY="0", WSIS_FUSE_BN_FIN="1")), ("plain", dict(WSIS_FUSE_BN_FIN="0")),
+                     ("default", dict(WSIS_FUSE_BN_FIN="1"))):
         f = str(tmp_path / (tag + ".npz"))
-        r = subprocess.run([sys.executable, "-c", _NET_CHILD, ROOT, f], env=dict(os.environ, WSIS_FUSE_BN_APPLY=v),
+        r = subprocess.run([sys.executable, "-c", _NET_CHILD, ROOT, f], env=dict(os.environ, **env),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
         outs[tag] = np.load(f)
-    a, b = outs["fused"], outs["plain"]
+    d, b = outs["default"], outs["plain"]
+    for k in d.files:
+        assert np.array_equal(d[k], b[k]), k
+    a = outs["fused"]
     assert np.array_equal(a["loss0"], b["loss0"]) and np.array_equal(a["sem"], b["sem"])
     assert np.array_equal(a["loss1"], b["loss1"])
     worst = 0.0
