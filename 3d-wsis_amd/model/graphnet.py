@@ -137,8 +137,14 @@ class GRUCellEx(nn.GRUCell):
 
 
 class RNNGraphConvModule(nn.Module):
-    """7 x { edge-conditioned message passing (mean over out-edges of x[target] @ W_e) -> GRUCellEx }
-    (spg_modules.py:152-185 with the PyG NNConv of :61-121: flow=target_to_source, aggr=mean)."""
+    """7 x { edge-conditioned message passing -> GRUCellEx } (spg_modules.py:152-185 with the PyG NNConv of :61-121).
+
+    Direction: a node receives the MEAN over its IN-edges (s -> t) of x[s] @ W_e.  NNConv's constructor names a
+    ``flow="target_to_source"`` parameter but never hands it to ``MessagePassing.__init__`` (spg_modules.py:61-72:
+    ``super().__init__(aggr=aggr, **kwargs)``), so PyG's default ``source_to_target`` is what runs: x_j = x[edge_index[0]]
+    aggregated at edge_index[1] -- the same sum the non-PyG branch forms (ecc/GraphConvModule.py:49-78: sources
+    ``idxn`` sorted by target, averaged over the in-degree).  Pinned by tests/golden/network_golden.npz, which runs the
+    reference's own module file (round 1-2 of this build had the two ends exchanged)."""
 
     def __init__(self, cell, filter_net, nfeat, vv=True, nrepeats=1, cat_all=False):
         super().__init__()
@@ -162,29 +168,29 @@ class RNNGraphConvModule(nn.Module):
                 and os.environ.get("WSIS_ECC_CONTRACT", "1") != "0")
 
     def _forward_contract(self, hx):
-        """7 x { U = x @ W' (per node) -> m_e = h_e . U_t (per edge, one kernel) -> mean over the out-edges -> GRU }:
+        """7 x { U = x @ W' (per node) -> m_e = h_e . U_s (per edge, one kernel) -> mean over the in-edges -> GRU }:
         the per-edge filters W_e = reshape(Wl h_e + bl) [E, 1024] of the reference (spg_modules.py:168-183) are never
         formed; what is kept per step is the per-node U [S, 65*32]."""
         import wsis_ops
         edge_indexes = self._gci.get_pyg_buffers()
-        src = edge_indexes[0]
+        tgt = edge_indexes[1]                      # messages are aggregated at the edge's target
         last = self._fnet[-1]
         h = _run_modules(list(self._fnet[:-1]), self._gci.get_buffers())     # fnet hidden state [E, 64]
         # W'[a, c*32 + b] = Wl[a*32 + b, c];  W'[a, 64*32 + b] = bl[a*32 + b]
         Waug = torch.cat([last.weight.view(32, 32, 64).permute(0, 2, 1).reshape(32, 64 * 32),
                           last.bias.view(32, 32)], 1)
-        csr, csr_dst = self._gci.csr(), self._gci.csr_dst()
+        csr_gat, csr_agg = self._gci.csr(), self._gci.csr_dst()      # gather side = sources, aggregation side = targets
         cell = self._cell
         if (os.environ.get("WSIS_GNN_LOOP", "1") != "0" and os.environ.get("WSIS_FUSE_GRU", "1") != "0"
                 and getattr(cell, "_ingate", False) and getattr(cell, "_layernorm", False) and cell.bias
                 and getattr(cell, "hidden_size", 0) == 32 and hx.shape[0] > 0 and h.shape[0] > 0):
             # the whole recurrence as one autograd node (same kernels, same order)
-            return wsis_ops.ecc_gru_loop(hx, h, Waug, cell, csr, csr_dst, self._nrepeats, self._cat_all)
+            return wsis_ops.ecc_gru_loop(hx, h, Waug, cell, csr_agg, csr_gat, self._nrepeats, self._cat_all)
         hxs = [hx]
         for _ in range(self._nrepeats):
             U = hx @ Waug                                                  # [S, 65*32]
-            msg = wsis_ops.ecc_contract(h, U, csr_dst)                     # [E, 32]
-            inp = scatter(msg, src, dim=0, dim_size=hx.size(0), reduce="mean", csr=csr)
+            msg = wsis_ops.ecc_contract(h, U, csr_gat)                     # [E, 32]: m_e = h_e . U[source_e]
+            inp = scatter(msg, tgt, dim=0, dim_size=hx.size(0), reduce="mean", csr=csr_agg)
             hx = self._cell(inp, hx)
             hxs.append(hx)
         return torch.cat(hxs, 1) if self._cat_all else hx
@@ -200,21 +206,22 @@ class RNNGraphConvModule(nn.Module):
         assert weights.size(1) in (nc, nc * nc)
         if weights.size(1) != nc:
             weights = weights.view(-1, nc, nc)
-        csr = self._gci.csr()
         fused = weights.dim() == 3 and nc <= 32 and hx.is_cuda
+        csr_agg = self._gci.csr_dst() if hx.is_cuda else None
         if fused:
             import wsis_ops
             src_c, dst_c = src.contiguous(), dst.contiguous()
-            csr_dst = self._gci.csr_dst()
+            csr_gat = self._gci.csr()
         hxs = [hx]
         for _ in range(self._nrepeats):
             if fused:
-                # gather + per-edge mat-vec + mean over the out-edges in ONE kernel (and one for the backward)
-                inp = wsis_ops.ecc_message(hx, weights, src_c, dst_c, csr, csr_dst)
+                # gather + per-edge mat-vec + mean over the in-edges in ONE kernel (and one for the backward):
+                # wsis_ops.ecc_message(x, w, agg_index, gather_index, csr over agg, csr over gather)
+                inp = wsis_ops.ecc_message(hx, weights, dst_c, src_c, csr_agg, csr_gat)
             else:
-                x_j = hx[dst]
+                x_j = hx[src]
                 msg = torch.bmm(x_j.unsqueeze(1), weights).squeeze(1) if weights.dim() == 3 else x_j * weights
-                inp = scatter(msg, src, dim=0, dim_size=hx.size(0), reduce="mean", csr=csr)
+                inp = scatter(msg, dst, dim=0, dim_size=hx.size(0), reduce="mean", csr=csr_agg)
             hx = self._cell(inp, hx)
             hxs.append(hx)
         return torch.cat(hxs, 1) if self._cat_all else hx

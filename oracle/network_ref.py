@@ -144,11 +144,14 @@ class RefRNNGraphConv(nn.Module):
     def forward(self, hx, edge_indexes, edgefeats):
         nc = hx.size(1)
         weights = self._fnet(edgefeats).view(-1, nc, nc)
+        # NNConv never forwards its ``flow`` argument to MessagePassing (spg_modules.py:61-72), so PyG's default
+        # source_to_target runs: x_j = x[edge_index[0]], aggregated at edge_index[1] -- the sum of the non-PyG branch too
+        # (ecc/GraphConvModule.py:49-78); pinned by tests/golden/network_golden.npz
         src, dst = edge_indexes[0], edge_indexes[1]
         hxs = [hx]
         for _ in range(self.reps):
-            msg = torch.matmul(hx[dst].unsqueeze(1), weights).squeeze(1)      # NNConv.message, vv=False
-            inp = scatter(msg, src, 0, hx.size(0), "mean")                     # aggr='mean', target_to_source
+            msg = torch.matmul(hx[src].unsqueeze(1), weights).squeeze(1)      # NNConv.message, vv=False
+            inp = scatter(msg, dst, 0, hx.size(0), "mean")                     # aggr='mean' over the in-edges
             hx = self._cell(inp, hx)
             hxs.append(hx)
         return torch.cat(hxs, 1)

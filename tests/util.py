@@ -32,3 +32,30 @@ def dense_from_sparse(indices, feats, batch, shape):
     ii = torch.as_tensor(indices).long()
     d[ii[:, 0], :, ii[:, 1], ii[:, 2], ii[:, 3]] = feats.double()
     return d
+
+
+def seeded_state_dict(shapes, seed=20260):
+    """deterministic weights for a model whose state-dict has the reference's names: every entry is drawn
+    from a generator seeded by its NAME, so the reference model (tests/golden/make_network_golden.py), the oracle and
+    the product all load the same values whatever their construction order.  ``shapes``: {name: shape}."""
+    import zlib
+    out = {}
+    for name in sorted(shapes):
+        shape = tuple(int(v) for v in shapes[name])
+        g = torch.Generator().manual_seed(seed + zlib.crc32(name.encode()))
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            out[name] = torch.zeros(shape, dtype=torch.int64)
+        elif leaf == "running_var":
+            out[name] = 1.0 + 0.2 * torch.rand(shape, generator=g)
+        elif leaf == "running_mean":
+            out[name] = 0.1 * torch.randn(shape, generator=g)
+        elif len(shape) == 1 and leaf == "weight":          # BatchNorm scale
+            out[name] = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif len(shape) == 1:                                # biases
+            out[name] = 0.1 * torch.randn(shape, generator=g)
+        else:
+            # conv [k0,k1,k2,Cin,Cout]: fan-in k^3 Cin; Linear / GRU [out, in]: fan-in = in
+            fan_in = int(np.prod(shape[:-1])) if len(shape) == 5 else shape[-1]
+            out[name] = torch.randn(shape, generator=g) * (1.5 / np.sqrt(fan_in))
+    return out
