@@ -71,6 +71,60 @@ class PlainGraph(object):
         return PlainGraph({k[3:]: z[k] for k in z.files if k.startswith("vs_")}, z["edges"], z["f"], z["is1ins"])
 
 
+class _PickledIGraph(object):
+    """What ``igraph.Graph.__reduce__`` stores: the constructor arguments ``(n, edges, directed, graph_attrs,
+    vertex_attrs, edge_attrs)`` (python-igraph 0.8 - 0.10: ``Graph.__reduce__`` returns ``(cls, (vcount, edgelist,
+    is_directed, gattrs, vattrs, eattrs), __dict__)``; ``write_pickle`` is ``pickle.dump(graph)``).  Stands in for the
+    class while a ``_spg.dat`` file is unpickled on a machine without igraph."""
+
+    def __init__(self, n=0, edges=None, directed=False, graph_attrs=None, vertex_attrs=None, edge_attrs=None, *rest):
+        self.n, self.edges, self.directed = int(n), list(edges or []), bool(directed)
+        self.graph_attrs, self.vertex_attrs, self.edge_attrs = dict(graph_attrs or {}), dict(vertex_attrs or {}), dict(edge_attrs or {})
+
+    def __setstate__(self, state):       # the instance __dict__ igraph appends (empty for a plain Graph)
+        pass
+
+
+class _SpgUnpickler(__import__("pickle").Unpickler):
+    """resolves ``igraph.Graph`` (whatever sub-module the installed version defined it in) to the stand-in and lets
+    numpy / builtins through; anything else in the stream is refused"""
+
+    _OK_PREFIX = ("numpy", "builtins", "collections", "copyreg", "_codecs")
+
+    def find_class(self, module, name):
+        if module.split(".")[0] == "igraph" and name == "Graph":
+            return _PickledIGraph
+        if module.split(".")[0] in self._OK_PREFIX:
+            return super().find_class(module, name)
+        raise __import__("pickle").UnpicklingError(f"_spg.dat: unexpected global {module}.{name}")
+
+
+def read_spg_pickle(path):
+    """``igraph.Graph.Read_Pickle(scene + '_spg.dat')`` (``scannetv2_dataset.py:79``) WITHOUT igraph -> PlainGraph.
+    The file is the pickle ``graph.write_pickle`` wrote (``prepare_data_inst_ScanNetV2.py:88,163``; gzip-compressed
+    streams are accepted like Read_Pickle does): vertex attributes ``v, semantic_label, instance_label,
+    superpoint_feature, superpoint_offset_vector``, directed edge list in the prep's sorted-tuple order with edge
+    attributes ``f`` (13 standardised features) and ``is1ins`` (``:268-280``)."""
+    import gzip
+    with open(path, "rb") as fh:
+        head = fh.read(2)
+    opener = gzip.open if head == b"\x1f\x8b" else open
+    with opener(path, "rb") as fh:
+        g = _SpgUnpickler(fh).load()
+    if not isinstance(g, _PickledIGraph):
+        raise ValueError(f"{path}: not an igraph.Graph pickle")
+    vs = {k: np.asarray(v) for k, v in g.vertex_attrs.items()}
+    for k, a in vs.items():
+        if len(a) != g.n:
+            raise ValueError(f"{path}: vertex attribute {k} has {len(a)} entries for {g.n} vertices")
+    if not vs:
+        vs = {"v": np.arange(g.n)}
+    edges = np.asarray(g.edges, dtype=np.int64).reshape(-1, 2)
+    f = np.asarray(g.edge_attrs["f"], dtype=np.float32).reshape(len(edges), -1) if "f" in g.edge_attrs else None
+    one = np.asarray(g.edge_attrs["is1ins"]).astype(np.int64) if "is1ins" in g.edge_attrs else None
+    return PlainGraph(vs, edges, f, one)
+
+
 def load_scene_file(path):
     """The reference's per-scene ``.pth``: ``(coords, colors, sem, inst, superpoint, scene_name)``
     (``prepare_data_inst_ScanNetV2.py:166``, read at ``scannetv2_dataset.py:62,72``)."""

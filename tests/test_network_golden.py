@@ -87,3 +87,42 @@ def test_hip_network_matches_the_reference_model_file():
     for k, v in net.state_dict().items():
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert np.allclose(v.cpu().numpy(), g["stat_" + k], rtol=2e-3, atol=2e-4), k
+
+
+@pytest.mark.gpu
+def test_reference_layout_checkpoint_loads_on_the_gpu_and_reproduces_the_reference_forward(tmp_path):
+    """utils/checkpoint.py:105-135 of the reference: the state dict sits under "model" (here with the "module." prefix a
+    DataParallel wrapper leaves), is stripped and loaded strictly; the network then reproduces the outputs the
+    reference's own model file computed for these weights (network_golden.npz).  save_checkpoint -> load_checkpoint
+    round-trips the container (utils/checkpoint.py:205-262: "meta", "model", "optimizer")."""
+    import spconv
+    import harness
+    from graphnet import GraphConvInfo
+    g = np.load(GOLD)
+    dev = "cuda"
+    cfg = harness.default_cfg()
+    model, crit, opt = harness.build_model(cfg, dev)
+    sd = seeded_state_dict({k: v.shape for k, v in model.state_dict().items()})
+    f1 = str(tmp_path / "epoch_00042.pth")
+    torch.save({"meta": {"epoch": 42, "iter": 5040}, "model": {"module." + k: v for k, v in sd.items()}}, f1)
+    ck = harness.load_checkpoint(model, f1, map_location="cpu", strict=True)
+    assert ck["meta"]["epoch"] == 42
+    assert all(p.is_cuda for p in model.parameters())
+    t = lambda k: torch.from_numpy(g["in_" + k]).to(dev)
+    S = int(g["in_superpoint"].max()) + 1
+    model.eval()
+    inp = spconv.SparseConvTensor(t("voxel_feats"), t("voxel_locs").int().contiguous(), g["in_spatial_shape"],
+                                  int(g["in_batch_size"]))
+    extra = {"superpoint": t("superpoint"), "GIs": [GraphConvInfo(t("edge_indexes"), t("edgefeats"), S)],
+             "superpoint_cenetr_xyz": t("centre"), "edge_u_list": t("edge_u"), "edge_v_list": t("edge_v")}
+    with torch.no_grad():
+        ret = model(inp, t("p2v_map"), extra)
+    _check(ret, g, "eval", 2e-3)
+    # container round trip, optimizer state included
+    f2 = str(tmp_path / "out" / "latest.pth")
+    harness.save_checkpoint(model, f2, optimizer=opt, meta={"epoch": 43})
+    model2, _, opt2 = harness.build_model(cfg, dev, seed=7)
+    ck2 = harness.load_checkpoint(model2, f2, optimizer=opt2)
+    assert ck2["meta"]["epoch"] == 43 and set(ck2) >= {"meta", "model", "optimizer"}
+    for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert torch.equal(a, b), k
