@@ -178,11 +178,9 @@ def synthetic_predictions(scene, seed=0, noise=0.02):
 
 
 # -------------------------------------------------------------------------------------------------------------
-def collate(scenes, mode=4, n_levels=5):
-    """Batch dict with the schema of scannetv2_dataset.py:460-474; host tensors.
-    ``n_levels``: UNet depth the host-side ``level_counts`` are computed for (config ``blocks``)."""
-    import pointgroup_ops
-    import spconv
+def _assemble_host(scenes):
+    """everything of ``collate_fn`` (scannetv2_dataset.py:343-474) that is plain concatenation: per-point and
+    per-superpoint arrays with batch / superpoint / instance offsets, the two edge orders, the ECC graph -- no hashing"""
     from graphnet import GraphConvInfo
     locs, locs_float, feats, sem, ins, sps = [], [], [], [], [], []
     sp_sem, sp_ins, sp_off, sp_vox, sp_size = [], [], [], [], []
@@ -219,12 +217,11 @@ def collate(scenes, mode=4, n_levels=5):
         sp_batch_offsets.append(sp_bias)
     locs = torch.cat(locs, 0)
     spatial_shape = np.clip((locs.max(0)[0][1:] + 1).numpy(), FULL_SCALE_MIN, None)
-    voxel_locs, p2v_map, v2p_map = pointgroup_ops.voxelization_idx(locs, len(scenes), mode)
     edge_indexes = torch.cat(edge_sorted, 0).t().contiguous()
     GIs = [GraphConvInfo(edge_indexes, torch.cat(edge_feats_sorted, 0), sp_bias)]
     edges = torch.cat(edges_ext, 0)
     return {
-        "locs": locs, "voxel_locs": voxel_locs, "p2v_map": p2v_map, "v2p_map": v2p_map,
+        "locs": locs,
         "locs_float": torch.cat(locs_float, 0).float(), "feats": torch.cat(feats, 0).float(),
         "semantic_labels": torch.cat(sem, 0).long(), "instance_labels": torch.cat(ins, 0).long(),
         "offsets": torch.tensor(batch_offsets, dtype=torch.int32), "spatial_shape": spatial_shape,
@@ -233,8 +230,6 @@ def collate(scenes, mode=4, n_levels=5):
         "edge_u_list": edges[:, 0].contiguous().long(), "edge_v_list": edges[:, 1].contiguous().long(),
         # rows of scatter(..., edge_u): known here on the host, so the device step never has to read it back
         "edge_src_rows": (int(edges[:, 0].max()) + 1) if edges.shape[0] else 0,
-        # active voxels of the UNet's strided levels, from the host-side coordinates (spconv.ops.level_voxel_counts)
-        "level_counts": spconv.ops.level_voxel_counts(voxel_locs.numpy(), spatial_shape, n_levels),
         "superpoint_semantic_labels": torch.cat(sp_sem, 0).long(),
         "superpoint_instance_labels": torch.cat(sp_ins, 0).long(),
         "superpoint_offset_vector": torch.cat(sp_off, 0).float(),
@@ -242,6 +237,37 @@ def collate(scenes, mode=4, n_levels=5):
         "superpoint_instance_size": torch.cat(sp_size, 0).float(),
         "scene_list": [f"synthetic_{i}" for i in range(len(scenes))],
     }
+
+
+def collate(scenes, mode=4, n_levels=5):
+    """Batch dict with the schema of scannetv2_dataset.py:460-474; host tensors: the voxel hash runs on
+    ONE host thread (libwsis_host.so), as in the reference's DataLoader workers (:445-449).
+    ``n_levels``: UNet depth the host-side ``level_counts`` are computed for (config ``blocks``)."""
+    import pointgroup_ops
+    import spconv
+    out = _assemble_host(scenes)
+    voxel_locs, p2v_map, v2p_map = pointgroup_ops.voxelization_idx(out["locs"], len(scenes), mode)
+    out.update(voxel_locs=voxel_locs, p2v_map=p2v_map, v2p_map=v2p_map)
+    # active voxels of the UNet's strided levels, from the host-side coordinates (spconv.ops.level_voxel_counts)
+    out["level_counts"] = spconv.ops.level_voxel_counts(voxel_locs.numpy(), out["spatial_shape"], n_levels)
+    return out
+
+
+def collate_device(scenes, device, mode=4, n_levels=5):
+    """The same batch with the hashing on the DEVICE (``voxelization_idx`` off the loader's host threads):
+    the host only concatenates the raw per-scene arrays and ships them; the GPU voxelizer (bit-exact first-occurrence
+    contract) builds voxel_locs / p2v / v2p and the pyramid's level counts come from one sort per level -- two small
+    read-backs in this loader stage (voxel count + list width, then the level counts), none in the training step.
+    Returns what ``to_device(collate(scenes))`` returns."""
+    import pointgroup_ops
+    import spconv
+    host = _assemble_host(scenes)
+    locs_d = host["locs"].to(device, non_blocking=True)
+    voxel_locs, p2v_map, v2p_map = pointgroup_ops.voxelization_idx(locs_d, len(scenes), mode)
+    counts = spconv.ops.level_voxel_counts_device(voxel_locs, host["spatial_shape"], n_levels)
+    host.update(voxel_locs=voxel_locs, p2v_map=p2v_map, v2p_map=v2p_map)
+    host["level_counts"] = [int(v) for v in counts.tolist()]
+    return to_device(host, device)
 
 
 _DEVICE_KEYS = ("voxel_locs", "p2v_map", "v2p_map", "locs_float", "feats", "semantic_labels", "instance_labels",
@@ -255,7 +281,7 @@ def to_device(batch, device):
     the edge lists) that are constant for the batch."""
     out = dict(batch)
     for k in _DEVICE_KEYS:
-        out[k] = batch[k].to(device)
+        out[k] = batch[k].to(device)          # (tensors a device-side collate already left on the GPU stay put)
     out["voxel_coords_int"] = out["voxel_locs"].int().contiguous()
     out["GIs"][0].cuda()
     ev = torch.cuda.Event()                # every index tensor of the batch is on the device behind this point

@@ -307,6 +307,31 @@ def level_voxel_counts(voxel_locs, spatial_shape, n_levels, ksize=2, stride=2):
     return counts
 
 
+def level_voxel_counts_device(voxel_locs, spatial_shape, n_levels):
+    """``level_voxel_counts`` on the device: ``voxel_locs`` int64 [M, 4] (batch, x, y, z) on the GPU -> the active voxels
+    of levels 1 .. n_levels-1 as ONE device tensor (a sort + neighbour compare per level; nothing is read back here:
+    the caller fetches the n_levels-1 numbers with a single copy).  A row survives to level l when floor(c / 2^j) lies
+    inside the level-j shape for every j <= l (an odd last plane is dropped by the k2 s2 convolution and stays dropped
+    below)."""
+    _n.require_cuda(voxel_locs)
+    idx = voxel_locs.long()
+    shape = [int(v) for v in spatial_shape]
+    b, c = idx[:, 0], idx[:, 1:]
+    ok = torch.ones(idx.shape[0], dtype=torch.bool, device=idx.device)
+    counts = []
+    for lvl in range(1, int(n_levels)):
+        shape = get_conv_output_size(shape, [2] * 3, [2] * 3, [0] * 3, [1] * 3)
+        o = c >> lvl
+        oa = torch.tensor(shape, dtype=torch.int64, device=idx.device)
+        ok = ok & (o < oa).all(1)
+        lin = ((b * shape[0] + o[:, 0]) * shape[1] + o[:, 1]) * shape[2] + o[:, 2]
+        lin = torch.where(ok, lin, torch.full_like(lin, -1))       # dropped rows: one extra key (-1)
+        k = torch.sort(lin).values
+        n_keys = (k[1:] != k[:-1]).sum() + 1 if k.numel() else torch.zeros((), dtype=torch.int64, device=idx.device)
+        counts.append(n_keys - (~ok).any().long())
+    return torch.stack(counts) if counts else torch.zeros(0, dtype=torch.int64, device=idx.device)
+
+
 def _down_rulebook_gen(indices, spatial_shape, ksize, stride, padding, deferred=None, m_out=None):
     """generator form: yields once, right before the host reads the output row count (the one sync of the level),
     so that a caller can do other work while the candidate / sort / unique kernels run (RulebookPipeline).

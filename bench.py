@@ -260,6 +260,26 @@ def side_measurements(harness, optimizer, device, args):
     out["graph_cluster_stage"] = {"workload": "clustering_in_graph on the C2 scene (host arrays in, host masks out)",
                                   "points": int(len(xyz)), "superpoints": int(sc["S"]), "instances": int(len(conf)),
                                   "ms": round((time.perf_counter() - t0) * 1e3, 2)}
+    # batch assembly: what ONE host thread needs per scene for the reference's collate (voxel hash + level
+    # counts on the host, then H2D) against the device-side collate (raw arrays shipped, hash + counts on the GPU);
+    # wall time of the calling thread, device drained on both sides
+    def _wall(fn, n=5):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    ms_host_collate = _wall(lambda: harness.collate([sc]))
+    ms_host_total = _wall(lambda: harness.to_device(harness.collate([sc]), device))
+    ms_dev_total = _wall(lambda: harness.collate_device([sc], device))
+    out["batch_assembly"] = {"workload": "one C2 scene: collate (+ H2D, per-batch CSRs) by one host thread vs on the device",
+                             "host_collate_ms_per_scene": round(ms_host_collate, 2),
+                             "host_collate_plus_to_device_ms_per_scene": round(ms_host_total, 2),
+                             "device_collate_ms_per_scene": round(ms_dev_total, 2),
+                             "scenes_per_s_one_host_thread": round(1e3 / ms_host_total, 1),
+                             "scenes_per_s_device_collate": round(1e3 / ms_dev_total, 1)}
     out["cluster_stage"] = {"workload": "C3: 4 synthetic scenes, non floor/wall points, r=0.03 m, threshold 50",
                             "points": int(coords.shape[0]), "neighbour_pairs": int(idx_c.numel()),
                             "clusters": int(cl_off.numel() - 1), "ballquery_ms": round(ms_bq, 3),

@@ -1,0 +1,42 @@
+"""Device-side batch assembly: ``harness.collate_device`` hashes the points on the GPU
+(``voxelization_idx`` with a CUDA LongTensor) and counts the pyramid's levels there; it must hand the step exactly the
+batch ``to_device(collate(...))`` builds with the reference's single host thread per worker
+(modules/datasets/scannetv2_dataset.py:445-449, train_scannetv2.py:149-194)."""
+import numpy as np
+import pytest
+import torch
+
+import harness
+from spconv import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("seeds,room", [((3,), (2.2, 1.8, 1.4)), ((4, 5, 6), (1.4, 1.2, 1.0))])
+def test_device_collate_equals_host_collate(seeds, room):
+    scenes = [harness.bench_scene(s, room=room, n_box=2) for s in seeds]
+    host = harness.to_device(harness.collate(scenes), DEV)
+    dev = harness.collate_device(scenes, DEV)
+    torch.cuda.synchronize()
+    for k in ("voxel_locs", "p2v_map", "v2p_map", "voxel_coords_int", "locs_float", "feats", "superpoint",
+              "edge_u_list", "edge_v_list", "semantic_labels", "superpoint_instance_labels"):
+        assert dev[k].is_cuda and torch.equal(dev[k], host[k]), k
+    assert list(dev["level_counts"]) == list(host["level_counts"])
+    assert np.array_equal(dev["spatial_shape"], host["spatial_shape"])
+    assert dev["sp_instance_slots"] == host["sp_instance_slots"] and dev["edge_src_rows"] == host["edge_src_rows"]
+    # the device counts against the oracle's pyramid as well
+    want = ops.level_voxel_counts(host["voxel_locs"].cpu().numpy(), host["spatial_shape"], 5)
+    got = ops.level_voxel_counts_device(dev["voxel_locs"], dev["spatial_shape"], 5).tolist()
+    assert [int(v) for v in got] == want
+
+
+def test_a_step_on_the_device_collated_batch_gives_the_same_loss():
+    cfg = harness.default_cfg()
+    scenes = [harness.bench_scene(8, room=(2.0, 1.6, 1.2), n_box=2)]
+    losses = []
+    for make in (lambda: harness.to_device(harness.collate(scenes), DEV), lambda: harness.collate_device(scenes, DEV)):
+        model, crit, opt = harness.build_model(cfg, DEV)
+        loss, _ = harness.train_step(model, crit, opt, make(), cfg)
+        losses.append(float(loss))
+    assert losses[0] == losses[1]
