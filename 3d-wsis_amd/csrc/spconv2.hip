@@ -1492,7 +1492,10 @@ Plan2 plan2(int64_t M_out, int K, int Cin, int Cout, bool noslab = false) {
   const int steps = K * (Cin / 32);     // steps of a dense work item
   int nw = 1;
   const int nwm = noslab ? nw_max_noslab : nw_max;
-  while (nw < nwm && items * nw * 2 <= target && nw * 2 <= steps) nw *= 2;
+  // up to 4 waves per work item while the launch stays below ~8192 waves (two rounds of the chip's ~4096 resident
+  // waves), beyond 4 only while ALL workgroups are resident at once: 8-wave workgroups take 70 KB of LDS (2 per CU) and
+  // a launch of 600 of them runs a second, mostly empty round (C2 level 2, 96 -> 96: 44.7 -> 38.3 us with 4 waves)
+  while (nw < nwm && items * nw * 2 <= target && nw * 2 <= steps && (nw < 4 || items * nw * 2 <= target / 2)) nw *= 2;
   if (nw_force > 0) nw = nw_force;
   int zs = 1;
   if (!noslab) {

@@ -190,7 +190,8 @@ def c1_cpu_leg(harness):
 
 def _gpu_ms(fn, iters):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fn()
+    for _ in range(3):          # lazy code-object loads and allocator growth happen in the first calls
+        fn()
     torch.cuda.synchronize()
     a.record()
     for _ in range(iters):
@@ -362,7 +363,11 @@ def cpu_baseline(full_voxels, args):
     keeps the passes that finished); the C1 leg (10 k-pt room, host plumbing) runs first in the same child."""
     import subprocess
     cores = os.cpu_count() or 1
-    threads = cores                      # SURVEY 8d: torch.set_num_threads(os.cpu_count())
+    # SURVEY 8d asks for torch.set_num_threads(os.cpu_count()); on the 256-logical-core GPU box that setting is the SLOWER
+    # baseline by two orders of magnitude (round 3: the 10 k-pt C1 leg 2,770 ms per pass at 256 threads against 19 ms at
+    # 32 -- thousands of small index_select / mm / index_add_ calls, each fanned out over every core -- and no C2 pass
+    # inside 240 s), so the baseline runs on min(cores, 32) threads and says so
+    threads = max(1, min(cores, int(os.environ.get("WSIS_CPU_BASELINE_THREADS", "32"))))
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-threads", str(threads),
            "--cpu-iters", str(args.cpu_iters), "--cpu-warmup", str(args.cpu_warmup), "--scene-seed",
            str(args.scene_seed)]

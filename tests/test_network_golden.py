@@ -110,14 +110,15 @@ def test_reference_layout_checkpoint_loads_on_the_gpu_and_reproduces_the_referen
     assert all(p.is_cuda for p in model.parameters())
     t = lambda k: torch.from_numpy(g["in_" + k]).to(dev)
     S = int(g["in_superpoint"].max()) + 1
-    model.eval()
-    inp = spconv.SparseConvTensor(t("voxel_feats"), t("voxel_locs").int().contiguous(), g["in_spatial_shape"],
-                                  int(g["in_batch_size"]))
-    extra = {"superpoint": t("superpoint"), "GIs": [GraphConvInfo(t("edge_indexes"), t("edgefeats"), S)],
-             "superpoint_cenetr_xyz": t("centre"), "edge_u_list": t("edge_u"), "edge_v_list": t("edge_v")}
-    with torch.no_grad():
-        ret = model(inp, t("p2v_map"), extra)
-    _check(ret, g, "eval", 2e-3)
+    for mode in ("train", "eval"):          # the fixture's order: the training pass moves the running statistics first
+        model.train(mode == "train")
+        inp = spconv.SparseConvTensor(t("voxel_feats"), t("voxel_locs").int().contiguous(), g["in_spatial_shape"],
+                                      int(g["in_batch_size"]))
+        extra = {"superpoint": t("superpoint"), "GIs": [GraphConvInfo(t("edge_indexes"), t("edgefeats"), S)],
+                 "superpoint_cenetr_xyz": t("centre"), "edge_u_list": t("edge_u"), "edge_v_list": t("edge_v")}
+        with torch.no_grad():
+            ret = model(inp, t("p2v_map"), extra)
+        _check(ret, g, mode, 2e-3)
     # container round trip, optimizer state included
     f2 = str(tmp_path / "out" / "latest.pth")
     harness.save_checkpoint(model, f2, optimizer=opt, meta={"epoch": 43})
