@@ -1011,21 +1011,26 @@ int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, i
 
 // grid of a producer-consumer launch over M x C elements: every workgroup resident (<= 2 per CU of this device),
 // a multiple of the channel groups; 0 when the one-launch form does not apply
-static int bn_fused_grid(int64_t M, int C, int need_chunk_wgs) {
-  static int on = -1, gmax = -1, n_cu = -1;
-  if (on < 0) {
-    const char* e = getenv("WSIS_BN_FUSED_APPLY");
-    on = e ? atoi(e) : 1;
-    const char* g = getenv("WSIS_BN_FUSED_GRID");
-    gmax = g ? atoi(g) : 256;
-    if (gmax < 64 || gmax > 512) gmax = 256;
-  }
+static int bn_fused_grid(int64_t M, int C, int need_chunk_wgs, int which = 0) {
+  // read per call (a test switches the form on): WSIS_BN_FUSED_APPLY for both directions, WSIS_BN_FUSED_FWD / _BWD per
+  // direction.  Default OFF since round 3: with the flag / ticket words in caller slots (one more arrival counter per
+  // workgroup) and the convolutions on one-launch plans the two-launch form measures faster -- 10.37 / 10.38 ms per C2
+  // step against 10.59 / 10.63 with both directions fused, 10.48 / 10.46 and 10.50 / 10.53 with one of them
+  // (alternating runs on one box) -- and no workgroup of the default path ever waits for another one inside a launch
+  const char* e = getenv("WSIS_BN_FUSED_APPLY");
+  const int on = e ? atoi(e) : 0;
+  const char* ed = getenv(which ? "WSIS_BN_FUSED_BWD" : "WSIS_BN_FUSED_FWD");
+  const int on_dir = ed ? atoi(ed) : on;
+  const char* g = getenv("WSIS_BN_FUSED_GRID");
+  int gmax = g ? atoi(g) : 256;
+  if (gmax < 64 || gmax > 512) gmax = 256;
+  int n_cu = 0;
   {   // per call: the CU count of the CURRENT device (cheap attribute query, no cache shared between devices)
     int dev = 0, v = 0;
     n_cu = (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? v : 0;
   }
-  if (!on || (C & 3) != 0) return 0;
+  if (!on_dir || (C & 3) != 0) return 0;
   const int cw = C >> 2;
   const int64_t work = (M * C) >> 2;
   int gcap = (work > 600000 && gmax == 256) ? 512 : gmax;     // level 0: two workgroups per CU for the apply pass
@@ -1100,7 +1105,7 @@ int wsis_bn_bwd_from_partials(const float* d_partials, int64_t n_part, const flo
   unsigned* tickets = bn_tickets(d_sync);
   if (d_dx) {     // reduction finish + apply in one launch (the form of wsis_bn_stats_finalize_apply)
     const int CG = (C + 31) / 32;
-    const int fgrid = tickets ? bn_fused_grid(M, C, G * CG) : 0;
+    const int fgrid = tickets ? bn_fused_grid(M, C, G * CG, 1) : 0;
     if (fgrid > 0) {
       hipLaunchKernelGGL(bn_bwd_finish_apply_kernel, dim3(fgrid), dim3(256), 0, st, d_partials, (int)n_part, (int)C, chunk, G,
                          d_dbeta, d_dgamma, static_cast<SyncSlot*>(d_sync), d_x, d_dy, d_mean,

@@ -1468,7 +1468,8 @@ struct Plan2 {
 // noslab: the product is finished by ONE launch whatever the level -- up to 16 waves of a workgroup split the offsets of
 // a work item and add through LDS, no offset slabs and no second (reduce) launch; the form of the fused-BatchNorm
 // convolutions (wsis_spconv_fwd_f) and, with WSIS_FWD2_NOSLAB=1 (default), of every launch
-Plan2 plan2(int64_t M_out, int K, int Cin, int Cout, bool noslab = false) {
+Plan2 plan2(int64_t M_out, int K, int Cin, int Cout, bool fused = false) {
+  bool noslab = fused;
   static int nb_pref = -1, target = -1, nw_force = -1, zs_force = -1, da_pref = -1, nw_max = -1, bd_pref = -1;
   static int noslab_all = -1, nw_max_noslab = 16;
   if (noslab_all < 0) {
@@ -1487,7 +1488,7 @@ Plan2 plan2(int64_t M_out, int K, int Cin, int Cout, bool noslab = false) {
   }
   Plan2 p;
   const int nblk = Cout / 32;
-  p.NB = (nb_pref >= 2 && nblk % 2 == 0) ? 2 : 1;
+  p.NB = (!fused && nb_pref >= 2 && nblk % 2 == 0) ? 2 : 1;
   const int64_t items = ceil_div(M_out, SL) * (nblk / p.NB);
   const int steps = K * (Cin / 32);     // steps of a dense work item
   int nw = 1;
@@ -1503,7 +1504,7 @@ Plan2 plan2(int64_t M_out, int K, int Cin, int Cout, bool noslab = false) {
     if (zs_force > 0) zs = zs_force;
     if (zs > K) zs = K;
   }
-  if (noslab) p.NB = 1;
+  if (fused) p.NB = 1;       // (recomputed below: the fused kernels are built for one output block per work item)
   p.NW = nw;
   p.ZS = zs;
   p.DA = (da_pref == 2 || nw >= 4) ? 2 : 3;     // 4+ waves per workgroup: two workgroups per CU need the short ring

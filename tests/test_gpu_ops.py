@@ -1196,7 +1196,8 @@ def test_batch_graphs_built_on_the_side_stream_equal_the_in_stream_build(monkeyp
 # ---------------------------------------------------------------- BatchNorm: statistics finish + apply in one launch
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,C", [(153685, 32), (40003, 64), (12011, 96), (3300, 128), (1100, 160), (70, 32), (200000, 256)])
-def test_bn_finalize_apply_in_one_launch_equals_the_two_calls(M, C):
+def test_bn_finalize_apply_in_one_launch_equals_the_two_calls(M, C, monkeypatch):
+    monkeypatch.setenv("WSIS_BN_FUSED_APPLY", "1")      # (the one-launch form is opt-in since round 3)
     """wsis_bn_stats_finalize_apply (chunk stage + tickets, epoch flag, apply by the waiting workgroups) against
     wsis_bn_stats_finalize followed by wsis_bn_apply on the same slice partials: mean, var, running statistics and y bit
     for bit, twice in a row (the flag / ticket / done counters are ready for the next launch), and y against torch."""
@@ -1247,7 +1248,8 @@ def test_bn_finalize_apply_in_one_launch_equals_the_two_calls(M, C):
 
 
 @pytest.mark.gpu
-def test_fused_batchnorm_launches_on_two_streams_concurrently_do_not_interfere():
+def test_fused_batchnorm_launches_on_two_streams_concurrently_do_not_interfere(monkeypatch):
+    monkeypatch.setenv("WSIS_BN_FUSED_APPLY", "1")
     """the sync words of the one-launch BatchNorm forms live in the caller's slots (no device globals): 1,000 launches on
     each of two streams at the same time, each stream with its own sync block, every result bit-identical to the
     two-launch form; no bounded wait runs out (SURVEY 8b: re-entrant, no global mutable state)"""
