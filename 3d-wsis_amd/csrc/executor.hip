@@ -6,9 +6,13 @@
 // Every op maps 1:1 onto the single-op entry points of this library (same kernels, same summation orders, so the
 // results are bit-identical to calling them one by one); CAT / SPLIT / ADD are the elementwise glue of the UNet
 // (torch.cat of the skip connection, its backward, gradient accumulation at the residual fan-out).
+#include <condition_variable>
 #include <cstdlib>
+#include <deque>
 #include <map>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -151,6 +155,97 @@ hipEvent_t next_fork_event(SideStream* s) {
     s->fork.push_back(e);
   }
   return s->fork[s->next++];
+}
+
+// ---- issuing the weight-gradient launches from a second host thread.  A backward pass is ~250 launches on the
+// caller's stream plus, per convolution, an event wait and two launches on the side stream; the issuing thread is the
+// longer side of a training step, and the side-stream calls do not depend on anything the caller's
+// thread does next.  The caller records the fork event and hands (op, event) to this worker, which makes the side
+// stream wait for the event and launches the dW product; the caller waits for the worker to drain before it records a
+// milestone or the join event.  One worker per process (lazily started); WSIS_DW_THREAD=0: everything from the caller.
+struct DwTask {
+  wsis_op op;
+  hipEvent_t ev;
+  int dev;
+  hipStream_t side;
+  char* ws;
+  int64_t ws_bytes;
+};
+int issue_dw(const wsis_op& op, char* dw_ws, int64_t dw_bytes, void* dw_stream) {
+  if (op.flags & WSIS_OPF_BN_IN)     // the forward input was relu(bn(in[0])) applied on the fly: own-rows form
+    return wsis_spconv_dw_bn((const float*)op.in[0], (const float*)op.in[7], (const float*)op.in[8], (const float*)op.in[9],
+                             (const float*)op.in[10], op.eps, (op.flags & WSIS_OPF_RELU) ? 1 : 0, (const int32_t*)op.in[5],
+                             (const int32_t*)op.in[6], (op.flags & WSIS_OPF_FLIP) ? 1 : 0, (const float*)op.in[2],
+                             (float*)op.out[1], op.M_in, op.M_out, op.K, op.Cin, op.Cout, dw_ws, dw_bytes, dw_stream);
+  return wsis_spconv_dw((const float*)op.in[0], (const int32_t*)op.in[3], (const int32_t*)op.in[4], (const float*)op.in[2],
+                        (float*)op.out[1], op.M_in, op.M_out, op.K, op.Cin, op.Cout, dw_ws, dw_bytes, dw_stream);
+}
+class DwWorker {
+ public:
+  void push(const DwTask& t) {
+    std::lock_guard<std::mutex> lock(mu_);
+    if (!started_) {
+      started_ = true;
+      std::thread(&DwWorker::run, this).detach();
+    }
+    q_.push_back(t);
+    ++pending_;
+    cv_.notify_one();
+  }
+  // waits until every task pushed so far has been issued; returns the first error of the batch (and its message)
+  int drain(std::string* msg) {
+    std::unique_lock<std::mutex> lock(mu_);
+    done_.wait(lock, [this] { return pending_ == 0; });
+    const int rc = err_;
+    if (rc != WSIS_OK && msg) *msg = err_msg_;
+    err_ = WSIS_OK;
+    err_msg_.clear();
+    return rc;
+  }
+
+ private:
+  void run() {
+    for (;;) {
+      DwTask t;
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_.wait(lock, [this] { return !q_.empty(); });
+        t = q_.front();
+        q_.pop_front();
+      }
+      int rc = WSIS_OK;
+      std::string msg;
+      hipError_t he = hipSetDevice(t.dev);
+      if (he == hipSuccess) he = hipStreamWaitEvent(t.side, t.ev, 0);
+      if (he != hipSuccess) {
+        rc = WSIS_ERR_HIP;
+        msg = std::string("dW worker: ") + hipGetErrorString(he);
+      } else {
+        rc = issue_dw(t.op, t.ws, t.ws_bytes, t.side);
+        if (rc != WSIS_OK) msg = wsis_last_error();
+      }
+      std::lock_guard<std::mutex> lock(mu_);
+      if (rc != WSIS_OK && err_ == WSIS_OK) {
+        err_ = rc;
+        err_msg_ = msg;
+      }
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  std::deque<DwTask> q_;
+  int pending_ = 0, err_ = WSIS_OK;
+  std::string err_msg_;
+  bool started_ = false;
+};
+DwWorker& dw_worker() {
+  static DwWorker* w = new DwWorker();      // never destroyed: its thread may outlive static destruction
+  return *w;
+}
+bool dw_thread_enabled() {
+  const char* e = getenv("WSIS_DW_THREAD");
+  return e ? atoi(e) != 0 : true;
 }
 
 bool dw_stream_enabled() {   // read per pass: bench.py switches it off for its event-instrumented roofline steps
@@ -371,6 +466,21 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   ws_bytes -= dw_bytes;
   SideStream* side = (dw_bytes > 0 && dw_stream_enabled()) ? side_stream_for(st) : nullptr;
   if (side) side->next = 0;
+  // the side-stream calls of the pass from a second host thread (not under stream capture, not while the profiler's
+  // event lists are being filled: those are single-threaded)
+  hipStreamCaptureStatus cap_state = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cap_state) != hipSuccess || cap_state != hipStreamCaptureStatusNone;
+  const bool use_worker = side != nullptr && dw_thread_enabled() && !g_prof_on && !capturing;
+  int cur_dev = 0;
+  if (use_worker && hipGetDevice(&cur_dev) != hipSuccess) return fail(WSIS_ERR_HIP, "hipGetDevice failed");
+  bool worker_busy = false;
+  auto drain_worker = [&]() -> int {      // every dW task pushed so far has been issued (and did it fail?)
+    if (!worker_busy) return WSIS_OK;
+    worker_busy = false;
+    std::string msg;
+    const int wrc = dw_worker().drain(&msg);
+    return wrc == WSIS_OK ? WSIS_OK : fail(wrc, "%s", msg.c_str());
+  };
   // inside the op loop nothing returns directly: an error after the fork still has to reach the join below
 #define RUN_LAUNCH_CHECK()                                                                              \
   do {                                                                                                  \
@@ -566,24 +676,27 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
           if (side) {   // dY is complete once everything enqueued so far on the caller's stream has run
             hipEvent_t e = next_fork_event(side);
             hipError_t he = e ? hipEventRecord(e, st) : hipErrorOutOfMemory;
-            if (he == hipSuccess) he = hipStreamWaitEvent(side->stream, e, 0);
+            if (he == hipSuccess && !use_worker) he = hipStreamWaitEvent(side->stream, e, 0);
             if (he != hipSuccess) {
               rc = fail(WSIS_ERR_HIP, "dW side-stream fork failed: %s", hipGetErrorString(he));
               break;
             }
             dw_stream = side->stream;
             forked = true;
+            if (use_worker) {     // the wait and the launches come from the worker thread, in push order
+              DwTask t;
+              t.op = op;
+              t.ev = e;
+              t.dev = cur_dev;
+              t.side = side->stream;
+              t.ws = dw_ws;
+              t.ws_bytes = dw_bytes;
+              dw_worker().push(t);
+              worker_busy = true;
+              break;
+            }
           }
-          if (op.flags & WSIS_OPF_BN_IN)     // the forward input was relu(bn(in[0])) applied on the fly: own-rows form
-            rc = wsis_spconv_dw_bn((const float*)op.in[0], (const float*)op.in[7], (const float*)op.in[8],
-                                   (const float*)op.in[9], (const float*)op.in[10], op.eps,
-                                   (op.flags & WSIS_OPF_RELU) ? 1 : 0, (const int32_t*)op.in[5], (const int32_t*)op.in[6],
-                                   (op.flags & WSIS_OPF_FLIP) ? 1 : 0, (const float*)op.in[2], (float*)op.out[1], op.M_in,
-                                   op.M_out, op.K, op.Cin, op.Cout, dw_ws, dw_bytes, dw_stream);
-          else
-            rc = wsis_spconv_dw((const float*)op.in[0], (const int32_t*)op.in[3], (const int32_t*)op.in[4],
-                                (const float*)op.in[2], (float*)op.out[1], op.M_in, op.M_out, op.K, op.Cin, op.Cout, dw_ws,
-                                dw_bytes, dw_stream);
+          rc = issue_dw(op, dw_ws, dw_bytes, dw_stream);
         }
         break;
       }
@@ -618,6 +731,13 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
       // weight-gradient side stream -- has run (gradient exchange of the finished part of the flat buffer while the
       // rest of the pass still executes)
       SideStream* ms = side ? side : side_stream_for(st);
+      {
+        const int wrc = drain_worker();     // the dW launches up to here are on the side stream before its event
+        if (wrc != WSIS_OK) {
+          first_err = wrc;
+          break;
+        }
+      }
       hipError_t e = ms ? hipEventRecord(ms->mark_main, st) : hipErrorOutOfMemory;
       if (e == hipSuccess) e = hipStreamWaitEvent(as_stream(waiter_stream), ms->mark_main, 0);
       if (e == hipSuccess && forked) {
@@ -631,6 +751,10 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
     }
   }
 #undef RUN_LAUNCH_CHECK
+  {
+    const int wrc = drain_worker();
+    if (wrc != WSIS_OK && first_err == WSIS_OK) first_err = wrc;
+  }
   if (forked) {   // join on EVERY exit path once forked: whatever follows on the caller's stream (optimizer, gradient
                   // all-reduce, the caller's error handling) is ordered behind every dW launch already issued
     const hipError_t e1 = hipEventRecord(side->join, side->stream);

@@ -831,4 +831,199 @@ int wsis_mask_order(const uint32_t* d_mask, int64_t M, int32_t* d_order, void* d
   return WSIS_OK;
 }
 
+
+// ---- the whole rulebook pyramid of a UBlock from ONE call -------------------------------------------------------
+// SubM k3 p1 table per level + SparseConv3d k2 s2 tables between levels (sparse_unet3d.py:130,261,292; [UPSTREAM
+// spconv getIndicePair]) when the row count of every level is known on the host (a loader has the level-0 coordinates
+// there: spconv.ops.level_voxel_counts) -- the chain then needs no device read-back, and issuing it from here instead
+// of ~25 Python-dispatched calls with ~20 tensor allocations takes the rulebook build out of the issuing thread's
+// budget (~1 ms of a 10 ms step).  The SAME entry points in the SAME order as the per-table path (wsis_hash_build,
+// wsis_rulebook_subm, wsis_rulebook_down_keys / _fill, wsis_tile_order_batch, wsis_rulebook_pack_batch): identical
+// tables.  Everything lives in one caller-allocated arena; the layout (byte offsets per level) is a pure function of
+// the row counts.  The device's own output counts stay in the arena (WSIS_PYR_COUNT) for the caller to check.
+namespace {
+inline int64_t pyr_up(int64_t v) { return (v + 255) / 256 * 256; }
+inline int64_t pow2_cap(int64_t m) {
+  int64_t cap = 16;
+  while (cap < 2 * m) cap <<= 1;
+  return cap;
+}
+struct PyrLayout {
+  int64_t off[8][WSIS_PYR_FIELDS];
+  int64_t tile_ws, tile_ws_bytes, order_all, total;
+};
+int pyr_layout(int64_t M0, const int64_t* counts, int n_levels, PyrLayout& L) {
+  if (n_levels < 1 || n_levels > 8 || M0 < 0) return -1;
+  int64_t M[8];
+  M[0] = M0;
+  for (int l = 1; l < n_levels; ++l) {
+    if (counts[l - 1] < 0) return -1;
+    M[l] = counts[l - 1];
+  }
+  int64_t cur = 0, n_all = 0;
+  auto take = [&](int64_t bytes) {
+    const int64_t o = cur;
+    cur += pyr_up(bytes > 0 ? bytes : 1);
+    return o;
+  };
+  for (int l = 0; l < n_levels; ++l) {
+    int64_t* o = L.off[l];
+    for (int f = 0; f < WSIS_PYR_FIELDS; ++f) o[f] = -1;
+    const int64_t cap = pow2_cap(M[l]);
+    o[WSIS_PYR_ROWS] = M[l];
+    o[WSIS_PYR_CAP] = cap;
+    o[WSIS_PYR_INDICES] = l == 0 ? -1 : take(M[l] * 16);
+    o[WSIS_PYR_KEYS] = take(cap * 8);
+    o[WSIS_PYR_VALS] = take(cap * 4);
+    o[WSIS_PYR_SUBM_NBR] = take(27 * M[l] * 4);
+    o[WSIS_PYR_SUBM_MASK] = take(M[l] * 4);
+    o[WSIS_PYR_SUBM_NBR_P] = take(27 * M[l] * 4);
+    n_all += M[l];
+    if (l + 1 < n_levels) {
+      const int64_t n_cand = M[l];               // k == s, p == 0: one candidate per input voxel
+      o[WSIS_PYR_CAND] = take(n_cand * 8);
+      o[WSIS_PYR_OUT_KEYS] = take(n_cand * 8);
+      o[WSIS_PYR_COUNT] = take(4);
+      o[WSIS_PYR_DOWN_WS] = take(wsis_rulebook_down_workspace_bytes(n_cand));
+      o[WSIS_PYR_DOWN_NBR] = take(8 * M[l + 1] * 4);
+      o[WSIS_PYR_UP_NBR] = take(8 * M[l] * 4);
+      o[WSIS_PYR_DOWN_MASK] = take(M[l + 1] * 4);
+      o[WSIS_PYR_UP_MASK] = take(M[l] * 4);
+      o[WSIS_PYR_DOWN_NBR_P] = take(8 * M[l + 1] * 4);
+      o[WSIS_PYR_UP_NBR_P] = take(8 * M[l] * 4);
+      n_all += M[l + 1] + M[l];
+    }
+  }
+  L.order_all = take(n_all * 4);
+  L.tile_ws_bytes = wsis_tile_order_batch_workspace_bytes(n_all);
+  L.tile_ws = take(L.tile_ws_bytes);
+  // tile orders: segments of order_all in the order subm(l), down(l), up(l), subm(l+1), ...
+  int64_t seg = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    L.off[l][WSIS_PYR_SUBM_ORDER] = L.order_all + seg * 4;
+    seg += M[l];
+    if (l + 1 < n_levels) {
+      L.off[l][WSIS_PYR_DOWN_ORDER] = L.order_all + seg * 4;
+      seg += M[l + 1];
+      L.off[l][WSIS_PYR_UP_ORDER] = L.order_all + seg * 4;
+      seg += M[l];
+    }
+  }
+  L.total = cur;
+  return 0;
+}
+}  // namespace
+
+int64_t wsis_rulebook_pyramid_layout(int64_t M0, const int64_t* h_counts, int32_t n_levels, int64_t* h_layout) {
+  PyrLayout L;
+  if ((n_levels > 1 && !h_counts) || pyr_layout(M0, h_counts, n_levels, L) != 0) return -1;
+  if (h_layout)
+    for (int l = 0; l < n_levels; ++l)
+      for (int f = 0; f < WSIS_PYR_FIELDS; ++f) h_layout[l * WSIS_PYR_FIELDS + f] = L.off[l][f];
+  return L.total;
+}
+
+int wsis_rulebook_pyramid(const int32_t* d_indices0, int64_t M0, const int32_t* h_shape3, const int64_t* h_counts,
+                          int32_t n_levels, int32_t batch_size, int32_t block_shift, void* d_arena, int64_t arena_bytes,
+                          void* stream) {
+  WSIS_REQUIRE(h_shape3 && d_arena && (M0 == 0 || d_indices0), "null pointer");
+  WSIS_REQUIRE(n_levels <= 5 || n_levels * 3 - 2 <= 16, "at most 16 gather tables per batched tile order");
+  PyrLayout L;
+  WSIS_REQUIRE((n_levels <= 1 || h_counts) && pyr_layout(M0, h_counts, n_levels, L) == 0, "bad level counts");
+  WSIS_REQUIRE(arena_bytes >= L.total && (reinterpret_cast<uintptr_t>(d_arena) & 255) == 0, "arena too small or unaligned");
+  char* A = static_cast<char*>(d_arena);
+  auto at = [&](int l, int f) -> void* { return L.off[l][f] < 0 ? nullptr : A + L.off[l][f]; };
+  const int32_t k3[3] = {3, 3, 3}, p1[3] = {1, 1, 1}, k2[3] = {2, 2, 2}, s2[3] = {2, 2, 2}, p0[3] = {0, 0, 0};
+  int32_t shape[3] = {h_shape3[0], h_shape3[1], h_shape3[2]};
+  const void* t_idx[16];
+  const void* t_mask[16];
+  int64_t t_M[16];
+  const void* pk_nbr[16];
+  const void* pk_order[16];
+  void* pk_out[16];
+  int64_t pk_M[16];
+  int32_t pk_K[16];
+  int nt = 0;
+  const int32_t* indices = d_indices0;
+  for (int l = 0; l < n_levels; ++l) {
+    const int64_t M = L.off[l][WSIS_PYR_ROWS], cap = L.off[l][WSIS_PYR_CAP];
+    int64_t* keys = static_cast<int64_t*>(at(l, WSIS_PYR_KEYS));
+    int32_t* vals = static_cast<int32_t*>(at(l, WSIS_PYR_VALS));
+    int rc;
+    if (l == 0) {        // deeper levels get their hash from the strided build of the level above
+      rc = wsis_hash_build(indices, M, shape, keys, vals, cap, stream);
+      if (rc != WSIS_OK) return rc;
+    }
+    rc = wsis_rulebook_subm(indices, M, shape, k3, p1, keys, vals, cap, static_cast<int32_t*>(at(l, WSIS_PYR_SUBM_NBR)),
+                            static_cast<uint32_t*>(at(l, WSIS_PYR_SUBM_MASK)), stream);
+    if (rc != WSIS_OK) return rc;
+    t_idx[nt] = indices;
+    t_mask[nt] = at(l, WSIS_PYR_SUBM_MASK);
+    t_M[nt] = M;
+    pk_nbr[nt] = at(l, WSIS_PYR_SUBM_NBR);
+    pk_order[nt] = at(l, WSIS_PYR_SUBM_ORDER);
+    pk_out[nt] = at(l, WSIS_PYR_SUBM_NBR_P);
+    pk_M[nt] = M;
+    pk_K[nt] = 27;
+    ++nt;
+    if (l + 1 == n_levels) break;
+    const int64_t M_out = L.off[l + 1][WSIS_PYR_ROWS];
+    int32_t out_shape[3];
+    for (int j = 0; j < 3; ++j) out_shape[j] = (shape[j] - 2) / 2 + 1;
+    rc = wsis_rulebook_down_keys(indices, M, shape, out_shape, k2, s2, p0, static_cast<int64_t*>(at(l, WSIS_PYR_CAND)),
+                                 static_cast<int64_t*>(at(l, WSIS_PYR_OUT_KEYS)), static_cast<int32_t*>(at(l, WSIS_PYR_COUNT)),
+                                 at(l, WSIS_PYR_DOWN_WS), wsis_rulebook_down_workspace_bytes(M), stream);
+    if (rc != WSIS_OK) return rc;
+    int32_t* idx_out = static_cast<int32_t*>(at(l + 1, WSIS_PYR_INDICES));
+    rc = wsis_rulebook_down_fill(indices, M, shape, out_shape, k2, s2, p0, static_cast<const int64_t*>(at(l, WSIS_PYR_OUT_KEYS)),
+                                 M_out, idx_out, static_cast<int64_t*>(at(l + 1, WSIS_PYR_KEYS)),
+                                 static_cast<int32_t*>(at(l + 1, WSIS_PYR_VALS)), L.off[l + 1][WSIS_PYR_CAP],
+                                 static_cast<int32_t*>(at(l, WSIS_PYR_DOWN_NBR)), static_cast<int32_t*>(at(l, WSIS_PYR_UP_NBR)),
+                                 static_cast<uint32_t*>(at(l, WSIS_PYR_DOWN_MASK)), static_cast<uint32_t*>(at(l, WSIS_PYR_UP_MASK)),
+                                 stream);
+    if (rc != WSIS_OK) return rc;
+    t_idx[nt] = idx_out;
+    t_mask[nt] = at(l, WSIS_PYR_DOWN_MASK);
+    t_M[nt] = M_out;
+    pk_nbr[nt] = at(l, WSIS_PYR_DOWN_NBR);
+    pk_order[nt] = at(l, WSIS_PYR_DOWN_ORDER);
+    pk_out[nt] = at(l, WSIS_PYR_DOWN_NBR_P);
+    pk_M[nt] = M_out;
+    pk_K[nt] = 8;
+    ++nt;
+    t_idx[nt] = indices;
+    t_mask[nt] = at(l, WSIS_PYR_UP_MASK);
+    t_M[nt] = M;
+    pk_nbr[nt] = at(l, WSIS_PYR_UP_NBR);
+    pk_order[nt] = at(l, WSIS_PYR_UP_ORDER);
+    pk_out[nt] = at(l, WSIS_PYR_UP_NBR_P);
+    pk_M[nt] = M;
+    pk_K[nt] = 8;
+    ++nt;
+    indices = idx_out;
+    for (int j = 0; j < 3; ++j) shape[j] = out_shape[j];
+  }
+  // all tile orders from one sort, all packed tables from one launch (the tables without rows are skipped inside)
+  {
+    const void* ti[16];
+    const void* tm[16];
+    int64_t tM[16];
+    int n = 0;
+    for (int t = 0; t < nt; ++t)
+      if (t_M[t] > 0) {
+        ti[n] = t_idx[t];
+        tm[n] = t_mask[t];
+        tM[n] = t_M[t];
+        ++n;
+      }
+    // (segments of order_all follow the tables WITH rows only when every table has rows; an empty level breaks the
+    // contiguity assumption of the layout, so such a pyramid takes the per-table path)
+    WSIS_REQUIRE(n == nt, "a level without voxels: use the per-table build");
+    const int rc = wsis_tile_order_batch(n, ti, tm, tM, block_shift, batch_size, reinterpret_cast<int32_t*>(A + L.order_all),
+                                         A + L.tile_ws, L.tile_ws_bytes, stream);
+    if (rc != WSIS_OK) return rc;
+  }
+  return wsis_rulebook_pack_batch(nt, pk_nbr, pk_order, pk_out, pk_M, pk_K, stream);
+}
+
 }  // extern "C"

@@ -202,6 +202,104 @@ int wsis_segment_csr(const int64_t* d_index, int64_t N, int64_t S, int32_t* d_pe
   return WSIS_OK;
 }
 
+// ---- the CSRs of up to 8 index vectors from ONE sort (a batch needs six: superpoint ids, point -> voxel map, the two
+// directions of the affinity graph and of the ECC graph): keys (table << 32 | index) sorted once with the row number
+// local to the table as value, so every table's perm is a contiguous segment of the result and -- the sort being stable
+// -- identical to what wsis_segment_csr gives for it; offsets of all tables by one launch.
+constexpr int CSRB_MAX = 8;
+struct CsrBatch {
+  const int64_t* index[CSRB_MAX];
+  int64_t base[CSRB_MAX + 1];      // first row of table t in the concatenation
+  int64_t S[CSRB_MAX];
+  int64_t obase[CSRB_MAX + 1];     // first offset word of table t
+  int n;
+};
+__global__ void csrb_keys_kernel(CsrBatch b, uint64_t* __restrict__ keys, int32_t* __restrict__ iota) {
+  const int64_t N = b.base[b.n];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    int t = 0;
+    while (t + 1 < b.n && i >= b.base[t + 1]) ++t;
+    const int64_t r = i - b.base[t];
+    keys[i] = ((uint64_t)t << 32) | (uint32_t)b.index[t][r];
+    iota[i] = (int32_t)r;
+  }
+}
+__global__ void csrb_offsets_kernel(CsrBatch b, const uint64_t* __restrict__ sorted, int32_t* __restrict__ offsets) {
+  const int64_t N = b.base[b.n];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    int t = 0;
+    while (t + 1 < b.n && i >= b.base[t + 1]) ++t;
+    const int64_t r = i - b.base[t], n_t = b.base[t + 1] - b.base[t], S = b.S[t];
+    int32_t* off = offsets + b.obase[t];
+    const int64_t cur = (int64_t)(uint32_t)sorted[i];
+    const int64_t prev = r > 0 ? (int64_t)(uint32_t)sorted[i - 1] : -1;
+    for (int64_t s = prev + 1; s <= cur && s <= S; ++s) off[s] = (int32_t)r;
+    if (r == n_t - 1)
+      for (int64_t s = cur + 1; s <= S; ++s) off[s] = (int32_t)n_t;
+  }
+}
+
+int64_t wsis_segment_csr_batch_workspace_bytes(int64_t N_all) {
+  if (N_all < 0) return -1;
+  if (N_all == 0) return 256;
+  size_t sort_bytes = 0;
+  uint64_t* kp = nullptr;
+  int32_t* vp = nullptr;
+  if (rocprim::radix_sort_pairs(nullptr, sort_bytes, kp, kp, vp, vp, (size_t)N_all, 0, 36, (hipStream_t)0) != hipSuccess)
+    return -1;
+  return (int64_t)(2 * align256((size_t)N_all * 8) + align256((size_t)N_all * 4) + align256(sort_bytes) + 256);
+}
+
+int wsis_segment_csr_batch(int32_t n, const void* const* h_index, const int64_t* h_N, const int64_t* h_S,
+                           int32_t* d_perm_all, int32_t* d_offsets_all, void* d_ws, int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(n >= 1 && n <= CSRB_MAX && h_index && h_N && h_S && d_offsets_all, "bad args (at most 8 index vectors)");
+  CsrBatch b;
+  b.n = n;
+  b.base[0] = 0;
+  b.obase[0] = 0;
+  for (int t = 0; t < n; ++t) {
+    WSIS_REQUIRE(h_N[t] >= 0 && h_S[t] >= 0 && h_S[t] < ((int64_t)1 << 31) && (h_N[t] == 0 || h_index[t]), "bad table");
+    b.index[t] = static_cast<const int64_t*>(h_index[t]);
+    b.S[t] = h_S[t];
+    b.base[t + 1] = b.base[t] + h_N[t];
+    b.obase[t + 1] = b.obase[t] + h_S[t] + 1;
+  }
+  const int64_t N = b.base[n];
+  WSIS_REQUIRE(N < ((int64_t)1 << 31), "sizes exceed int32");
+  hipStream_t st = as_stream(stream);
+  // tables without rows: all their offsets are zero (the offsets kernel never visits them)
+  for (int t = 0; t < n; ++t)
+    if (h_N[t] == 0)
+      WSIS_HIP_CHECK(hipMemsetAsync(d_offsets_all + b.obase[t], 0, sizeof(int32_t) * (size_t)(h_S[t] + 1), st));
+  if (N == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_perm_all && d_ws, "null pointer");
+  char* ws = static_cast<char*>(d_ws);
+  const size_t a8 = align256((size_t)N * 8), a4 = align256((size_t)N * 4);
+  WSIS_REQUIRE((int64_t)(2 * a8 + a4) < ws_bytes, "workspace too small");
+  uint64_t* keys = reinterpret_cast<uint64_t*>(ws);
+  uint64_t* keys_sorted = reinterpret_cast<uint64_t*>(ws + a8);
+  int32_t* iota = reinterpret_cast<int32_t*>(ws + 2 * a8);
+  void* temp = ws + 2 * a8 + a4;
+  size_t temp_bytes = (size_t)ws_bytes - (2 * a8 + a4);
+  hipLaunchKernelGGL(csrb_keys_kernel, dim3(grid_for(N, 256)), dim3(256), 0, st, b, keys, iota);
+  WSIS_LAUNCH_CHECK();
+  int64_t s_max = 0;
+  for (int t = 0; t < n; ++t) s_max = h_S[t] > s_max ? h_S[t] : s_max;
+  int idx_bits = 1;
+  while (idx_bits < 32 && ((int64_t)1 << idx_bits) < s_max + 1) ++idx_bits;
+  // the table number sits at bit 32: sort the low index bits, then the table bits (stable radix sort: two ranges of
+  // one key would need two sorts, so the whole span up to the table bits is sorted -- 36 bits at most)
+  const int end_bit = 32 + 3;
+  (void)idx_bits;
+  size_t need = 0;
+  WSIS_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, need, keys, keys_sorted, iota, d_perm_all, (size_t)N, 0, end_bit, st));
+  WSIS_REQUIRE(need <= temp_bytes, "workspace too small for sort");
+  WSIS_HIP_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, iota, d_perm_all, (size_t)N, 0, end_bit, st));
+  hipLaunchKernelGGL(csrb_offsets_kernel, dim3(grid_for(N, 256)), dim3(256), 0, st, b, keys_sorted, d_offsets_all);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
 int wsis_segment_reduce_fwd(const float* d_src, const int32_t* d_perm, const int32_t* d_offsets,
                             float* d_out, int32_t* d_argmax, int64_t N, int64_t S, int32_t C,
                             int32_t reduce, void* stream) {

@@ -250,10 +250,14 @@ template <int NB, int NW, int DA, bool BD, bool DIAG = false, bool FB = false>
 __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ WT, const float* __restrict__ bias, const float* __restrict__ residual,
-    float* __restrict__ out, float* __restrict__ partial, int64_t M_out, int K, int Cin, int Cout, int flip,
+    float* __restrict__ out, float* __restrict__ partial, int64_t M_out, int K, int Cin, int Cout, int flip_deal,
     uint32_t x_bytes, float* __restrict__ stats, BnEpi epi, BnIn bin, StatFin fin,
     unsigned long long* __restrict__ dbg = nullptr) {
   static_assert(!FB || (BD && NB == 1), "the fused input BatchNorm is built for the weights-to-registers form");
+  // flip_deal: bit 0 = offset k uses weight slice K - 1 - k; bit 1 = the waves of a work item are dealt the slice's
+  // ACTIVE offsets round-robin (see the ownership block below)
+  const int flip = flip_deal & 1;
+  const bool deal_active = (flip_deal & 2) != 0;
   // stats (optional, final pass only): per-slice BatchNorm partials of the FINISHED output rows (bias and residual
   // included), stats[(slice * 2 + {0: sum, 1: sum of squared deviations from the SLICE mean}) * Cout + channel] -- the
   // statistics pass of the BatchNorm that consumes this tensor (sparse_unet3d.py:128-137) without re-reading it.
@@ -327,7 +331,21 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
   {
     const int zs = gridDim.z, z = blockIdx.z;
     const int P = zs * NW, r = z + zs * wave;         // k belongs to this wave iff k mod (zs NW) == z + zs wave
-    if ((P & (P - 1)) == 0) {
+    if (deal_active && NW > 1 && zs == 1) {
+      // the j-th ACTIVE offset of the slice goes to wave j % NW: every wave of the work item gets the same number of
+      // steps (+- one offset) whatever the slice's geometry -- with ownership by offset INDEX the waves of a
+      // workgroup differ by up to 3x and the work item lasts as long as its busiest wave.  The price: which wave adds
+      // which offset now depends on the slice's active set, so an output row's order of additions depends on the rows
+      // it shares a slice with (still fixed for a given input: run-to-run identical, not tile-order independent).
+      uint32_t m = mask;
+      int j = 0;
+      while (m) {
+        const int k = __builtin_ctz(m);
+        m &= m - 1u;
+        if (j == wave) mymask |= 1u << k;
+        j = j + 1 == NW ? 0 : j + 1;
+      }
+    } else if ((P & (P - 1)) == 0) {
       // the launch plans only produce powers of two: the owner test is a periodic bit pattern (the 27-iteration walk
       // with two runtime divisions per offset was ~1,600 scalar instructions of every work item's prologue)
       uint32_t pat = P == 1 ? 0xffffffffu : P == 2 ? 0x55555555u : P == 4 ? 0x11111111u : P == 8 ? 0x01010101u
@@ -1636,6 +1654,12 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
   }
   hipStream_t st = as_stream(stream);
   const dim3 grid((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32 / p.NB), (unsigned)p.ZS);
+  // WSIS_FWD2_DEAL=1 (read per call; default 0): active offsets dealt round-robin to the waves of a work item instead
+  // of ownership by offset index.  Measured neutral on the C2 step (level 1: 1046 -> 1035-1050 us per step, level 2:
+  // 855 -> 835) -- the waves of a work item are not what its lifetime waits for -- and it gives up the tile-order
+  // independence of the results, so it stays off.
+  const char* deal_env = getenv("WSIS_FWD2_DEAL");
+  const int flip_deal = (flip ? 1 : 0) | (((deal_env ? atoi(deal_env) : 0) != 0 && p.ZS == 1) ? 2 : 0);
   ProfScope prof(0, st);
   // the persistent form pays where a launch is split into offset slabs (deep levels: 15 % faster at level 3 of the
   // C2 scene); WSIS_FWD3=2 forces it wherever it applies, 0 disables it
@@ -1680,8 +1704,8 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
       attr_set = ldsb;                                                                                           \
     }                                                                                                            \
     hipLaunchKernelGGL((spconv_fwd2_kernel<nb, nw, da, bd, false, fb>), grid, dim3(64 * nw), ldsb, st, d_X, d_nbr, \
-                       d_order, d_WT, d_bias, d_residual, d_out, partial, M_out, K, Cin, Cout, flip, x_bytes, d_stats, \
-                       epi, bin, fin);                                                                           \
+                       d_order, d_WT, d_bias, d_residual, d_out, partial, M_out, K, Cin, Cout, flip_deal, x_bytes,    \
+                       d_stats, epi, bin, fin);                                                                  \
   } while (0)
 #define WSIS_F2(nb, nw, da)             \
   if (p.BD)                             \

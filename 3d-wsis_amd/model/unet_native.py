@@ -466,6 +466,19 @@ class UNetProgram(object):
         self.Mvec = np.zeros(L, dtype=np.int64)
         self.table_lut = np.zeros(L * 6, dtype=np.uint64)
         self.table_tensors = [None] * (L * 6)
+        pyr = getattr(tensor.indice_dict, "pyramid", None)
+        if pyr is not None and pyr.n_levels == L:
+            # the pyramid came from one native call into one arena: row counts and table pointers straight from its
+            # layout, no per-table tensor views (they are made only if the profiler asks for pair counts)
+            lay, base = pyr.layout, np.uint64(pyr.base)
+            self.Mvec[:] = lay[:, sp_ops.PYR_ROWS]
+            fields = (sp_ops.PYR_SUBM_NBR_P, sp_ops.PYR_SUBM_ORDER, sp_ops.PYR_DOWN_NBR_P, sp_ops.PYR_DOWN_ORDER,
+                      sp_ops.PYR_UP_NBR_P, sp_ops.PYR_UP_ORDER)
+            off = lay[:, fields]                                   # [L, 6]
+            self.table_lut[:] = np.where(off >= 0, off.astype(np.uint64) + base, np.uint64(0)).reshape(-1)
+            self.table_tensors = _LazyTables(tensor.indice_dict, L)
+            self.keep = [tensor.indice_dict]
+            return
         for lvl in range(L):
             rb = tensor.indice_dict["subm%d" % (lvl + 1)]
             self.Mvec[lvl] = rb.in_indices.shape[0]
@@ -486,6 +499,21 @@ class UNetProgram(object):
             t = tensors[nbr & _ID_MASK] if nbr else None
             P = prof.pairs(t, int(Mvec[lvl]))
             prof.end(name, None, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout, (int(Mvec[lvl]), Cin, Cout, P))
+
+
+class _LazyTables(object):
+    """table_tensors[level*6 + slot] made on demand from the pyramid's rulebooks (the profiler's pair counts)"""
+
+    def __init__(self, indice_dict, L):
+        self.d, self.L = indice_dict, L
+
+    def __getitem__(self, i):
+        lvl, slot = divmod(int(i), 6)
+        if slot < 2:
+            rb = self.d["subm%d" % (lvl + 1)]
+            return (rb.nbr_p, rb.order)[slot]
+        rd = self.d["spconv%d" % (lvl + 1)]
+        return (rd.nbr_p, rd.order, rd.nbr_up_p, rd.order_up)[slot - 2]
 
 
 def _arena_tensor(nbytes, device, zero=False):
@@ -520,10 +548,12 @@ class UNetFunction(Function):
         luts = {_FWD: fwd_lut, _TBL: table_lut, _EXT: np.array([x.data_ptr(), 0], dtype=np.uint64), _BWD: none,
                 _PAR: none}
         _run(_n.hip(), c.fwd.instantiate(Mvec, luts), x.device)
-        # tables sized from the batch's host-side level counts: the device's own counts are compared NOW, inside the
-        # same pass (they were written at the top of the rulebook chain on the side stream, long before the host got
-        # here: the read waits for that stream only), before any result or gradient of this pass is used
-        sp_ops.verify_pending_counts()
+        # tables sized from the batch's host-side level counts: the device's own counts are compared inside the SAME
+        # pass -- an inference pass right here (its result is used next; the read waits for the rulebook chain on the
+        # side stream only), a training pass at the end of its backward pass, i.e. before the optimizer can use a
+        # gradient (reading here would park the issuing thread for the length of the rulebook chain, ~1 ms per step)
+        if not (torch.is_grad_enabled() and (need_dx or any(p.requires_grad for p in params))):
+            sp_ops.verify_pending_counts()
         prog.account(c.acc_f, Mvec, tensors)
         out = _view(arena, base, offs[c.out_id], (int(Mvec[0]), c.out_channels))
         ctx.prog, ctx.c, ctx.arena, ctx.fwd_lut, ctx.x = prog, c, arena, fwd_lut, x
@@ -572,6 +602,7 @@ class UNetFunction(Function):
         t0 = first + (ptotal + 3) // 4
         prog.flat_tail = pflat[t0:t0 + prog.tail_floats] if prog.tail_floats else None
         dx = _view(garena, gbase, boffs[c.dx_id], tuple(ctx.x.shape)) if c.dx_id >= 0 else None
+        sp_ops.verify_pending_counts()       # (see forward: the counts of this pass's rulebooks, long written by now)
         return (dx, None) + tuple(grads)
 
 

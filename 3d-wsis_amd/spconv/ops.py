@@ -664,6 +664,141 @@ def _build_pyramid_gen(tensor, n_levels, subm_key, down_key, first_id):
     return built
 
 
+# field numbers of wsis_rulebook_pyramid_layout (include/wsis_hip.h WSIS_PYR_*)
+(PYR_ROWS, PYR_CAP, PYR_INDICES, PYR_KEYS, PYR_VALS, PYR_SUBM_NBR, PYR_SUBM_MASK, PYR_SUBM_ORDER, PYR_SUBM_NBR_P, PYR_CAND,
+ PYR_OUT_KEYS, PYR_COUNT, PYR_DOWN_WS, PYR_DOWN_NBR, PYR_UP_NBR, PYR_DOWN_MASK, PYR_UP_MASK, PYR_DOWN_ORDER, PYR_UP_ORDER,
+ PYR_DOWN_NBR_P, PYR_UP_NBR_P, PYR_FIELDS) = range(22)
+
+
+class Pyramid(object):
+    """All rulebooks of a UBlock pyramid in ONE device arena, built by one native call (wsis_rulebook_pyramid) from the
+    batch's host-side level counts.  ``ptr(level, field)`` gives device pointers without creating tensors (what the
+    op-list executor needs); ``rulebook(key)`` materialises the ``Rulebook`` views of one table on demand (module walk,
+    tests, the profiler's pair counts)."""
+
+    def __init__(self, arena, layout, indices0, shapes, n_levels, subm_key, down_key, first_id):
+        self.arena, self.layout, self.indices0, self.shapes, self.n_levels = arena, layout, indices0, shapes, n_levels
+        self.base = arena.data_ptr()
+        self.keys = {}
+        for l in range(n_levels):
+            self.keys[subm_key.format(first_id + l)] = ("subm", l)
+            if l + 1 < n_levels:
+                self.keys[down_key.format(first_id + l)] = ("down", l)
+        self._made = {}
+
+    def rows(self, level):
+        return int(self.layout[level, PYR_ROWS])
+
+    def ptr(self, level, field):
+        off = int(self.layout[level, field])
+        return 0 if off < 0 else self.base + off
+
+    def view(self, level, field, dtype, shape):
+        off = int(self.layout[level, field])
+        n = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+        return self.arena[off:off + n].view(dtype).view(shape)
+
+    def indices(self, level):
+        return self.indices0 if level == 0 else self.view(level, PYR_INDICES, torch.int32, (self.rows(level), 4))
+
+    def hash_tab(self, level):
+        cap = int(self.layout[level, PYR_CAP])
+        return (self.view(level, PYR_KEYS, torch.int64, (cap,)), self.view(level, PYR_VALS, torch.int32, (cap,)), cap)
+
+    def rulebook(self, key):
+        rb = self._made.get(key)
+        if rb is not None:
+            return rb
+        kind, l = self.keys[key]
+        M = self.rows(l)
+        if kind == "subm":
+            rb = Rulebook("subm", [3, 3, 3], [1, 1, 1], [1, 1, 1], self.indices(l), self.indices(l), list(self.shapes[l]),
+                          list(self.shapes[l]))
+            rb.nbr = self.view(l, PYR_SUBM_NBR, torch.int32, (27, M))
+            rb.order = self.view(l, PYR_SUBM_ORDER, torch.int32, (M,))
+            rb.nbr_p = self.view(l, PYR_SUBM_NBR_P, torch.int32, (27, M))
+            rb.out_hash = self.hash_tab(l)
+        else:
+            Mo = self.rows(l + 1)
+            rb = Rulebook("down", [2, 2, 2], [2, 2, 2], [0, 0, 0], self.indices(l), self.indices(l + 1),
+                          list(self.shapes[l]), list(self.shapes[l + 1]))
+            rb.nbr = self.view(l, PYR_DOWN_NBR, torch.int32, (8, Mo))
+            rb.nbr_up = self.view(l, PYR_UP_NBR, torch.int32, (8, M))
+            rb.order = self.view(l, PYR_DOWN_ORDER, torch.int32, (Mo,))
+            rb.order_up = self.view(l, PYR_UP_ORDER, torch.int32, (M,))
+            rb.nbr_p = self.view(l, PYR_DOWN_NBR_P, torch.int32, (8, Mo))
+            rb.nbr_up_p = self.view(l, PYR_UP_NBR_P, torch.int32, (8, M))
+            rb.out_hash = self.hash_tab(l + 1)
+        self._made[key] = rb
+        return rb
+
+
+class PyramidDict(dict):
+    """``indice_dict`` of a tensor whose rulebooks live in a ``Pyramid``: the keys are there at once, the ``Rulebook``
+    objects are made when somebody asks for one"""
+
+    def __init__(self, pyramid):
+        super().__init__()
+        self.pyramid = pyramid
+        for k in pyramid.keys:
+            dict.__setitem__(self, k, None)
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if v is None and k in self.pyramid.keys:
+            v = self.pyramid.rulebook(k)
+            dict.__setitem__(self, k, v)
+        return v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def values(self):
+        return [self[k] for k in self]
+
+    def items(self):
+        return [(k, self[k]) for k in self]
+
+
+def _pyramid_native_ok(tensor, n_levels, keys):
+    hints = getattr(tensor, "_level_counts", None)
+    return (os.environ.get("WSIS_PYRAMID_NATIVE", "1") != "0" and os.environ.get("WSIS_LEVEL_COUNTS", "1") != "0"
+            and hints is not None and len(hints) == n_levels - 1 and all(int(h) > 0 for h in hints)
+            and tensor.indices.shape[0] > 0 and not any(k in tensor.indice_dict for k in keys)
+            and getattr(tensor, "_hash", None) is None and _tile_batch_enabled(int(getattr(tensor, "batch_size", 0) or 0))
+            and 3 * n_levels - 2 <= 16)
+
+
+def _build_pyramid_native(tensor, n_levels, subm_key, down_key, first_id):
+    """wsis_rulebook_pyramid on the current stream -> Pyramid (and the tensors it allocated)"""
+    import ctypes
+    lib = _n.hip()
+    indices = tensor.indices
+    _check_indices(indices)
+    M0 = int(indices.shape[0])
+    hints = [int(h) for h in tensor._level_counts]
+    h_counts = (ctypes.c_int64 * max(len(hints), 1))(*hints)
+    layout = np.zeros((n_levels, PYR_FIELDS), dtype=np.int64)
+    total = lib.wsis_rulebook_pyramid_layout(M0, h_counts, n_levels, layout.ctypes.data)
+    if total < 0:
+        raise _n.WsisError("rulebook pyramid layout query failed")
+    arena = torch.empty(total + 256, dtype=torch.uint8, device=indices.device)
+    skip = (-arena.data_ptr()) % 256
+    arena = arena[skip:skip + total]
+    shapes = [[int(s) for s in tensor.spatial_shape]]
+    for _ in range(n_levels - 1):
+        shapes.append(get_conv_output_size(shapes[-1], [2] * 3, [2] * 3, [0] * 3, [1] * 3))
+    _n.check(lib.wsis_rulebook_pyramid(_n.ptr(indices), M0, _n.i32x3(shapes[0]), h_counts, n_levels,
+                                       int(tensor.batch_size), _tile_block_shift(), _n.ptr(arena), total,
+                                       _n.stream_ptr()), "rulebook_pyramid")
+    pyr = Pyramid(arena, layout, indices, shapes, n_levels, subm_key, down_key, first_id)
+    ev = torch.cuda.Event()
+    ev.record()                          # behind every count of the chain on the building stream
+    for l in range(n_levels - 1):
+        _PENDING_COUNTS.append((pyr.view(l, PYR_COUNT, torch.int32, (1,)), hints[l], ev))
+    return pyr
+
+
 def prebuild_unet_rulebooks(tensor, n_levels, subm_key="subm{}", down_key="spconv{}", first_id=1, side_stream=None):
     """Builds every rulebook of a UBlock pyramid (SubM k3 p1 per level, k2 s2 between levels) up front and
     stores them in ``tensor.indice_dict`` under the keys the modules will look up.
@@ -695,7 +830,13 @@ def prebuild_unet_rulebooks(tensor, n_levels, subm_key="subm{}", down_key="spcon
             side.wait_stream(main)
     with ctx:
         verify_pending_counts()      # counts of the PREVIOUS build that was sized from host values (long finished)
-        built = _build_pyramid(tensor, n_levels, subm_key, down_key, first_id)
+        if _pyramid_native_ok(tensor, n_levels, keys):
+            # every level's row count is known on the host: the whole chain is ONE native call into one arena
+            pyr = _build_pyramid_native(tensor, n_levels, subm_key, down_key, first_id)
+            tensor.indice_dict = PyramidDict(pyr)
+            built = [pyr.arena]
+        else:
+            built = _build_pyramid(tensor, n_levels, subm_key, down_key, first_id)
     if side is not None:
         main.wait_stream(side)
         for t in built:          # allocated on the side stream, consumed on the main stream

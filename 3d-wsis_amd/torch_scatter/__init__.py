@@ -12,7 +12,7 @@ from torch.autograd import Function
 import wsis_native as _n
 
 __all__ = ["scatter", "scatter_sum", "scatter_add", "scatter_mean", "scatter_max", "scatter_min",
-           "SegmentCSR", "segment_csr"]
+           "SegmentCSR", "segment_csr", "segment_csr_batch"]
 
 _RED = {"sum": 0, "add": 0, "mean": 1, "max": 2}
 
@@ -46,6 +46,43 @@ class SegmentCSR(object):
 
 def segment_csr(index, dim_size=None):
     return SegmentCSR(index, dim_size)
+
+
+def segment_csr_batch(pairs):
+    """``[(index, dim_size), ...]`` (at most 8, all on one device, sizes known on the host) -> the SegmentCSR of each
+    from ONE sort (wsis_segment_csr_batch): the per-batch structures of a step -- superpoint ids, p2v map, the edge
+    lists of the affinity and ECC graphs -- cost one chain of ~12 launches instead of six."""
+    import ctypes
+    assert 1 <= len(pairs) <= 8
+    idx = []
+    for index, S in pairs:
+        _n.require_cuda(index)
+        index = index.contiguous()
+        idx.append(index if index.dtype == torch.int64 else index.long())
+    dev = idx[0].device
+    n = len(idx)
+    Ns = [int(t.numel()) for t in idx]
+    Ss = [int(S) for _, S in pairs]
+    lib = _n.hip()
+    ws_bytes = lib.wsis_segment_csr_batch_workspace_bytes(sum(Ns))
+    if ws_bytes < 0:
+        raise _n.WsisError("segment_csr_batch workspace query failed")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    perm_all = torch.empty(max(sum(Ns), 1), dtype=torch.int32, device=dev)
+    off_all = torch.empty(sum(Ss) + n, dtype=torch.int32, device=dev)
+    _n.check(lib.wsis_segment_csr_batch(n, (ctypes.c_void_p * n)(*[t.data_ptr() for t in idx]), (ctypes.c_int64 * n)(*Ns),
+                                        (ctypes.c_int64 * n)(*Ss), _n.ptr(perm_all), _n.ptr(off_all), _n.ptr(ws), ws_bytes,
+                                        _n.stream_ptr()), "segment_csr_batch")
+    out, p0, o0 = [], 0, 0
+    for index, N, S in zip(idx, Ns, Ss):
+        c = SegmentCSR.__new__(SegmentCSR)
+        c.index, c.N, c.S = index, N, S
+        c.perm = perm_all[p0:p0 + max(N, 1)] if N > 0 else torch.empty(1, dtype=torch.int32, device=dev)
+        c.offsets = off_all[o0:o0 + S + 1]
+        out.append(c)
+        p0 += N
+        o0 += S + 1
+    return out
 
 
 class _SegmentReduce(Function):

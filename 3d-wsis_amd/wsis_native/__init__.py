@@ -91,6 +91,8 @@ _HIP_SIGS = {
     "wsis_spconv_dw_bn_supported": (I32, [I32, I32, I32]),
     "wsis_spconv_dw_bn_workspace_bytes": (I64, [I64, I32, I32, I32]),
     "wsis_spconv_dw_bn": (I32, [P, P, P, P, P, F32, I32, P, P, I32, P, P, I64, I64, I32, I32, I32, P, I64, P]),
+    "wsis_rulebook_pyramid_layout": (I64, [I64, P, I32, P]),
+    "wsis_rulebook_pyramid": (I32, [P, I64, P, P, I32, I32, I32, P, I64, P]),
     "wsis_rulebook_pack": (I32, [P, P, P, I64, I32, P]),
     "wsis_rulebook_pack_batch": (I32, [I32, P, P, P, P, P, P]),
     "wsis_prof_enable": (I32, [I32]),
@@ -102,6 +104,8 @@ _HIP_SIGS = {
     "wsis_bn_bwd": (I32, [P, P, P, P, P, P, F32, I32, I32, P, P, P, P, I64, I32, P, I64, P]),
     "wsis_segment_csr_workspace_bytes": (I64, [I64, I64]),
     "wsis_segment_csr": (I32, [P, I64, I64, P, P, P, I64, P]),
+    "wsis_segment_csr_batch_workspace_bytes": (I64, [I64]),
+    "wsis_segment_csr_batch": (I32, [I32, P, P, P, P, P, P, I64, P]),
     "wsis_segment_reduce_fwd": (I32, [P, P, P, P, P, I64, I64, I32, I32, P]),
     "wsis_segment_reduce_bwd": (I32, [P, P, P, P, P, I64, I64, I32, I32, P]),
     "wsis_gather_rows": (I32, [P, P, I32, P, I64, I32, P]),

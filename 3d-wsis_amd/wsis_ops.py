@@ -16,7 +16,7 @@ from torch_scatter import SegmentCSR
 class EdgeGraph(object):
     """CSR over sources and over targets of a directed edge list (built once per batch)."""
 
-    def __init__(self, edge_u, edge_v, num_nodes, num_src=None):
+    def __init__(self, edge_u, edge_v, num_nodes, num_src=None, csr_u=None, csr_v=None):
         """``num_src`` = edge_u.max() + 1, the row count of the reference's ``scatter(..., edge_u, dim=0)``
         (backbone_3D_WSIS.py:232).  Read from the device when not given: that D2H copy waits for everything queued
         on the stream (a whole training step when the host runs ahead), so loaders pass the value they know from
@@ -31,8 +31,10 @@ class EdgeGraph(object):
             assert 0 <= self.Su <= self.S
         else:
             self.Su = int(self.eu.max().item()) + 1 if self.E > 0 else 0
-        self.csr_u = SegmentCSR(self.eu, self.Su)
-        self.csr_v = SegmentCSR(self.ev, self.S)
+        # (a caller that builds all CSRs of a batch with one sort hands them in: torch_scatter.segment_csr_batch)
+        self.csr_u = csr_u if csr_u is not None else SegmentCSR(self.eu, self.Su)
+        self.csr_v = csr_v if csr_v is not None else SegmentCSR(self.ev, self.S)
+        assert self.csr_u.S == self.Su and self.csr_v.S == self.S
 
 
 class _EdgeAffinity(Function):

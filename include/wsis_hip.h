@@ -175,6 +175,24 @@ int wsis_rulebook_pack(const int32_t* d_nbr, const int32_t* d_order, int32_t* d_
 int wsis_rulebook_pack_batch(int32_t n, const void* const* h_nbr, const void* const* h_order,
                              void* const* h_nbr_packed, const int64_t* h_M, const int32_t* h_K, void* stream);
 
+/* The whole rulebook pyramid of a UBlock from ONE call (SubM k3 p1 table per level, SparseConv3d k2 s2 tables between
+ * levels: sparse_unet3d.py:130,261,292) when every level's row count is known on the host (h_counts[l-1] = rows of
+ * level l, e.g. from the loader's host-side coordinates): no device read-back, one arena, the same entry points in the
+ * same order as the per-table build (identical tables).  wsis_rulebook_pyramid_layout returns the arena size and
+ * fills h_layout [n_levels][WSIS_PYR_FIELDS] with byte offsets into the arena (-1: not present; ROWS / CAP are values):
+ * the packed tables + tile orders the convolutions take, the unpacked tables, masks, coordinate hashes, the coarse
+ * levels' indices, and the device's own output count per strided level (int32 at COUNT: compare with h_counts). */
+enum {
+  WSIS_PYR_ROWS = 0, WSIS_PYR_CAP, WSIS_PYR_INDICES, WSIS_PYR_KEYS, WSIS_PYR_VALS, WSIS_PYR_SUBM_NBR, WSIS_PYR_SUBM_MASK,
+  WSIS_PYR_SUBM_ORDER, WSIS_PYR_SUBM_NBR_P, WSIS_PYR_CAND, WSIS_PYR_OUT_KEYS, WSIS_PYR_COUNT, WSIS_PYR_DOWN_WS,
+  WSIS_PYR_DOWN_NBR, WSIS_PYR_UP_NBR, WSIS_PYR_DOWN_MASK, WSIS_PYR_UP_MASK, WSIS_PYR_DOWN_ORDER, WSIS_PYR_UP_ORDER,
+  WSIS_PYR_DOWN_NBR_P, WSIS_PYR_UP_NBR_P, WSIS_PYR_FIELDS
+};
+int64_t wsis_rulebook_pyramid_layout(int64_t M0, const int64_t* h_counts, int32_t n_levels, int64_t* h_layout);
+int wsis_rulebook_pyramid(const int32_t* d_indices0, int64_t M0, const int32_t* h_shape3, const int64_t* h_counts,
+                          int32_t n_levels, int32_t batch_size, int32_t block_shift, void* d_arena, int64_t arena_bytes,
+                          void* stream);
+
 /* ---- a7-a11: sparse convolution [UPSTREAM spconv indiceConv / indiceConvBackward] -----------
  * out[r,:] = sum_k X[nbr[k][r],:] @ W[k]  (rows with nbr<0 contribute nothing), fp32.
  *   SubMConv3d fwd      : X=in,   nbr=subm table,  W=weight [K,Cin,Cout]
@@ -351,6 +369,13 @@ int wsis_bn_bwd(const float* d_x, const float* d_dy, const float* d_mean, const 
 int64_t wsis_segment_csr_workspace_bytes(int64_t N, int64_t S);
 int wsis_segment_csr(const int64_t* d_index, int64_t N, int64_t S, int32_t* d_perm, int32_t* d_offsets,
                      void* d_ws, int64_t ws_bytes, void* stream);
+/* The CSRs of up to 8 index vectors from ONE sort (a batch of 3D-WSIS needs six: superpoint ids, p2v map, the two
+ * directions of the affinity graph and of the ECC graph): h_index[t] device int64 [h_N[t]], h_S[t] segments.  Table t's
+ * perm is d_perm_all[sum_{u<t} h_N[u] ...] (row numbers local to the table), its offsets d_offsets_all[sum_{u<t}
+ * (h_S[u] + 1) ...]; identical to wsis_segment_csr per table. */
+int64_t wsis_segment_csr_batch_workspace_bytes(int64_t N_all);
+int wsis_segment_csr_batch(int32_t n, const void* const* h_index, const int64_t* h_N, const int64_t* h_S,
+                           int32_t* d_perm_all, int32_t* d_offsets_all, void* d_ws, int64_t ws_bytes, void* stream);
 /* reduce: 0 = sum, 1 = mean (sum / max(count,1)), 2 = max (empty segments -> 0).
  * out [S,C]; d_argmax int32 [S,C] only for max (row index into src, -1 for empty). Points are
  * accumulated in ascending original position => deterministic. */

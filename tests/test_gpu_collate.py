@@ -40,3 +40,25 @@ def test_a_step_on_the_device_collated_batch_gives_the_same_loss():
         loss, _ = harness.train_step(model, crit, opt, make(), cfg)
         losses.append(float(loss))
     assert losses[0] == losses[1]
+
+
+def test_batched_csr_build_equals_the_single_builds():
+    """torch_scatter.segment_csr_batch: the CSRs of several index vectors from one sort, identical to SegmentCSR each
+    (stable sort, local row numbers), empty vector and unsorted ids included"""
+    from torch_scatter import SegmentCSR, segment_csr_batch
+    g = torch.Generator(device=DEV).manual_seed(3)
+    pairs = [(torch.randint(0, 700, (20011,), device=DEV, generator=g), 700),
+             (torch.randint(0, 15000, (19000,), device=DEV, generator=g).int(), 15001),
+             (torch.randint(0, 50, (3,), device=DEV, generator=g), 64),
+             (torch.zeros(0, dtype=torch.int64, device=DEV), 5),
+             (torch.randint(0, 2289, (20054,), device=DEV, generator=g), 2289),
+             (torch.arange(999, -1, -1, device=DEV), 1000)]
+    got = segment_csr_batch(pairs)
+    torch.cuda.synchronize()
+    for (index, S), c in zip(pairs, got):
+        ref = SegmentCSR(index, S)
+        assert c.N == ref.N and c.S == ref.S
+        assert torch.equal(c.offsets, ref.offsets)
+        if c.N:
+            assert torch.equal(c.perm[:c.N], ref.perm[:ref.N])
+        assert torch.equal(c.index, ref.index)

@@ -1,27 +1,31 @@
-"""Host-side (Python / dispatcher) cost of one training step, by operator: torch.profiler, CPU activity only.
-   python tools/host_profile.py [n_rows]"""
-import importlib, sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); importlib.import_module("3d-wsis_amd")
+"""cProfile of the issuing thread over N training steps (device drained before each step, so the numbers are pure
+issue time): which Python functions the host spends a step in.  python tools/host_profile.py [N]"""
+import cProfile, importlib, os, pstats, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); importlib.import_module("3d-wsis_amd")
 import torch, harness
-from torch.profiler import profile, ProfilerActivity
-dev = torch.device('cuda:0')
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = torch.device("cuda:0")
 cfg = harness.default_cfg()
-b = harness.to_device(harness.collate([harness.make_scene(1)]), dev)
 model, crit, opt = harness.build_model(cfg, dev)
-for _ in range(3):
+b = harness.to_device(harness.collate([harness.bench_scene(1)]), dev)
+def step():
+    harness.build_batch_graphs(b)
     harness.train_step(model, crit, opt, b, cfg)
+for _ in range(100): step()
 torch.cuda.synchronize()
-N = 5
-t0 = time.perf_counter()
+pr = cProfile.Profile()
 for _ in range(N):
-    harness.train_step(model, crit, opt, b, cfg)
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print(f"host issue {(t1-t0)/N*1e3:.2f} ms/step, wall {(t2-t0)/N*1e3:.2f} ms/step")
-with profile(activities=[ProfilerActivity.CPU]) as prof:
-    for _ in range(N):
-        harness.train_step(model, crit, opt, b, cfg)
     torch.cuda.synchronize()
-rows = int(sys.argv[1]) if len(sys.argv) > 1 else 45
-print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=rows, max_name_column_width=48))
+    pr.enable(); step(); pr.disable()
+st = pstats.Stats(pr)
+st.sort_stats("cumulative")
+import io
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(70)
+for line in s.getvalue().splitlines():
+    line = line.replace(ROOT + "/", "")
+    print(line[:170])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(30)
+print("---- by own time")
+for line in s.getvalue().splitlines()[6:]:
+    print(line.replace(ROOT + "/", "")[:170])
