@@ -185,16 +185,17 @@ __device__ __forceinline__ bool bn_chunk_centred_stage(const float* __restrict__
       bn_finish_centred(S, Q, W, M, c, mean, var, running_mean, running_var, momentum);
     } else {
       double* o = chunk + (int64_t)g0 * 3 * C;
-      o[c] = S;
-      o[C + c] = Q;
-      o[2 * C + c] = W;
+      st_sc1(o + c, S);
+      st_sc1(o + C + c, Q);
+      st_sc1(o + 2 * C + c, W);
     }
   }
   if (G == 1) return true;
   if (!ticket) return false;
   // ---- the workgroup that arrives last (per channel group) adds the chunks, always in chunk order: one launch instead
-  // of two.  Release / acquire at agent scope around the ticket (the chunk rows come from other XCDs' L2s).
-  __threadfence();
+  // of two.  The chunk rows cross XCDs as sc1 stores / sc1 loads around the ticket (common.h): no fences, each of which
+  // costs more than the rest of this stage.
+  wait_stores_left();
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned t = atomicAdd(ticket + cgi, 1u);
@@ -203,14 +204,13 @@ __device__ __forceinline__ bool bn_chunk_centred_stage(const float* __restrict__
   }
   __syncthreads();
   if (!s_last) return false;
-  __threadfence();
   double s2 = 0.0, q2 = 0.0, w2 = 0.0;
   if (c < C)
     for (int g = pl; g < G; g += 8) {
-      const volatile double* o = chunk + (int64_t)g * 3 * C;
-      s2 += o[c];
-      q2 += o[C + c];
-      w2 += o[2 * C + c];
+      const double* o = chunk + (int64_t)g * 3 * C;
+      s2 += ld_sc1(o + c);
+      q2 += ld_sc1(o + C + c);
+      w2 += ld_sc1(o + 2 * C + c);
     }
   __syncthreads();
   red[0][pl][cl] = s2;
@@ -529,14 +529,14 @@ __device__ __forceinline__ bool bn_sum_chunk_stage(const float* __restrict__ par
       dbeta[c] = (float)A;
       dgamma[c] = (float)B;
     } else {
-      chunk[(int64_t)g0 * 2 * C + c] = A;
-      chunk[(int64_t)g0 * 2 * C + C + c] = B;
+      st_sc1(chunk + (int64_t)g0 * 2 * C + c, A);
+      st_sc1(chunk + (int64_t)g0 * 2 * C + C + c, B);
     }
   }
   if (G == 1) return true;
   if (!ticket) return false;
   // the last workgroup to arrive adds the chunks in chunk order (see bn_chunk_centred_stage)
-  __threadfence();
+  wait_stores_left();
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned t = atomicAdd(ticket + cgi, 1u);
@@ -545,13 +545,12 @@ __device__ __forceinline__ bool bn_sum_chunk_stage(const float* __restrict__ par
   }
   __syncthreads();
   if (!s_last) return false;
-  __threadfence();
   double a2 = 0.0, b2 = 0.0;
   if (c < C)
     for (int g = pl; g < G; g += 8) {
-      const volatile double* o = chunk + (int64_t)g * 2 * C;
-      a2 += o[c];
-      b2 += o[C + c];
+      const double* o = chunk + (int64_t)g * 2 * C;
+      a2 += ld_sc1(o + c);
+      b2 += ld_sc1(o + C + c);
     }
   __syncthreads();
   red[0][pl][cl] = a2;
@@ -912,8 +911,9 @@ int wsis_bn_stats(const float* d_x, int64_t M, int32_t C, float* d_mean, float* 
 // 256 threads = (C/4 float4 column lanes) x (row lanes); every workgroup sums a block of rows, the one that arrives
 // last adds the block results in block order.
 
-__device__ __forceinline__ void colsum_block(const float* __restrict__ x, int64_t lo, int64_t hi, int C4, float4* red,
-                                             float* __restrict__ out) {
+// CROSS: the rows read (IN) or the row written (OUT) are handed between workgroups of this launch -> sc1 accesses
+__device__ __forceinline__ void colsum_block(const bool IN, const bool OUT, const float* __restrict__ x, int64_t lo,
+                                             int64_t hi, int C4, float4* red, float* __restrict__ out) {
   const int RL = 256 / C4;
   const int cl = threadIdx.x % C4, rl = threadIdx.x / C4;
   float4 a = {0.f, 0.f, 0.f, 0.f};
@@ -921,7 +921,13 @@ __device__ __forceinline__ void colsum_block(const float* __restrict__ x, int64_
     const float4* x4 = reinterpret_cast<const float4*>(x);
 #pragma unroll 4
     for (int64_t r = lo + rl; r < hi; r += RL) {
-      const float4 v = x4[r * C4 + cl];
+      float4 v;
+      if (IN) {
+        const float* p = x + (r * C4 + cl) * 4;
+        v = make_float4(ld_sc1(p), ld_sc1(p + 1), ld_sc1(p + 2), ld_sc1(p + 3));
+      } else {
+        v = x4[r * C4 + cl];
+      }
       a.x += v.x;
       a.y += v.y;
       a.z += v.z;
@@ -939,7 +945,15 @@ __device__ __forceinline__ void colsum_block(const float* __restrict__ x, int64_
       s.z += v.z;
       s.w += v.w;
     }
-    reinterpret_cast<float4*>(out)[threadIdx.x] = s;
+    if (OUT) {
+      float* p = out + threadIdx.x * 4;
+      st_sc1(p, s.x);
+      st_sc1(p + 1, s.y);
+      st_sc1(p + 2, s.z);
+      st_sc1(p + 3, s.w);
+    } else {
+      reinterpret_cast<float4*>(out)[threadIdx.x] = s;
+    }
   }
 }
 
@@ -952,11 +966,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   const int64_t lo = (int64_t)blockIdx.x * per;
   const int64_t hi = lo + per < M ? lo + per : M;
   if (gridDim.x == 1) {
-    colsum_block(x, lo, hi, C4, red, out);
+    colsum_block(false, false, x, lo, hi, C4, red, out);
     return;
   }
-  colsum_block(x, lo, hi, C4, red, chunk + (int64_t)blockIdx.x * C);
-  __threadfence();
+  colsum_block(false, true, x, lo, hi, C4, red, chunk + (int64_t)blockIdx.x * C);
+  wait_stores_left();
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned t = atomicAdd(ticket, 1u);
@@ -965,8 +979,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
-  colsum_block(chunk, 0, gridDim.x, C4, red, out);
+  __syncthreads();            // `red` of the first pass has been read by everyone
+  colsum_block(true, false, chunk, 0, gridDim.x, C4, red, out);
 }
 
 // ticket row of a two-level reduction: the caller's sync slot (nullptr without one, or with WSIS_BN_TICKET=0: the finish

@@ -74,6 +74,22 @@ struct ProfScope {
 };
 
 
+#ifdef __HIPCC__
+// sc1 (write-through) stores / loads of the words that another workgroup of the SAME launch reads (statistics partials,
+// chunk rows): no release fence, no acquire -- cdna_hip_programming.md Guideline 16, counter form:
+// {sc1 stores -> s_waitcnt vmcnt(0) in every storing wave -> barrier -> one agent-scope atomic add}; the workgroup whose
+// add came back last reads with sc1 loads
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float* p) {
+  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double* p) {
+  return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wait_stores_left() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+
 // ---- cross-workgroup sync words of the one-launch reductions (no global mutable state).  The words live in
 // CALLER memory: a slot is 4 KiB, zero-filled once by the caller; every kernel that uses a slot leaves it zero
 // again (the last arrival of a ticket resets it, the last workgroup to leave a flag wait resets flag and counter), so

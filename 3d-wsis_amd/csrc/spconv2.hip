@@ -120,17 +120,6 @@ __device__ __forceinline__ void dma16(const void* src, void* lds_dst) {
 // ds_read_b128 (rows 0-3,12-15,20-27 / 4-11,16-19,28-31 of one half) then covers 16 distinct 16-byte bank groups
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
-// sc1 (write-through) stores / loads of the words that another workgroup of the SAME launch reads (statistics partials,
-// chunk rows): no release fence, no acquire -- cdna_hip_programming.md Guideline 16, counter form
-__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_sc1(const float* p) {
-  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ld_sc1(const double* p) {
-  return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // In-launch finish of the BatchNorm statistics of the tensor this launch writes (StatFin), called by ONE wave of the
 // workgroup that has just stored the partials of slice `slice`, channels col0 .. col0 + 31 (block cbk of CB).
 // Level 1: the last workgroup of a chunk of slices to arrive adds the chunk's partial rows; level 2: the last chunk adds
