@@ -919,7 +919,7 @@ __device__ __forceinline__ void colsum_block(const bool IN, const bool OUT, cons
   float4 a = {0.f, 0.f, 0.f, 0.f};
   if (rl < RL) {
     const float4* x4 = reinterpret_cast<const float4*>(x);
-#pragma unroll 4
+#pragma unroll 8
     for (int64_t r = lo + rl; r < hi; r += RL) {
       float4 v;
       if (IN) {
@@ -1186,7 +1186,9 @@ int64_t wsis_sync_bytes(void) { return (int64_t)kSyncSlots * (int64_t)sizeof(Syn
 
 int64_t wsis_colsum_workspace_bytes(int64_t M, int32_t C) {
   if (M < 0 || C < 4) return -1;
-  int64_t per = (M + 1023) / 1024;
+  // <= 128 chunks: every chunk ends in an agent-scope ticket add on ONE word (~50 ns each, serialised across the XCDs)
+  // and the last workgroup walks the chunk rows -- 781 chunks of 256 rows made the [199790, 20] bias gradient 58 us
+  int64_t per = (M + 127) / 128;
   if (per < 256) per = 256;
   const int64_t G = (M + per - 1) / per;
   return (G > 1 ? G : 1) * (int64_t)C * (int64_t)sizeof(float) + 256;
@@ -1202,7 +1204,7 @@ int wsis_colsum(const float* d_x, int64_t M, int32_t C, float* d_out, void* d_ws
   }
   WSIS_REQUIRE(d_x && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0,
                "colsum: 16-byte alignment");
-  int64_t per = (M + 1023) / 1024;
+  int64_t per = (M + 127) / 128;      // as wsis_colsum_workspace_bytes
   if (per < 256) per = 256;
   const int64_t G = (M + per - 1) / per;
   float* chunk = nullptr;

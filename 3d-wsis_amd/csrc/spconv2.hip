@@ -397,8 +397,11 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
   uint32_t a_po[4];                      // swizzled 16-byte piece of this lane in instruction i
 #pragma unroll
   for (int i = 0; i < 4; ++i) a_po[i] = (uint32_t)((d_piece ^ swz(i * 8 + d_row)) << 4);
+  // DIAG experiments (tools/conv2_stamps.py, never in a product launch): flip_deal bit 4 = the weight registers are
+  // loaded for the first step only, bit 5 = every gathered row is row 0 (what the two operand streams cost)
+  const bool dbg_noB = DIAG && (flip_deal & 16), dbg_row0 = DIAG && (flip_deal & 32);
   auto issueA1 = [&](const Gen& g, const int32_t (&nb)[4], int slot, int i) {
-    const uint32_t off = g.valid ? (uint32_t)nb[i] + a_po[i] : NO_ROW;
+    const uint32_t off = g.valid ? (dbg_row0 ? (uint32_t)(i * 8 + d_row) * a_pitch32 : (uint32_t)nb[i]) + a_po[i] : NO_ROW;
     bdma16(rsX, off, (uint32_t)g.c * 128u, Aring + slot * A_BYTES + i * 1024);
   };
   auto issueB1 = [&](const Gen& g, int slot, int i) {
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
       if (t + 1 < T) {
         readfrag(arS, 0, an, bn);
         arS = arS + 1 == DA ? 0 : arS + 1;
-        loadB(gB, bn);
+        if (!dbg_noB) loadB(gB, bn);
         gen_next(gB);
       }
       const bool more = t + DA < T;
@@ -1496,15 +1499,24 @@ Plan2 plan2(int64_t M_out, int K, int Cin, int Cout, bool fused = false) {
   Plan2 p;
   const int nblk = Cout / 32;
   p.NB = (!fused && nb_pref >= 2 && nblk % 2 == 0) ? 2 : 1;
-  const int64_t items = ceil_div(M_out, SL) * (nblk / p.NB);
   const int steps = K * (Cin / 32);     // steps of a dense work item
-  int nw = 1;
   const int nwm = noslab ? nw_max_noslab : nw_max;
-  // up to 4 waves per work item while the launch stays below ~8192 waves (two rounds of the chip's ~4096 resident
-  // waves), beyond 4 only while ALL workgroups are resident at once: 8-wave workgroups take 70 KB of LDS (2 per CU) and
-  // a launch of 600 of them runs a second, mostly empty round (C2 level 2, 96 -> 96: 44.7 -> 38.3 us with 4 waves)
-  while (nw < nwm && items * nw * 2 <= target && nw * 2 <= steps && (nw < 4 || items * nw * 2 <= target / 2)) nw *= 2;
-  if (nw_force > 0) nw = nw_force;
+  int nw = 1;
+  int64_t items = 0;
+  for (;;) {
+    items = ceil_div(M_out, SL) * (nblk / p.NB);
+    nw = 1;
+    // up to 4 waves per work item while the launch stays below ~8192 waves (two rounds of the chip's ~4096 resident
+    // waves), beyond 4 only while ALL workgroups are resident at once: 8-wave workgroups take 70 KB of LDS (2 per CU)
+    // and a launch of 600 of them runs a second, mostly empty round (C2 level 2, 96 -> 96: 44.7 -> 38.3 us with 4 waves)
+    while (nw < nwm && items * nw * 2 <= target && nw * 2 <= steps && (nw < 4 || items * nw * 2 <= target / 2)) nw *= 2;
+    if (nw_force > 0) nw = nw_force;
+    if (p.NB == 2 && nw > 4) {      // two output blocks per work item are built for up to 4 waves
+      p.NB = 1;
+      continue;
+    }
+    break;
+  }
   int zs = 1;
   if (!noslab) {
     while (zs < 8 && items * nw * zs * 2 <= target && zs * 2 <= K && steps / (nw * zs * 2) >= 2) zs *= 2;
@@ -1648,6 +1660,8 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
   // 855 -> 835) -- the waves of a work item are not what its lifetime waits for -- and it gives up the tile-order
   // independence of the results, so it stays off.
   const char* deal_env = getenv("WSIS_FWD2_DEAL");
+  // (wave priorities by step count -- s_setprio 1..3 for waves with many steps, the launch lasts as long as its longest
+  // wave -- measured neutral on every level: not kept)
   const int flip_deal = (flip ? 1 : 0) | (((deal_env ? atoi(deal_env) : 0) != 0 && p.ZS == 1) ? 2 : 0);
   ProfScope prof(0, st);
   // the persistent form pays where a launch is split into offset slabs (deep levels: 15 % faster at level 3 of the
@@ -1767,10 +1781,12 @@ int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_
   WSIS_REQUIRE(wsis_spconv_fwd_t_supported(K, Cin, Cout) && d_dbg, "bad args");
   const dim3 grid((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32), 1);
   hipStream_t st = as_stream(stream);
+  const int dflags = (variant >> 8) << 4;      // experiment bits (see the kernel)
+  variant &= 0xff;
   if (variant == 0) {
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 2, true, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order, d_WT,
-                       (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, 0,
+                       (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, dflags,
                        (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, d_dbg);
   } else if (variant >= 100 && !d_sync) {
     return fail(WSIS_ERR_ARG, "the persistent form needs a sync slot");
@@ -1792,7 +1808,7 @@ int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_
     const dim3 g4((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32), (unsigned)(variant - 1));
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES * 4;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 4, 2, true, true>), g4, dim3(256), ldsb, st, d_X, d_nbr, d_order, d_WT,
-                       (const float*)nullptr, (const float*)nullptr, d_out, d_out, M_out, K, Cin, Cout, 0,
+                       (const float*)nullptr, (const float*)nullptr, d_out, d_out, M_out, K, Cin, Cout, dflags,
                        (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, d_dbg);
   } else {
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 3, false>::WAVE_BYTES;

@@ -1,5 +1,7 @@
 """Per-wave timeline of the wave-autonomous conv kernel (DIAG build: s_memtime / s_memrealtime stamps per workgroup):
-   python tools/conv2_stamps.py [level] [variant]      variant 0: B direct / ring 2, 1: both rings / ring 3"""
+   python tools/conv2_stamps.py [level] [variant]      variant 0: B direct / ring 2, 1: both rings / ring 3,
+   n >= 2: 4 waves per work item and n - 1 offset slabs, 100 + z: the persistent form with z slabs;
+   + 256: weights loaded for the first step only, + 512: every gathered row is row 0 (what the operand streams cost)"""
 import importlib, sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); importlib.import_module("3d-wsis_amd")
 import numpy as np, torch, harness, wsis_native as _n
@@ -16,7 +18,7 @@ C = 32 * (level + 1); M = idx.shape[0]
 X = torch.randn(M, C, device=dev); W = torch.randn(27, C, C, device=dev) * 0.05
 WT = ops._weight_t(W, 0)
 n_wg = (M + 31) // 32 * (C // 32)
-out = torch.empty(max(variant - 1, 1) * M, C, device=dev)   # variant >= 2: the slabs land here
+out = torch.empty(max((variant & 0xff) - 1, 1) * M, C, device=dev)   # variant >= 2: the slabs land here
 dbg = torch.zeros(n_wg * 8, dtype=torch.int64, device=dev)
 lib = _n.hip()
 fn = lib.wsis_debug_spconv2_diag
@@ -45,5 +47,11 @@ for lo, hi in ((1, 6), (6, 12), (12, 20), (20, 200)):
 # concurrency over time
 for t in np.arange(0, end_us.max(), end_us.max() / 12):
     print(f"  t={t:5.1f} us: {int(((start_us <= t) & (end_us > t)).sum()):5d} waves resident")
+for lo, hi in ((0, 1), (1, 15), (15, 22), (22, 1e9)):
+    m = (start_us >= lo) & (start_us < hi)
+    if m.any():
+        print(f"  started {lo:4.0f}-{hi:4.0f} us: {m.sum():5d} wgs, steps p50 {np.median(T[m]):.0f}; us: prologue p50 {np.median(pro[m]) / 2100:.1f} "
+              f"p90 {np.percentile(pro[m], 90) / 2100:.1f}, steps p50 {np.median(walk[m]) / 2100:.1f} p90 {np.percentile(walk[m], 90) / 2100:.1f}, "
+              f"epilogue p50 {np.median(epi[m]) / 2100:.1f} p90 {np.percentile(epi[m], 90) / 2100:.1f}, lifetime p50 {np.median((end_us - start_us)[m]):.1f}")
 late = np.argsort(-end_us)[:8]
-print("last finishers: " + ", ".join(f"(wg {i} steps {int(T[i])} start {start_us[i]:.1f} end {end_us[i]:.1f} cyc/step {per[i]:.0f})" for i in late))
+print("last finishers: " + ", ".join(f"(wg {i} steps {int(T[i])} start {start_us[i]:.1f} end {end_us[i]:.1f} cyc/step {per[i]:.0f} pro {pro[i] / 2100:.1f} epi {epi[i] / 2100:.1f} us)" for i in late))
