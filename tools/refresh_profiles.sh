@@ -1,10 +1,10 @@
 : "${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}"   # the repo root (gpurun exports it; derived from the script path otherwise)
 export GRAFT_REPO_ROOT
-# Regenerates the evidence under profiles/ for round $R (default r02) on the GPU box:
+# Regenerates the evidence under profiles/ for round $R (default r03) on the GPU box:
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh'
 # then copy gpurun_out/${R}_* into profiles/ (see profiles/README.md).
 set -x
-R=${R:-r02}
+R=${R:-r03}
 cd $GRAFT_REPO_ROOT
 timeout 900 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
 tail -c 400 gpurun_out/${R}_bench_default.json
