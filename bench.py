@@ -596,7 +596,9 @@ def main():
                        "edges": int(batch_host["edge_u_list"].shape[0]), "scenes_per_gpu": spg,
                        "global_batch": spg * world, "scene_seeds_rank0": seeds,
                        "untimed_setup_steps": args.setup_steps,
-                       "parallelism": f"scene-sharded dp{world}", "loss": float(loss)},
+                       "parallelism": f"scene-sharded dp{world}",
+                       "batchnorm": "per-rank batch statistics (no SyncBatchNorm; the reference converts when num_gpus > 1)",
+                       "loss": float(loss)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         out.update(extra)
