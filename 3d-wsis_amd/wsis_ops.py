@@ -502,8 +502,14 @@ class _TallLinear(Function):
         dx = dy @ weight if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
+            # the dW kernel takes Cin % 32 == 0 and Cout % 4 == 0: narrow layers (the 3 -> 16 -> 1 position MLP, the
+            # 13-wide first layer of the filter net over the edge rows) are zero-padded for this product only --
+            # hipBLASLt runs their [Cin x rows] @ [rows x Cout] gradient as one 16x16 tile per workgroup (43-87 us)
             cout, cin = weight.shape
-            dw = sp_ops._dw(x.contiguous(), None, None, dy, 1, cin, cout).view(cin, cout).t()
+            cin_p, cout_p = (cin + 31) // 32 * 32, (cout + 3) // 4 * 4
+            xp = x.contiguous() if cin_p == cin else torch.nn.functional.pad(x, (0, cin_p - cin))
+            dyp = dy if cout_p == cout else torch.nn.functional.pad(dy, (0, cout_p - cout))
+            dw = sp_ops._dw(xp, None, None, dyp, 1, cin_p, cout_p).view(cin_p, cout_p)[:cin, :cout].t()
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy)
@@ -511,11 +517,17 @@ class _TallLinear(Function):
 
 
 def tall_linear(x, linear):
-    # rows from which the row-split dW reduction beats the one-workgroup GEMM (measured at 2.3 k rows: 15 -> 7 us);
-    # shapes the conv dW kernel takes: Cin a multiple of 32, Cout a multiple of 4
-    if (not x.is_cuda or x.shape[0] < _TALL_MIN_ROWS or linear.in_features % 32 != 0 or linear.out_features % 4 != 0):
+    # rows from which the row-split dW reduction beats the one-workgroup GEMM (measured at 2.3 k rows: 15 -> 7 us)
+    if not x.is_cuda or x.dim() != 2 or x.shape[0] < _TALL_MIN_ROWS or x.dtype != torch.float32:
         return linear(x)
     return _TallLinear.apply(x, linear.weight, linear.bias)
+
+
+def tall_sequential(seq, x):
+    """an nn.Sequential of Linear / activation layers over many rows: the Linear layers through tall_linear"""
+    for m in seq:
+        x = tall_linear(x, m) if type(m) is torch.nn.Linear else m(x)
+    return x
 
 
 # ---- a14: voxel -> point gather with a deterministic backward ---------------------------------------------------
