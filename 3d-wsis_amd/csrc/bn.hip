@@ -1147,6 +1147,20 @@ int wsis_bn_bwd_from_partials(const float* d_partials, int64_t n_part, const flo
   return WSIS_OK;
 }
 
+int wsis_bn_bwd_apply(const float* d_x, const float* d_dy, const float* d_mean, const float* d_var,
+                      const float* d_gamma, const float* d_beta, const float* d_sum_dz_xhat, const float* d_sum_dz,
+                      float eps, int32_t relu, float* d_dx, const float* d_addend, int64_t M, int32_t C, void* stream) {
+  WSIS_REQUIRE(M >= 1 && C >= 1 && d_x && d_dy && d_mean && d_var && d_sum_dz_xhat && d_sum_dz && d_dx, "bad args");
+  const int64_t work = (C & 3) == 0 ? (M * C) >> 2 : M * C;
+  const int cw = (C & 3) == 0 ? C >> 2 : C;
+  int grid = grid_for(work, 256);
+  if (grid > cw) grid -= grid % cw;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, as_stream(stream), d_x, d_dy, d_mean, d_var, d_gamma,
+                     d_beta, d_sum_dz_xhat, d_sum_dz, d_addend, eps, relu, 1, d_dx, M, C);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
 int wsis_bn_bwd(const float* d_x, const float* d_dy, const float* d_mean, const float* d_var,
                 const float* d_gamma, const float* d_beta, float eps, int32_t relu, int32_t training,
                 float* d_dx, float* d_dgamma, float* d_dbeta, const float* d_addend, int64_t M, int32_t C, void* d_ws,

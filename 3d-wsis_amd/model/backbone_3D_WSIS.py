@@ -112,7 +112,9 @@ class Network(nn.Module):
             getattr(self, name).eval()
 
         import os
-        if input.features.is_cuda and os.environ.get("WSIS_NATIVE_UNET", "1") != "0":
+        import wsis_parallel
+        sync_bn = self.training and wsis_parallel.sync_batchnorm_active(self)   # collectives between the layers:
+        if input.features.is_cuda and os.environ.get("WSIS_NATIVE_UNET", "1") != "0" and not sync_bn:   # module walk
             # input_conv -> unet -> output_layer recorded as an op list and issued by one native call per pass
             # (model/unet_native.py); WSIS_NATIVE_UNET=0 walks the modules instead (same kernels, same results)
             import unet_native

@@ -88,6 +88,10 @@ class SparseSequential(SparseModule):
                         import wsis_ops
                         input.features = wsis_ops.batch_norm_relu(input.features, module, relu=True)
                         i += 1
+                    elif (isinstance(module, nn.BatchNorm1d) and input.features.is_cuda
+                          and getattr(module, "_wsis_sync", None) is not None):
+                        import wsis_ops          # statistics shared across ranks (wsis_parallel.convert_sync_batchnorm)
+                        input.features = wsis_ops.batch_norm_relu(input.features, module, relu=False)
                     else:
                         input.features = module(input.features)
             else:

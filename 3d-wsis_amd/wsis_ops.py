@@ -216,6 +216,92 @@ class _BatchNormReLU(Function):
         return dx, gw, gb, None, None, None, None, None, None
 
 
+class _SyncBatchNormReLU(Function):
+    """_BatchNormReLU with the batch statistics taken over ALL ranks' rows: what torch.nn.SyncBatchNorm computes, which
+    the reference converts every BatchNorm to when num_gpus > 1 (train_scannetv2.py:734-736).  Forward: local
+    (mean, var) -> (count, sum, sum of squares) in fp64 -> one all-reduce -> global mean / biased var (running
+    statistics from the global unbiased var) -> apply.  Backward: local (sum dz, sum dz*xhat) -> one all-reduce ->
+    dx with the global sums and count; dgamma / dbeta stay the LOCAL sums (the gradient exchange averages them, as
+    DistributedDataParallel does behind SyncBatchNorm).  Two small collectives per layer and pass: opt-in
+    (wsis_parallel.convert_sync_batchnorm), and the UNet then runs as the module walk."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu, group):
+        import torch.distributed as dist
+        _n.require_cuda(x)
+        x = x.contiguous().float()
+        M, C = x.shape
+        lib, st, dev = _n.hip(), _n.stream_ptr(), x.device
+        mean_l = torch.zeros(C, dtype=torch.float32, device=dev)
+        var_l = torch.zeros(C, dtype=torch.float32, device=dev)
+        if M > 0:
+            ws_bytes = lib.wsis_bn_workspace_bytes(M, C)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _n.check(lib.wsis_bn_stats(_n.ptr(x), M, C, _n.ptr(mean_l), _n.ptr(var_l), None, None, float(momentum),
+                                       _n.ptr(ws), ws_bytes, st), "bn_stats")
+        m64 = mean_l.double()
+        t = torch.cat((m64 * M, (var_l.double() + m64 * m64) * M, torch.full((1,), float(M), dtype=torch.float64, device=dev)))
+        dist.all_reduce(t, group=group)
+        N = t[2 * C]
+        mean64 = t[:C] / N
+        var64 = (t[C:2 * C] / N - mean64 * mean64).clamp_min_(0.0)
+        mean, var = mean64.float(), var64.float()
+        if running_mean is not None:
+            unb = var64 * (N / (N - 1.0).clamp_min(1.0))
+            running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+            running_var.mul_(1.0 - momentum).add_(unb.float(), alpha=momentum)
+        y = torch.empty_like(x)
+        if M > 0:
+            _n.check(lib.wsis_bn_apply(_n.ptr(x), _n.ptr(mean), _n.ptr(var), _n.ptr(weight), _n.ptr(bias), float(eps),
+                                       int(relu), _n.ptr(y), M, C, st), "bn_apply")
+        ctx.save_for_backward(x, mean, var, weight, bias, N)
+        ctx.cfg = (float(eps), int(relu), group)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        x, mean, var, weight, bias, N = ctx.saved_tensors
+        eps, relu, group = ctx.cfg
+        dy = dy.contiguous().float()
+        M, C = x.shape
+        lib, st, dev = _n.hip(), _n.stream_ptr(), x.device
+        dgamma = torch.zeros(C, dtype=torch.float32, device=dev)
+        dbeta = torch.zeros(C, dtype=torch.float32, device=dev)
+        if M > 0:
+            ws_bytes = lib.wsis_bn_workspace_bytes(M, C)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _n.check(lib.wsis_bn_bwd(_n.ptr(x), _n.ptr(dy), _n.ptr(mean), _n.ptr(var), _n.ptr(weight), _n.ptr(bias), eps,
+                                     relu, 1, None, _n.ptr(dgamma), _n.ptr(dbeta), None, M, C, _n.ptr(ws), ws_bytes, st),
+                     "bn_bwd")
+        g = torch.cat((dgamma, dbeta)).double()
+        dist.all_reduce(g, group=group)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            if M > 0:
+                sc = (g * (float(M) / N)).float()             # the kernel divides by the local row count
+                _n.check(lib.wsis_bn_bwd_apply(_n.ptr(x), _n.ptr(dy), _n.ptr(mean), _n.ptr(var), _n.ptr(weight),
+                                               _n.ptr(bias), _n.ptr(sc[:C]), _n.ptr(sc[C:]), eps, relu, _n.ptr(dx), None,
+                                               M, C, st), "bn_bwd_apply")
+        gw = dgamma if (weight is not None and ctx.needs_input_grad[1]) else None
+        gb = dbeta if (bias is not None and ctx.needs_input_grad[2]) else None
+        return dx, gw, gb, None, None, None, None, None, None
+
+
+def sync_group(bn):
+    """the process group a BatchNorm module shares its batch statistics with (None: it does not).  Set by
+    wsis_parallel.convert_sync_batchnorm; only in training mode, with a group of more than one rank."""
+    g = getattr(bn, "_wsis_sync", None)
+    if g is None or not bn.training:
+        return None
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized():
+        return None
+    grp = dist.group.WORLD if g is True else g
+    return grp if dist.get_world_size(grp) > 1 else None
+
+
 def _flush_batch_count(bn, *args):
     n = getattr(bn, "_wsis_pending_batches", 0)
     if n:
@@ -246,6 +332,10 @@ def batch_norm_relu(x, bn, relu=True):
         else:
             _defer_batch_count(bn)               # one tiny kernel per BN per step otherwise: flushed lazily
     momentum = 0.1 if bn.momentum is None else bn.momentum
+    grp = sync_group(bn)
+    if grp is not None:
+        return _SyncBatchNormReLU.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                                        bn.running_var if bn.track_running_stats else None, momentum, bn.eps, relu, grp)
     return _BatchNormReLU.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                                 bn.running_var if bn.track_running_stats else None, bn.training, momentum, bn.eps,
                                 relu)

@@ -37,6 +37,27 @@ def shard_scenes(scene_ids, rank, world):
     return [s for i, s in enumerate(scene_ids) if i % world == rank]
 
 
+def convert_sync_batchnorm(model, group=None):
+    """torch.nn.SyncBatchNorm.convert_sync_batchnorm for this build (train_scannetv2.py:734-736 converts when
+    num_gpus > 1): every BatchNorm1d keeps its class, parameters and state-dict names and is marked to take its batch
+    statistics over all ranks of ``group`` (wsis_ops._SyncBatchNormReLU: two small all-reduces per layer and pass).
+    The UNet then runs as the per-module walk -- the one-call executor has no collective inside.  Default of this
+    build without the call: per-rank statistics.  Returns the model."""
+    n = 0
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m._wsis_sync = True if group is None else group
+            n += 1
+    model._wsis_sync_bn = n > 0
+    return model
+
+
+def sync_batchnorm_active(model):
+    """True when ``model`` was converted and a process group of more than one rank is up"""
+    return bool(getattr(model, "_wsis_sync_bn", False)) and dist.is_available() and dist.is_initialized() \
+        and dist.get_world_size() > 1
+
+
 class GradSync(object):
     """Averages gradients across ranks with flat buckets (default 16 MiB; 11.1 M fp32 parameters -> 3 buckets)."""
 

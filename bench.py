@@ -86,6 +86,9 @@ def parse():
                     help="build the per-batch segment CSRs / edge graph once outside the step (round-1 behaviour) "
                          "instead of inside every timed step")
     ap.add_argument("--small", action="store_true", help="debug: a small room instead of the C2 scene")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N > 1: BatchNorm statistics over all ranks (the reference's SyncBatchNorm conversion); the UNet "
+                         "then runs as the per-module walk with two small collectives per BatchNorm layer and pass")
     return ap.parse_args()
 
 
@@ -445,6 +448,9 @@ def main():
     model, criterion, optimizer = harness.build_model(cfg, device)
     use_dist = dist.is_initialized()
     grad_sync = parallel.GradSync(model) if use_dist else None
+    sync_bn = bool(args.sync_bn) and use_dist
+    if sync_bn:     # the reference's behaviour for num_gpus > 1 (train_scannetv2.py:734-736); default here: per-rank
+        parallel.convert_sync_batchnorm(model)
     if os.environ.get("WSIS_BENCH_NOSYNC", "0") == "1":   # diagnostics only: process group up, no gradient exchange
         grad_sync = None
     if use_dist:   # identical initial weights on every rank
@@ -597,7 +603,10 @@ def main():
                        "global_batch": spg * world, "scene_seeds_rank0": seeds,
                        "untimed_setup_steps": args.setup_steps,
                        "parallelism": f"scene-sharded dp{world}",
-                       "batchnorm": "per-rank batch statistics (no SyncBatchNorm; the reference converts when num_gpus > 1)",
+                       "batchnorm": ("statistics shared across the ranks (--sync-bn: wsis_parallel.convert_sync_batchnorm, "
+                                     "UNet as the module walk)" if sync_bn else
+                                     "per-rank batch statistics (the reference converts to SyncBatchNorm when num_gpus > 1: "
+                                     "--sync-bn)"),
                        "loss": float(loss)},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -363,6 +363,14 @@ int wsis_bn_bwd(const float* d_x, const float* d_dy, const float* d_mean, const 
                 float* d_dx, float* d_dgamma, float* d_dbeta, const float* d_addend, int64_t M, int32_t C, void* d_ws,
                 int64_t ws_bytes, void* stream);
 
+/* the apply pass of wsis_bn_bwd alone, from reduced sums: dx = gamma*rstd*(dz - d_sum_dz/M - xhat*d_sum_dz_xhat/M)
+ * (+ addend).  For BatchNorm statistics shared across ranks (torch.nn.SyncBatchNorm, train_scannetv2.py:734-736:
+ * mean / var over all ranks' rows) the caller all-reduces the two sum vectors of wsis_bn_bwd (d_dx = NULL) and passes
+ * them scaled by M / N_global. */
+int wsis_bn_bwd_apply(const float* d_x, const float* d_dy, const float* d_mean, const float* d_var,
+                      const float* d_gamma, const float* d_beta, const float* d_sum_dz_xhat, const float* d_sum_dz,
+                      float eps, int32_t relu, float* d_dx, const float* d_addend, int64_t M, int32_t C, void* stream);
+
 /* ---- a14/a15: row gather and torch_scatter.scatter  backbone_3D_WSIS.py:179,188,225,232,244 --
  * CSR of a (possibly unsorted) index vector: d_perm int32 [N] = stable argsort(index),
  * d_offsets int32 [S+1].  d_index is int64 [N] (torch_scatter takes LongTensor). */

@@ -7,7 +7,9 @@ replacement of the reference's never-initialised DDP wrapper (train_scannetv2.py
 parent test compares: local (unsynchronised) gradients of the last step, the synchronised gradients, counters.
 
     python tests/_two_rank_worker.py <out_dir> <scenario>      (RANK / WORLD_SIZE / MASTER_* from the environment)
-scenario "steady": 6 steps, overlap on;  "broken": rank 1 breaks its flat gradient layout during plan agreement."""
+scenario "steady": 6 steps, overlap on;  "broken": rank 1 breaks its flat gradient layout during plan agreement;
+"syncbn": BatchNorm statistics shared across the ranks (wsis_parallel.convert_sync_batchnorm): one layer on a split
+tensor, then two training steps of the converted Network."""
 import importlib
 import os
 import sys
@@ -53,6 +55,42 @@ def main():
         dist.broadcast(t.data, 0)
     sync = parallel.GradSync(model)
     info = {"rank": rank, "voxels": int(batch["voxel_locs"].shape[0])}
+
+    if scenario == "syncbn":
+        import wsis_ops
+        # (1) one BatchNorm(+ReLU) layer: the ranks hold 700 / 1300 rows of one seeded [2000, 24] tensor
+        g = torch.Generator().manual_seed(5)
+        x_full = torch.randn(2000, 24, generator=g) * 2.0 + 0.5
+        w_full = torch.randn(2000, 24, generator=g)
+        gamma, beta = torch.rand(24, generator=g) + 0.5, torch.randn(24, generator=g) * 0.1
+        rows = slice(0, 700) if rank == 0 else slice(700, 2000)
+        bn = torch.nn.BatchNorm1d(24, eps=1e-4, momentum=0.1).to(dev)
+        with torch.no_grad():
+            bn.weight.copy_(gamma)
+            bn.bias.copy_(beta)
+        parallel.convert_sync_batchnorm(bn)
+        xr = x_full[rows].to(dev).requires_grad_(True)
+        y = wsis_ops.batch_norm_relu(xr, bn, relu=True)
+        (y * w_full[rows].to(dev)).sum().backward()
+        layer = {"y": y.detach().cpu(), "dx": xr.grad.cpu(), "dgamma": bn.weight.grad.cpu(), "dbeta": bn.bias.grad.cpu(),
+                 "running_mean": bn.running_mean.cpu(), "running_var": bn.running_var.cpu(), "rows": (rows.start, rows.stop)}
+        # (2) the converted Network: two steps, statistics and weights must stay identical across the ranks
+        parallel.convert_sync_batchnorm(model)
+        assert parallel.sync_batchnorm_active(model)
+        losses = []
+        for _ in range(2):
+            harness.build_batch_graphs(batch)
+            loss, _ = harness.train_step(model, crit, opt, batch, cfg, grad_sync=sync)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        info.update(losses=losses, native_prog=getattr(model, "_native_prog", None) is not None)
+        torch.save({"layer": layer, "info": info,
+                    "weights": {n: p.detach().cpu() for n, p in model.named_parameters()},
+                    "buffers": {n: b.detach().cpu() for n, b in model.named_buffers()}},
+                   os.path.join(out_dir, f"syncbn{rank}.pt"))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
     if scenario == "broken":
         # call 1 of the plan agreement: rank 1's UNet gradients no longer live in the flat buffer (one was replaced)

@@ -94,3 +94,40 @@ def test_a_rank_without_the_flat_layout_puts_every_rank_on_the_bucket_path(tmp_p
         want = (r0["local"][n].double() + l1.double()) / 2
         scale = float(want.abs().max()) + 1e-30
         assert float((r0["synced"][n].double() - want).abs().max()) / scale <= 2e-6, n
+
+
+@pytest.mark.timeout(900)
+def test_batchnorm_statistics_shared_across_two_ranks(tmp_path):
+    """wsis_parallel.convert_sync_batchnorm (the reference converts to SyncBatchNorm when num_gpus > 1,
+    train_scannetv2.py:734-736): a layer on a tensor split 700 / 1300 over the ranks equals fp64 BatchNorm1d + ReLU over
+    the whole tensor -- outputs, input gradients, running statistics; the ranks' dgamma / dbeta add up to the
+    full-batch ones --, and the converted Network keeps identical weights and running statistics on both ranks."""
+    r = _run_two(tmp_path, "syncbn")
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(2000, 24, generator=g) * 2.0 + 0.5).double().requires_grad_(True)
+    w = torch.randn(2000, 24, generator=g).double()
+    gamma, beta = (torch.rand(24, generator=g) + 0.5).double(), (torch.randn(24, generator=g) * 0.1).double()
+    bn = torch.nn.BatchNorm1d(24, eps=1e-4, momentum=0.1).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    y = torch.relu(bn(x))
+    (y * w).sum().backward()
+    for rr in r:
+        a, b = rr["layer"]["rows"]
+        assert torch.allclose(rr["layer"]["y"].double(), y[a:b].detach(), rtol=1e-5, atol=1e-5)
+        assert torch.allclose(rr["layer"]["dx"].double(), x.grad[a:b], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(rr["layer"]["running_mean"].double(), bn.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(rr["layer"]["running_var"].double(), bn.running_var, rtol=1e-5, atol=1e-6)
+    for k, want in (("dgamma", bn.weight.grad), ("dbeta", bn.bias.grad)):
+        got = r[0]["layer"][k].double() + r[1]["layer"][k].double()
+        assert torch.allclose(got, want, rtol=1e-4, atol=1e-4), k
+    assert not r[0]["info"]["native_prog"] and not r[1]["info"]["native_prog"], "the UNet must run as the module walk"
+    assert r[0]["info"]["voxels"] != r[1]["info"]["voxels"]
+    for n in r[0]["weights"]:
+        assert torch.equal(r[0]["weights"][n], r[1]["weights"][n]), n
+    stats = [n for n in r[0]["buffers"] if n.endswith("running_mean") or n.endswith("running_var")]
+    assert len(stats) > 80
+    for n in stats:
+        assert torch.equal(r[0]["buffers"][n], r[1]["buffers"][n]), n
+    assert all(l == l for l in r[0]["info"]["losses"] + r[1]["info"]["losses"])
