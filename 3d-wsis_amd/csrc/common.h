@@ -1,6 +1,7 @@
 // Shared helpers for libwsis_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -53,15 +54,34 @@ struct ProfScope {
   int which;
   hipStream_t st;
   ProfRec r{};
-  int stage = 0;           // 1: a recorded, 2: b recorded
-  ProfScope(int w, hipStream_t s) : which(w), st(s) {
+  int stage = 0;           // 1: a recorded (or, exact: created), 2: b recorded
+  bool exact = false;      // a / b are the start / stop events of ONE launch (hipExtLaunchKernelGGL): its own duration, as
+                           // rocprofv3 reads it -- events recorded around a launch also measure the two marker packets
+  ProfScope(int w, hipStream_t s, bool exact_events = false) : which(w), st(s) {
     if (g_prof_on && hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess) {
+      exact = exact_events && prof_exact();
+      stage = exact ? 1 : (hipEventRecord(r.a, st) == hipSuccess ? 1 : 0);
+    }
+  }
+  static bool prof_exact() {
+    static int on = -1;
+    if (on < 0) {
+      const char* e = getenv("WSIS_PROF_EXACT");
+      on = e ? atoi(e) : 1;
+    }
+    return on != 0;
+  }
+  void bracket() {          // this launch does not take start / stop events: record around it after all
+    if (exact && stage == 1) {
+      exact = false;
       stage = hipEventRecord(r.a, st) == hipSuccess ? 1 : 0;
     }
   }
+  hipEvent_t ka() const { return (exact && stage == 1) ? r.a : nullptr; }      // for hipExtLaunchKernelGGL
+  hipEvent_t kb() const { return (exact && stage == 1) ? r.b : nullptr; }
   void stop() {             // behind the main kernel
     if (stage == 1) {
-      (void)hipEventRecord(r.b, st);
+      if (!exact) (void)hipEventRecord(r.b, st);
       stage = 2;
     }
   }

@@ -1663,7 +1663,7 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
   // (wave priorities by step count -- s_setprio 1..3 for waves with many steps, the launch lasts as long as its longest
   // wave -- measured neutral on every level: not kept)
   const int flip_deal = (flip ? 1 : 0) | (((deal_env ? atoi(deal_env) : 0) != 0 && p.ZS == 1) ? 2 : 0);
-  ProfScope prof(0, st);
+  ProfScope prof(0, st, /*exact_events=*/true);
   // the persistent form pays where a launch is split into offset slabs (deep levels: 15 % faster at level 3 of the
   // C2 scene); WSIS_FWD3=2 forces it wherever it applies, 0 disables it
   static int fwd3_on = -1, fwd3_wgs = 768, fwd3_min = 2;
@@ -1691,6 +1691,7 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
         attr3 = true;
       }
+      prof.bracket();
       hipLaunchKernelGGL((spconv_fwd3_kernel<4, false>), g3, dim3(256), ldsb, st, d_X, d_nbr, d_order, d_WT, d_bias,
                          d_residual, d_out, partial, M_out, K, Cin, Cout, flip, x_bytes, d_stats, epi,
                          static_cast<SyncSlot*>(d_sync)->ctr, (unsigned long long*)nullptr);
@@ -1706,9 +1707,10 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));               \
       attr_set = ldsb;                                                                                           \
     }                                                                                                            \
-    hipLaunchKernelGGL((spconv_fwd2_kernel<nb, nw, da, bd, false, fb>), grid, dim3(64 * nw), ldsb, st, d_X, d_nbr, \
-                       d_order, d_WT, d_bias, d_residual, d_out, partial, M_out, K, Cin, Cout, flip_deal, x_bytes,    \
-                       d_stats, epi, bin, fin);                                                                  \
+    hipExtLaunchKernelGGL((spconv_fwd2_kernel<nb, nw, da, bd, false, fb>), grid, dim3(64 * nw), (uint32_t)ldsb, st, \
+                          prof.ka(), prof.kb(), 0u, d_X, d_nbr, d_order, d_WT, d_bias, d_residual, d_out, partial,   \
+                          M_out, K, Cin, Cout, flip_deal, x_bytes, d_stats, epi, bin, fin,                          \
+                          (unsigned long long*)nullptr);                                                            \
   } while (0)
 #define WSIS_F2(nb, nw, da)             \
   if (p.BD)                             \
