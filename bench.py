@@ -554,9 +554,10 @@ def main():
                     "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2),
                     "mfma_frac_fp32": round(k["flops"] / (k["ms"] * 1e-3) / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4),
                     "per_level": per_level(k["per_launch"], args.profile_steps),
-                    "measured": "HIP events around every product (main kernel + its slab sum where there is one) in "
-                                "%d extra steps with the dW side stream off (kernel alone on the GPU); rocprofv3 of "
-                                "WSIS_DW_STREAM=0 agrees, see profiles/" % args.profile_steps}
+                    "measured": "start / stop HIP events of every product's launch on its stream (hipExtLaunchKernelGGL; "
+                                "WSIS_PROF_EXACT=0: events recorded around it; a slab sum, where there is one, is "
+                                "counted with its product) in %d extra steps with the dW side stream off (kernel alone "
+                                "on the GPU); rocprofv3 of WSIS_DW_STREAM=0 agrees, see profiles/" % args.profile_steps}
         d = summ.get("spconv_dw_kernel")
         if d and d["ms"] > 0:
             extra["dw_kernel"] = {"achieved_GBs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),
