@@ -94,7 +94,16 @@ __global__ __launch_bounds__(1024) void sem_loss_final_kernel(const float* __res
   const int v = threadIdx.x >> 3, sub = threadIdx.x & 7;
   double s = 0.0;
   if (v < SL_VALS)
-    for (int b = sub; b < nblk; b += 8) s += (double)partial[(int64_t)b * SL_VALS + v];
+    for (int b = sub; b < nblk; b += 64) {      // eight loads in flight per trip, added in the same (ascending) order
+      float t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int bb = b + 8 * j;
+        t[j] = bb < nblk ? partial[(int64_t)bb * SL_VALS + v] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (double)t[j];
+    }
   s += __shfl_xor(s, 1, 64);
   s += __shfl_xor(s, 2, 64);
   s += __shfl_xor(s, 4, 64);

@@ -124,6 +124,51 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(
   }
 }
 
+// Many tiny segments (the voxel <- point sum behind the row gather: 153,685 segments of 1.3 rows): eight lanes per
+// segment (float4 each), eight segments per wave -- a wave per segment spends three dependent memory latencies on
+// every segment it walks (29.7 us for that tensor).  Channels 16 < C <= 32, C % 4 == 0: the wave-per-segment kernel
+// then runs two row groups (rows beg, beg + 2, ... and beg + 1, beg + 3, ...) and adds them once; the same two sums
+// in the same order here, so the results are bit-identical.
+template <int REDUCE>  // 0 sum, 1 mean
+__global__ __launch_bounds__(256) void segment_reduce_narrow_kernel(
+    const float* __restrict__ src, const int32_t* __restrict__ perm, const int32_t* __restrict__ offsets,
+    float* __restrict__ out, int64_t S, int C) {
+  const int sub = threadIdx.x & 7;
+  const int c = sub * 4;
+  const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 3);
+  for (int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 3) + (threadIdx.x >> 3); s < S; s += stride) {
+    const int beg = offsets[s], end = offsets[s + 1];
+    if (c >= C) continue;
+    float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    int j = beg;
+    for (; j + 3 < end; j += 4) {       // four rows in flight
+      const int32_t p0 = perm[j], p1 = perm[j + 1], p2 = perm[j + 2], p3 = perm[j + 3];
+      const float4 v0 = *reinterpret_cast<const float4*>(src + (int64_t)p0 * C + c);
+      const float4 v1 = *reinterpret_cast<const float4*>(src + (int64_t)p1 * C + c);
+      const float4 v2 = *reinterpret_cast<const float4*>(src + (int64_t)p2 * C + c);
+      const float4 v3 = *reinterpret_cast<const float4*>(src + (int64_t)p3 * C + c);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+      a0.x += v2.x; a0.y += v2.y; a0.z += v2.z; a0.w += v2.w;
+      a1.x += v3.x; a1.y += v3.y; a1.z += v3.z; a1.w += v3.w;
+    }
+    for (; j < end; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)perm[j] * C + c);
+      if (((j - beg) & 1) == 0) {
+        a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w;
+      } else {
+        a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+      }
+    }
+    float4 r = {a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w};
+    if (REDUCE == 1) {
+      const float cnt = (float)(end - beg > 0 ? end - beg : 1);
+      r.x = r.x / cnt; r.y = r.y / cnt; r.z = r.z / cnt; r.w = r.w / cnt;
+    }
+    *reinterpret_cast<float4*>(out + s * C + c) = r;
+  }
+}
+
 __global__ void segment_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ index,
                                    const int32_t* __restrict__ offsets, float* __restrict__ dsrc, int64_t N,
                                    int C, int reduce) {
@@ -310,9 +355,24 @@ int wsis_segment_reduce_fwd(const float* d_src, const int32_t* d_perm, const int
   int CP = 1;
   while (CP < C && CP < 64) CP <<= 1;
   const int block = 256;
+  hipStream_t st = as_stream(stream);
+  const char* narrow_env = getenv("WSIS_SEGMENT_NARROW");      // (read per call: 0 keeps the wave-per-segment kernel)
+  if ((!narrow_env || atoi(narrow_env) != 0) && reduce != 2 && CP == 32 && (C & 3) == 0 && N < 4 * S &&
+      (reinterpret_cast<uintptr_t>(d_src) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(d_out) & 15) == 0) {
+    int64_t gn = ceil_div(S, block / 8);
+    if (gn > 256 * 16) gn = 256 * 16;
+    if (reduce == 0)
+      hipLaunchKernelGGL(segment_reduce_narrow_kernel<0>, dim3((unsigned)gn), dim3(block), 0, st, d_src, d_perm,
+                         d_offsets, d_out, S, C);
+    else
+      hipLaunchKernelGGL(segment_reduce_narrow_kernel<1>, dim3((unsigned)gn), dim3(block), 0, st, d_src, d_perm,
+                         d_offsets, d_out, S, C);
+    WSIS_LAUNCH_CHECK();
+    return WSIS_OK;
+  }
   int64_t g = ceil_div(S, block / 64);
   if (g > 256 * 16) g = 256 * 16;
-  hipStream_t st = as_stream(stream);
   if (reduce == 0)
     hipLaunchKernelGGL(segment_reduce_kernel<0>, dim3((unsigned)g), dim3(block), 0, st, d_src, d_perm,
                        d_offsets, d_out, d_argmax, S, C, CP);

@@ -250,6 +250,26 @@ def test_scatter_empty_segments_and_determinism():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+@pytest.mark.parametrize("C", [32, 20])
+def test_scatter_many_small_segments_takes_the_narrow_kernel_bit_identically(monkeypatch, reduce, C):
+    """N < 4 S with 16 < C <= 32: eight lanes per segment (segment_reduce_narrow_kernel) -- same values, bit for bit, as
+    the wave-per-segment kernel (WSIS_SEGMENT_NARROW=0) and the oracle's scatter; empty segments and a segment of 11."""
+    g = torch.Generator().manual_seed(3 + C)
+    S, N = 6000, 9000
+    index = torch.randint(0, S, (N,), generator=g)
+    index[:11] = 17
+    index[index == 4] = 5                     # an empty segment
+    src = torch.randn(N, C, generator=g)
+    xs, idx = src.to(DEV), index.to(DEV)
+    got = torch_scatter.scatter(xs, idx, dim=0, reduce=reduce, dim_size=S)
+    monkeypatch.setenv("WSIS_SEGMENT_NARROW", "0")
+    wide = torch_scatter.scatter(xs, idx, dim=0, reduce=reduce, dim_size=S)
+    assert torch.equal(got, wide)
+    assert close(got, scatter_ref.scatter(src.double(), index, 0, S, reduce))
+    assert float(got[4].abs().max()) == 0.0
+
+
 # ---------------------------------------------------------------- edge affinity (a16)
 def _graph(seed, S, deg):
     rng = np.random.default_rng(seed)
