@@ -125,3 +125,33 @@ def test_all_points_in_one_voxel_eval_forward():
     for k in KEYS:
         assert ret[k].shape == r_ret[k].shape and torch.isfinite(ret[k]).all(), k
         assert _rel(ret[k], r_ret[k]) < 2e-3, (k, _rel(ret[k], r_ret[k]))
+
+
+def test_s3dis_class_count_through_the_whole_path():
+    """13 semantic classes (config/S3DIS_3D_WSIS.yaml): the point- and superpoint-level heads are 32 -> 13 / 64 -> 13
+    Linear layers (widths the row-split weight-gradient kernel only takes zero-padded), the point-level loss kernels run
+    with 13 classes"""
+    cfg = harness.default_cfg()
+    cfg.model.classes = 13
+    scene = harness.make_scene(31, room=(1.3, 1.1, 0.9), n_box=1, classes=13)
+    host = harness.collate([scene])
+    model, crit, opt = harness.build_model(cfg, "cuda")
+    ref = network_ref.RefNetwork(classes=13)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=True)
+    batch = harness.to_device(host, "cuda")
+    model.train()
+    ref.train()
+    loss, ret = harness.forward_loss(model, crit, batch, cfg)
+    loss.backward()
+    r_loss, r_ret = network_ref.forward_loss_cpu(ref, crit, host)
+    r_loss.backward()
+    assert ret["semantic_scores"].shape[1] == 13 and ret["sp_semantic_scores"].shape[1] == 13
+    for k in KEYS:
+        assert _rel(ret[k], r_ret[k]) < 2e-3, (k, _rel(ret[k], r_ret[k]))
+    assert abs(float(loss.detach()) - float(r_loss.detach())) < 2e-3 * abs(float(r_loss.detach()))
+    ref_params = dict(ref.named_parameters())
+    gmax = max(float(p.grad.norm()) for p in ref.parameters() if p.grad is not None)
+    for name in ("linear.3.weight", "linear.3.bias", "sp_sem_seg.3.weight", "sp_sem_seg.3.bias", "linear.0.weight"):
+        p, rp = dict(model.named_parameters())[name], ref_params[name]
+        e = float((p.grad.detach().cpu().double() - rp.grad.double()).norm()) / (float(rp.grad.norm()) + 1e-5 * gmax)
+        assert e < 2e-2, (name, e)
