@@ -720,6 +720,177 @@ __global__ __launch_bounds__(256) void bn_bwd_finish_apply_kernel(
   bn_bwd_apply_body<true>(x, dy, mean, var, gamma, beta, dgamma, dbeta, addend, eps, relu, 1, dx, M, C);
 }
 
+// ---- levels of fewer than 4,096 rows (n_part < 128: ONE chunk): statistics finish + apply, and backward reduction finish +
+// apply, as ONE launch WITHOUT any hand-off between workgroups.  Grid (row blocks, 32-channel groups); every workgroup
+// runs the (single-chunk) finish of ITS channel group itself -- <= 127 partial rows of 32 channels, the arithmetic and
+// order of bn_chunk_centred_stage / bn_sum_chunk_stage with G == 1 -- keeps the coefficients in LDS and applies them to
+// its rows; row block 0 also writes mean / var / running statistics (dgamma / dbeta).  The finish launch it replaces is
+// 4-5 us + a kernel boundary for a few hundred floats of work.  Same values as the two launches, bit for bit.
+constexpr int BN_SF_ROWS = 256;      // rows per workgroup (32 rows x 8 float4 lanes per pass)
+
+__global__ __launch_bounds__(256) void bn_small_finish_apply_kernel(
+    const float* __restrict__ partial, int nblk, int C, int64_t M, float* __restrict__ mean, float* __restrict__ var,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, const float* __restrict__ x,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu, float* __restrict__ y) {
+  __shared__ double red[3][8][33];
+  __shared__ float s_mu[32], s_sc[32], s_bt[32];
+  const int cgi = blockIdx.y;
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = cgi * 32 + cl;
+  double s = 0.0, q = 0.0, w = 0.0;
+  if (c < C) {
+#pragma unroll 4
+    for (int b = pl; b < nblk; b += 8) {
+      const float sf = partial[(int64_t)b * 2 * C + c];
+      const float qf = partial[(int64_t)b * 2 * C + C + c];
+      const int64_t left = M - (int64_t)b * 32;
+      const double si = sf;
+      s += si;
+      q += qf;
+      w += si * si * (left < 32 ? 1.0 / (double)left : 0.03125);
+    }
+  }
+  red[0][pl][cl] = s;
+  red[1][pl][cl] = q;
+  red[2][pl][cl] = w;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    double S = 0.0, Q = 0.0, W = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {      // fixed order
+      S += red[0][j][cl];
+      Q += red[1][j][cl];
+      W += red[2][j][cl];
+    }
+    const double n = (double)M;        // (bn_finish_centred)
+    const double mu = S / n;
+    double v = (Q + (W - n * mu * mu)) / n;
+    if (v < 0.0) v = 0.0;
+    const float muf = (float)mu, vf = (float)v;
+    if (blockIdx.x == 0) {
+      mean[c] = muf;
+      var[c] = vf;
+      if (running_mean) {
+        const double unb = n > 1 ? v * n / (n - 1) : v;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+      }
+    }
+    s_mu[cl] = muf;
+    s_sc[cl] = (gamma ? gamma[c] : 1.0f) * rsqrtf(vf + eps);
+    s_bt[cl] = beta ? beta[c] : 0.0f;
+  }
+  __syncthreads();
+  const int q4 = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c4 = cgi * 32 + q4 * 4;
+  if (c4 >= C) return;
+  float mu4[4], sc4[4], bt4[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    mu4[e] = s_mu[q4 * 4 + e];
+    sc4[e] = s_sc[q4 * 4 + e];
+    bt4[e] = s_bt[q4 * 4 + e];
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * BN_SF_ROWS;
+#pragma unroll 4
+  for (int it = 0; it < BN_SF_ROWS / 32; ++it) {
+    const int64_t r = r0 + it * 32 + rl;
+    if (r < M) {
+      const float4 vx = *reinterpret_cast<const float4*>(x + r * C + c4);
+      float o[4] = {vx.x, vx.y, vx.z, vx.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float z = __builtin_fmaf(o[e] - mu4[e], sc4[e], bt4[e]);      // (bn_apply_body)
+        if (relu) z = fmaxf(z, 0.0f);
+        o[e] = z;
+      }
+      *reinterpret_cast<float4*>(y + r * C + c4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_small_bwd_finish_apply_kernel(
+    const float* __restrict__ partial, int nblk, int C, int64_t M, const float* __restrict__ x,
+    const float* __restrict__ dy, const float* __restrict__ mean, const float* __restrict__ var,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ addend, float eps, int relu,
+    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double red[2][8][33];
+  __shared__ float s_k1[32], s_k2[32];
+  const int cgi = blockIdx.y;
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = cgi * 32 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+#pragma unroll 4
+    for (int k = pl; k < nblk; k += 8) {
+      a += partial[(int64_t)k * 2 * C + c];
+      b += partial[(int64_t)k * 2 * C + C + c];
+    }
+  }
+  red[0][pl][cl] = a;
+  red[1][pl][cl] = b;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    double A = 0.0, B = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {      // fixed order
+      A += red[0][j][cl];
+      B += red[1][j][cl];
+    }
+    const float db = (float)A, dg = (float)B;
+    if (blockIdx.x == 0) {
+      dbeta[c] = db;
+      dgamma[c] = dg;
+    }
+    const float inv_m = 1.0f / (float)M;      // (bn_bwd_apply_body)
+    s_k1[cl] = db * inv_m;
+    s_k2[cl] = dg * inv_m;
+  }
+  __syncthreads();
+  const int q4 = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c4 = cgi * 32 + q4 * 4;
+  if (c4 >= C) return;
+  float mu[4], rstd[4], gm[4], bt[4], k1[4], k2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int cc = c4 + e;
+    mu[e] = mean[cc];
+    rstd[e] = rsqrtf(var[cc] + eps);
+    gm[e] = gamma ? gamma[cc] : 1.0f;
+    bt[e] = beta ? beta[cc] : 0.0f;
+    k1[e] = s_k1[q4 * 4 + e];
+    k2[e] = s_k2[q4 * 4 + e];
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * BN_SF_ROWS;
+#pragma unroll 2
+  for (int it = 0; it < BN_SF_ROWS / 32; ++it) {
+    const int64_t r = r0 + it * 32 + rl;
+    if (r < M) {
+      const float4 vx = *reinterpret_cast<const float4*>(x + r * C + c4);
+      const float4 vd = *reinterpret_cast<const float4*>(dy + r * C + c4);
+      float4 va = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (addend) va = *reinterpret_cast<const float4*>(addend + r * C + c4);
+      const float xv[4] = {vx.x, vx.y, vx.z, vx.w}, dv[4] = {vd.x, vd.y, vd.z, vd.w}, av[4] = {va.x, va.y, va.z, va.w};
+      float ov[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[e] - mu[e]) * rstd[e];
+        float dz = dv[e];
+        if (relu && xh * gm[e] + bt[e] <= 0.0f) dz = 0.0f;
+        const float rr = dz - k1[e] - xh * k2[e];
+        ov[e] = gm[e] * rstd[e] * rr;
+        if (addend) ov[e] += av[e];
+      }
+      *reinterpret_cast<float4*>(dx + r * C + c4) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
+  }
+}
+
+static bool bn_small_fused_on() {      // WSIS_BN_SMALL_FUSED=0 (read per call): the two launches
+  const char* e = getenv("WSIS_BN_SMALL_FUSED");
+  return !e || atoi(e) != 0;
+}
+
 // ---- small inputs (M <= bn_small_rows): the whole reduction in ONE launch, one workgroup per channel group of 4.
 // Two launches (partial + final) of a few microseconds each are pure latency at the deep UNet levels (<= 4096 rows;
 // above that the 16-byte-per-row slices of one workgroup per channel group stall on cache-line throughput).
@@ -1075,6 +1246,14 @@ int wsis_bn_stats_finalize_apply(const float* d_partials, int64_t n_part, int64_
   // the one-launch form needs: a sync slot (tickets + flag), every workgroup resident, vector rows
   const int grid = tickets ? bn_fused_grid(M, C, G * CG) : 0;
   const bool fused = grid > 0;
+  if (G == 1 && (C & 3) == 0 && bn_small_fused_on() && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(d_y) & 15) == 0) {      // one chunk: finish + apply without any hand-off
+    hipLaunchKernelGGL(bn_small_finish_apply_kernel, dim3((unsigned)ceil_div(M, BN_SF_ROWS), (unsigned)CG), dim3(256), 0,
+                       st, d_partials, (int)n_part, (int)C, M, d_mean, d_var, d_running_mean, d_running_var, momentum, d_x,
+                       d_gamma, d_beta, eps, (int)relu, d_y);
+    WSIS_LAUNCH_CHECK();
+    return WSIS_OK;
+  }
   if (!fused) {
     const int rc = wsis_bn_stats_finalize(d_partials, n_part, M, C, d_mean, d_var, d_running_mean, d_running_var, momentum,
                                           d_ws, ws_bytes, d_sync, stream);
@@ -1117,6 +1296,15 @@ int wsis_bn_bwd_from_partials(const float* d_partials, int64_t n_part, const flo
   hipStream_t st = as_stream(stream);
   WSIS_REQUIRE(C <= 512, "more than 512 channels");
   unsigned* tickets = bn_tickets(d_sync);
+  if (d_dx && G == 1 && (C & 3) == 0 && bn_small_fused_on() && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(d_dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_dx) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(d_addend) & 15) == 0) {
+    hipLaunchKernelGGL(bn_small_bwd_finish_apply_kernel, dim3((unsigned)ceil_div(M, BN_SF_ROWS), (unsigned)((C + 31) / 32)),
+                       dim3(256), 0, st, d_partials, (int)n_part, (int)C, M, d_x, d_dy, d_mean, d_var, d_gamma, d_beta,
+                       d_addend, eps, (int)relu, d_dx, d_dgamma, d_dbeta);
+    WSIS_LAUNCH_CHECK();
+    return WSIS_OK;
+  }
   if (d_dx) {     // reduction finish + apply in one launch (the form of wsis_bn_stats_finalize_apply)
     const int CG = (C + 31) / 32;
     const int fgrid = tickets ? bn_fused_grid(M, C, G * CG, 1) : 0;

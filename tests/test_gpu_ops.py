@@ -1319,3 +1319,51 @@ def test_fused_batchnorm_launches_on_two_streams_concurrently_do_not_interfere(m
     assert _n.sync_errors() == []
     for c in cases:
         assert not c["sync"].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,C,addend", [(3300, 128, True), (1100, 160, False), (70, 32, True), (344, 160, True)])
+def test_small_level_batchnorm_backward_finish_and_apply_in_one_launch(M, C, addend, monkeypatch):
+    """fewer than 4,096 rows (one chunk of slice partials): wsis_bn_bwd_from_partials runs the reduction finish and the
+    apply pass as ONE launch without any hand-off between workgroups (bn_small_bwd_finish_apply_kernel) -- dx, dgamma,
+    dbeta bit for bit equal to the two launches (WSIS_BN_SMALL_FUSED=0), and dx equal to autograd through BatchNorm+ReLU"""
+    import wsis_native as _n
+    lib = _n.hip()
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + C)
+    x = torch.randn(M, C, device=DEV, generator=g) * 1.3 + 0.2
+    dy = torch.randn(M, C, device=DEV, generator=g)
+    add = torch.randn(M, C, device=DEV, generator=g) if addend else None
+    gamma, beta = torch.rand(C, device=DEV, generator=g) + 0.5, torch.randn(C, device=DEV, generator=g) * 0.3
+    eps = 1e-4
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    xh = (x - mean) * torch.rsqrt(var + eps)
+    dz = torch.where(xh * gamma + beta > 0, dy, torch.zeros_like(dy))
+    n_part = (M + 31) // 32
+    pad = n_part * 32 - M
+    def slices(t):
+        tp = torch.cat([t, torch.zeros(pad, C, device=DEV)]) if pad else t
+        return tp.view(n_part, 32, C).sum(1)
+    partial = torch.stack([slices(dz), slices(dz * xh)], 1).contiguous()          # [n_part, 2, C]
+    ws_bytes = lib.wsis_bn_stats_finalize_workspace_bytes(n_part, C)
+
+    def run():
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+        dx = torch.empty_like(x)
+        dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        _n.check(lib.wsis_bn_bwd_from_partials(_n.ptr(partial), n_part, _n.ptr(x), _n.ptr(dy), _n.ptr(mean), _n.ptr(var),
+                                               _n.ptr(gamma), _n.ptr(beta), eps, 1, _n.ptr(dx), _n.ptr(dg), _n.ptr(db),
+                                               _n.ptr(add) if addend else None, M, C, _n.ptr(ws), ws_bytes,
+                                               _n.ptr(_n.sync_block()), _n.stream_ptr()), "bn_bwd_from_partials")
+        torch.cuda.synchronize()
+        return dx, dg, db
+
+    one = run()
+    monkeypatch.setenv("WSIS_BN_SMALL_FUSED", "0")
+    two = run()
+    for a, b in zip(one, two):
+        assert torch.equal(a, b)
+    xr = x.double().requires_grad_(True)
+    yr = torch.relu(torch.nn.functional.batch_norm(xr, None, None, gamma.double(), beta.double(), True, 0.1, eps))
+    yr.backward(dy.double())
+    want = xr.grad + (add.double() if addend else 0)
+    assert float((one[0].double() - want).abs().max()) <= 2e-4 * float(want.abs().max())
