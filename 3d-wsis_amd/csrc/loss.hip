@@ -352,12 +352,20 @@ __global__ __launch_bounds__(DL_THREADS) void disc_loss_fwd_kernel(const float* 
     const int a = u >> 3, d = u & 7;
     const int r0 = (int)((int64_t)S * ch / nch), r1 = (int)((int64_t)S * (ch + 1) / nch);
     float s = 0.f;
-    if (d < DL_D) {
-      for (int r = r0; r < r1; ++r)
-        if (slot[r] == a) s += xs[r * DL_D + d];
-    } else {
-      for (int r = r0; r < r1; ++r)
-        if (slot[r] == a) s += 1.0f;
+    // eight rows per trip, their slot / value reads issued together (a read, a compare and a dependent read per row was
+    // ~150 cycles per row: 250 rows per thread = most of the kernel's 44 us); same additions in the same order
+    for (int r = r0; r < r1; r += 8) {
+      short sl[8];
+      float v[8];
+#pragma unroll
+      for (int u8 = 0; u8 < 8; ++u8) {
+        const int rr = r + u8 < r1 ? r + u8 : r1 - 1;
+        sl[u8] = slot[rr];
+        v[u8] = d < DL_D ? xs[rr * DL_D + d] : 1.0f;
+      }
+#pragma unroll
+      for (int u8 = 0; u8 < 8; ++u8)
+        if (r + u8 < r1 && sl[u8] == a) s += v[u8];
     }
     psum[threadIdx.x] = s;
   }
