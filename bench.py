@@ -351,7 +351,12 @@ def per_level(records, steps):
         nbytes, flops = sum(r[4] for r in sel), sum(r[5] for r in sel)
         ms_main, ms = sum(r[6] for r in sel), sum(r[7] for r in sel)
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        # ceiling of every product of the level: the larger of its HBM time on the algorithmic bytes and its fp32-MFMA
+        # time on the pair flops (the layers of 96 channels and more sit above the 19.6 FLOP/B ridge)
+        ceil_ms = sum(max(r[4] / (HBM_PEAK_GBS * 1e9), r[5] / (MFMA_FP32_PEAK_TFLOPS * 1e12)) for r in sel) * 1e3
         out.append({"level": lvl, "rows": int(m), "launches": len(sel) // steps, "us": round(ms * 1e3 / steps, 1),
+                    "ceiling_us": round(ceil_ms * 1e3 / steps, 1),
+                    "frac_of_binding_ceiling": round(ceil_ms / ms, 4) if ms > 0 else 0.0,
                     "us_main_kernel_only": round(ms_main * 1e3 / steps, 1),
                     "alg_MB": round(nbytes / steps / 1e6, 1), "alg_GBs": round(gbs, 1),
                     "frac": round(gbs / HBM_PEAK_GBS, 4),
@@ -554,6 +559,8 @@ def main():
                     "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2),
                     "mfma_frac_fp32": round(k["flops"] / (k["ms"] * 1e-3) / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4),
                     "per_level": per_level(k["per_launch"], args.profile_steps),
+                    "frac_of_binding_ceiling": round(sum(max(r[4] / (HBM_PEAK_GBS * 1e9), r[5] / (MFMA_FP32_PEAK_TFLOPS * 1e12))
+                                                         for r in k["per_launch"]) * 1e3 / k["ms"], 4),
                     "measured": "start / stop HIP events of every product's launch on its stream (hipExtLaunchKernelGGL; "
                                 "WSIS_PROF_EXACT=0: events recorded around it; a slab sum, where there is one, is "
                                 "counted with its product) in %d extra steps with the dW side stream off (kernel alone "
