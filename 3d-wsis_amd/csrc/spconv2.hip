@@ -1381,8 +1381,11 @@ __global__ __launch_bounds__(256) void spconv2_reduce_stats_kernel(const float4*
                                                                   int zs, float* __restrict__ stats, BnEpi epi) {
   __shared__ float sred[256 * 4];
   const int64_t total4 = M_out * cout4;
-  const int lanes = 256 / cout4;                         // row lanes (cout4 <= 64)
-  const int c4 = threadIdx.x % cout4, rl = threadIdx.x / cout4;
+  // gridDim.y > 1: the workgroup takes the 32 channels (8 float4 columns) of block blockIdx.y -- 32 row lanes, one row
+  // per thread, five times the workgroups at 160 channels (11 workgroups walked 6 rows x 8 slabs per thread: 10 us)
+  const int cw = gridDim.y > 1 ? 8 : cout4, cb = gridDim.y > 1 ? (int)blockIdx.y * 8 : 0;
+  const int lanes = 256 / cw;                            // row lanes (cw <= 64)
+  const int c4l = threadIdx.x % cw, c4 = cb + c4l, rl = threadIdx.x / cw;
   const int64_t r0 = (int64_t)blockIdx.x * 32;
   const int nrows = (int)min((int64_t)32, M_out - r0);
   constexpr int MAXR = 8;                                // rows per thread: ceil(32 / lanes), lanes >= 4
@@ -1399,9 +1402,15 @@ __global__ __launch_bounds__(256) void spconv2_reduce_stats_kernel(const float4*
     if (rl < lanes && rr < nrows) {
       const int64_t t = (r0 + rr) * cout4 + c4;
       float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      for (int z = 0; z < zs; ++z) {
-        const float4 v = partial[(int64_t)z * total4 + t];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      for (int z0 = 0; z0 < zs; z0 += 8) {      // the slabs of a row in flight together (zs <= 8 in every plan), added in z order
+        float4 pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv[j] = partial[(int64_t)(z0 + j < zs ? z0 + j : z0) * total4 + t];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (z0 + j < zs) {
+            s.x += pv[j].x; s.y += pv[j].y; s.z += pv[j].z; s.w += pv[j].w;
+          }
       }
       if (bias) {
         const float4 v = bias[c4];
@@ -1436,7 +1445,7 @@ __global__ __launch_bounds__(256) void spconv2_reduce_stats_kernel(const float4*
   if (rl < lanes)
     for (int j = 0; j < lanes; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ta[e] += sred[(j * cout4 + c4) * 4 + e];
+      for (int e = 0; e < 4; ++e) ta[e] += sred[(j * cw + c4l) * 4 + e];
   float sb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int it = 0; it < MAXR; ++it) {
@@ -1455,16 +1464,16 @@ __global__ __launch_bounds__(256) void spconv2_reduce_stats_kernel(const float4*
 #pragma unroll
   for (int e = 0; e < 4; ++e) sred[threadIdx.x * 4 + e] = sb[e];
   __syncthreads();
-  if (threadIdx.x < cout4) {
+  if (threadIdx.x < cw) {
     float tb[4] = {0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < lanes; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) tb[e] += sred[(j * cout4 + threadIdx.x) * 4 + e];
+      for (int e = 0; e < 4; ++e) tb[e] += sred[(j * cw + threadIdx.x) * 4 + e];
     const int Cout = cout4 * 4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      stats[((int64_t)blockIdx.x * 2 + 0) * Cout + threadIdx.x * 4 + e] = ta[e];
-      stats[((int64_t)blockIdx.x * 2 + 1) * Cout + threadIdx.x * 4 + e] = tb[e];
+      stats[((int64_t)blockIdx.x * 2 + 0) * Cout + (cb + threadIdx.x) * 4 + e] = ta[e];
+      stats[((int64_t)blockIdx.x * 2 + 1) * Cout + (cb + threadIdx.x) * 4 + e] = tb[e];
     }
   }
 }
@@ -1764,7 +1773,7 @@ launched:
   prof.stop();
   WSIS_LAUNCH_CHECK();
   if (p.ZS > 1 && d_stats) {
-    hipLaunchKernelGGL(spconv2_reduce_stats_kernel, dim3((unsigned)ceil_div(M_out, SL)), dim3(256), 0, st,
+    hipLaunchKernelGGL(spconv2_reduce_stats_kernel, dim3((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32)), dim3(256), 0, st,
                        reinterpret_cast<const float4*>(partial), reinterpret_cast<const float4*>(d_bias),
                        reinterpret_cast<const float4*>(d_residual), reinterpret_cast<float4*>(d_out), M_out, Cout / 4,
                        p.ZS, d_stats, epi);
