@@ -1500,8 +1500,8 @@ Plan2 plan2(int64_t M_out, int K, int Cin, int Cout, bool fused = false) {
   // the C2 scene is 55 items of 135 steps each -- 16 waves of one CU need 16.5 us of matrix-pipe time for an item while
   // 200 CUs idle; its 3x3x3 products split over offset slabs (+ the fixed-order sum) take 14.5 us instead of 25.5.
   // The 2x2x2 strided products of such a level are faster without slabs (9.6 against 13.3 us).
-  static int slab_items = -1;
-  if (slab_items < 0) slab_items = env_int("WSIS_FWD2_SLAB_ITEMS", 96);
+  const char* slab_env = getenv("WSIS_FWD2_SLAB_ITEMS");      // (read per call)
+  const int slab_items = slab_env ? atoi(slab_env) : 96;
   if (!fused && noslab && K >= 16 && ceil_div(M_out, SL) * (Cout / 32) <= slab_items) noslab = false;
   if (nb_pref < 0) {
     bd_pref = env_int("WSIS_FWD2_BD", 1);

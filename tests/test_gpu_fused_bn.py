@@ -103,7 +103,10 @@ def pyramid():
 
 
 @pytest.mark.parametrize("level,kind,cin,cout,res", CASES)
-def test_fused_conv_equals_the_unfused_sequence_bit_for_bit(pyramid, level, kind, cin, cout, res):
+def test_fused_conv_equals_the_unfused_sequence_bit_for_bit(pyramid, level, kind, cin, cout, res, monkeypatch):
+    # the fused forms finish every product in one launch; compared with the unfused sequence on the same plan (the default
+    # plan gives launches of <= 96 work items offset slabs: another, equally fixed, order of additions)
+    monkeypatch.setenv("WSIS_FWD2_SLAB_ITEMS", "0")
     g = torch.Generator(device=DEV).manual_seed(100 * level + cin + cout)
     if kind == "subm":
         rb = pyramid["subm%d" % (level + 1)]
@@ -240,6 +243,7 @@ def test_network_with_and_without_the_batchnorm_fusion(tmp_path):
     for tag, env in (("fused", dict(WSIS_FUSE_BN_APPLY="0", WSIS_FUSE_BN_FIN="1")), ("plain", dict(WSIS_FUSE_BN_FIN="0")),
                      ("default", dict(WSIS_FUSE_BN_FIN="1"))):
         f = str(tmp_path / (tag + ".npz"))
+        env = dict(env, WSIS_FWD2_SLAB_ITEMS="0")      # (same plan on both sides: see the operator test above)
         r = subprocess.run([sys.executable, "-c", _NET_CHILD, ROOT, f], env=dict(os.environ, **env),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-3000:]
