@@ -388,6 +388,180 @@ __global__ void colmax_kernel(const double* __restrict__ T, const int32_t* __res
   }
 }
 
+// ---- a17, sparse form.  T0_c = rownorm(A * adj * sem_c) has the sparsity of the edge list (~9 entries per row) and only
+// the rows of the superpoints LABELLED c of T0_c^(n+1) are ever looked at (scannetv2_dataset.py:707-714), so the dense
+// S^3 product per class and iteration (24 GFLOP at S = 2,289) is a chain of (row vector) x (sparse matrix) products:
+//   W0 = A * adj as CSR (class independent; one pass over the dense inputs per scene)
+//   D[c][k] = sum_j W0[k][j] sem_c(k, j)      (0 -> 1)
+//   x_0 = e_r^T T0_c ; x_{i+1}[j] = sum_k x_i[k] W0[k][j] sem_c(k, j) / D[c][k]   (k ascending: the order of a dot product)
+// one wavefront per labelled superpoint r (class c = label[r]) keeps x in LDS; all classes run in ONE launch.
+__global__ __launch_bounds__(256) void prop_nz_count_kernel(const double* __restrict__ A, const uint8_t* __restrict__ adj,
+                                                            int64_t S, int32_t* __restrict__ rowcnt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= S) return;
+  int n = 0;
+  for (int64_t j0 = 0; j0 < S; j0 += 64) {
+    const int64_t j = j0 + lane;
+    const bool nz = j < S && A[r * S + j] * (double)adj[r * S + j] != 0.0;
+    n += __builtin_popcountll(__ballot(nz));
+  }
+  if (lane == 0) rowcnt[r] = n;
+}
+
+// exclusive scan of n ints by one workgroup (n ~ 10^3 - 10^4); out[n] = total
+__global__ __launch_bounds__(1024) void prop_scan_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int n) {
+  __shared__ int part[1024];
+  const int per = (n + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += in[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int base = threadIdx.x ? part[threadIdx.x - 1] : 0;
+  for (int i = lo; i < hi; ++i) {
+    out[i] = base;
+    base += in[i];
+  }
+  if (threadIdx.x == 1023) out[n] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void prop_nz_fill_kernel(const double* __restrict__ A, const uint8_t* __restrict__ adj,
+                                                           int64_t S, const int32_t* __restrict__ rowptr,
+                                                           int32_t* __restrict__ col, double* __restrict__ val,
+                                                           int64_t cap) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= S) return;
+  int base = rowptr[r];
+  for (int64_t j0 = 0; j0 < S; j0 += 64) {          // ascending columns
+    const int64_t j = j0 + lane;
+    const double w = j < S ? A[r * S + j] * (double)adj[r * S + j] : 0.0;
+    const unsigned long long m = __ballot(w != 0.0);
+    if (w != 0.0) {
+      const int pos = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (pos < cap) {      // (the caller sized col / val from the non-zeros of A: never exceeded)
+        col[pos] = (int32_t)j;
+        val[pos] = w;
+      }
+    }
+    base += __builtin_popcountll(m);
+  }
+}
+
+__device__ __forceinline__ bool prop_sem(const int32_t* pred, const float* conf, const int32_t* label, int cls, float thr,
+                                         int k, int j) {
+  const bool mk = pred[k] == cls && conf[k] > thr;
+  const bool mj = pred[j] == cls && conf[j] > thr;
+  return (mk && mj) || (j == k && label[k] == cls);
+}
+
+// D[ci][k], ci = index of a PRESENT class; one wavefront per (k, ci); entries added in column order
+__global__ __launch_bounds__(256) void prop_rowsum_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                          const double* __restrict__ val, const int32_t* __restrict__ pred,
+                                                          const float* __restrict__ conf, const int32_t* __restrict__ label,
+                                                          const int32_t* __restrict__ cls_of, float thr, int64_t S,
+                                                          double* __restrict__ D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= S) return;
+  const int cls = cls_of[blockIdx.y];
+  double d = 0.0;
+  const int lo = rowptr[k], hi = rowptr[k + 1];
+  for (int e0 = lo; e0 < hi; e0 += 64) {
+    const int e = e0 + lane;
+    double w = 0.0;
+    if (e < hi && prop_sem(pred, conf, label, cls, thr, (int)k, col[e])) w = val[e];
+    // lanes in order: a fixed (sequential) sum over the row's entries
+    for (int l = 0; l < 64 && e0 + l < hi; ++l) d += __shfl(w, l, 64);
+  }
+  if (lane == 0) D[(int64_t)blockIdx.y * S + k] = d == 0.0 ? 1.0 : d;
+}
+
+// one wavefront per superpoint r with label[r] = a present class: row r of T0_c^(iterations + 1) -> X[r][:]
+__global__ __launch_bounds__(64) void prop_rows_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                       const double* __restrict__ val, const int32_t* __restrict__ pred,
+                                                       const float* __restrict__ conf, const int32_t* __restrict__ label,
+                                                       const int32_t* __restrict__ ci_of_cls, int class_num, float thr,
+                                                       int iterations, int64_t S, const double* __restrict__ D,
+                                                       double* __restrict__ X) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char prop_lds[];
+  const int lane = threadIdx.x;
+  const int r = blockIdx.x;
+  const int cls = label[r];
+  if (cls < 0 || cls >= class_num) return;
+  const int ci = ci_of_cls[cls];
+  if (ci < 0) return;
+  const double* Dc = D + (int64_t)ci * S;
+  double* cur = reinterpret_cast<double*>(prop_lds);
+  double* nxt = cur + S;
+  int32_t* nzl = reinterpret_cast<int32_t*>(nxt + S);       // ascending list of the non-zero positions of cur
+  for (int64_t j = lane; j < S; j += 64) cur[j] = 0.0;
+  {
+    const int lo = rowptr[r], hi = rowptr[r + 1];
+    const double d = Dc[r];
+    for (int e = lo + lane; e < hi; e += 64) {
+      const int j = col[e];
+      if (prop_sem(pred, conf, label, cls, thr, r, j)) cur[j] = val[e] / d;
+    }
+  }
+  __syncthreads();
+  for (int it = 0; it < iterations; ++it) {
+    int n = 0;
+    for (int64_t j0 = 0; j0 < S; j0 += 64) {
+      const int64_t j = j0 + lane;
+      const bool nz = j < S && cur[j] != 0.0;
+      const unsigned long long m = __ballot(nz);
+      if (nz) nzl[n + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int32_t)j;
+      n += __builtin_popcountll(m);
+      if (j < S) nxt[j] = 0.0;
+    }
+    __syncthreads();      // (one wavefront per workgroup: orders the LDS passes for the compiler, costs nothing)
+    for (int i = 0; i < n; ++i) {
+      const int k = nzl[i];
+      const double xk = cur[k];
+      const double d = Dc[k];
+      const int lo = rowptr[k], hi = rowptr[k + 1];
+      for (int e = lo + lane; e < hi; e += 64) {      // the columns of one CSR row are distinct: no collisions
+        const int j = col[e];
+        if (prop_sem(pred, conf, label, cls, thr, k, j)) nxt[j] += xk * (val[e] / d);
+      }
+      __syncthreads();
+    }
+    double* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  double* out = X + (int64_t)r * S;
+  for (int64_t j = lane; j < S; j += 64) out[j] = cur[j];
+}
+
+// colmax_kernel for every present class at once (blockIdx.y = class index); rows of other classes are never read
+__global__ void prop_colmax_kernel(const double* __restrict__ X, const int32_t* __restrict__ label,
+                                   const int32_t* __restrict__ cls_of, double* __restrict__ scores,
+                                   int32_t* __restrict__ arg, int64_t S) {
+  const int cls = cls_of[blockIdx.y];
+  const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j >= S) return;
+  double best = 0.0;
+  int32_t bi = -1;
+  for (int64_t r = 0; r < S; ++r) {
+    const double v = (label[r] == cls) ? X[r * S + j] : 0.0;
+    if (bi < 0 || v > best) {
+      best = v;
+      bi = (int32_t)r;
+    }
+  }
+  scores[(int64_t)blockIdx.y * S + j] = best;
+  arg[(int64_t)blockIdx.y * S + j] = bi < 0 ? 0 : bi;
+}
+
 int waves_grid(int64_t segments) {
   int64_t g = ceil_div(segments, 4);
   if (g < 1) g = 1;
@@ -484,6 +658,53 @@ int wsis_affinity_colmax(const double* d_T, const int32_t* d_label, int32_t cls,
   WSIS_REQUIRE(d_T && d_label && d_scores && d_arg, "null pointer");
   hipLaunchKernelGGL(colmax_kernel, dim3(grid_for(S, 64)), dim3(64), 0, as_stream(stream), d_T, d_label, cls,
                      d_scores, d_arg, S);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int64_t wsis_affinity_propagate_sparse_workspace_bytes(int64_t S, int32_t n_present) {
+  if (S < 0 || n_present < 0) return -1;
+  return (int64_t)(2 * (S + 2)) * 4 + (int64_t)n_present * S * 8 + S * S * 8 + 1024;
+}
+
+int wsis_affinity_propagate_sparse(const double* d_A, const uint8_t* d_adj, const int32_t* d_pred, const float* d_conf,
+                                   const int32_t* d_label, const int32_t* d_cls_of, const int32_t* d_ci_of_cls,
+                                   int32_t n_present, int32_t class_num, float thr, int32_t iterations, int64_t S,
+                                   int32_t* d_col, double* d_val, int64_t nnz_cap, double* d_scores, int32_t* d_arg,
+                                   void* d_ws, int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(S >= 0 && n_present >= 0 && iterations >= 0 && class_num >= 0 && nnz_cap >= 0, "bad sizes");
+  if (S == 0 || n_present == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_A && d_adj && d_pred && d_conf && d_label && d_cls_of && d_ci_of_cls && d_scores && d_arg && d_ws &&
+               (nnz_cap == 0 || (d_col && d_val)), "null pointer");
+  WSIS_REQUIRE(ws_bytes >= wsis_affinity_propagate_sparse_workspace_bytes(S, n_present), "workspace too small");
+  const size_t lds = (size_t)S * 20 + 64;
+  WSIS_REQUIRE(lds <= 160 * 1024, "sparse propagation keeps two rows of S doubles in LDS: S <= 8188 (use the dense path)");
+  hipStream_t st = as_stream(stream);
+  char* w = static_cast<char*>(d_ws);
+  int32_t* rowcnt = reinterpret_cast<int32_t*>(w);
+  int32_t* rowptr = rowcnt + (S + 2);
+  double* D = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(rowptr + (S + 2)) + 255) & ~(uintptr_t)255);
+  double* X = D + (int64_t)n_present * S;
+  const unsigned rows4 = (unsigned)ceil_div(S, 4);
+  hipLaunchKernelGGL(prop_nz_count_kernel, dim3(rows4), dim3(256), 0, st, d_A, d_adj, S, rowcnt);
+  WSIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(prop_scan_kernel, dim3(1), dim3(1024), 0, st, rowcnt, rowptr, (int)S);
+  WSIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(prop_nz_fill_kernel, dim3(rows4), dim3(256), 0, st, d_A, d_adj, S, rowptr, d_col, d_val, nnz_cap);
+  WSIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(prop_rowsum_kernel, dim3(rows4, (unsigned)n_present), dim3(256), 0, st, rowptr, d_col, d_val, d_pred,
+                     d_conf, d_label, d_cls_of, thr, S, D);
+  WSIS_LAUNCH_CHECK();
+  static size_t attr = 0;
+  if (attr < lds) {
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)prop_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = lds;
+  }
+  hipLaunchKernelGGL(prop_rows_kernel, dim3((unsigned)S), dim3(64), lds, st, rowptr, d_col, d_val, d_pred, d_conf, d_label,
+                     d_ci_of_cls, (int)class_num, thr, (int)iterations, S, D, X);
+  WSIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(prop_colmax_kernel, dim3((unsigned)ceil_div(S, 64), (unsigned)n_present), dim3(64), 0, st, X, d_label,
+                     d_cls_of, d_scores, d_arg, S);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

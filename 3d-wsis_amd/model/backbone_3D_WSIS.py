@@ -33,7 +33,7 @@ class _Head(nn.Sequential):
         if not x.is_cuda:
             return super().forward(x)
         x = wsis_ops.tall_linear(x, self[0])
-        if os.environ.get("WSIS_FUSE_BN", "1") == "0":
+        if os.environ.get("WSIS_FUSE_BN", "1") == "0" and wsis_ops.sync_group(self[1]) is None:
             x = self[2](self[1](x))
         else:
             x = wsis_ops.batch_norm_relu(x, self[1], relu=True)

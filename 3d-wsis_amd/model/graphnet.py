@@ -82,6 +82,12 @@ def _run_modules(mods, x):
         m = mods[i]
         if tall and type(m) is nn.Linear and x.dim() == 2:
             x = wsis_ops.tall_linear(x, m)
+        elif type(m) is nn.BatchNorm1d and x.dim() == 2 and wsis_ops.sync_group(m) is not None:
+            # statistics shared across ranks: always the collective form (zero / one row and non-affine layers included;
+            # a rank on another path would leave its peers waiting in the all-reduce)
+            relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+            x = wsis_ops.batch_norm_relu(x.float(), m, relu=relu)
+            i += 1 if relu else 0
         elif (fuse_bn and type(m) is nn.BatchNorm1d and x.dim() == 2 and m.affine and x.shape[0] > 1
               and x.dtype == torch.float32):
             relu = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU

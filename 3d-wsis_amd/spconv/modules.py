@@ -79,7 +79,19 @@ class SparseSequential(SparseModule):
             if is_spconv_module(module):
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
-                if input.indices.shape[0] != 0:
+                synced = False
+                if isinstance(module, nn.BatchNorm1d) and input.features.is_cuda:
+                    import wsis_ops
+                    synced = wsis_ops.sync_group(module) is not None
+                if synced:
+                    # statistics shared across ranks (wsis_parallel.convert_sync_batchnorm): EVERY rank enters the
+                    # collective, also with zero rows here and whatever WSIS_FUSE_BN says -- a rank that skipped the
+                    # layer would leave its peers waiting in the all-reduce
+                    nxt = mods[i + 1] if i + 1 < len(mods) else None
+                    relu = type(nxt) is nn.ReLU
+                    input.features = wsis_ops.batch_norm_relu(input.features, module, relu=relu)
+                    i += 1 if relu else 0
+                elif input.indices.shape[0] != 0:
                     # peephole: BatchNorm1d followed by ReLU runs as ONE fused HIP operator (same module
                     # objects, parameters and state-dict; only the execution is fused)
                     nxt = mods[i + 1] if i + 1 < len(mods) else None
@@ -88,10 +100,6 @@ class SparseSequential(SparseModule):
                         import wsis_ops
                         input.features = wsis_ops.batch_norm_relu(input.features, module, relu=True)
                         i += 1
-                    elif (isinstance(module, nn.BatchNorm1d) and input.features.is_cuda
-                          and getattr(module, "_wsis_sync", None) is not None):
-                        import wsis_ops          # statistics shared across ranks (wsis_parallel.convert_sync_batchnorm)
-                        input.features = wsis_ops.batch_norm_relu(input.features, module, relu=False)
                     else:
                         input.features = module(input.features)
             else:

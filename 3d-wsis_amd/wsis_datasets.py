@@ -86,15 +86,23 @@ class _PickledIGraph(object):
 
 
 class _SpgUnpickler(__import__("pickle").Unpickler):
-    """resolves ``igraph.Graph`` (whatever sub-module the installed version defined it in) to the stand-in and lets
-    numpy / builtins through; anything else in the stream is refused"""
+    """resolves ``igraph.Graph`` (whatever sub-module the installed version defined it in) to the stand-in and lets exactly
+    the globals a pickled graph with numpy attributes needs through -- an allow-list of (module, name) PAIRS, not of
+    modules: ``builtins.eval`` / ``numpy.testing...runstring`` reachable through REDUCE would be code execution.
+    Anything else in the stream raises ``UnpicklingError``."""
 
-    _OK_PREFIX = ("numpy", "builtins", "collections", "copyreg", "_codecs")
+    _OK = frozenset(
+        [(m, "_reconstruct") for m in ("numpy.core.multiarray", "numpy._core.multiarray")] +
+        [(m, "scalar") for m in ("numpy.core.multiarray", "numpy._core.multiarray")] +
+        [(m, "_frombuffer") for m in ("numpy.core.numeric", "numpy._core.numeric")] +      # (pickle protocol 5 arrays)
+        [("numpy", "ndarray"), ("numpy", "dtype"), ("_codecs", "encode"), ("collections", "OrderedDict")] +
+        [("builtins", n) for n in ("list", "dict", "tuple", "set", "frozenset", "int", "float", "complex", "str", "bytes",
+                                   "bytearray", "bool", "slice", "range")])
 
     def find_class(self, module, name):
         if module.split(".")[0] == "igraph" and name == "Graph":
             return _PickledIGraph
-        if module.split(".")[0] in self._OK_PREFIX:
+        if (module, name) in self._OK:
             return super().find_class(module, name)
         raise __import__("pickle").UnpicklingError(f"_spg.dat: unexpected global {module}.{name}")
 

@@ -127,6 +127,8 @@ _HIP_SIGS = {
     "wsis_affinity_transition": (I32, [P, P, P, P, P, I32, F32, P, I64, P]),
     "wsis_dgemm": (I32, [P, P, P, I64, I64, I64, P]),
     "wsis_affinity_colmax": (I32, [P, P, I32, P, P, I64, P]),
+    "wsis_affinity_propagate_sparse_workspace_bytes": (I64, [I64, I32]),
+    "wsis_affinity_propagate_sparse": (I32, [P, P, P, P, P, P, P, I32, I32, F32, I32, I64, P, P, I64, P, P, P, I64, P]),
     "wsis_ballquery_workspace_bytes": (I64, [I64]),
     "wsis_ballquery_count": (I32, [P, P, P, I64, I32, F32, P, P, P, I64, P]),
     "wsis_ballquery_fill": (I32, [P, P, P, I64, I32, F32, P, P, I64, P, I64, P]),

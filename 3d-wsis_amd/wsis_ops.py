@@ -5,6 +5,8 @@
 * ``affinity_matrix`` / ``propagate_class`` / ``weak_label_propagation`` -- the dense S x S fp64 affinity
   product of train_scannetv2.py:562-570 and modules/datasets/scannetv2_dataset.py:664-736 on the f64 MFMA.
 """
+import os
+
 import numpy as np
 import torch
 from torch.autograd import Function
@@ -125,31 +127,69 @@ def propagate_class(A, adj_u8, pred, conf, label, cls, iterations_num, thr=0.7):
     return scores, arg
 
 
+def propagate_sparse(A, adj_u8, pred, conf, label, present, class_num, iterations_num, thr=0.7):
+    """All present classes of modules/datasets/scannetv2_dataset.py:689-721 in ONE call on the sparse structure
+    (``wsis_affinity_propagate_sparse``): T0_c has the sparsity of the edge list and only the rows of the superpoints
+    labelled c of T0_c^(n+1) are used, so the S^3 dense product per class and iteration is a chain of sparse
+    row-vector products.  returns (scores fp64 [n_present, S], arg int32 [n_present, S])."""
+    S = A.shape[0]
+    dev = A.device
+    lib = _n.hip()
+    n_present = len(present)
+    cls_of = torch.tensor(list(present), dtype=torch.int32, device=dev)
+    ci = np.full(class_num, -1, dtype=np.int32)
+    ci[np.asarray(present, dtype=np.int64)] = np.arange(n_present, dtype=np.int32)
+    ci_of_cls = torch.from_numpy(ci).to(dev)
+    nnz = int(torch.count_nonzero(A))          # (stage boundary, once per scene: one read-back)
+    col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+    val = torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
+    scores = torch.empty((n_present, S), dtype=torch.float64, device=dev)
+    arg = torch.empty((n_present, S), dtype=torch.int32, device=dev)
+    ws_bytes = lib.wsis_affinity_propagate_sparse_workspace_bytes(S, n_present)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _n.check(lib.wsis_affinity_propagate_sparse(_n.ptr(A), _n.ptr(adj_u8), _n.ptr(pred), _n.ptr(conf), _n.ptr(label),
+                                                _n.ptr(cls_of), _n.ptr(ci_of_cls), n_present, int(class_num), float(thr),
+                                                int(iterations_num), S, _n.ptr(col), _n.ptr(val), nnz, _n.ptr(scores),
+                                                _n.ptr(arg), _n.ptr(ws), ws_bytes, _n.stream_ptr()),
+             "affinity_propagate_sparse")
+    return scores, arg
+
+
+PROP_SPARSE_MAX_S = 8188       # two rows of S doubles + the non-zero list in 160 KB of LDS
+
+
 def weak_label_propagation(A, adjacency, sp_semantic_value, superpoint_pred_semantic, superpoint_semantic_label,
-                           iterations_num, class_num):
+                           iterations_num, class_num, dense=None):
     """Device version of ScanNetV2Inst_spg.weak_label_propagation up to ``pseudo_label_final``
     (modules/datasets/scannetv2_dataset.py:664-736).  ``adjacency`` is the [S,S] adjacency (without the
     identity; it is added here like ``:681-682``).  Returns (pseudo_label_final [S] float64 numpy with -100
-    for unknown, pseudo_label_scores [S])."""
+    for unknown, pseudo_label_scores [S]).  Default: the sparse form (``propagate_sparse``); ``dense=True`` (or
+    WSIS_PROP_DENSE=1, or S > 8188) runs the per-class dense products on the f64 matrix cores."""
     dev = A.device
     S = A.shape[0]
+    if dense is None:
+        dense = os.environ.get("WSIS_PROP_DENSE", "0") != "0"
+    dense = dense or S > PROP_SPARSE_MAX_S
     adj = torch.as_tensor(adjacency, device=dev)
     adj_u8 = (adj.to(torch.int32) + torch.eye(S, dtype=torch.int32, device=dev)).to(torch.uint8).contiguous()
     pred = torch.as_tensor(superpoint_pred_semantic, device=dev).to(torch.int32).contiguous()
     conf = torch.as_tensor(sp_semantic_value, device=dev).to(torch.float32).contiguous()
     label_np = np.asarray(superpoint_semantic_label)
     label = torch.as_tensor(label_np, device=dev).to(torch.int32).contiguous()
-    scores_list, pseudo_list = [], []
-    for c in range(class_num):
-        if (label_np == c).sum() == 0:
-            continue
-        s, a = propagate_class(A, adj_u8, pred, conf, label, c, iterations_num)
-        scores_list.append(s)
-        pseudo_list.append(a)
-    if not scores_list:
+    present = [c for c in range(class_num) if (label_np == c).sum() != 0]
+    if not present:
         return np.ones(S) * -100, np.zeros(S)
-    scores = torch.stack(scores_list).cpu().numpy()
-    pseudo = torch.stack(pseudo_list).cpu().numpy()
+    if dense:
+        scores_list, pseudo_list = [], []
+        for c in present:
+            s, a = propagate_class(A, adj_u8, pred, conf, label, c, iterations_num)
+            scores_list.append(s)
+            pseudo_list.append(a)
+        scores = torch.stack(scores_list).cpu().numpy()
+        pseudo = torch.stack(pseudo_list).cpu().numpy()
+    else:
+        s, a = propagate_sparse(A.contiguous(), adj_u8, pred, conf, label, present, class_num, iterations_num)
+        scores, pseudo = s.cpu().numpy(), a.cpu().numpy()
     _ind = np.argmax(scores, axis=0)
     pseudo_label = np.choose(_ind, pseudo)
     pseudo_label_scores = np.choose(_ind, scores)
@@ -239,12 +279,19 @@ class _SyncBatchNormReLU(Function):
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             _n.check(lib.wsis_bn_stats(_n.ptr(x), M, C, _n.ptr(mean_l), _n.ptr(var_l), None, None, float(momentum),
                                        _n.ptr(ws), ws_bytes, st), "bn_stats")
-        m64 = mean_l.double()
-        t = torch.cat((m64 * M, (var_l.double() + m64 * m64) * M, torch.full((1,), float(M), dtype=torch.float64, device=dev)))
-        dist.all_reduce(t, group=group)
-        N = t[2 * C]
-        mean64 = t[:C] / N
-        var64 = (t[C:2 * C] / N - mean64 * mean64).clamp_min_(0.0)
+        # every rank's (mean, biased var, count) gathered in ONE collective and combined in fp64 with Chan's formula:
+        # var = sum n_i (var_i + (mean_i - mean)^2) / N.  (count, sum, sum of squares) from the fp32-rounded local
+        # statistics cancels when |mean| >> sigma: the rounding of mean_i alone is ~1e-7 mean^2 against var.)
+        t = torch.cat((mean_l.double(), var_l.double(), torch.full((1,), float(M), dtype=torch.float64, device=dev)))
+        world = dist.get_world_size(group)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=group)
+        g = torch.stack(parts)                                   # [world, 2C + 1]
+        n_i = g[:, 2 * C:2 * C + 1]                              # [world, 1]
+        N = n_i.sum()
+        mean64 = (g[:, :C] * n_i).sum(0) / N
+        dm = g[:, :C] - mean64
+        var64 = ((g[:, C:2 * C] + dm * dm) * n_i).sum(0) / N
         mean, var = mean64.float(), var64.float()
         if running_mean is not None:
             unb = var64 * (N / (N - 1.0).clamp_min(1.0))

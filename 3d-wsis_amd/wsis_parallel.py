@@ -53,9 +53,13 @@ def convert_sync_batchnorm(model, group=None):
 
 
 def sync_batchnorm_active(model):
-    """True when ``model`` was converted and a process group of more than one rank is up"""
-    return bool(getattr(model, "_wsis_sync_bn", False)) and dist.is_available() and dist.is_initialized() \
-        and dist.get_world_size() > 1
+    """True when ``model`` -- or any module inside it: the conversion may have been applied to a wrapper or to a
+    sub-module -- carries marked BatchNorm layers and a process group of more than one rank is up"""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return False
+    if getattr(model, "_wsis_sync_bn", False):
+        return True
+    return any(getattr(m, "_wsis_sync", None) is not None for m in model.modules())
 
 
 class GradSync(object):

@@ -41,6 +41,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+# fp64 matrix peak: AMD's MI355X datasheet figure (78.6 TFLOP/s, v_mfma_f64_16x16x4_f64: 256 FLOP/clk/CU x 256 CUs x
+# 2.4 GHz = 157 -- the datasheet halves it for fp64); MI355X_MICROARCH.md has no fp64 row, so the datasheet number is used
+FP64_MATRIX_PEAK_TF = 78.6
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "conv_traffic.json")   # written by profiles/collect_traffic.py
 
 
@@ -284,12 +287,69 @@ def side_measurements(harness, optimizer, device, args):
                              "device_collate_ms_per_scene": round(ms_dev_total, 2),
                              "scenes_per_s_one_host_thread": round(1e3 / ms_host_total, 1),
                              "scenes_per_s_device_collate": round(1e3 / ms_dev_total, 1)}
+    out["propagation_stage"] = propagation_stage(harness, sc, device, args)
     out["cluster_stage"] = {"workload": "C3: 4 synthetic scenes, non floor/wall points, r=0.03 m, threshold 50",
                             "points": int(coords.shape[0]), "neighbour_pairs": int(idx_c.numel()),
                             "clusters": int(cl_off.numel() - 1), "ballquery_ms": round(ms_bq, 3),
                             "bfs_cluster_ms": round(ms_bfs_dev, 3), "bfs_cluster_host_ms": round(ms_bfs, 3),
                             "device_equals_host": same}
     return out
+
+
+def propagation_stage(harness, sc, device, args):
+    """a17 on the C2 scene (train_scannetv2.py:562-575 -> scannetv2_dataset.py:664-736): dense S x S fp64 affinity matrix
+    from the edge list, then the per-class propagation for iterations_num = 0, 1, 2 -- the sparse chain (default) and the
+    dense f64-MFMA products, ms per scene each; the dense form's TFLOP/s against the fp64 matrix peak."""
+    import wsis_ops
+    S = int(sc["S"])
+    rng = np.random.default_rng(args.scene_seed)
+    eu = torch.from_numpy(sc["edges"][:, 0].copy()).to(device)
+    ev = torch.from_numpy(sc["edges"][:, 1].copy()).to(device)
+    aff = torch.from_numpy(rng.random(len(sc["edges"])).astype(np.float32)).to(device)
+    adjacency = np.zeros((S, S), dtype=np.int64)
+    adjacency[sc["edges"][:, 0], sc["edges"][:, 1]] = 1
+    adjacency = torch.from_numpy(adjacency).to(device)
+    label = sc["sp_sem"]
+    pred, _, _, _ = harness.synthetic_predictions(sc, args.scene_seed)
+    pred = np.where(label >= 0, label, pred)
+    conf = (0.5 + 0.5 * rng.random(S)).astype(np.float32)
+    classes = 20
+    n_present = int(len(np.unique(label[label >= 0])))
+    A = wsis_ops.affinity_matrix(eu, ev, aff, S)
+    res = {"workload": "C2 scene: weak_label_propagation over all present classes (fp64), affinity matrix resident",
+           "superpoints": S, "edges": int(len(sc["edges"])), "classes_present": n_present,
+           "labelled_superpoints": int((label >= 0).sum()), "fp64_matrix_peak_TFLOPs": FP64_MATRIX_PEAK_TF, "iterations": {}}
+    ms_build = _gpu_ms(lambda: wsis_ops.affinity_matrix(eu, ev, aff, S), 5)
+    res["affinity_matrix_build_ms"] = round(ms_build, 3)
+    for it in (0, 1, 2):
+        def sparse():
+            return wsis_ops.weak_label_propagation(A, adjacency, conf, pred, label, it, classes, dense=False)
+
+        def dense():
+            return wsis_ops.weak_label_propagation(A, adjacency, conf, pred, label, it, classes, dense=True)
+        f_s, s_s = sparse()
+        f_d, s_d = dense()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sparse()
+        ms_s = (time.perf_counter() - t0) / 3 * 1e3
+        t0 = time.perf_counter()
+        dense()
+        ms_d = (time.perf_counter() - t0) * 1e3
+        # device time of the dense products alone (the part the f64 matrix cores run)
+        T0 = torch.rand((S, S), dtype=torch.float64, device=device)
+        ms_gemm = _gpu_ms(lambda: wsis_ops.dgemm(T0, T0), 3)
+        flops = 2.0 * S ** 3
+        row = {"sparse_ms_per_scene": round(ms_s, 3), "dense_ms_per_scene": round(ms_d, 3),
+               "speedup": round(ms_d / ms_s, 1), "labels_equal": bool(np.array_equal(f_s, f_d)),
+               "max_abs_score_diff": float(np.abs(s_s - s_d).max()), "propagated": int((f_s != -100).sum())}
+        if it == 1:
+            row["dense_product_ms"] = round(ms_gemm, 3)
+            row["dense_product_TFLOPs"] = round(flops / (ms_gemm * 1e-3) / 1e12, 2)
+            row["dense_product_frac_of_fp64_matrix_peak"] = round(flops / (ms_gemm * 1e-3) / 1e12 / FP64_MATRIX_PEAK_TF, 4)
+        res["iterations"][str(it)] = row
+    return res
 
 
 def other_configs(harness, device, args):

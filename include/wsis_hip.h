@@ -490,6 +490,20 @@ int wsis_dgemm(const double* d_A, const double* d_B, double* d_C, int64_t M, int
  * scores fp64 [S], arg int32 [S]  (np.max/np.argmax(axis=0) semantics, first max wins). */
 int wsis_affinity_colmax(const double* d_T, const int32_t* d_label, int32_t cls, double* d_scores,
                          int32_t* d_arg, int64_t S, void* stream);
+/* The whole per-scene propagation of scannetv2_dataset.py:689-721 for ALL present classes in one call, exploiting that
+ * T0_c = rownorm(A * adj * sem_c) is as sparse as the edge list and that only the rows of the superpoints labelled c of
+ * T0_c^(iterations+1) are looked at: W0 = A * adj as CSR (d_col / d_val: caller buffers of nnz_cap >= nnz(A) entries),
+ * per class row sums, then per labelled superpoint a chain of (row vector) x (sparse matrix) products in LDS (fp64,
+ * k-ascending sums = the order of a dot product) and the column max / first argmax of wsis_affinity_colmax.
+ * d_cls_of int32 [n_present] = the present classes ascending, d_ci_of_cls int32 [class_num] = index into d_cls_of or -1;
+ * d_scores fp64 [n_present, S], d_arg int32 [n_present, S].  S <= 8188 (two rows of S doubles in LDS); beyond that use
+ * wsis_affinity_transition / wsis_dgemm / wsis_affinity_colmax. */
+int64_t wsis_affinity_propagate_sparse_workspace_bytes(int64_t S, int32_t n_present);
+int wsis_affinity_propagate_sparse(const double* d_A, const uint8_t* d_adj, const int32_t* d_pred, const float* d_conf,
+                                   const int32_t* d_label, const int32_t* d_cls_of, const int32_t* d_ci_of_cls,
+                                   int32_t n_present, int32_t class_num, float thr, int32_t iterations, int64_t S,
+                                   int32_t* d_col, double* d_val, int64_t nnz_cap, double* d_scores, int32_t* d_arg,
+                                   void* d_ws, int64_t ws_bytes, void* stream);
 
 /* ---- a19/a20: ballquery_batch_p / bfs_cluster [UPSTREAM PG_OP] ------------------------------
  * For point p: ascending indices k of same-batch points with |x_p-x_k|^2 < r^2 (strict, incl. p),

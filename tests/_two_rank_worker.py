@@ -74,6 +74,12 @@ def main():
         (y * w_full[rows].to(dev)).sum().backward()
         layer = {"y": y.detach().cpu(), "dx": xr.grad.cpu(), "dgamma": bn.weight.grad.cpu(), "dbeta": bn.bias.grad.cpu(),
                  "running_mean": bn.running_mean.cpu(), "running_var": bn.running_var.cpu(), "rows": (rows.start, rows.stop)}
+        # (1b) |mean| = 1000 sigma: the cross-rank merge must not cancel (Chan's combination, not E[x^2] - mean^2)
+        x_big = torch.randn(2000, 24, generator=g) * 0.05 + 50.0
+        bn_b = torch.nn.BatchNorm1d(24, eps=1e-6, momentum=0.1).to(dev)
+        parallel.convert_sync_batchnorm(bn_b)
+        yb = wsis_ops.batch_norm_relu(x_big[rows].to(dev), bn_b, relu=False)
+        layer["big_y"], layer["big_running_var"] = yb.detach().cpu(), bn_b.running_var.cpu()
         # (2) the converted Network: two steps, statistics and weights must stay identical across the ranks
         parallel.convert_sync_batchnorm(model)
         assert parallel.sync_batchnorm_active(model)

@@ -98,8 +98,9 @@ def test_propagation_oracle_matches_reference_golden(it):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dense", [False, True])
 @pytest.mark.parametrize("it", [0, 1, 2])
-def test_propagation_hip_matches_reference_golden(it):
+def test_propagation_hip_matches_reference_golden(it, dense):
     import wsis_ops
     z = np.load(os.path.join(G, "propagation_golden.npz"))
     S = int(z["S"])
@@ -107,7 +108,7 @@ def test_propagation_hip_matches_reference_golden(it):
     A = wsis_ops.affinity_matrix(torch.from_numpy(z["edge_u"]).to(dev), torch.from_numpy(z["edge_v"]).to(dev),
                                  torch.from_numpy(z["affinity"]).to(dev), S)
     final, scores = wsis_ops.weak_label_propagation(A, _adjacency(z), z["conf"], z["pred"], z["sem_label"], it,
-                                                    int(z["classes"]))
+                                                    int(z["classes"]), dense=dense)
     sem, ins = _expected_labels(z, final)
     assert np.array_equal(sem, z[f"it{it}_semantic"])
     assert np.array_equal(ins, z[f"it{it}_instance"])

@@ -311,8 +311,10 @@ def test_dgemm_f64_mfma(M, N, K):
     assert torch.allclose(C.cpu(), A @ B, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("dense", [False, True])
 @pytest.mark.parametrize("iterations", [0, 1, 2])
-def test_label_propagation(iterations):
+def test_label_propagation(iterations, dense):
+    """sparse form (default) and dense f64-MFMA form against the numpy restatement of scannetv2_dataset.py:664-736"""
     S, classes = 180, 6
     eu, ev = _graph(5, S, 8)
     both = np.unique(np.concatenate([np.stack([eu, ev], 1), np.stack([ev, eu], 1)]), axis=0)
@@ -331,9 +333,38 @@ def test_label_propagation(iterations):
     A = wsis_ops.affinity_matrix(torch.from_numpy(eu).to(DEV), torch.from_numpy(ev).to(DEV),
                                  torch.from_numpy(aff).to(DEV), S)
     assert np.array_equal(A.cpu().numpy(), A_ref)
-    final, scores = wsis_ops.weak_label_propagation(A, adjacency, conf, pred, label, iterations, classes)
+    final, scores = wsis_ops.weak_label_propagation(A, adjacency, conf, pred, label, iterations, classes, dense=dense)
     assert np.allclose(scores, e_scores, rtol=1e-10, atol=1e-14)
     assert np.array_equal(final, e_final)
+
+
+def test_label_propagation_sparse_equals_dense_on_a_scene_sized_graph():
+    """S = 1,500 superpoints, 20 classes, multi-edges in the adjacency (igraph counts them) and a self edge: the sparse
+    chain and the dense products agree to 1e-12 and pick the same labels"""
+    S, classes = 1500, 20
+    eu, ev = _graph(11, S, 9)
+    both = np.unique(np.concatenate([np.stack([eu, ev], 1), np.stack([ev, eu], 1)]), axis=0)
+    eu, ev = both[:, 0], both[:, 1]
+    rng = np.random.default_rng(3)
+    aff = rng.random(len(eu)).astype(np.float32)
+    adjacency = np.zeros((S, S), dtype=np.int64)
+    adjacency[eu, ev] = 1
+    adjacency[eu[:40], ev[:40]] = 2                     # multi-edges
+    pred = rng.integers(0, classes, S)
+    conf = (0.4 + 0.6 * rng.random(S)).astype(np.float32)
+    label = np.full(S, -100)
+    lab_ids = rng.choice(S, 150, replace=False)
+    label[lab_ids] = pred[lab_ids] = rng.integers(0, classes - 2, 150)
+    A = wsis_ops.affinity_matrix(torch.from_numpy(eu).to(DEV), torch.from_numpy(ev).to(DEV),
+                                 torch.from_numpy(aff).to(DEV), S)
+    A[5, 5] = 0.25                                      # a self edge
+    for it in (0, 1, 2):
+        f_s, s_s = wsis_ops.weak_label_propagation(A, adjacency, conf, pred, label, it, classes, dense=False)
+        f_d, s_d = wsis_ops.weak_label_propagation(A, adjacency, conf, pred, label, it, classes, dense=True)
+        e_f, e_s, _ = affinity_ref.weak_label_propagation(A.cpu().numpy(), adjacency, conf, pred, label, it, classes)
+        assert np.allclose(s_s, e_s, rtol=1e-10, atol=1e-14) and np.allclose(s_d, e_s, rtol=1e-10, atol=1e-14)
+        assert np.array_equal(f_s, e_f) and np.array_equal(f_d, e_f)
+        assert (f_s != -100).sum() > 20
 
 
 # ---------------------------------------------------------------- ball query (a19) + clustering (a20)

@@ -119,6 +119,14 @@ def test_batchnorm_statistics_shared_across_two_ranks(tmp_path):
         assert torch.allclose(rr["layer"]["dx"].double(), x.grad[a:b], rtol=1e-4, atol=1e-5)
         assert torch.allclose(rr["layer"]["running_mean"].double(), bn.running_mean, rtol=1e-5, atol=1e-6)
         assert torch.allclose(rr["layer"]["running_var"].double(), bn.running_var, rtol=1e-5, atol=1e-6)
+    # |mean| = 1000 sigma: E[x^2] - mean^2 over fp32-rounded local means would be off by ~10 % here
+    xb = (torch.randn(2000, 24, generator=g) * 0.05 + 50.0)
+    bnb = torch.nn.BatchNorm1d(24, eps=1e-6, momentum=0.1).double()
+    yb = bnb(xb.double())
+    for rr in r:
+        a, b = rr["layer"]["rows"]
+        assert torch.allclose(rr["layer"]["big_running_var"].double(), bnb.running_var, rtol=2e-3, atol=0), "cancellation"
+        assert torch.allclose(rr["layer"]["big_y"].double(), yb[a:b].detach(), rtol=2e-3, atol=2e-3)
     for k, want in (("dgamma", bn.weight.grad), ("dbeta", bn.bias.grad)):
         got = r[0]["layer"][k].double() + r[1]["layer"][k].double()
         assert torch.allclose(got, want, rtol=1e-4, atol=1e-4), k

@@ -76,3 +76,28 @@ def test_spg_pickle_refuses_other_globals(tmp_path):
         pickle.dump(types.SimpleNamespace(a=1), fh)
     with pytest.raises(pickle.UnpicklingError):
         ds.read_spg_pickle(path)
+
+
+class _Evil(object):
+    """a pickle that would run code through REDUCE if a whole top-level module were allow-listed"""
+
+    def __init__(self, fn, args):
+        self.fn, self.args = fn, args
+
+    def __reduce__(self):
+        return (self.fn, self.args)
+
+
+@pytest.mark.parametrize("payload", [
+    _Evil(eval, ("__import__('os').getpid()",)),
+    _Evil(getattr, (int, "__add__")),
+    _Evil(__import__, ("os",)),
+    _Evil(np.testing.assert_equal, (1, 1)),
+])
+def test_spg_pickle_refuses_callables_of_allowed_modules(tmp_path, payload):
+    """builtins.eval / getattr / __import__ and arbitrary numpy callables must not resolve"""
+    path = str(tmp_path / "evil_spg.dat")
+    with open(path, "wb") as fh:
+        pickle.dump(payload, fh)
+    with pytest.raises(pickle.UnpicklingError):
+        ds.read_spg_pickle(path)
