@@ -76,7 +76,7 @@ def main():
                  "running_mean": bn.running_mean.cpu(), "running_var": bn.running_var.cpu(), "rows": (rows.start, rows.stop)}
         # (1b) |mean| = 1000 sigma: the cross-rank merge must not cancel (Chan's combination, not E[x^2] - mean^2)
         x_big = torch.randn(2000, 24, generator=g) * 0.05 + 50.0
-        bn_b = torch.nn.BatchNorm1d(24, eps=1e-6, momentum=0.1).to(dev)
+        bn_b = torch.nn.BatchNorm1d(24, eps=1e-6, momentum=1.0).to(dev)      # running_var = this batch
         parallel.convert_sync_batchnorm(bn_b)
         yb = wsis_ops.batch_norm_relu(x_big[rows].to(dev), bn_b, relu=False)
         layer["big_y"], layer["big_running_var"] = yb.detach().cpu(), bn_b.running_var.cpu()

@@ -121,7 +121,7 @@ def test_batchnorm_statistics_shared_across_two_ranks(tmp_path):
         assert torch.allclose(rr["layer"]["running_var"].double(), bn.running_var, rtol=1e-5, atol=1e-6)
     # |mean| = 1000 sigma: E[x^2] - mean^2 over fp32-rounded local means would be off by ~10 % here
     xb = (torch.randn(2000, 24, generator=g) * 0.05 + 50.0)
-    bnb = torch.nn.BatchNorm1d(24, eps=1e-6, momentum=0.1).double()
+    bnb = torch.nn.BatchNorm1d(24, eps=1e-6, momentum=1.0).double()
     yb = bnb(xb.double())
     for rr in r:
         a, b = rr["layer"]["rows"]
