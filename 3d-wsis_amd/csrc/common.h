@@ -46,9 +46,15 @@ inline int grid_for(int64_t work_items, int block) {
 // dominant kernels (not around the host wrapper), enabled by wsis_prof_enable().
 struct ProfRec {
   hipEvent_t a, b, c;      // a -> b: the main kernel; b -> c: the fixed-order slab sum that finishes it (c == nullptr: none)
+  // a product that ran as phases of the resident deep-level kernel (deep.hip): no events; its time is the difference of
+  // two in-kernel s_memrealtime stamps (100 MHz) -- from the end of the previous phase to the end of the (last) phase of
+  // the product, grid barrier included: stamps[s1] - stamps[s0] (main: [s0, sm])
+  const unsigned long long* d_stamps = nullptr;
+  int s0 = 0, sm = 0, s1 = 0;
 };
 inline bool g_prof_on = false;
 inline std::vector<ProfRec> g_prof[2];   // 0 = spconv_fwd_kernel, 1 = spconv_dw_kernel
+inline std::vector<void*> g_prof_bufs;    // stamp buffers of profiled resident launches (freed when profiling restarts)
 
 struct ProfScope {
   int which;
@@ -123,9 +129,11 @@ struct SyncSlot {
 };
 static_assert(sizeof(SyncSlot) == 4096, "sync slot layout");
 constexpr int kSyncSlots = 64;
+constexpr int kSyncSlotsTotal = kSyncSlots + 1;      // + the barrier words of the resident deep-level kernel (deep.hip)
 inline SyncSlot* sync_slot(void* d_sync, int i) {
   return d_sync ? static_cast<SyncSlot*>(d_sync) + (i % kSyncSlots) : nullptr;
 }
+inline void* deep_sync_slot(void* d_sync) { return d_sync ? static_cast<SyncSlot*>(d_sync) + kSyncSlots : nullptr; }
 
 // mean / biased variance (+ running statistics) of one channel from the fp64 totals of the centred slice partials:
 // S = sum of slice sums, Q = sum of the slices' centred sums of squares, W = sum S_i^2 / n_i (Chan's combination)

@@ -1,0 +1,640 @@
+// Resident kernel for the deep levels of the sparse UNet (sparse_unet3d.py:321-350 walked at levels of a few thousand
+// rows; SURVEY 7 "Hard parts": "deep levels are launch-latency-bound -> ... persistent kernels").
+//
+// On the C2 scene levels 2-4 hold 6,572 / 1,520 / 344 voxels: their 54 convolution products and ~100 BatchNorm launches
+// per step are chains of dependent launches of 5-40 us each whose work would take a few microseconds at the roofline.
+// This file runs a CONTIGUOUS RUN of the executor's op list (csrc/executor.hip) whose tensors have at most
+// WSIS_DEEP_ROWS rows as ONE launch: 256 workgroups of 1024 threads (one per CU, all resident) walk a device-side phase
+// table; a phase is what used to be a launch, the launch boundary becomes a grid barrier.
+//
+//   * convolution phases run fwd2_body (spconv2_body.h) -- the SAME code, launch plan (waves per work item, offset
+//     slabs) and therefore the same order of additions as the one-shot spconv_fwd2_kernel: results are bit-identical.
+//     A workgroup runs up to four work items side by side (sub-groups of NW waves with an LDS arrival counter as their
+//     barrier), work items are dealt so that every CU gets the same number of busy sub-groups;
+//   * BatchNorm phases: tile = (256 rows, 32 channels); every tile finishes the statistics (or the backward sums) of ITS
+//     channel group itself from the slice partials the convolution epilogues wrote -- the arithmetic and order of
+//     bn_chunk_centred_stage / bn_sum_chunk_stage (bn.hip), chunks included -- and applies; row block 0 writes
+//     mean / var / running statistics (dgamma / dbeta).  No finish launch, no hand-off inside the phase;
+//   * slab sums (levels with <= 96 work items keep their offset slabs), concat / split copies: phases of their own.
+//
+// Hand-off between phases (cdna_hip_programming.md Guideline 16): every byte another workgroup reads in a later phase is
+// stored write-through (sc1), every storing wave drains (s_waitcnt vmcnt(0)), then the grid barrier: XCD-style
+// hierarchy of agent-scope counters (8 group counters -> top counter -> 8 generation words), one acquire per workgroup
+// behind it.  Every buffer written inside the launch is written ONCE and only read in later phases (private workspace
+// per phase), so no line can be resident anywhere before it is final.  All waits are bounded (2 s) and set an error
+// word the host checks.
+#include <mutex>
+#include <vector>
+
+#include <cstring>
+
+#include "deep.h"
+#include "spconv2_body.h"
+
+namespace {
+
+constexpr int DEEP_THREADS = 1024;
+constexpr int DEEP_LDS_CTRL = 256;                                   // sub-group arrival counters (64 bytes apart)
+constexpr int DEEP_ITEM_WAVE = Layout<1, 2, true>::WAVE_BYTES;       // 8 KB: two-slot ring of gathered rows per wave
+constexpr int DEEP_LDS_BYTES = DEEP_LDS_CTRL + 4 * (HDR_BYTES + 4 * DEEP_ITEM_WAVE);      // NW = 4 x 4 sub-groups: the maximum
+
+struct DeepSync {             // zeroed by the host before every launch
+  unsigned grp[8][32];        // arrival counters of the 8 workgroup groups (blockIdx.x % 8), one 128-byte line each
+  unsigned top[32];
+  unsigned gen[8][32];
+};
+// the error word of a bounded wait that ran out: word 19 of the slot, where wsis_native.sync_errors() looks (SyncSlot::err)
+#define DEEP_ERR_WORD(s) (&(s)->grp[0][19])
+static_assert(sizeof(DeepSync) <= kDeepSyncBytes, "fits a caller sync slot");
+
+// bn_fin_chunks (common.h) on the device: chunks of the two-level statistics finish -- must stay identical
+__device__ __forceinline__ int deep_fin_chunks(int n_part) {
+  int g = n_part / 64;
+  if (g < 1) g = 1;
+  if (g > kBnFinChunks) g = kBnFinChunks;
+  return g;
+}
+
+constexpr unsigned long long DEEP_SPIN_LIMIT = 200000000ull;      // s_memrealtime ticks (100 MHz): 2 s
+
+__device__ __forceinline__ unsigned ld_u32_sc1(const unsigned* p) {
+  return __hip_atomic_load(const_cast<unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// grid barrier number `epoch` (1, 2, ...) of this launch.  fence bit 0: acquire behind it, bit 1: release in front
+__device__ __forceinline__ void deep_grid_barrier(DeepSync* s, unsigned epoch, int fence) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its (write-through) stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (fence & 2) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const unsigned nwg = gridDim.x, g = blockIdx.x & 7u;
+    const unsigned ngrp = nwg < 8u ? nwg : 8u;
+    const unsigned gsize = (nwg - g + 7u) / 8u;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned t = __hip_atomic_fetch_add(&s->grp[g][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == epoch * gsize - 1u) {      // the last of its group: reports to the top counter, then releases the group
+      __hip_atomic_fetch_add(&s->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (ld_u32_sc1(&s->top[0]) < epoch * ngrp) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > DEEP_SPIN_LIMIT) {
+          __hip_atomic_store(DEEP_ERR_WORD(s), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      __hip_atomic_store(&s->gen[g][0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (ld_u32_sc1(&s->gen[g][0]) < epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > DEEP_SPIN_LIMIT) {
+          __hip_atomic_store(DEEP_ERR_WORD(s), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+    }
+    if (fence & 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+}
+
+// barrier of the NW waves that share a work item (a sub-group of the workgroup): arrival counter in LDS
+template <int NW>
+struct SubSync {
+  unsigned* ctr;
+  unsigned target;
+  __device__ __forceinline__ void operator()() {
+    target += (unsigned)NW;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0)
+      __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+};
+
+__device__ __forceinline__ BnEpi deep_epi(const DeepOp& op) {
+  BnEpi e;
+  e.x = (const float*)op.p[9];
+  e.mean = (const float*)op.p[10];
+  e.var = (const float*)op.p[11];
+  e.gamma = (const float*)op.p[12];
+  e.beta = (const float*)op.p[13];
+  e.eps = op.eps;
+  e.relu = op.relu;
+  return e;
+}
+
+// ---- convolution phase: work items (slice bx, block by, slab bz), SG = min(16 / NW, 4) side by side per workgroup
+template <int NW>
+__device__ __attribute__((noinline)) void deep_conv(const DeepOp& op, unsigned char* lds, unsigned* sub_epoch) {
+  constexpr int SG = (16 / NW) < 4 ? (16 / NW) : 4;
+  constexpr int ITEM_BYTES = HDR_BYTES + NW * DEEP_ITEM_WAVE;
+  static_assert(DEEP_LDS_CTRL + SG * ITEM_BYTES <= DEEP_LDS_BYTES, "LDS budget");
+  const int sub = __builtin_amdgcn_readfirstlane((int)threadIdx.x / (64 * NW));
+  if (sub >= SG) return;
+  const int ltid = (int)threadIdx.x - sub * (64 * NW);
+  const int gx = (int)((op.M_out + SL - 1) / SL), gy = op.Cout / 32, gz = op.ZS;
+  const int total = gx * gy * gz;
+  unsigned char* base = lds + DEEP_LDS_CTRL + sub * ITEM_BYTES;
+  const BnEpi epi = deep_epi(op);
+  const BnIn bin{};
+  const StatFin fin{};
+  float* const partial = (float*)const_cast<void*>(op.p[7]);
+  float* const stats = (float*)const_cast<void*>(op.p[8]);
+  const int nwg = (int)gridDim.x;
+  if (NW == 16) {
+    WgSync sync;
+    for (int item = (int)blockIdx.x; item < total; item += nwg) {
+      const int bx = item % gx, r = item / gx;
+      fwd2_body<1, NW, 2, true, false, false, true>(
+          (const float*)op.p[0], (const int32_t*)op.p[1], (const int32_t*)op.p[2], (const float*)op.p[3],
+          (const float*)op.p[4], (const float*)op.p[5], (float*)const_cast<void*>(op.p[6]), partial, op.M_out, op.K, op.Cin,
+          op.Cout, op.flip, op.x_bytes, stats, epi, bin, fin, nullptr, bx, r % gy, r / gy, gy, gz, base, ltid, sync);
+      sync();        // the next work item re-writes the header and the rings
+    }
+  } else {
+    unsigned* ctr = reinterpret_cast<unsigned*>(lds + sub * 64);
+    SubSync<NW> sync{ctr, *sub_epoch};
+    // item = round * (nwg SG) + sub * nwg + workgroup: every CU gets the same number of busy sub-groups
+    for (int item = sub * nwg + (int)blockIdx.x; item < total; item += nwg * SG) {
+      const int bx = item % gx, r = item / gx;
+      fwd2_body<1, NW, 2, true, false, false, true>(
+          (const float*)op.p[0], (const int32_t*)op.p[1], (const int32_t*)op.p[2], (const float*)op.p[3],
+          (const float*)op.p[4], (const float*)op.p[5], (float*)const_cast<void*>(op.p[6]), partial, op.M_out, op.K, op.Cin,
+          op.Cout, op.flip, op.x_bytes, stats, epi, bin, fin, nullptr, bx, r % gy, r / gy, gy, gz, base, ltid, sync);
+      if (NW > 1) sync();
+    }
+    *sub_epoch = sync.target;
+  }
+}
+
+// ---- slab sum: out = sum_z partial[z] (+ bias + residual), with the slice partials of the BatchNorm behind it
+__device__ __attribute__((noinline)) void deep_reduce(const DeepOp& op, unsigned char* lds) {
+  const float4* partial = (const float4*)op.p[7];
+  const float4* bias = (const float4*)op.p[4];
+  const float4* residual = (const float4*)op.p[5];
+  float4* out = (float4*)const_cast<void*>(op.p[6]);
+  float* stats = (float*)const_cast<void*>(op.p[8]);
+  const int cout4 = op.Cout / 4;
+  if (!stats) {
+    reduce_body<true>(partial, bias, residual, out, op.M_out * cout4, cout4, op.ZS,
+                      (int64_t)blockIdx.x * DEEP_THREADS + threadIdx.x, (int64_t)gridDim.x * DEEP_THREADS);
+    return;
+  }
+  // spconv2_reduce_stats_kernel: grid (ceil(M / 32), Cout / 32) of 256 threads; four virtual blocks per workgroup, all
+  // four walk the same number of rounds (the barriers inside are workgroup barriers)
+  const BnEpi epi = deep_epi(op);
+  const int sub = (int)threadIdx.x >> 8, tid = (int)threadIdx.x & 255;
+  float* sred = reinterpret_cast<float*>(lds + DEEP_LDS_CTRL) + sub * 1024;
+  const int gx = (int)((op.M_out + 31) / 32), gy = op.Cout / 32;
+  const int total = gx * gy, nwg = (int)gridDim.x;
+  WgSync sync;
+  for (int base = 0; base < total; base += nwg * 4) {
+    const int item = base + sub * nwg + (int)blockIdx.x;
+    // (a virtual block past the end runs on block 0's rows with its stores masked: M_out = 0 rows masks everything)
+    const bool live = item < total;
+    const int bx = live ? item % gx : 0, by = live ? item / gx : 0;
+    reduce_stats_body<true>(partial, bias, residual, out, live ? op.M_out : (int64_t)0, cout4, op.ZS, stats, epi, bx, by, gy, tid,
+                            sred, sync, live);
+    __syncthreads();
+  }
+}
+
+// ---- BatchNorm forward: statistics finish (training) + apply; tile = (256 rows, 32 channels) per 256-thread quarter
+__device__ __attribute__((noinline)) void deep_bn_fwd(const DeepOp& op, unsigned char* lds) {
+  const int sub = (int)threadIdx.x >> 8, tid = (int)threadIdx.x & 255;
+  double(*red)[8][33] = reinterpret_cast<double(*)[8][33]>(lds + DEEP_LDS_CTRL + sub * 8192);      // [3][8][33] doubles
+  float* s_mu = reinterpret_cast<float*>(lds + DEEP_LDS_CTRL + sub * 8192 + 6400);
+  float* s_sc = s_mu + 32;
+  float* s_bt = s_sc + 32;
+  const int C = op.Cin, C0 = op.C0;
+  const int64_t M = op.M_in;
+  const float* x = (const float*)op.p[0];
+  const float* gamma = (const float*)op.p[1];
+  const float* beta = (const float*)op.p[2];
+  float* rmean = (float*)const_cast<void*>(op.p[3]);
+  float* rvar = (float*)const_cast<void*>(op.p[4]);
+  float* y = (float*)const_cast<void*>(op.p[7]);
+  float* mean = (float*)const_cast<void*>(op.p[8]);
+  float* var = (float*)const_cast<void*>(op.p[9]);
+  const int nblk = (int)((M + 31) / 32);
+  const int G = deep_fin_chunks(nblk), per = (nblk + G - 1) / G;
+  const int CG = C / 32, RB = (int)((M + 255) / 256);
+  const int total = y ? RB * CG : CG;            // statistics only: one tile per channel group
+  const int nwg = (int)gridDim.x;
+  const int cl = tid & 31, pl = tid >> 5;
+  for (int base = 0; base < total; base += nwg * 4) {
+    const int item = base + sub * nwg + (int)blockIdx.x;
+    const bool live = item < total;
+    const int cgi = live ? item % CG : 0, rb = live ? item / CG : 0;
+    const int c = cgi * 32 + cl;
+    if (op.training) {
+      // partial source of this channel group (a concatenation has two producers)
+      const bool first = c < C0;
+      const float* part = (const float*)(first ? op.p[5] : op.p[6]);
+      const int Cs = first ? C0 : C - C0, cs = first ? c : c - C0;
+      double acc2[3][8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc2[0][j] = acc2[1][j] = acc2[2][j] = 0.0;
+      for (int g = 0; g < G; ++g) {
+        const int lo = g * per, hi = lo + per < nblk ? lo + per : nblk;
+        double s = 0.0, q = 0.0, w = 0.0;
+        if (live) {
+#pragma unroll 4
+          for (int b = lo + pl; b < hi; b += 8) {
+            const float sf = part[(int64_t)b * 2 * Cs + cs];
+            const float qf = part[(int64_t)b * 2 * Cs + Cs + cs];
+            const int64_t left = M - (int64_t)b * 32;
+            const double si = sf;
+            s += si;
+            q += qf;
+            w += si * si * (left < 32 ? 1.0 / (double)left : 0.03125);
+          }
+        }
+        __syncthreads();
+        red[0][pl][cl] = s;
+        red[1][pl][cl] = q;
+        red[2][pl][cl] = w;
+        __syncthreads();
+        if (pl == 0) {
+          double S = 0.0, Q = 0.0, W = 0.0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {      // fixed order (bn_chunk_centred_stage)
+            S += red[0][j][cl];
+            Q += red[1][j][cl];
+            W += red[2][j][cl];
+          }
+          // second level: chunk g belongs to partial lane g % 8, lanes added in order
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j == (g & 7)) {
+              acc2[0][j] += S;
+              acc2[1][j] += Q;
+              acc2[2][j] += W;
+            }
+        }
+      }
+      if (pl == 0) {
+        double S, Q, W;
+        if (G == 1) {
+          S = acc2[0][0];
+          Q = acc2[1][0];
+          W = acc2[2][0];
+        } else {
+          S = Q = W = 0.0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            S += acc2[0][j];
+            Q += acc2[1][j];
+            W += acc2[2][j];
+          }
+        }
+        const double n = (double)M;        // (bn_finish_centred)
+        const double mu = S / n;
+        double v = (Q + (W - n * mu * mu)) / n;
+        if (v < 0.0) v = 0.0;
+        const float muf = (float)mu, vf = (float)v;
+        if (live && rb == 0) {
+          mean[c] = muf;
+          var[c] = vf;
+          if (rmean) {
+            const double unb = n > 1 ? v * n / (n - 1) : v;
+            rmean[c] = (float)((1.0 - op.momentum) * rmean[c] + op.momentum * mu);
+            rvar[c] = (float)((1.0 - op.momentum) * rvar[c] + op.momentum * unb);
+          }
+        }
+        s_mu[cl] = muf;
+        s_sc[cl] = (gamma ? gamma[c] : 1.0f) * rsqrtf(vf + op.eps);
+        s_bt[cl] = beta ? beta[c] : 0.0f;
+      }
+    } else if (pl == 0) {        // evaluation: the running statistics (op.p[3], op.p[4])
+      s_mu[cl] = rmean[c];
+      s_sc[cl] = (gamma ? gamma[c] : 1.0f) * rsqrtf(rvar[c] + op.eps);
+      s_bt[cl] = beta ? beta[c] : 0.0f;
+    }
+    __syncthreads();
+    if (y && live) {
+      const int q4 = tid & 7, rl = tid >> 3;
+      const int c4 = cgi * 32 + q4 * 4;
+      float mu4[4], sc4[4], bt4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mu4[e] = s_mu[q4 * 4 + e];
+        sc4[e] = s_sc[q4 * 4 + e];
+        bt4[e] = s_bt[q4 * 4 + e];
+      }
+      const int64_t r0 = (int64_t)rb * 256;
+      float4 vx[8];
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int64_t r = r0 + it * 32 + rl;
+        vx[it] = *reinterpret_cast<const float4*>(x + (r < M ? r : 0) * C + c4);
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int64_t r = r0 + it * 32 + rl;
+        if (r < M) {
+          float o[4] = {vx[it].x, vx[it].y, vx[it].z, vx[it].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float z = __builtin_fmaf(o[e] - mu4[e], sc4[e], bt4[e]);      // (bn_apply_body)
+            if (op.relu) z = fmaxf(z, 0.0f);
+            o[e] = z;
+          }
+          st4_sc1(y + r * C + c4, make_float4(o[0], o[1], o[2], o[3]));
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- BatchNorm backward from the slice partials (sum dz, sum dz xhat) of the dIn epilogue: finish + dx (+ addend)
+__device__ __attribute__((noinline)) void deep_bn_bwd(const DeepOp& op, unsigned char* lds) {
+  const int sub = (int)threadIdx.x >> 8, tid = (int)threadIdx.x & 255;
+  double(*red)[8][33] = reinterpret_cast<double(*)[8][33]>(lds + DEEP_LDS_CTRL + sub * 8192);      // [2][8][33]
+  float* s_k1 = reinterpret_cast<float*>(lds + DEEP_LDS_CTRL + sub * 8192 + 6400);
+  float* s_k2 = s_k1 + 32;
+  const int C = op.Cin;
+  const int64_t M = op.M_in;
+  const float* x = (const float*)op.p[0];
+  const float* dy = (const float*)op.p[1];
+  const float* mean = (const float*)op.p[2];
+  const float* var = (const float*)op.p[3];
+  const float* gamma = (const float*)op.p[4];
+  const float* beta = (const float*)op.p[5];
+  const float* addend = (const float*)op.p[6];
+  const float* part = (const float*)op.p[7];
+  float* dx = (float*)const_cast<void*>(op.p[8]);
+  float* dgamma = (float*)const_cast<void*>(op.p[9]);
+  float* dbeta = (float*)const_cast<void*>(op.p[10]);
+  const int nblk = (int)((M + 31) / 32);
+  const int G = deep_fin_chunks(nblk), per = (nblk + G - 1) / G;
+  const int CG = C / 32, RB = (int)((M + 255) / 256);
+  const int total = RB * CG, nwg = (int)gridDim.x;
+  const int cl = tid & 31, pl = tid >> 5;
+  for (int base = 0; base < total; base += nwg * 4) {
+    const int item = base + sub * nwg + (int)blockIdx.x;
+    const bool live = item < total;
+    const int cgi = live ? item % CG : 0, rb = live ? item / CG : 0;
+    const int c = cgi * 32 + cl;
+    double acc2[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc2[0][j] = acc2[1][j] = 0.0;
+    for (int g = 0; g < G; ++g) {
+      const int lo = g * per, hi = lo + per < nblk ? lo + per : nblk;
+      double a = 0.0, b = 0.0;
+      if (live) {
+#pragma unroll 4
+        for (int k = lo + pl; k < hi; k += 8) {
+          a += part[(int64_t)k * 2 * C + c];
+          b += part[(int64_t)k * 2 * C + C + c];
+        }
+      }
+      __syncthreads();
+      red[0][pl][cl] = a;
+      red[1][pl][cl] = b;
+      __syncthreads();
+      if (pl == 0) {
+        double A = 0.0, B = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {      // fixed order (bn_sum_chunk_stage)
+          A += red[0][j][cl];
+          B += red[1][j][cl];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j == (g & 7)) {
+            acc2[0][j] += A;
+            acc2[1][j] += B;
+          }
+      }
+    }
+    if (pl == 0) {
+      double A, B;
+      if (G == 1) {
+        A = acc2[0][0];
+        B = acc2[1][0];
+      } else {
+        A = B = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          A += acc2[0][j];
+          B += acc2[1][j];
+        }
+      }
+      const float db = (float)A, dg = (float)B;
+      if (live && rb == 0) {
+        dbeta[c] = db;
+        dgamma[c] = dg;
+      }
+      const float inv_m = 1.0f / (float)M;      // (bn_bwd_apply_body)
+      s_k1[cl] = db * inv_m;
+      s_k2[cl] = dg * inv_m;
+    }
+    __syncthreads();
+    if (live) {
+      const int q4 = tid & 7, rl = tid >> 3;
+      const int c4 = cgi * 32 + q4 * 4;
+      float mu[4], rstd[4], gm[4], bt[4], k1[4], k2[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int cc = c4 + e;
+        mu[e] = mean[cc];
+        rstd[e] = rsqrtf(var[cc] + op.eps);
+        gm[e] = gamma ? gamma[cc] : 1.0f;
+        bt[e] = beta ? beta[cc] : 0.0f;
+        k1[e] = s_k1[q4 * 4 + e];
+        k2[e] = s_k2[q4 * 4 + e];
+      }
+      const int64_t r0 = (int64_t)rb * 256;
+#pragma unroll 2
+      for (int it = 0; it < 8; it += 2) {
+        float4 vx[2], vd[2], va[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int64_t r = r0 + (it + u) * 32 + rl;
+          const int64_t rr = r < M ? r : 0;
+          vx[u] = *reinterpret_cast<const float4*>(x + rr * C + c4);
+          vd[u] = *reinterpret_cast<const float4*>(dy + rr * C + c4);
+          va[u] = addend ? *reinterpret_cast<const float4*>(addend + rr * C + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int64_t r = r0 + (it + u) * 32 + rl;
+          if (r < M) {
+            const float xv[4] = {vx[u].x, vx[u].y, vx[u].z, vx[u].w}, dv[4] = {vd[u].x, vd[u].y, vd[u].z, vd[u].w};
+            const float av[4] = {va[u].x, va[u].y, va[u].z, va[u].w};
+            float ov[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float xh = (xv[e] - mu[e]) * rstd[e];
+              float dz = dv[e];
+              if (op.relu && xh * gm[e] + bt[e] <= 0.0f) dz = 0.0f;
+              const float rr2 = dz - k1[e] - xh * k2[e];
+              ov[e] = gm[e] * rstd[e] * rr2;
+              if (addend) ov[e] += av[e];
+            }
+            st4_sc1(dx + r * C + c4, make_float4(ov[0], ov[1], ov[2], ov[3]));
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// out[r] = [a[r] | b[r]]  /  a[r], b[r] = halves of in[r]   (float4 granules)
+__device__ __attribute__((noinline)) void deep_cat(const DeepOp& op, bool split) {
+  const int Ca4 = op.Cin / 4, C4 = (op.Cin + op.Cout) / 4;
+  const int64_t total = op.M_in * C4;
+  const float* a = (const float*)op.p[0];
+  const float* b = (const float*)op.p[1];
+  float* o = (float*)const_cast<void*>(op.p[2]);
+  for (int64_t t = (int64_t)blockIdx.x * DEEP_THREADS + threadIdx.x; t < total; t += (int64_t)gridDim.x * DEEP_THREADS) {
+    const int64_t r = t / C4;
+    const int c = (int)(t - r * C4);
+    if (!split) {
+      const float* src = c < Ca4 ? a + (r * Ca4 + c) * 4 : b + (r * (C4 - Ca4) + (c - Ca4)) * 4;
+      st4_sc1(o + t * 4, *reinterpret_cast<const float4*>(src));
+    } else {      // split: p0 = in, p1 = first half out, p2 = second half out
+      float* dst = c < Ca4 ? const_cast<float*>(b) + (r * Ca4 + c) * 4 : o + (r * (C4 - Ca4) + (c - Ca4)) * 4;
+      st4_sc1(dst, *reinterpret_cast<const float4*>(a + t * 4));
+    }
+  }
+}
+
+__global__ __launch_bounds__(DEEP_THREADS) void deep_run_kernel(const DeepOp* __restrict__ ops, int n, DeepSync* sync,
+                                                                   int fence, unsigned long long* __restrict__ stamps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  if (threadIdx.x < DEEP_LDS_CTRL / 4) reinterpret_cast<unsigned*>(lds)[threadIdx.x] = 0u;
+  __syncthreads();
+  unsigned sub_epoch = 0u;           // arrivals so far at this wave's sub-group counter (all sub-group sizes share it)
+  if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < n; ++i) {
+    const DeepOp& op = ops[i];
+    switch (op.kind) {
+      case DK_CONV:
+        // (the arrival counter is shared by sub-groups of different sizes over the phases: it restarts per phase)
+        if (op.NW == 16) {
+          deep_conv<16>(op, lds, &sub_epoch);
+        } else {
+          __syncthreads();
+          if (threadIdx.x < DEEP_LDS_CTRL / 4) reinterpret_cast<unsigned*>(lds)[threadIdx.x] = 0u;
+          __syncthreads();
+          sub_epoch = 0u;
+          if (op.NW == 8) deep_conv<8>(op, lds, &sub_epoch);
+          else if (op.NW == 4) deep_conv<4>(op, lds, &sub_epoch);
+          else if (op.NW == 2) deep_conv<2>(op, lds, &sub_epoch);
+          else deep_conv<1>(op, lds, &sub_epoch);
+        }
+        break;
+      case DK_REDUCE: deep_reduce(op, lds); break;
+      case DK_BN_FWD: deep_bn_fwd(op, lds); break;
+      case DK_BN_BWD: deep_bn_bwd(op, lds); break;
+      case DK_CAT: deep_cat(op, false); break;
+      case DK_SPLIT: deep_cat(op, true); break;
+      default: break;
+    }
+    if (i + 1 < n) deep_grid_barrier(sync, (unsigned)(i + 1), fence);
+    if (stamps && op.stamp >= 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+      // (the last phase: its stores are complete when this workgroup's are -- a lower bound by at most one item)
+      if (i + 1 == n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamps[op.stamp] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------------------------
+// host side: called by the executor (csrc/executor.hip) with a run of ops it found eligible
+namespace wsis {
+
+bool deep_enabled() {
+  const char* e = getenv("WSIS_DEEP");
+  return e ? atoi(e) != 0 : true;
+}
+
+int64_t deep_max_rows() {
+  static const int64_t v = [] {
+    const char* e = getenv("WSIS_DEEP_ROWS");
+    return e ? (int64_t)atoll(e) : (int64_t)8192;
+  }();
+  return v;
+}
+
+// launch plan of a product inside the resident kernel = the plan of the one-shot kernel (same order of additions)
+bool deep_conv_plan(int64_t M_out, int K, int Cin, int Cout, int* NW, int* ZS) {
+  if (M_out < 1 || K < 1 || K > KMAX || Cin < 32 || Cin % 32 || Cout < 32 || Cout % 32) return false;
+  const Plan2 p = plan2(M_out, K, Cin, Cout);
+  if (p.NB != 1 || p.DA != 2 || !p.BD) return false;
+  if (p.NW != 1 && p.NW != 2 && p.NW != 4 && p.NW != 8 && p.NW != 16) return false;
+  *NW = p.NW;
+  *ZS = p.ZS;
+  return true;
+}
+
+namespace {
+std::mutex g_deep_mu;
+struct PinnedRing {
+  static constexpr int N = 16;
+  static constexpr size_t BYTES = 64 * 1024;
+  char* buf[N] = {};
+  hipEvent_t ev[N] = {};
+  bool used[N] = {};
+  int next = 0;
+};
+PinnedRing g_ring;
+}  // namespace
+
+// ops: the phase table (host); runs it on `st`.  d_table: device memory for the table (n * sizeof(DeepOp)), d_sync: a
+// zero-able 4 KiB slot, d_stamps: optional device buffer of (max stamp index + 1) u64
+int deep_launch(const DeepOp* h_ops, int n, void* d_table, void* d_sync, unsigned long long* d_stamps, hipStream_t st) {
+  if (n == 0) return WSIS_OK;
+  WSIS_REQUIRE((size_t)n * sizeof(DeepOp) <= PinnedRing::BYTES, "too many phases for one resident launch");
+  static int cus = 0;           // one process per GPU (include/wsis_hip.h): the device of the first call
+  if (!cus) {
+    int dev = 0;
+    WSIS_HIP_CHECK(hipGetDevice(&dev));
+    WSIS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)deep_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DEEP_LDS_BYTES));
+    const char* e = getenv("WSIS_DEEP_WGS");
+    if (e && atoi(e) > 0 && atoi(e) < cus) cus = atoi(e);
+  }
+  char* staging = nullptr;
+  hipEvent_t ev = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_deep_mu);
+    const int slot = g_ring.next;
+    g_ring.next = (g_ring.next + 1) % PinnedRing::N;
+    if (!g_ring.buf[slot]) {
+      WSIS_HIP_CHECK(hipHostMalloc((void**)&g_ring.buf[slot], PinnedRing::BYTES, hipHostMallocDefault));
+      WSIS_HIP_CHECK(hipEventCreateWithFlags(&g_ring.ev[slot], hipEventDisableTiming));
+    }
+    if (g_ring.used[slot]) WSIS_HIP_CHECK(hipEventSynchronize(g_ring.ev[slot]));      // the copy of 16 launches ago
+    g_ring.used[slot] = true;
+    staging = g_ring.buf[slot];
+    ev = g_ring.ev[slot];
+  }
+  memcpy(staging, h_ops, (size_t)n * sizeof(DeepOp));
+  WSIS_HIP_CHECK(hipMemcpyAsync(d_table, staging, (size_t)n * sizeof(DeepOp), hipMemcpyHostToDevice, st));
+  WSIS_HIP_CHECK(hipEventRecord(ev, st));
+  WSIS_HIP_CHECK(hipMemsetAsync(d_sync, 0, sizeof(DeepSync), st));
+  static int fence = -1;
+  if (fence < 0) {
+    const char* e = getenv("WSIS_DEEP_FENCE");
+    fence = e ? atoi(e) : 1;
+  }
+  hipLaunchKernelGGL(deep_run_kernel, dim3((unsigned)cus), dim3(DEEP_THREADS), DEEP_LDS_BYTES, st,
+                     static_cast<const DeepOp*>(d_table), n, static_cast<DeepSync*>(d_sync), fence, d_stamps);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+}  // namespace wsis

@@ -19,6 +19,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "deep.h"
 
 using namespace wsis;
 
@@ -306,6 +307,288 @@ int64_t op_ws_bytes(const wsis_op& op, bool on) {
   }
 }
 
+
+// ---- resident deep-level kernel (deep.hip): which ops of a pass can run as phases of ONE launch ------------------------
+// rows of the tensor an op WRITES (a dIn product writes M_in rows); 0: the op writes nothing on the caller's stream
+inline int64_t deep_rows(const wsis_op& op) {
+  switch (op.kind) {
+    case WSIS_OP_CONV: return op.M_out;
+    case WSIS_OP_CONV_BWD: return op.out[0] ? op.M_in : 0;
+    default: return op.M_in;
+  }
+}
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// the BatchNorm backward op that takes the slice partials of dIn op i (see run_ops_impl)
+inline int paired_bn(const wsis_op* ops, int n, int i) {
+  const wsis_op& op = ops[i];
+  for (int j = i + 1; j < n && j <= i + 4; ++j)
+    if (ops[j].kind == WSIS_OP_BN_RELU_BWD && ops[j].in[1] == op.out[0] && (ops[j].flags & WSIS_OPF_STATS)) return j;
+  return -1;
+}
+
+bool deep_op_ok(const wsis_op* ops, int n, int i, bool fwd2_on) {
+  const wsis_op& op = ops[i];
+  const int64_t R = deep_max_rows();
+  int nw = 0, zs = 0;
+  switch (op.kind) {
+    case WSIS_OP_CONV:
+      if (op.flags & (WSIS_OPF_BN_IN | WSIS_OPF_STAT_FIN)) return false;
+      if (!use_fwd2(op, fwd2_on) || op.M_out < 1 || op.M_out > R) return false;
+      if ((int64_t)op.K * op.M_out * 4 >= ((int64_t)1 << 31)) return false;
+      return deep_conv_plan(op.M_out, op.K, op.Cin, op.Cout, &nw, &zs) && aligned16(op.in[0]) && aligned16(op.out[0]);
+    case WSIS_OP_CONV_BWD: {
+      if (op.flags & WSIS_OPF_BN_IN) return false;
+      if (!op.out[0]) return op.M_in <= R;            // weight gradient only: nothing on the caller's stream
+      if (!use_fwd2(op, fwd2_on) || op.M_in < 1 || op.M_in > R) return false;
+      if (!deep_conv_plan(op.M_in, op.K, op.Cout, op.Cin, &nw, &zs)) return false;
+      if (op.flags & WSIS_OPF_STATS) {
+        const int j = paired_bn(ops, n, i);
+        if (j < 0 || !ops[j].in[7] || ops[j].M_in != op.M_in || ops[j].Cin != op.Cin) return false;
+      }
+      return aligned16(op.in[2]) && aligned16(op.out[0]);
+    }
+    case WSIS_OP_BN_RELU:
+      if (op.M_in < 1 || op.M_in > R || op.Cin % 32) return false;
+      if (op.flags & WSIS_OPF_TRAINING) {
+        if (!(op.flags & WSIS_OPF_STATS) || !op.in[5]) return false;
+        if (op.in[6] && (op.K % 32 || op.K <= 0 || op.K >= op.Cin)) return false;
+      } else if (!op.out[0]) {
+        return false;
+      }
+      return aligned16(op.in[0]) && (!op.out[0] || aligned16(op.out[0]));
+    case WSIS_OP_BN_RELU_BWD:
+      if (op.M_in < 1 || op.M_in > R || op.Cin % 32) return false;
+      if (!(op.flags & WSIS_OPF_TRAINING) || !(op.flags & WSIS_OPF_STATS) || !op.in[7]) return false;
+      return aligned16(op.in[0]) && aligned16(op.in[1]) && aligned16(op.out[0]) && (!op.in[6] || aligned16(op.in[6]));
+    case WSIS_OP_CAT:
+      return op.M_in >= 1 && op.M_in <= R && vec4_ok(op, op.in[0], op.in[1], op.out[0]);
+    case WSIS_OP_SPLIT:
+      return op.M_in >= 1 && op.M_in <= R && vec4_ok(op, op.in[0], op.out[0], op.out[1]);
+    default:
+      return false;
+  }
+}
+
+// end (exclusive) of the run of eligible ops that starts at i0 (i0 itself must be eligible); a dIn product and the
+// BatchNorm backward that takes its partials stay together; `stop`: an op index the run must not pass (milestone)
+int deep_run_end(const wsis_op* ops, int n, int i0, int stop, bool fwd2_on) {
+  int i1 = i0;
+  while (i1 < n && (stop < 0 || i1 <= stop) && deep_op_ok(ops, n, i1, fwd2_on)) ++i1;
+  // a pair cut by the end of the run: end the run in front of the dIn product
+  for (int i = i0; i < i1; ++i)
+    if (ops[i].kind == WSIS_OP_CONV_BWD && ops[i].out[0] && (ops[i].flags & WSIS_OPF_STATS)) {
+      const int j = paired_bn(ops, n, i);
+      if (j >= i1) {
+        i1 = i;
+        break;
+      }
+    }
+  // a BatchNorm backward whose producer is not in the run cannot take partials either
+  for (int j = i0; j < i1; ++j)
+    if (ops[j].kind == WSIS_OP_BN_RELU_BWD) {
+      bool found = false;
+      for (int i = j - 1; i >= i0 && i >= j - 4 && !found; --i)
+        found = ops[i].kind == WSIS_OP_CONV_BWD && ops[i].out[0] == ops[j].in[1] && (ops[i].flags & WSIS_OPF_STATS);
+      if (!found) {
+        i1 = j;
+        break;
+      }
+    }
+  return i1;
+}
+
+constexpr int kDeepMinOps = 4;          // shorter runs stay ordinary launches
+inline int64_t deep_table_bytes(int n_ops) { return up((int64_t)(2 * n_ops + 2) * (int64_t)sizeof(DeepOp)); }
+
+// slab workspace of the phases of ops [i0, i1) (every phase its own region: written once inside the launch)
+int64_t deep_slab_bytes(const wsis_op* ops, int i0, int i1) {
+  int64_t b = 0;
+  for (int i = i0; i < i1; ++i) {
+    const wsis_op& op = ops[i];
+    int nw = 0, zs = 1;
+    if (op.kind == WSIS_OP_CONV && deep_conv_plan(op.M_out, op.K, op.Cin, op.Cout, &nw, &zs) && zs > 1)
+      b += up((int64_t)zs * op.M_out * op.Cout * 4);
+    if (op.kind == WSIS_OP_CONV_BWD && op.out[0] && deep_conv_plan(op.M_in, op.K, op.Cout, op.Cin, &nw, &zs) && zs > 1)
+      b += up((int64_t)zs * op.M_in * op.Cin * 4);
+  }
+  return b;
+}
+
+// workspace of the resident launches of a pass: table + slabs of the largest run (runs execute one after the other)
+int64_t deep_ws_bytes(const wsis_op* ops, int n, bool fwd2_on) {
+  if (!deep_enabled()) return 0;
+  int64_t best = 0;
+  for (int i = 0; i < n;) {
+    if (!deep_op_ok(ops, n, i, fwd2_on)) {
+      ++i;
+      continue;
+    }
+    const int i1 = deep_run_end(ops, n, i, -1, fwd2_on);
+    if (i1 - i >= kDeepMinOps) best = std::max(best, deep_table_bytes(i1 - i) + deep_slab_bytes(ops, i, i1));
+    i = i1 > i ? i1 : i + 1;
+  }
+  return best;
+}
+
+// phases of ops [i0, i1) -> table; wt_base / wt_off: the transposed weights of the pass; slab: private slab regions
+int deep_build(const wsis_op* ops, int n, int i0, int i1, const char* wt_base, const std::vector<int64_t>& wt_off, char* slab,
+               bool stamps, std::vector<DeepOp>& tab, std::vector<std::pair<int, std::pair<int, int>>>& conv_stamps) {
+  tab.clear();
+  conv_stamps.clear();
+  auto push = [&](DeepOp& d) {
+    d.stamp = stamps ? (int)tab.size() + 1 : -1;
+    tab.push_back(d);
+  };
+  for (int i = i0; i < i1; ++i) {
+    const wsis_op& op = ops[i];
+    DeepOp d{};
+    d.NW = 1;
+    d.ZS = 1;
+    switch (op.kind) {
+      case WSIS_OP_CONV:
+      case WSIS_OP_CONV_BWD: {
+        const bool fwd = op.kind == WSIS_OP_CONV;
+        if (!fwd && !op.out[0]) break;
+        const int64_t Mo = fwd ? op.M_out : op.M_in, Mg = fwd ? op.M_in : op.M_out;
+        const int Ci = fwd ? op.Cin : op.Cout, Co = fwd ? op.Cout : op.Cin;
+        int nw = 1, zs = 1;
+        if (!deep_conv_plan(Mo, op.K, Ci, Co, &nw, &zs)) return fail(WSIS_ERR_ARG, "deep: op %d has no plan", i);
+        d.kind = DK_CONV;
+        d.NW = nw;
+        d.ZS = zs;
+        d.K = op.K;
+        d.Cin = Ci;
+        d.Cout = Co;
+        d.M_in = Mg;
+        d.M_out = Mo;
+        d.x_bytes = (uint32_t)(Mg * Ci * 4);
+        const void* stats = nullptr;
+        DeepOp epi{};
+        if (fwd) {
+          d.p[0] = op.in[0];
+          d.p[1] = op.in[1];
+          d.p[2] = op.in[2];
+          d.p[3] = wt_base + wt_off[i];
+          d.p[4] = op.in[4];
+          d.p[5] = op.in[5];
+          d.p[6] = op.out[0];
+          d.flip = 0;
+          if (op.flags & WSIS_OPF_STATS) stats = op.out[1];
+        } else {
+          d.p[0] = op.in[2];
+          d.p[1] = op.in[5];
+          d.p[2] = op.in[6];
+          d.p[3] = op.in[1];
+          d.p[6] = op.out[0];
+          d.flip = (op.flags & WSIS_OPF_FLIP) ? 1 : 0;
+          if (op.flags & WSIS_OPF_STATS) {
+            const wsis_op& bn = ops[paired_bn(ops, n, i)];
+            stats = bn.in[7];
+            epi.p[9] = bn.in[0];
+            epi.p[10] = bn.in[2];
+            epi.p[11] = bn.in[3];
+            epi.p[12] = bn.in[4];
+            epi.p[13] = bn.in[5];
+            epi.eps = bn.eps;
+            epi.relu = (bn.flags & WSIS_OPF_RELU) ? 1 : 0;
+          }
+        }
+        WSIS_REQUIRE(d.p[1] || (op.K == 1 && Mg == Mo), "nbr may be null only for the dense 1x1 case");
+        const int s0 = (int)tab.size();
+        if (zs > 1) {
+          DeepOp r = d;              // the slab sum finishes the product: bias / residual / partials move there
+          d.p[7] = slab;
+          d.p[4] = d.p[5] = nullptr;
+          push(d);
+          r.kind = DK_REDUCE;
+          r.p[7] = slab;
+          r.p[8] = stats;
+          for (int k = 9; k <= 13; ++k) r.p[k] = epi.p[k];
+          r.eps = epi.eps;
+          r.relu = epi.relu;
+          push(r);
+          slab += up((int64_t)zs * Mo * Co * 4);
+        } else {
+          d.p[8] = stats;
+          for (int k = 9; k <= 13; ++k) d.p[k] = epi.p[k];
+          d.eps = epi.eps;
+          d.relu = epi.relu;
+          push(d);
+        }
+        conv_stamps.push_back({i, {s0, (int)tab.size()}});      // stamps s0 (start) .. s0 + 1 (main) .. size (product done)
+        break;
+      }
+      case WSIS_OP_BN_RELU: {
+        const bool training = (op.flags & WSIS_OPF_TRAINING) != 0;
+        const bool upd = (op.flags & WSIS_OPF_UPDATE_RUNNING) != 0;
+        d.kind = DK_BN_FWD;
+        d.training = training ? 1 : 0;
+        d.relu = (op.flags & WSIS_OPF_RELU) ? 1 : 0;
+        d.Cin = op.Cin;
+        d.M_in = op.M_in;
+        d.eps = op.eps;
+        d.momentum = op.momentum;
+        d.C0 = op.in[6] ? op.K : op.Cin;
+        d.p[0] = op.in[0];
+        d.p[1] = op.in[1];
+        d.p[2] = op.in[2];
+        d.p[3] = (training && !upd) ? nullptr : op.in[3];
+        d.p[4] = (training && !upd) ? nullptr : op.in[4];
+        d.p[5] = op.in[5];
+        d.p[6] = op.in[6];
+        d.p[7] = op.out[0];
+        d.p[8] = op.out[1];
+        d.p[9] = op.out[2];
+        push(d);
+        break;
+      }
+      case WSIS_OP_BN_RELU_BWD:
+        d.kind = DK_BN_BWD;
+        d.relu = (op.flags & WSIS_OPF_RELU) ? 1 : 0;
+        d.Cin = op.Cin;
+        d.M_in = op.M_in;
+        d.eps = op.eps;
+        d.p[0] = op.in[0];
+        d.p[1] = op.in[1];
+        d.p[2] = op.in[2];
+        d.p[3] = op.in[3];
+        d.p[4] = op.in[4];
+        d.p[5] = op.in[5];
+        d.p[6] = op.in[6];
+        d.p[7] = op.in[7];
+        d.p[8] = op.out[0];
+        d.p[9] = op.out[1];
+        d.p[10] = op.out[2];
+        push(d);
+        break;
+      case WSIS_OP_CAT:
+        d.kind = DK_CAT;
+        d.Cin = op.Cin;
+        d.Cout = op.Cout;
+        d.M_in = op.M_in;
+        d.p[0] = op.in[0];
+        d.p[1] = op.in[1];
+        d.p[2] = op.out[0];
+        push(d);
+        break;
+      case WSIS_OP_SPLIT:
+        d.kind = DK_SPLIT;
+        d.Cin = op.Cin;
+        d.Cout = op.Cout;
+        d.M_in = op.M_in;
+        d.p[0] = op.in[0];
+        d.p[1] = op.out[0];
+        d.p[2] = op.out[1];
+        push(d);
+        break;
+      default:
+        return fail(WSIS_ERR_ARG, "deep: op %d of kind %d is not a phase", i, op.kind);
+    }
+  }
+  return WSIS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -325,7 +608,7 @@ int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n) {
       if (d > dw) dw = d;
     }
   }
-  return wt + dw + need + ALIGN;
+  return wt + dw + need + deep_ws_bytes(ops, n, on) + ALIGN;
 }
 
 int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream) {
@@ -465,6 +748,11 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   char* const dw_ws = ws;
   ws += dw_bytes;
   ws_bytes -= dw_bytes;
+  // resident deep-level launches (deep.hip): phase table + private slab regions of the largest run
+  const int64_t deep_bytes = deep_ws_bytes(ops, n, on);
+  char* const deep_ws = ws;
+  ws += deep_bytes;
+  ws_bytes -= deep_bytes;
   SideStream* side = (dw_bytes > 0 && dw_stream_enabled()) ? side_stream_for(st) : nullptr;
   if (side) side->next = 0;
   // the side-stream calls of the pass from a second host thread (not under stream capture, not while the profiler's
@@ -490,10 +778,75 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   } while (0)
   bool forked = false;
   int first_err = WSIS_OK;
+  // weight gradient of a CONV_BWD op: forked to the side stream behind everything enqueued so far on the caller's stream
+  auto dw_issue = [&](const wsis_op& op) -> int {
+    void* dw_stream = stream;
+    if (side) {   // dY is complete once everything enqueued so far on the caller's stream has run
+      hipEvent_t e = next_fork_event(side);
+      hipError_t he = e ? hipEventRecord(e, st) : hipErrorOutOfMemory;
+      if (he == hipSuccess && !use_worker) he = hipStreamWaitEvent(side->stream, e, 0);
+      if (he != hipSuccess) return fail(WSIS_ERR_HIP, "dW side-stream fork failed: %s", hipGetErrorString(he));
+      dw_stream = side->stream;
+      forked = true;
+      if (use_worker) {     // the wait and the launches come from the worker thread, in push order
+        DwTask t;
+        t.op = op;
+        t.ev = e;
+        t.dev = cur_dev;
+        t.side = side->stream;
+        t.ws = dw_ws;
+        t.ws_bytes = dw_bytes;
+        dw_worker().push(t);
+        worker_busy = true;
+        return WSIS_OK;
+      }
+    }
+    return issue_dw(op, dw_ws, dw_bytes, dw_stream);
+  };
+  const bool deep_on = deep_bytes > 0 && d_sync != nullptr && !capturing;
+  std::vector<DeepOp> deep_tab;
+  std::vector<std::pair<int, std::pair<int, int>>> deep_convs;
+  const char* slab_bn_env = getenv("WSIS_SLAB_BN_PARTIALS");      // one-shot path: slab-split dIn products write the
+  const bool slab_bn_partials = slab_bn_env && atoi(slab_bn_env) != 0;   // BatchNorm partials too (the resident kernel's form)
   std::vector<char> bn_unfused(n, 0);     // BatchNorm backward ops whose dIn pass did not write partials this run
   for (int i = 0; i < n; ++i) {
-    const wsis_op& op = ops[i];
     int rc = WSIS_OK;
+    if (deep_on && deep_op_ok(ops, n, i, on)) {
+      const int i1 = deep_run_end(ops, n, i, mark_op >= i ? mark_op : -1, on);
+      if (i1 - i >= kDeepMinOps) {
+        // ---- ops [i, i1) as ONE resident launch; their weight gradients follow on the side stream
+        char* slab = deep_ws + deep_table_bytes(i1 - i);
+        rc = deep_build(ops, n, i, i1, wt_base, wt_off, slab, g_prof_on, deep_tab, deep_convs);
+        unsigned long long* d_stamps = nullptr;
+        if (rc == WSIS_OK && g_prof_on && !deep_tab.empty()) {
+          if (hipMalloc((void**)&d_stamps, (deep_tab.size() + 1) * sizeof(unsigned long long)) != hipSuccess)
+            rc = fail(WSIS_ERR_HIP, "deep: stamp buffer allocation failed");
+          else
+            g_prof_bufs.push_back(d_stamps);
+        }
+        if (rc == WSIS_OK)
+          rc = deep_launch(deep_tab.data(), (int)deep_tab.size(), deep_ws, deep_sync_slot(d_sync), d_stamps, st);
+        if (rc == WSIS_OK && d_stamps)
+          for (const auto& cs : deep_convs) {
+            ProfRec r{};
+            r.d_stamps = d_stamps;
+            r.s0 = cs.second.first;
+            r.sm = cs.second.first + 1;
+            r.s1 = cs.second.second;
+            g_prof[0].push_back(r);
+          }
+        for (int k = i; k < i1 && rc == WSIS_OK; ++k)
+          if (ops[k].kind == WSIS_OP_CONV_BWD && ops[k].out[1]) rc = dw_issue(ops[k]);
+        if (rc != WSIS_OK) {
+          first_err = rc;
+          break;
+        }
+        i = i1 - 1;
+        goto op_done;
+      }
+    }
+    {
+    const wsis_op& op = ops[i];
     switch (op.kind) {
       case WSIS_OP_CONV:
         if (op.flags & (WSIS_OPF_BN_IN | WSIS_OPF_STAT_FIN)) {
@@ -646,7 +999,7 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
               rc = fail(WSIS_ERR_ARG, "op %d: no BatchNorm backward takes the partials of this dIn pass", i);
               break;
             }
-            if (wsis_spconv_fwd_t_slabs(op.M_in, op.K, op.Cout, op.Cin) > 1) {
+            if (!slab_bn_partials && wsis_spconv_fwd_t_slabs(op.M_in, op.K, op.Cout, op.Cin) > 1) {
               // few slices: the product is split into offset slabs and summed by a second kernel; the BatchNorm's own
               // small-level reduction (one launch) is cheaper than a statistics variant of that sum
               bn_unfused[bn - ops] = 1;
@@ -672,33 +1025,7 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
           if (rc != WSIS_OK) break;
         }
       din_done:
-        if (op.out[1]) {
-          void* dw_stream = stream;
-          if (side) {   // dY is complete once everything enqueued so far on the caller's stream has run
-            hipEvent_t e = next_fork_event(side);
-            hipError_t he = e ? hipEventRecord(e, st) : hipErrorOutOfMemory;
-            if (he == hipSuccess && !use_worker) he = hipStreamWaitEvent(side->stream, e, 0);
-            if (he != hipSuccess) {
-              rc = fail(WSIS_ERR_HIP, "dW side-stream fork failed: %s", hipGetErrorString(he));
-              break;
-            }
-            dw_stream = side->stream;
-            forked = true;
-            if (use_worker) {     // the wait and the launches come from the worker thread, in push order
-              DwTask t;
-              t.op = op;
-              t.ev = e;
-              t.dev = cur_dev;
-              t.side = side->stream;
-              t.ws = dw_ws;
-              t.ws_bytes = dw_bytes;
-              dw_worker().push(t);
-              worker_busy = true;
-              break;
-            }
-          }
-          rc = issue_dw(op, dw_ws, dw_bytes, dw_stream);
-        }
+        if (op.out[1]) rc = dw_issue(op);
         break;
       }
       case WSIS_OP_BN_RELU_BWD:
@@ -723,10 +1050,12 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
       default:
         rc = fail(WSIS_ERR_ARG, "wsis_run_ops: unknown op kind");
     }
+    }
     if (rc != WSIS_OK) {
       first_err = rc;
       break;
     }
+  op_done:
     if (i == mark_op) {
       // milestone: waiter_stream continues once everything issued so far -- on the caller's stream AND on the
       // weight-gradient side stream -- has run (gradient exchange of the finished part of the flat buffer while the

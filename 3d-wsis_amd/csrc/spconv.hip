@@ -974,6 +974,10 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
 }
 
 int wsis_prof_enable(int32_t on) {
+  if (on && !g_prof_on && g_prof[0].empty() && g_prof[1].empty()) {      // a new session: the stamp buffers of the last one
+    for (void* b : g_prof_bufs) (void)hipFree(b);
+    g_prof_bufs.clear();
+  }
   g_prof_on = on != 0;
   return WSIS_OK;
 }
@@ -982,6 +986,14 @@ int wsis_prof_summary(int32_t which, double* total_ms, int64_t* launches) {
   WSIS_REQUIRE(which >= 0 && which < 2 && total_ms && launches, "bad args");
   double ms = 0.0;
   for (ProfRec& r : g_prof[which]) {
+    if (r.d_stamps) {
+      unsigned long long t[2];
+      WSIS_HIP_CHECK(hipDeviceSynchronize());
+      WSIS_HIP_CHECK(hipMemcpy(&t[0], r.d_stamps + r.s0, 8, hipMemcpyDeviceToHost));
+      WSIS_HIP_CHECK(hipMemcpy(&t[1], r.d_stamps + r.s1, 8, hipMemcpyDeviceToHost));
+      ms += (double)(t[1] - t[0]) * 1e-5;      // 100 MHz ticks -> ms
+      continue;
+    }
     hipEvent_t last = r.c ? r.c : r.b;
     WSIS_HIP_CHECK(hipEventSynchronize(last));
     float t = 0.0f;
@@ -1002,6 +1014,17 @@ int wsis_prof_records(int32_t which, double* h_main_ms, double* h_total_ms, int6
   WSIS_REQUIRE((int64_t)g_prof[which].size() <= cap, "record buffer too small");
   int64_t i = 0;
   for (ProfRec& r : g_prof[which]) {
+    if (r.d_stamps) {
+      unsigned long long t[3];
+      WSIS_HIP_CHECK(hipDeviceSynchronize());
+      WSIS_HIP_CHECK(hipMemcpy(&t[0], r.d_stamps + r.s0, 8, hipMemcpyDeviceToHost));
+      WSIS_HIP_CHECK(hipMemcpy(&t[1], r.d_stamps + r.sm, 8, hipMemcpyDeviceToHost));
+      WSIS_HIP_CHECK(hipMemcpy(&t[2], r.d_stamps + r.s1, 8, hipMemcpyDeviceToHost));
+      h_main_ms[i] = (double)(t[1] - t[0]) * 1e-5;
+      h_total_ms[i] = (double)(t[2] - t[0]) * 1e-5;
+      ++i;
+      continue;
+    }
     hipEvent_t last = r.c ? r.c : r.b;
     WSIS_HIP_CHECK(hipEventSynchronize(last));
     float t0 = 0.0f, t1 = 0.0f;

@@ -37,6 +37,7 @@ importlib.import_module("3d-wsis_amd")
 if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("WSIS_FORCE_DIST", "0") == "1":
     os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

@@ -350,11 +350,11 @@ def test_label_propagation_sparse_equals_dense_on_a_scene_sized_graph():
     adjacency = np.zeros((S, S), dtype=np.int64)
     adjacency[eu, ev] = 1
     adjacency[eu[:40], ev[:40]] = 2                     # multi-edges
-    pred = rng.integers(0, classes, S)
+    pred = rng.integers(0, 5, S) * 3                    # classes 0, 3, 6, 9, 12 predicted: neighbours often agree
     conf = (0.4 + 0.6 * rng.random(S)).astype(np.float32)
     label = np.full(S, -100)
     lab_ids = rng.choice(S, 150, replace=False)
-    label[lab_ids] = pred[lab_ids] = rng.integers(0, classes - 2, 150)
+    label[lab_ids] = pred[lab_ids] = rng.integers(0, 4, 150) * 3          # class 12 predicted but never labelled
     A = wsis_ops.affinity_matrix(torch.from_numpy(eu).to(DEV), torch.from_numpy(ev).to(DEV),
                                  torch.from_numpy(aff).to(DEV), S)
     A[5, 5] = 0.25                                      # a self edge
