@@ -561,12 +561,9 @@ bool deep_enabled() {
   return e ? atoi(e) != 0 : true;
 }
 
-int64_t deep_max_rows() {
-  static const int64_t v = [] {
-    const char* e = getenv("WSIS_DEEP_ROWS");
-    return e ? (int64_t)atoll(e) : (int64_t)8192;
-  }();
-  return v;
+int64_t deep_max_rows() {      // (read per call: a test raises it to put a whole small network into one launch)
+  const char* e = getenv("WSIS_DEEP_ROWS");
+  return e ? (int64_t)atoll(e) : (int64_t)8192;
 }
 
 // launch plan of a product inside the resident kernel = the plan of the one-shot kernel (same order of additions)
@@ -579,6 +576,8 @@ bool deep_conv_plan(int64_t M_out, int K, int Cin, int Cout, int* NW, int* ZS) {
   *ZS = p.ZS;
   return true;
 }
+
+int64_t g_deep_launches = 0, g_deep_phases = 0;
 
 namespace {
 std::mutex g_deep_mu;
@@ -634,7 +633,15 @@ int deep_launch(const DeepOp* h_ops, int n, void* d_table, void* d_sync, unsigne
   hipLaunchKernelGGL(deep_run_kernel, dim3((unsigned)cus), dim3(DEEP_THREADS), DEEP_LDS_BYTES, st,
                      static_cast<const DeepOp*>(d_table), n, static_cast<DeepSync*>(d_sync), fence, d_stamps);
   WSIS_LAUNCH_CHECK();
+  ++g_deep_launches;
+  g_deep_phases += n;
   return WSIS_OK;
 }
 
 }  // namespace wsis
+
+extern "C" {
+// resident launches / phases issued by this process so far (tests: the resident path was really taken)
+int64_t wsis_deep_launches(void) { return wsis::g_deep_launches; }
+int64_t wsis_deep_phases(void) { return wsis::g_deep_phases; }
+}

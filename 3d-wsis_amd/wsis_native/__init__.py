@@ -81,6 +81,8 @@ _HIP_SIGS = {
     "wsis_spconv_fwd_f": (I32, [P, P, P, P, P, I32, P, P, P, P, P, I32, I64, I64, I32, I32, I32, P, I64, P, P]),
     "wsis_bn_bwd_from_partials": (I32, [P, I64, P, P, P, P, P, P, F32, I32, P, P, P, P, I64, I32, P, I64, P, P]),
     "wsis_sync_bytes": (I64, []),
+    "wsis_deep_launches": (I64, []),
+    "wsis_deep_phases": (I64, []),
     "wsis_bn_bwd_apply": (I32, [P, P, P, P, P, P, P, P, F32, I32, P, P, I64, I32, P]),
     "wsis_spconv_fwd_t_bn": (I32, [P, P, P, P, I32, P, P, P, P, P, P, P, F32, I32, I64, I64, I32, I32, I32, P, I64, P, P]),
     "wsis_bn_stats_finalize_workspace_bytes": (I64, [I64, I32]),

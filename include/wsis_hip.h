@@ -632,6 +632,12 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
  * pass still runs (the reference's DDP buckets, train_scannetv2.py:738).  mark_op < 0: no milestone. */
 int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream,
                         int32_t mark_op, void* waiter_stream);
+/* A run of consecutive ops whose output tensors have at most WSIS_DEEP_ROWS (8192) rows -- the deep UNet levels of a
+ * scene, sparse_unet3d.py:321-350 -- is issued as ONE resident launch (csrc/deep.hip: 256 workgroups walk the ops as
+ * phases with grid barriers between them; same kernels' code, same order of additions, results identical to the
+ * launch-by-launch form).  WSIS_DEEP=0 switches it off.  Counters of this process, for tests: */
+int64_t wsis_deep_launches(void);
+int64_t wsis_deep_phases(void);
 #ifdef __cplusplus
 }
 #endif

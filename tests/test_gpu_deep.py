@@ -62,8 +62,12 @@ def test_resident_kernel_equals_launch_by_launch_training(monkeypatch, room, n_b
     """small room: every level below 0 fits the row limit (levels 1-4 are one launch per pass); 4 m room: levels 2-4"""
     cfg = harness.default_cfg()
     batch_host = harness.collate([harness.make_scene(31, room=room, n_box=n_box)])
+    lib = wsis_native.hip()
     l0, g0, s0, y0 = _one_pass(monkeypatch, False, batch_host, cfg)
+    n0, p0 = lib.wsis_deep_launches(), lib.wsis_deep_phases()
     l1, g1, s1, y1 = _one_pass(monkeypatch, True, batch_host, cfg)
+    assert lib.wsis_deep_launches() - n0 == 2                 # one resident launch per pass ...
+    assert lib.wsis_deep_phases() - p0 > 100                  # ... of > 100 phases together
     assert torch.equal(y0, y1)
     assert l0 == l1
     assert set(g0) == set(g1) and len(g0) > 150
@@ -87,9 +91,13 @@ def test_resident_kernel_with_a_batch_of_scenes_and_whole_network_below_the_limi
     cfg.batch_size = 2
     batch_host = harness.collate([harness.make_scene(41, room=(1.2, 1.0, 0.8), n_box=1),
                                   harness.make_scene(42, room=(1.0, 1.1, 0.9), n_box=2)])
-    assert batch_host["voxel_locs"].shape[0] < 8192
+    assert batch_host["voxel_locs"].shape[0] < 65536
+    monkeypatch.setenv("WSIS_DEEP_ROWS", "65536")
+    lib = wsis_native.hip()
     l0, g0, s0, y0 = _one_pass(monkeypatch, False, batch_host, cfg)
+    p0 = lib.wsis_deep_phases()
     l1, g1, s1, y1 = _one_pass(monkeypatch, True, batch_host, cfg)
+    assert lib.wsis_deep_phases() - p0 > 250                  # 97 of the 98 ops each way + the slab sums
     assert torch.equal(y0, y1) and l0 == l1
     assert [n for n in g0 if not torch.equal(g0[n], g1[n])] == []
     assert [n for n in s0 if not torch.equal(s0[n], s1[n])] == []
