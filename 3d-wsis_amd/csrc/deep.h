@@ -33,6 +33,7 @@ bool deep_enabled();
 int64_t deep_max_rows();
 // launch plan of a product inside the resident kernel = the one-shot kernel's (same order of additions); false: not eligible
 bool deep_conv_plan(int64_t M_out, int K, int Cin, int Cout, int* NW, int* ZS);
+bool deep_bn_rows_ok(int64_t M);      // rows a BatchNorm phase can take (two-level finish of <= 16 chunks)
 constexpr size_t kDeepSyncBytes = 4096;
 int deep_launch(const DeepOp* h_ops, int n, void* d_table, void* d_sync, unsigned long long* d_stamps, hipStream_t st);
 

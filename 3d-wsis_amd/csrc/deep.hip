@@ -26,6 +26,7 @@
 #include <mutex>
 #include <vector>
 
+#include <cstddef>
 #include <cstring>
 
 #include "deep.h"
@@ -36,12 +37,16 @@ namespace {
 constexpr int DEEP_THREADS = 1024;
 constexpr int DEEP_LDS_CTRL = 256;                                   // sub-group arrival counters (64 bytes apart)
 constexpr int DEEP_ITEM_WAVE = Layout<1, 2, true>::WAVE_BYTES;       // 8 KB: two-slot ring of gathered rows per wave
+constexpr int DEEP_BN_CHUNKS = 16;                                   // two-level finish of at most 16 chunks: <= 34,784 rows
+constexpr int DEEP_BN_LDS = 6912 + 3 * DEEP_BN_CHUNKS * 32 * 8;      // per 256-thread quarter: red, coefficients, chunk sums
 constexpr int DEEP_LDS_BYTES = DEEP_LDS_CTRL + 4 * (HDR_BYTES + 4 * DEEP_ITEM_WAVE);      // NW = 4 x 4 sub-groups: the maximum
 
 struct DeepSync {             // zeroed by the host before every launch
   unsigned grp[8][32];        // arrival counters of the 8 workgroup groups (blockIdx.x % 8), one 128-byte line each
-  unsigned top[32];
-  unsigned gen[8][32];
+  unsigned members[32];       // XCC-aware form: workgroups resident on XCC x (counted at the start of the launch)
+  unsigned xcnt[8][32];       //   arrival counter of XCC x, touched by that XCC only: atomics in its own L2
+  unsigned xgen[8][32];       //   generation word of XCC x, written by the XCC's last arriver, polled through L2
+  unsigned top[32];           //   the eight XCC leaders (agent scope)
 };
 // the error word of a bounded wait that ran out: word 19 of the slot, where wsis_native.sync_errors() looks (SyncSlot::err)
 #define DEEP_ERR_WORD(s) (&(s)->grp[0][19])
@@ -55,48 +60,95 @@ __device__ __forceinline__ int deep_fin_chunks(int n_part) {
   return g;
 }
 
-constexpr unsigned long long DEEP_SPIN_LIMIT = 200000000ull;      // s_memrealtime ticks (100 MHz): 2 s
+constexpr unsigned DEEP_SPIN_LIMIT = 4000000u;      // polls of ~0.5 us each: ~2 s
 
 __device__ __forceinline__ unsigned ld_u32_sc1(const unsigned* p) {
   return __hip_atomic_load(const_cast<unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// grid barrier number `epoch` (1, 2, ...) of this launch.  fence bit 0: acquire behind it, bit 1: release in front
+// grid barrier number `epoch` (1, 2, ...) of this launch.  Every workgroup adds to the counter of its group
+// (blockIdx.x % 8: eight counters on lines of their own, so the 256 arrivals serialise 32 deep instead of 256 deep) with
+// an atomic that returns nothing, then eight lanes of its first wave poll the eight counters together (sc1 loads) until
+// all have reached epoch x group size: one one-way trip + one poll round trip, no top-level counter, no second hop.
+// mode 0: the hierarchical form of the first version (group counter -> top counter -> generation word) for A/B runs.
+// fence bit 0: agent-scope acquire behind the barrier, bit 1: release in front (the payload is stored write-through and
+// every buffer is written once per launch, so neither is needed: see the file header; kept as switches)
 __device__ __forceinline__ void deep_grid_barrier(DeepSync* s, unsigned epoch, int fence) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its (write-through) stores have left
   __syncthreads();
-  if (threadIdx.x == 0) {
-    if (fence & 2) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+  if (threadIdx.x < 64) {
+    const unsigned lane = threadIdx.x;
     const unsigned nwg = gridDim.x, g = blockIdx.x & 7u;
     const unsigned ngrp = nwg < 8u ? nwg : 8u;
-    const unsigned gsize = (nwg - g + 7u) / 8u;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    const unsigned t = __hip_atomic_fetch_add(&s->grp[g][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == epoch * gsize - 1u) {      // the last of its group: reports to the top counter, then releases the group
-      __hip_atomic_fetch_add(&s->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while (ld_u32_sc1(&s->top[0]) < epoch * ngrp) {
-        __builtin_amdgcn_s_sleep(2);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > DEEP_SPIN_LIMIT) {
-          __hip_atomic_store(DEEP_ERR_WORD(s), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-      }
-      __hip_atomic_store(&s->gen[g][0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      while (ld_u32_sc1(&s->gen[g][0]) < epoch) {
-        __builtin_amdgcn_s_sleep(2);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > DEEP_SPIN_LIMIT) {
-          __hip_atomic_store(DEEP_ERR_WORD(s), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
+    if (fence & 2) {
+      if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (lane == 0) __hip_atomic_fetch_add(&s->grp[g][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned mine = lane < ngrp ? lane : 0u;
+    const unsigned need = epoch * ((nwg - mine + 7u) / 8u);
+    unsigned spins = 0;
+    for (;;) {
+      const unsigned v = ld_u32_sc1(&s->grp[mine][0]);
+      if (__all((int)(v - need) >= 0)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > DEEP_SPIN_LIMIT) {      // ~2 s of polling: a workgroup of this launch never became resident
+        if (lane == 0) __hip_atomic_store(DEEP_ERR_WORD(s), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
       }
     }
     if (fence & 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (lane == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+}
+
+
+// ---- XCC-aware grid barrier (MI355X_MICROARCH.md, price list "barrier-xcd").  The workgroups of one XCC share an L2:
+// their arrival counter and generation word never leave it (atomic without sc1, polls that bypass L1 only), one returned
+// L2 atomic tells the last arriver of the XCC, which alone crosses the fabric (agent-scope add + poll of the top counter)
+// and then releases its XCC.  Placement is read from HW_REG_XCC_ID, never assumed; the member counts are taken at the start
+// of every launch behind one flat barrier.
+__device__ __forceinline__ unsigned deep_xcc_id() { return __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u; }
+__device__ __forceinline__ unsigned l2_atomic_inc(unsigned* p) {
+  unsigned old;
+  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(p), "v"(1u) : "memory");
+  return old;
+}
+__device__ __forceinline__ unsigned l2_load(const unsigned* p) {
+  unsigned v;
+  asm volatile("global_load_dword %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+struct XccState {
+  unsigned xcc, members, nxcc;
+};
+__device__ __forceinline__ void deep_xcc_barrier(DeepSync* s, unsigned epoch, const XccState& x) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = l2_atomic_inc(&s->xcnt[x.xcc][0]);
+    unsigned spins = 0;
+    if (t == epoch * x.members - 1u) {
+      __hip_atomic_fetch_add(&s->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while ((int)(ld_u32_sc1(&s->top[0]) - epoch * x.nxcc) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > DEEP_SPIN_LIMIT) {
+          __hip_atomic_store(DEEP_ERR_WORD(s), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
+      *reinterpret_cast<volatile unsigned*>(&s->xgen[x.xcc][0]) = epoch;      // (L1 is write-through: the word lands in L2)
+    } else {
+      while ((int)(l2_load(&s->xgen[x.xcc][0]) - epoch) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > DEEP_SPIN_LIMIT) {
+          __hip_atomic_store(DEEP_ERR_WORD(s), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
     }
   }
   __syncthreads();
@@ -117,6 +169,41 @@ struct SubSync {
   }
 };
 
+// a field of the phase record by a scalar load the optimiser cannot move or keep (see LateVals in spconv2_body.h)
+template <int BYTE_OFF>
+__device__ __forceinline__ unsigned long long deep_ld64(const DeepOp* op) {
+  unsigned long long v;
+  asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(op), "i"(BYTE_OFF) : "memory");
+  return v;
+}
+template <int BYTE_OFF>
+__device__ __forceinline__ unsigned deep_ld32(const DeepOp* op) {
+  unsigned v;
+  asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(op), "i"(BYTE_OFF) : "memory");
+  return v;
+}
+constexpr int DEEP_P_OFF = 72;      // offsetof(DeepOp, p)
+static_assert(offsetof(DeepOp, p) == DEEP_P_OFF && offsetof(DeepOp, eps) == 56 && offsetof(DeepOp, relu) == 12, "phase record");
+struct LateOp {
+  const DeepOp* op;
+  __device__ __forceinline__ const float* bias() const { return (const float*)deep_ld64<DEEP_P_OFF + 4 * 8>(op); }
+  __device__ __forceinline__ const float* residual() const { return (const float*)deep_ld64<DEEP_P_OFF + 5 * 8>(op); }
+  __device__ __forceinline__ float* out() const { return (float*)deep_ld64<DEEP_P_OFF + 6 * 8>(op); }
+  __device__ __forceinline__ float* partial() const { return (float*)deep_ld64<DEEP_P_OFF + 7 * 8>(op); }
+  __device__ __forceinline__ float* stats() const { return (float*)deep_ld64<DEEP_P_OFF + 8 * 8>(op); }
+  __device__ __forceinline__ BnEpi epi() const {
+    BnEpi e;
+    e.x = (const float*)deep_ld64<DEEP_P_OFF + 9 * 8>(op);
+    e.mean = (const float*)deep_ld64<DEEP_P_OFF + 10 * 8>(op);
+    e.var = (const float*)deep_ld64<DEEP_P_OFF + 11 * 8>(op);
+    e.gamma = (const float*)deep_ld64<DEEP_P_OFF + 12 * 8>(op);
+    e.beta = (const float*)deep_ld64<DEEP_P_OFF + 13 * 8>(op);
+    e.eps = __uint_as_float(deep_ld32<56>(op));
+    e.relu = (int)deep_ld32<12>(op);
+    return e;
+  }
+};
+
 __device__ __forceinline__ BnEpi deep_epi(const DeepOp& op) {
   BnEpi e;
   e.x = (const float*)op.p[9];
@@ -131,7 +218,7 @@ __device__ __forceinline__ BnEpi deep_epi(const DeepOp& op) {
 
 // ---- convolution phase: work items (slice bx, block by, slab bz), SG = min(16 / NW, 4) side by side per workgroup
 template <int NW>
-__device__ __attribute__((noinline)) void deep_conv(const DeepOp& op, unsigned char* lds, unsigned* sub_epoch) {
+__device__ __forceinline__ void deep_conv(const DeepOp& op, unsigned char* lds, unsigned* sub_epoch) {
   constexpr int SG = (16 / NW) < 4 ? (16 / NW) : 4;
   constexpr int ITEM_BYTES = HDR_BYTES + NW * DEEP_ITEM_WAVE;
   static_assert(DEEP_LDS_CTRL + SG * ITEM_BYTES <= DEEP_LDS_BYTES, "LDS budget");
@@ -141,20 +228,22 @@ __device__ __attribute__((noinline)) void deep_conv(const DeepOp& op, unsigned c
   const int gx = (int)((op.M_out + SL - 1) / SL), gy = op.Cout / 32, gz = op.ZS;
   const int total = gx * gy * gz;
   unsigned char* base = lds + DEEP_LDS_CTRL + sub * ITEM_BYTES;
-  const BnEpi epi = deep_epi(op);
+  const LateOp late{&op};
   const BnIn bin{};
   const StatFin fin{};
-  float* const partial = (float*)const_cast<void*>(op.p[7]);
-  float* const stats = (float*)const_cast<void*>(op.p[8]);
   const int nwg = (int)gridDim.x;
   if (NW == 16) {
     WgSync sync;
     for (int item = (int)blockIdx.x; item < total; item += nwg) {
       const int bx = item % gx, r = item / gx;
+      // nothing of one work item is kept in registers for the next: without the two statements below hipcc hoists
+      // every lane constant of the body out of the item AND the phase loop and spills them around the MFMA walk
+      asm volatile("" ::: "memory");
+      int t2 = ltid;
+      asm volatile("" : "+v"(t2));
       fwd2_body<1, NW, 2, true, false, false, true>(
-          (const float*)op.p[0], (const int32_t*)op.p[1], (const int32_t*)op.p[2], (const float*)op.p[3],
-          (const float*)op.p[4], (const float*)op.p[5], (float*)const_cast<void*>(op.p[6]), partial, op.M_out, op.K, op.Cin,
-          op.Cout, op.flip, op.x_bytes, stats, epi, bin, fin, nullptr, bx, r % gy, r / gy, gy, gz, base, ltid, sync);
+          (const float*)op.p[0], (const int32_t*)op.p[1], (const int32_t*)op.p[2], (const float*)op.p[3], late, op.M_out,
+          op.K, op.Cin, op.Cout, op.flip, op.x_bytes, bin, fin, nullptr, bx, r % gy, r / gy, gy, gz, base, t2, sync);
       sync();        // the next work item re-writes the header and the rings
     }
   } else {
@@ -163,10 +252,14 @@ __device__ __attribute__((noinline)) void deep_conv(const DeepOp& op, unsigned c
     // item = round * (nwg SG) + sub * nwg + workgroup: every CU gets the same number of busy sub-groups
     for (int item = sub * nwg + (int)blockIdx.x; item < total; item += nwg * SG) {
       const int bx = item % gx, r = item / gx;
+      // nothing of one work item is kept in registers for the next: without the two statements below hipcc hoists
+      // every lane constant of the body out of the item AND the phase loop and spills them around the MFMA walk
+      asm volatile("" ::: "memory");
+      int t2 = ltid;
+      asm volatile("" : "+v"(t2));
       fwd2_body<1, NW, 2, true, false, false, true>(
-          (const float*)op.p[0], (const int32_t*)op.p[1], (const int32_t*)op.p[2], (const float*)op.p[3],
-          (const float*)op.p[4], (const float*)op.p[5], (float*)const_cast<void*>(op.p[6]), partial, op.M_out, op.K, op.Cin,
-          op.Cout, op.flip, op.x_bytes, stats, epi, bin, fin, nullptr, bx, r % gy, r / gy, gy, gz, base, ltid, sync);
+          (const float*)op.p[0], (const int32_t*)op.p[1], (const int32_t*)op.p[2], (const float*)op.p[3], late, op.M_out,
+          op.K, op.Cin, op.Cout, op.flip, op.x_bytes, bin, fin, nullptr, bx, r % gy, r / gy, gy, gz, base, t2, sync);
       if (NW > 1) sync();
     }
     *sub_epoch = sync.target;
@@ -174,7 +267,7 @@ __device__ __attribute__((noinline)) void deep_conv(const DeepOp& op, unsigned c
 }
 
 // ---- slab sum: out = sum_z partial[z] (+ bias + residual), with the slice partials of the BatchNorm behind it
-__device__ __attribute__((noinline)) void deep_reduce(const DeepOp& op, unsigned char* lds) {
+__device__ __forceinline__ void deep_reduce(const DeepOp& op, unsigned char* lds) {
   const float4* partial = (const float4*)op.p[7];
   const float4* bias = (const float4*)op.p[4];
   const float4* residual = (const float4*)op.p[5];
@@ -189,7 +282,9 @@ __device__ __attribute__((noinline)) void deep_reduce(const DeepOp& op, unsigned
   // spconv2_reduce_stats_kernel: grid (ceil(M / 32), Cout / 32) of 256 threads; four virtual blocks per workgroup, all
   // four walk the same number of rounds (the barriers inside are workgroup barriers)
   const BnEpi epi = deep_epi(op);
-  const int sub = (int)threadIdx.x >> 8, tid = (int)threadIdx.x & 255;
+  int tid_ = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int sub = tid_ >> 8, tid = tid_ & 255;
   float* sred = reinterpret_cast<float*>(lds + DEEP_LDS_CTRL) + sub * 1024;
   const int gx = (int)((op.M_out + 31) / 32), gy = op.Cout / 32;
   const int total = gx * gy, nwg = (int)gridDim.x;
@@ -206,12 +301,15 @@ __device__ __attribute__((noinline)) void deep_reduce(const DeepOp& op, unsigned
 }
 
 // ---- BatchNorm forward: statistics finish (training) + apply; tile = (256 rows, 32 channels) per 256-thread quarter
-__device__ __attribute__((noinline)) void deep_bn_fwd(const DeepOp& op, unsigned char* lds) {
-  const int sub = (int)threadIdx.x >> 8, tid = (int)threadIdx.x & 255;
-  double(*red)[8][33] = reinterpret_cast<double(*)[8][33]>(lds + DEEP_LDS_CTRL + sub * 8192);      // [3][8][33] doubles
-  float* s_mu = reinterpret_cast<float*>(lds + DEEP_LDS_CTRL + sub * 8192 + 6400);
+__device__ __forceinline__ void deep_bn_fwd(const DeepOp& op, unsigned char* lds) {
+  int tid_ = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid_));      // (lane constants stay inside the phase: see deep_conv)
+  const int sub = tid_ >> 8, tid = tid_ & 255;
+  double(*red)[8][33] = reinterpret_cast<double(*)[8][33]>(lds + DEEP_LDS_CTRL + sub * DEEP_BN_LDS);      // [3][8][33] doubles
+  float* s_mu = reinterpret_cast<float*>(lds + DEEP_LDS_CTRL + sub * DEEP_BN_LDS + 6400);
   float* s_sc = s_mu + 32;
   float* s_bt = s_sc + 32;
+  double* chunkS = reinterpret_cast<double*>(lds + DEEP_LDS_CTRL + sub * DEEP_BN_LDS + 6912);      // [3][16][32] doubles
   const int C = op.Cin, C0 = op.C0;
   const int64_t M = op.M_in;
   const float* x = (const float*)op.p[0];
@@ -238,22 +336,32 @@ __device__ __attribute__((noinline)) void deep_bn_fwd(const DeepOp& op, unsigned
       const bool first = c < C0;
       const float* part = (const float*)(first ? op.p[5] : op.p[6]);
       const int Cs = first ? C0 : C - C0, cs = first ? c : c - C0;
-      double acc2[3][8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc2[0][j] = acc2[1][j] = acc2[2][j] = 0.0;
+      // level 1: the G chunk sums of this channel (fixed order inside a chunk) -> chunkS[3][G][32] in LDS
       for (int g = 0; g < G; ++g) {
         const int lo = g * per, hi = lo + per < nblk ? lo + per : nblk;
         double s = 0.0, q = 0.0, w = 0.0;
         if (live) {
-#pragma unroll 4
-          for (int b = lo + pl; b < hi; b += 8) {
-            const float sf = part[(int64_t)b * 2 * Cs + cs];
-            const float qf = part[(int64_t)b * 2 * Cs + Cs + cs];
-            const int64_t left = M - (int64_t)b * 32;
-            const double si = sf;
-            s += si;
-            q += qf;
-            w += si * si * (left < 32 ? 1.0 / (double)left : 0.03125);
+          // the rows lo + pl, + 8, ... of the chunk, sixteen loads in flight at a time, added in ascending order
+          for (int b0 = lo + pl; b0 < hi; b0 += 8 * 16) {
+            float sf[16], qf[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const int b = b0 + 8 * u;
+              const int bb = b < hi ? b : lo;
+              sf[u] = part[(int64_t)bb * 2 * Cs + cs];
+              qf[u] = part[(int64_t)bb * 2 * Cs + Cs + cs];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              const int b = b0 + 8 * u;
+              if (b < hi) {
+                const int64_t left = M - (int64_t)b * 32;
+                const double si = sf[u];
+                s += si;
+                q += qf[u];
+                w += si * si * (left < 32 ? 1.0 / (double)left : 0.03125);
+              }
+            }
           }
         }
         __syncthreads();
@@ -269,31 +377,39 @@ __device__ __attribute__((noinline)) void deep_bn_fwd(const DeepOp& op, unsigned
             Q += red[1][j][cl];
             W += red[2][j][cl];
           }
-          // second level: chunk g belongs to partial lane g % 8, lanes added in order
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (j == (g & 7)) {
-              acc2[0][j] += S;
-              acc2[1][j] += Q;
-              acc2[2][j] += W;
-            }
+          chunkS[(0 * DEEP_BN_CHUNKS + g) * 32 + cl] = S;
+          chunkS[(1 * DEEP_BN_CHUNKS + g) * 32 + cl] = Q;
+          chunkS[(2 * DEEP_BN_CHUNKS + g) * 32 + cl] = W;
         }
       }
-      if (pl == 0) {
-        double S, Q, W;
-        if (G == 1) {
-          S = acc2[0][0];
-          Q = acc2[1][0];
-          W = acc2[2][0];
-        } else {
-          S = Q = W = 0.0;
+      double S = 0.0, Q = 0.0, W = 0.0;
+      if (G > 1) {
+        // level 2: partial lane pl adds chunks pl, pl + 8, ...; the eight lanes are added in order
+        __syncthreads();
+        double s2 = 0.0, q2 = 0.0, w2 = 0.0;
+        for (int g = pl; g < G; g += 8) {
+          s2 += chunkS[(0 * DEEP_BN_CHUNKS + g) * 32 + cl];
+          q2 += chunkS[(1 * DEEP_BN_CHUNKS + g) * 32 + cl];
+          w2 += chunkS[(2 * DEEP_BN_CHUNKS + g) * 32 + cl];
+        }
+        red[0][pl][cl] = s2;
+        red[1][pl][cl] = q2;
+        red[2][pl][cl] = w2;
+        __syncthreads();
+        if (pl == 0) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            S += acc2[0][j];
-            Q += acc2[1][j];
-            W += acc2[2][j];
+            S += red[0][j][cl];
+            Q += red[1][j][cl];
+            W += red[2][j][cl];
           }
         }
+      } else if (pl == 0) {
+        S = chunkS[(0 * DEEP_BN_CHUNKS + 0) * 32 + cl];
+        Q = chunkS[(1 * DEEP_BN_CHUNKS + 0) * 32 + cl];
+        W = chunkS[(2 * DEEP_BN_CHUNKS + 0) * 32 + cl];
+      }
+      if (pl == 0) {
         const double n = (double)M;        // (bn_finish_centred)
         const double mu = S / n;
         double v = (Q + (W - n * mu * mu)) / n;
@@ -355,11 +471,14 @@ __device__ __attribute__((noinline)) void deep_bn_fwd(const DeepOp& op, unsigned
 }
 
 // ---- BatchNorm backward from the slice partials (sum dz, sum dz xhat) of the dIn epilogue: finish + dx (+ addend)
-__device__ __attribute__((noinline)) void deep_bn_bwd(const DeepOp& op, unsigned char* lds) {
-  const int sub = (int)threadIdx.x >> 8, tid = (int)threadIdx.x & 255;
-  double(*red)[8][33] = reinterpret_cast<double(*)[8][33]>(lds + DEEP_LDS_CTRL + sub * 8192);      // [2][8][33]
-  float* s_k1 = reinterpret_cast<float*>(lds + DEEP_LDS_CTRL + sub * 8192 + 6400);
+__device__ __forceinline__ void deep_bn_bwd(const DeepOp& op, unsigned char* lds) {
+  int tid_ = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int sub = tid_ >> 8, tid = tid_ & 255;
+  double(*red)[8][33] = reinterpret_cast<double(*)[8][33]>(lds + DEEP_LDS_CTRL + sub * DEEP_BN_LDS);      // [2][8][33]
+  float* s_k1 = reinterpret_cast<float*>(lds + DEEP_LDS_CTRL + sub * DEEP_BN_LDS + 6400);
   float* s_k2 = s_k1 + 32;
+  double* chunkS = reinterpret_cast<double*>(lds + DEEP_LDS_CTRL + sub * DEEP_BN_LDS + 6912);
   const int C = op.Cin;
   const int64_t M = op.M_in;
   const float* x = (const float*)op.p[0];
@@ -383,17 +502,25 @@ __device__ __attribute__((noinline)) void deep_bn_bwd(const DeepOp& op, unsigned
     const bool live = item < total;
     const int cgi = live ? item % CG : 0, rb = live ? item / CG : 0;
     const int c = cgi * 32 + cl;
-    double acc2[2][8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc2[0][j] = acc2[1][j] = 0.0;
     for (int g = 0; g < G; ++g) {
       const int lo = g * per, hi = lo + per < nblk ? lo + per : nblk;
       double a = 0.0, b = 0.0;
       if (live) {
-#pragma unroll 4
-        for (int k = lo + pl; k < hi; k += 8) {
-          a += part[(int64_t)k * 2 * C + c];
-          b += part[(int64_t)k * 2 * C + C + c];
+        for (int k0 = lo + pl; k0 < hi; k0 += 8 * 16) {      // sixteen loads in flight, added in ascending order
+          float af[16], bf[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int k = k0 + 8 * u;
+            const int kk = k < hi ? k : lo;
+            af[u] = part[(int64_t)kk * 2 * C + c];
+            bf[u] = part[(int64_t)kk * 2 * C + C + c];
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (k0 + 8 * u < hi) {
+              a += af[u];
+              b += bf[u];
+            }
         }
       }
       __syncthreads();
@@ -407,27 +534,33 @@ __device__ __attribute__((noinline)) void deep_bn_bwd(const DeepOp& op, unsigned
           A += red[0][j][cl];
           B += red[1][j][cl];
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (j == (g & 7)) {
-            acc2[0][j] += A;
-            acc2[1][j] += B;
-          }
+        chunkS[(0 * DEEP_BN_CHUNKS + g) * 32 + cl] = A;
+        chunkS[(1 * DEEP_BN_CHUNKS + g) * 32 + cl] = B;
       }
     }
-    if (pl == 0) {
-      double A, B;
-      if (G == 1) {
-        A = acc2[0][0];
-        B = acc2[1][0];
-      } else {
-        A = B = 0.0;
+    double A = 0.0, B = 0.0;
+    if (G > 1) {
+      __syncthreads();
+      double a2 = 0.0, b2 = 0.0;
+      for (int g = pl; g < G; g += 8) {
+        a2 += chunkS[(0 * DEEP_BN_CHUNKS + g) * 32 + cl];
+        b2 += chunkS[(1 * DEEP_BN_CHUNKS + g) * 32 + cl];
+      }
+      red[0][pl][cl] = a2;
+      red[1][pl][cl] = b2;
+      __syncthreads();
+      if (pl == 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          A += acc2[0][j];
-          B += acc2[1][j];
+          A += red[0][j][cl];
+          B += red[1][j][cl];
         }
       }
+    } else if (pl == 0) {
+      A = chunkS[(0 * DEEP_BN_CHUNKS + 0) * 32 + cl];
+      B = chunkS[(1 * DEEP_BN_CHUNKS + 0) * 32 + cl];
+    }
+    if (pl == 0) {
       const float db = (float)A, dg = (float)B;
       if (live && rb == 0) {
         dbeta[c] = db;
@@ -490,7 +623,7 @@ __device__ __attribute__((noinline)) void deep_bn_bwd(const DeepOp& op, unsigned
 }
 
 // out[r] = [a[r] | b[r]]  /  a[r], b[r] = halves of in[r]   (float4 granules)
-__device__ __attribute__((noinline)) void deep_cat(const DeepOp& op, bool split) {
+__device__ __forceinline__ void deep_cat(const DeepOp& op, bool split) {
   const int Ca4 = op.Cin / 4, C4 = (op.Cin + op.Cout) / 4;
   const int64_t total = op.M_in * C4;
   const float* a = (const float*)op.p[0];
@@ -515,6 +648,31 @@ __global__ __launch_bounds__(DEEP_THREADS) void deep_run_kernel(const DeepOp* __
   if (threadIdx.x < DEEP_LDS_CTRL / 4) reinterpret_cast<unsigned*>(lds)[threadIdx.x] = 0u;
   __syncthreads();
   unsigned sub_epoch = 0u;           // arrivals so far at this wave's sub-group counter (all sub-group sizes share it)
+  // fence bit 2: the XCC-aware barrier.  Member counts of the XCCs first (one flat barrier per launch)
+  XccState xs{0u, 1u, 1u};
+  if (fence & 4) {
+    xs.xcc = deep_xcc_id();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&sync->members[xs.xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    deep_grid_barrier(sync, 1u, 0);
+    unsigned mine = 0u, any = 0u;
+    if (threadIdx.x < 64) {
+      const unsigned m = threadIdx.x < 8 ? ld_u32_sc1(&sync->members[threadIdx.x]) : 0u;
+      any = (unsigned)__builtin_popcountll(__ballot(m != 0u));
+      mine = __shfl(m, (int)xs.xcc, 64);
+    }
+    xs.members = __builtin_amdgcn_readfirstlane(mine);
+    xs.nxcc = __builtin_amdgcn_readfirstlane(any);
+    // (threads of the other waves: through LDS)
+    unsigned* xw = reinterpret_cast<unsigned*>(lds) + 32;
+    if (threadIdx.x == 0) {
+      xw[0] = xs.members;
+      xw[1] = xs.nxcc;
+    }
+    __syncthreads();
+    xs.members = xw[0];
+    xs.nxcc = xw[1];
+    __syncthreads();
+  }
   if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = __builtin_amdgcn_s_memrealtime();
   for (int i = 0; i < n; ++i) {
     const DeepOp& op = ops[i];
@@ -529,9 +687,7 @@ __global__ __launch_bounds__(DEEP_THREADS) void deep_run_kernel(const DeepOp* __
           __syncthreads();
           sub_epoch = 0u;
           if (op.NW == 8) deep_conv<8>(op, lds, &sub_epoch);
-          else if (op.NW == 4) deep_conv<4>(op, lds, &sub_epoch);
-          else if (op.NW == 2) deep_conv<2>(op, lds, &sub_epoch);
-          else deep_conv<1>(op, lds, &sub_epoch);
+          else deep_conv<4>(op, lds, &sub_epoch);
         }
         break;
       case DK_REDUCE: deep_reduce(op, lds); break;
@@ -541,7 +697,12 @@ __global__ __launch_bounds__(DEEP_THREADS) void deep_run_kernel(const DeepOp* __
       case DK_SPLIT: deep_cat(op, true); break;
       default: break;
     }
-    if (i + 1 < n) deep_grid_barrier(sync, (unsigned)(i + 1), fence);
+    if (i + 1 < n) {
+      if (fence & 4)
+        deep_xcc_barrier(sync, (unsigned)(i + 1), xs);
+      else
+        deep_grid_barrier(sync, (unsigned)(i + 1), fence);
+    }
     if (stamps && op.stamp >= 0 && blockIdx.x == 0 && threadIdx.x == 0) {
       // (the last phase: its stores are complete when this workgroup's are -- a lower bound by at most one item)
       if (i + 1 == n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -556,9 +717,12 @@ __global__ __launch_bounds__(DEEP_THREADS) void deep_run_kernel(const DeepOp* __
 // host side: called by the executor (csrc/executor.hip) with a run of ops it found eligible
 namespace wsis {
 
+// default OFF: measured on the C2 scene the resident launches take 1.41 + 1.45 ms against ~2.45 ms of the same ops launch by
+// launch (kernels + boundaries) -- every phase, however small, costs a cold load, a write-through store and the barrier
+// (~7 us), where a launch boundary costs ~1.7 us on top of the same latencies
 bool deep_enabled() {
   const char* e = getenv("WSIS_DEEP");
-  return e ? atoi(e) != 0 : true;
+  return e ? atoi(e) != 0 : false;
 }
 
 int64_t deep_max_rows() {      // (read per call: a test raises it to put a whole small network into one launch)
@@ -566,14 +730,21 @@ int64_t deep_max_rows() {      // (read per call: a test raises it to put a whol
   return e ? (int64_t)atoll(e) : (int64_t)8192;
 }
 
+// BatchNorm phases finish the statistics in at most DEEP_BN_CHUNKS chunks (LDS)
+bool deep_bn_rows_ok(int64_t M) { return M >= 1 && bn_fin_chunks((M + 31) / 32) <= DEEP_BN_CHUNKS; }
+
 // launch plan of a product inside the resident kernel = the plan of the one-shot kernel (same order of additions)
 bool deep_conv_plan(int64_t M_out, int K, int Cin, int Cout, int* NW, int* ZS) {
   if (M_out < 1 || K < 1 || K > KMAX || Cin < 32 || Cin % 32 || Cout < 32 || Cout % 32) return false;
   const Plan2 p = plan2(M_out, K, Cin, Cout);
   if (p.NB != 1 || p.DA != 2 || !p.BD) return false;
-  if (p.NW != 1 && p.NW != 2 && p.NW != 4 && p.NW != 8 && p.NW != 16) return false;
-  *NW = p.NW;
   *ZS = p.ZS;
+  if (K == 1) {      // one offset: wave 0 of the work item does all the steps whatever NW is (the others add zeros)
+    *NW = 4;
+    return p.ZS == 1;
+  }
+  if (p.NW != 4 && p.NW != 8 && p.NW != 16) return false;      // (1 and 2 waves per work item: > 1024 work items)
+  *NW = p.NW;
   return true;
 }
 
@@ -628,7 +799,7 @@ int deep_launch(const DeepOp* h_ops, int n, void* d_table, void* d_sync, unsigne
   static int fence = -1;
   if (fence < 0) {
     const char* e = getenv("WSIS_DEEP_FENCE");
-    fence = e ? atoi(e) : 1;
+    fence = e ? atoi(e) : 0;
   }
   hipLaunchKernelGGL(deep_run_kernel, dim3((unsigned)cus), dim3(DEEP_THREADS), DEEP_LDS_BYTES, st,
                      static_cast<const DeepOp*>(d_table), n, static_cast<DeepSync*>(d_sync), fence, d_stamps);

@@ -349,7 +349,7 @@ bool deep_op_ok(const wsis_op* ops, int n, int i, bool fwd2_on) {
       return aligned16(op.in[2]) && aligned16(op.out[0]);
     }
     case WSIS_OP_BN_RELU:
-      if (op.M_in < 1 || op.M_in > R || op.Cin % 32) return false;
+      if (op.M_in < 1 || op.M_in > R || op.Cin % 32 || !deep_bn_rows_ok(op.M_in)) return false;
       if (op.flags & WSIS_OPF_TRAINING) {
         if (!(op.flags & WSIS_OPF_STATS) || !op.in[5]) return false;
         if (op.in[6] && (op.K % 32 || op.K <= 0 || op.K >= op.Cin)) return false;
@@ -358,7 +358,7 @@ bool deep_op_ok(const wsis_op* ops, int n, int i, bool fwd2_on) {
       }
       return aligned16(op.in[0]) && (!op.out[0] || aligned16(op.out[0]));
     case WSIS_OP_BN_RELU_BWD:
-      if (op.M_in < 1 || op.M_in > R || op.Cin % 32) return false;
+      if (op.M_in < 1 || op.M_in > R || op.Cin % 32 || !deep_bn_rows_ok(op.M_in)) return false;
       if (!(op.flags & WSIS_OPF_TRAINING) || !(op.flags & WSIS_OPF_STATS) || !op.in[7]) return false;
       return aligned16(op.in[0]) && aligned16(op.in[1]) && aligned16(op.out[0]) && (!op.in[6] || aligned16(op.in[6]));
     case WSIS_OP_CAT:
@@ -399,6 +399,8 @@ int deep_run_end(const wsis_op* ops, int n, int i0, int stop, bool fwd2_on) {
 }
 
 constexpr int kDeepMinOps = 4;          // shorter runs stay ordinary launches
+// the phases and stamps of the profiled resident launches since profiling was switched on (tools/deep_phases.py)
+std::vector<std::pair<std::vector<DeepOp>, const unsigned long long*>> g_deep_log;
 inline int64_t deep_table_bytes(int n_ops) { return up((int64_t)(2 * n_ops + 2) * (int64_t)sizeof(DeepOp)); }
 
 // slab workspace of the phases of ops [i0, i1) (every phase its own region: written once inside the launch)
@@ -826,6 +828,10 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
         }
         if (rc == WSIS_OK)
           rc = deep_launch(deep_tab.data(), (int)deep_tab.size(), deep_ws, deep_sync_slot(d_sync), d_stamps, st);
+        if (rc == WSIS_OK && d_stamps) {
+          if (g_deep_log.size() > 64) g_deep_log.clear();
+          g_deep_log.push_back({deep_tab, d_stamps});
+        }
         if (rc == WSIS_OK && d_stamps)
           for (const auto& cs : deep_convs) {
             ProfRec r{};
@@ -1093,6 +1099,32 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
       return fail(WSIS_ERR_HIP, "side-stream join failed: %s", hipGetErrorString(e2));
   }
   return first_err;
+}
+
+// diagnostic (not part of the ABI header): phases of profiled resident launch `which` (0 = first since profiling was
+// switched on): kind, NW, ZS, rows, Cin, Cout, K and the time from the end of the previous phase to the end of this one
+// (grid barrier included) in microseconds; returns the number of phases (or -1)
+int wsis_debug_deep_phases(int32_t which, int32_t* info, double* us, int32_t cap) {
+  if (which < 0 || which >= (int)g_deep_log.size()) return -1;
+  const auto& rec = g_deep_log[which];
+  const int n = (int)rec.first.size();
+  if (n > cap) return -1;
+  std::vector<unsigned long long> t(n + 1);
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(t.data(), rec.second, (n + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  for (int i = 0; i < n; ++i) {
+    const DeepOp& d = rec.first[i];
+    info[i * 8 + 0] = d.kind;
+    info[i * 8 + 1] = d.NW;
+    info[i * 8 + 2] = d.ZS;
+    info[i * 8 + 3] = (int32_t)(d.kind == DK_CONV || d.kind == DK_REDUCE ? d.M_out : d.M_in);
+    info[i * 8 + 4] = d.Cin;
+    info[i * 8 + 5] = d.Cout;
+    info[i * 8 + 6] = d.K;
+    info[i * 8 + 7] = (int32_t)d.M_in;
+    us[i] = (double)(t[i + 1] - t[i]) * 0.01;
+  }
+  return n;
 }
 
 }  // extern "C"

@@ -30,9 +30,10 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
     unsigned long long* __restrict__ dbg = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   WgSync sync;
-  fwd2_body<NB, NW, DA, BD, DIAG, FB, false>(X, nbrS, order, WT, bias, residual, out, partial, M_out, K, Cin, Cout, flip_deal,
-                                            x_bytes, stats, epi, bin, fin, dbg, (int)blockIdx.x, (int)blockIdx.y,
-                                            (int)blockIdx.z, (int)gridDim.y, (int)gridDim.z, lds, (int)threadIdx.x, sync);
+  const LateVals late{bias, residual, out, partial, stats, epi};
+  fwd2_body<NB, NW, DA, BD, DIAG, FB, false>(X, nbrS, order, WT, late, M_out, K, Cin, Cout, flip_deal, x_bytes, bin, fin, dbg,
+                                            (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.y,
+                                            (int)gridDim.z, lds, (int)threadIdx.x, sync);
 }
 
 // out = sum_z partial[z] (+ bias, + residual)

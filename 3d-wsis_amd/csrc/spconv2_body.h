@@ -231,12 +231,30 @@ struct WgSync {
 // `sync`.  spconv_fwd2_kernel runs it once per workgroup; the resident deep-level kernel (deep.hip) runs it in a loop,
 // several work items of one workgroup side by side.  WT: every store another workgroup of the SAME launch reads later
 // (output rows, statistics partials) is write-through (sc1) -- the hand-off form of cdna_hip_programming.md Guideline 16.
-template <int NB, int NW, int DA, bool BD, bool DIAG, bool FB, bool WT, typename Sync>
+// The operands only the epilogue needs (bias, residual, output, slab workspace, statistics partials, the BatchNorm of the
+// backward reduction) come through `late`, asked for where the epilogue starts: as kernel arguments (LateVals) the
+// compiler re-loads them from the kernarg segment at will; as fields of a phase record in memory (deep.hip) they would
+// otherwise sit in ~24 scalar registers through the whole walk, and the resident kernel runs at the 102-SGPR limit.
+struct LateVals {
+  const float* bias_;
+  const float* residual_;
+  float* out_;
+  float* partial_;
+  float* stats_;
+  BnEpi epi_;
+  __device__ __forceinline__ const float* bias() const { return bias_; }
+  __device__ __forceinline__ const float* residual() const { return residual_; }
+  __device__ __forceinline__ float* out() const { return out_; }
+  __device__ __forceinline__ float* partial() const { return partial_; }
+  __device__ __forceinline__ float* stats() const { return stats_; }
+  __device__ __forceinline__ BnEpi epi() const { return epi_; }
+};
+
+template <int NB, int NW, int DA, bool BD, bool DIAG, bool FB, bool WT, typename Sync, typename Late>
 __device__ __forceinline__ void fwd2_body(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
-    const float* __restrict__ WTp, const float* __restrict__ bias, const float* __restrict__ residual,
-    float* __restrict__ out, float* __restrict__ partial, int64_t M_out, int K, int Cin, int Cout, int flip_deal,
-    uint32_t x_bytes, float* __restrict__ stats, const BnEpi& epi, const BnIn& bin, const StatFin& fin,
+    const float* __restrict__ WTp, const Late& late, int64_t M_out, int K, int Cin, int Cout, int flip_deal,
+    uint32_t x_bytes, const BnIn& bin, const StatFin& fin,
     unsigned long long* __restrict__ dbg, const int bx, const int by, const int bz, const int gy, const int gz,
     unsigned char* const lds, const int tid, Sync& sync) {
   static_assert(!FB || (BD && NB == 1), "the fused input BatchNorm is built for the weights-to-registers form");
@@ -682,8 +700,12 @@ __device__ __forceinline__ void fwd2_body(
   if (DIAG) d_t2 = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue.  C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * half
+  const float* bias = late.bias();
+  const float* residual = late.residual();
+  float* const stats = late.stats();
+  const BnEpi epi = late.epi();
   const bool final_pass = gz == 1;
-  float* const dst = final_pass ? out : partial + (int64_t)bz * M_out * Cout;
+  float* const dst = final_pass ? late.out() : late.partial() + (int64_t)bz * M_out * Cout;
   if (!final_pass) {
     bias = nullptr;
     residual = nullptr;

@@ -89,15 +89,15 @@ def test_resident_kernel_with_a_batch_of_scenes_and_whole_network_below_the_limi
     the whole UNet but its 6-channel input conv is ONE launch per pass"""
     cfg = harness.default_cfg()
     cfg.batch_size = 2
-    batch_host = harness.collate([harness.make_scene(41, room=(1.2, 1.0, 0.8), n_box=1),
-                                  harness.make_scene(42, room=(1.0, 1.1, 0.9), n_box=2)])
-    assert batch_host["voxel_locs"].shape[0] < 65536
+    batch_host = harness.collate([harness.make_scene(41, room=(1.0, 0.9, 0.7), n_box=1),
+                                  harness.make_scene(42, room=(0.9, 1.0, 0.8), n_box=2)])
+    assert batch_host["voxel_locs"].shape[0] < 34000          # (BatchNorm phases: at most 16 chunks of 64 slices)
     monkeypatch.setenv("WSIS_DEEP_ROWS", "65536")
     lib = wsis_native.hip()
     l0, g0, s0, y0 = _one_pass(monkeypatch, False, batch_host, cfg)
     p0 = lib.wsis_deep_phases()
     l1, g1, s1, y1 = _one_pass(monkeypatch, True, batch_host, cfg)
-    assert lib.wsis_deep_phases() - p0 > 250                  # 97 of the 98 ops each way + the slab sums
+    assert lib.wsis_deep_phases() - p0 > 150                  # everything but the level-0 convolutions (1 or 2 waves per item)
     assert torch.equal(y0, y1) and l0 == l1
     assert [n for n in g0 if not torch.equal(g0[n], g1[n])] == []
     assert [n for n in s0 if not torch.equal(s0[n], s1[n])] == []

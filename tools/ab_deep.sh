@@ -8,7 +8,7 @@ for rep in 1 2; do
 import json,sys
 l=[x for x in sys.stdin.read().split('\n') if x.startswith('{')][-1]
 d=json.loads(l); r=d['roofline']
-print('DEEP=$d rep$rep', 'ms/step', d['ms_per_step'], 'scenes/s', d['value'], 'frac', r['frac'], 'avg_us', r.get('avg_launch_us'), 'per_level', [(p['level'], p['us_per_step'], p['frac']) for p in r.get('per_level', [])])
+print('DEEP=$d rep$rep', 'ms/step', d['ms_per_step'], 'scenes/s', d['value'], 'frac', r['frac'], 'avg_us', r.get('avg_launch_us'), 'per_level', [(p['level'], p['us'], p['frac']) for p in r.get('per_level', [])])
 "
   done
 done
