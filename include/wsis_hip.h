@@ -220,8 +220,7 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
  *                                            slice K-1-k), 0 for the coupled strided / inverse tables
  * with NW = 1 bit-identical to wsis_spconv_fwd; small levels split the offsets over the waves of a workgroup (added
  * through LDS in wave order) and, below that, over blockIdx.z into partial slabs in d_ws (fixed order).  d_sync: a
- * sync slot (wsis_sync_bytes; may be NULL): with one, slab-split launches run as the persistent kernel whose
- * workgroups draw their slices from a counter in the slot -- the same results bit for bit. */
+ * sync slot (wsis_sync_bytes; may be NULL; reserved for in-launch reductions: wsis_spconv_fwd_f). */
 int32_t wsis_spconv_fwd_t_supported(int32_t K, int32_t Cin, int32_t Cout);
 /* number of offset slabs the launch plan of wsis_spconv_fwd_t uses for this shape (1 = one kernel, no second pass) */
 int32_t wsis_spconv_fwd_t_slabs(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout);
@@ -314,7 +313,10 @@ int wsis_prof_records(int32_t which, double* h_main_ms, double* h_total_ms, int6
  * caller zero-fills ONCE (e.g. torch.zeros); every launch leaves its slot zero again, so consecutive launches on one
  * stream may share a slot, launches that may overlap on different streams need different slots.  d_sync == NULL selects
  * the multi-launch form of the operator.  wsis_run_ops takes a block of wsis_sync_bytes() bytes (64 slots, one per op
- * index modulo 64).  A wait that does not see its producers within 2 s sets word 19 of the slot (nothing hangs). */
+ * index modulo 64, + one slot for the barrier words of the resident deep-level launches, which the library itself
+ * zeroes in front of every such launch).  A wait that does not see its producers within 2 s sets word 19 of the slot
+ * (nothing hangs).  One process drives one GPU: the launch plans cache device properties (CU count, LDS
+ * limits) of the first device they ran on. */
 int64_t wsis_sync_bytes(void);
 
 /* ---- a12: BatchNorm1d(+ReLU) over the active voxels  sparse_unet3d.py:128-137, backbone_3D_WSIS.py:47,52-55 ---

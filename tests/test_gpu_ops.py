@@ -1294,7 +1294,7 @@ def test_bn_finalize_apply_in_one_launch_equals_the_two_calls(M, C, monkeypatch)
             assert torch.equal(a, b)
     want = torch.relu(torch.nn.functional.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-4))
     assert torch.allclose(ref[4], want, rtol=1e-4, atol=1e-4)
-    assert not _n.sync_block().any(), "every launch must leave its sync slot zero"
+    assert not _n.sync_block()[:64 * 4096].any(), "every launch must leave its sync slot zero"
     assert _n.sync_errors() == []
 
 
