@@ -270,6 +270,129 @@ def collate_device(scenes, device, mode=4, n_levels=5):
     return to_device(host, device)
 
 
+# ---- packed scenes: the loader's per-sample output as ONE pinned buffer, the batch assembled on the device -------------
+_PACK_FIELDS = (("xyz", np.float32, 3), ("rgb", np.float32, 3), ("sem_label", np.int64, 0), ("ins_label", np.int64, 0),
+                ("superpoint", np.int64, 0), ("sp_sem", np.int64, 0), ("sp_ins", np.int64, 0), ("sp_offset", np.float32, 3),
+                ("sp_voxnum", np.float32, 0), ("sp_size", np.float32, 0), ("edges", np.int64, 2), ("edge_feats", np.float32, 13),
+                ("vmin", np.int64, 0))
+
+
+def pack_scene(sc, pin=True):
+    """What a loader worker hands over per sample (the output of ``__getitem__``, scannetv2_dataset.py:96-190): every
+    per-scene array in its final dtype, back to back in ONE (pinned) buffer, plus the few numbers the host needs to lay
+    out the batch without looking at the data again -- point / superpoint / edge / instance counts, the voxel extent
+    (floor is monotonic: the extent of floor(xyz * 50) follows from xyz.min / xyz.max alone), the largest edge source and
+    the instance-slot bound.  ``collate_packed`` ships the buffer with one H2D copy and does the concatenations, label
+    offsets, edge sort, voxel hash and level counts on the device."""
+    xyz = np.ascontiguousarray(sc["xyz"], dtype=np.float32)
+    lo = np.floor(xyz.min(0).astype(np.float64) * SCALE).astype(np.int64)
+    hi = np.floor(xyz.max(0).astype(np.float64) * SCALE).astype(np.int64)
+    arrays = dict(sc, xyz=xyz, vmin=lo)
+    layout, off = {}, 0
+    parts = []
+    for name, dt, width in _PACK_FIELDS:
+        a = np.ascontiguousarray(arrays[name], dtype=dt)
+        layout[name] = (off, a.shape, dt)
+        parts.append((off, a))
+        off = (off + a.nbytes + 15) // 16 * 16
+    buf = torch.empty(off, dtype=torch.uint8, pin_memory=bool(pin and torch.cuda.is_available()))
+    view = buf.numpy()
+    for o, a in parts:
+        view[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
+    sp_ins, E = sc["sp_ins"], sc["edges"]
+    return {"buf": buf, "layout": layout, "N": int(xyz.shape[0]), "S": int(sc["S"]), "E": int(E.shape[0]),
+            "n_inst": int(sc["n_inst"]), "extent": (hi - lo + 1), "edge_src_max": int(E[:, 0].max()) if len(E) else -1,
+            "slots": max(int(sp_ins.max()) + 1, 1) if len(sp_ins) else 1}
+
+
+_TORCH_DT = {np.float32: torch.float32, np.int64: torch.int64}
+
+
+def collate_packed(packs, device, mode=4, n_levels=5):
+    """Batch of packed scenes (``pack_scene``) assembled ON THE DEVICE: per scene one H2D copy of its pinned buffer; the
+    concatenations, batch / superpoint / instance offsets (scannetv2_dataset.py:383-396), the target-sorted edge order of
+    the ECC graph (ecc/GraphConvInfo.py:54), voxel hash and pyramid counts all run there.  The host thread only lays out
+    the batch from the packs' counts (a few dozen Python statements per scene).  Returns what
+    ``to_device(collate(scenes))`` returns."""
+    import pointgroup_ops
+    import spconv
+    from graphnet import GraphConvInfo
+    dev = torch.device(device)
+    cols = {k: [] for k in ("locs", "locs_float", "feats", "sem", "ins", "sps", "sp_sem", "sp_ins", "sp_off", "sp_vox",
+                            "sp_size", "edge_sorted", "edge_feats_sorted", "edges_ext")}
+    batch_offsets, sp_batch_offsets = [0], [0]
+    sp_bias, inst_bias = 0, 0
+    extent = np.zeros(3, dtype=np.int64)
+    edge_src_rows, slots = 0, []
+    for b, pk in enumerate(packs):
+        d = pk["buf"].to(dev, non_blocking=True)
+
+        def f(name):
+            off, shape, dt = pk["layout"][name]
+            n = int(np.prod(shape)) * np.dtype(dt).itemsize
+            return d[off:off + n].view(_TORCH_DT[dt]).view(shape)
+        xyz = f("xyz")
+        v = torch.floor(xyz.double() * SCALE).long() - f("vmin")
+        cols["locs"].append(torch.cat([torch.full((pk["N"], 1), b, dtype=torch.int64, device=dev), v], 1))
+        cols["locs_float"].append(xyz)
+        cols["feats"].append(f("rgb"))
+        cols["sem"].append(f("sem_label"))
+        il, si = f("ins_label"), f("sp_ins")
+        cols["ins"].append(torch.where(il != -100, il + inst_bias, il) if inst_bias else il)
+        cols["sp_ins"].append(torch.where(si != -100, si + inst_bias, si) if inst_bias else si)
+        cols["sps"].append(f("superpoint") + sp_bias if sp_bias else f("superpoint"))
+        cols["sp_sem"].append(f("sp_sem"))
+        cols["sp_off"].append(f("sp_offset"))
+        cols["sp_vox"].append(f("sp_voxnum"))
+        cols["sp_size"].append(f("sp_size"))
+        E = f("edges")
+        order = torch.argsort(E[:, 1], stable=True)
+        Eb = E + sp_bias if sp_bias else E
+        cols["edge_sorted"].append(Eb[order])
+        cols["edge_feats_sorted"].append(f("edge_feats")[order])
+        cols["edges_ext"].append(Eb)
+        if pk["edge_src_max"] >= 0:
+            edge_src_rows = max(edge_src_rows, pk["edge_src_max"] + sp_bias + 1)
+        slots.append(pk["slots"])
+        extent = np.maximum(extent, pk["extent"])
+        sp_bias += pk["S"]
+        inst_bias += pk["n_inst"]
+        batch_offsets.append(batch_offsets[-1] + pk["N"])
+        sp_batch_offsets.append(sp_bias)
+
+    def cat(k):
+        return cols[k][0] if len(cols[k]) == 1 else torch.cat(cols[k], 0)
+    locs = cat("locs").contiguous()
+    edges = cat("edges_ext")
+    out = {
+        "locs": locs, "locs_float": cat("locs_float").contiguous(), "feats": cat("feats").contiguous(),
+        "semantic_labels": cat("sem").contiguous(), "instance_labels": cat("ins").contiguous(),
+        "offsets": torch.tensor(batch_offsets, dtype=torch.int32),
+        "spatial_shape": np.clip(extent, FULL_SCALE_MIN, None),
+        "superpoint": cat("sps").contiguous(),
+        "GIs": [GraphConvInfo(cat("edge_sorted").t().contiguous(), cat("edge_feats_sorted").contiguous(), sp_bias)],
+        "sp_batch_offsets": torch.tensor(sp_batch_offsets, dtype=torch.int32),
+        "edge_u_list": edges[:, 0].contiguous(), "edge_v_list": edges[:, 1].contiguous(),
+        "edge_src_rows": edge_src_rows,
+        "superpoint_semantic_labels": cat("sp_sem").contiguous(), "superpoint_instance_labels": cat("sp_ins").contiguous(),
+        "superpoint_offset_vector": cat("sp_off").contiguous(),
+        "superpoint_instance_voxel_num": torch.log(cat("sp_vox")),
+        "superpoint_instance_size": cat("sp_size").contiguous(),
+        "scene_list": [f"synthetic_{i}" for i in range(len(packs))],
+        "sp_instance_slots": slots,
+    }
+    voxel_locs, p2v_map, v2p_map = pointgroup_ops.voxelization_idx(locs, len(packs), mode)
+    counts = spconv.ops.level_voxel_counts_device(voxel_locs, out["spatial_shape"], n_levels)
+    out.update(voxel_locs=voxel_locs, p2v_map=p2v_map, v2p_map=v2p_map)
+    out["level_counts"] = [int(c) for c in counts.tolist()]
+    out["voxel_coords_int"] = voxel_locs.int().contiguous()
+    ev = torch.cuda.Event()
+    ev.record()
+    out["coords_ready_event"] = ev
+    build_batch_graphs(out)
+    return out
+
+
 _DEVICE_KEYS = ("voxel_locs", "p2v_map", "v2p_map", "locs_float", "feats", "semantic_labels", "instance_labels",
                 "superpoint", "edge_u_list", "edge_v_list", "superpoint_semantic_labels",
                 "superpoint_instance_labels", "superpoint_offset_vector", "superpoint_instance_voxel_num",

@@ -282,12 +282,35 @@ def side_measurements(harness, optimizer, device, args):
     ms_host_collate = _wall(lambda: harness.collate([sc]))
     ms_host_total = _wall(lambda: harness.to_device(harness.collate([sc]), device))
     ms_dev_total = _wall(lambda: harness.collate_device([sc], device))
+    pk = harness.pack_scene(sc)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        harness.pack_scene(sc)
+    ms_pack = (time.perf_counter() - t0) / 5 * 1e3
+    ms_packed = _wall(lambda: harness.collate_packed([pk], device))
+
+    def _host_only(fn, n=5):          # time the calling thread spends before it could start on the next batch
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        dt = (time.perf_counter() - t0) / n * 1e3
+        torch.cuda.synchronize()
+        return dt
+    ms_packed_host = _host_only(lambda: harness.collate_packed([pk], device))
     out["batch_assembly"] = {"workload": "one C2 scene: collate (+ H2D, per-batch CSRs) by one host thread vs on the device",
                              "host_collate_ms_per_scene": round(ms_host_collate, 2),
                              "host_collate_plus_to_device_ms_per_scene": round(ms_host_total, 2),
-                             "device_collate_ms_per_scene": round(ms_dev_total, 2),
+                             "device_collate_ms_per_scene": round(ms_packed, 2),
+                             "device_collate_unpacked_ms_per_scene": round(ms_dev_total, 2),
+                             "pack_scene_ms": round(ms_pack, 2),
+                             "packed_collate_host_thread_ms_per_scene": round(ms_packed_host, 2),
+                             "packed": "pack_scene: the per-sample arrays in one pinned buffer (a loader worker's output); "
+                                       "collate_packed: one H2D per scene, concatenation / offsets / edge sort / voxel hash / "
+                                       "level counts / CSRs on the device, device drained; host_thread: without the drain",
                              "scenes_per_s_one_host_thread": round(1e3 / ms_host_total, 1),
-                             "scenes_per_s_device_collate": round(1e3 / ms_dev_total, 1)}
+                             "scenes_per_s_device_collate": round(1e3 / ms_packed, 1)}
     out["propagation_stage"] = propagation_stage(harness, sc, device, args)
     out["cluster_stage"] = {"workload": "C3: 4 synthetic scenes, non floor/wall points, r=0.03 m, threshold 50",
                             "points": int(coords.shape[0]), "neighbour_pairs": int(idx_c.numel()),

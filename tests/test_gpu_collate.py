@@ -31,6 +31,43 @@ def test_device_collate_equals_host_collate(seeds, room):
     assert [int(v) for v in got] == want
 
 
+@pytest.mark.parametrize("seeds,room", [((3,), (2.2, 1.8, 1.4)), ((4, 5, 6), (1.4, 1.2, 1.0))])
+def test_packed_collate_equals_host_collate(seeds, room):
+    """``pack_scene`` (one pinned buffer per sample) + ``collate_packed`` (one H2D per scene, everything else on the
+    device): every tensor of the batch, the ECC graph and the host-side numbers equal ``to_device(collate(scenes))``"""
+    scenes = [harness.bench_scene(s, room=room, n_box=2) for s in seeds]
+    host = harness.to_device(harness.collate(scenes), DEV)
+    dev = harness.collate_packed([harness.pack_scene(sc) for sc in scenes], DEV)
+    torch.cuda.synchronize()
+    for k in ("voxel_locs", "p2v_map", "v2p_map", "voxel_coords_int", "locs_float", "feats", "superpoint",
+              "edge_u_list", "edge_v_list", "semantic_labels", "instance_labels", "superpoint_semantic_labels",
+              "superpoint_instance_labels", "superpoint_offset_vector", "superpoint_instance_voxel_num",
+              "superpoint_instance_size"):
+        assert dev[k].is_cuda and dev[k].dtype == host[k].dtype and torch.equal(dev[k], host[k]), k
+    for k in ("offsets", "sp_batch_offsets"):
+        assert torch.equal(dev[k].cpu(), host[k].cpu()), k
+    assert list(dev["level_counts"]) == list(host["level_counts"])
+    assert np.array_equal(dev["spatial_shape"], host["spatial_shape"])
+    assert dev["sp_instance_slots"] == host["sp_instance_slots"] and dev["edge_src_rows"] == host["edge_src_rows"]
+    gd, gh = dev["GIs"][0], host["GIs"][0]
+    assert gd.num_nodes == gh.num_nodes and torch.equal(gd.get_pyg_buffers(), gh.get_pyg_buffers())
+    assert torch.equal(gd.get_buffers(), gh.get_buffers())
+    for k in ("superpoint_csr", "p2v_csr"):
+        assert torch.equal(dev[k].perm, host[k].perm) and torch.equal(dev[k].offsets, host[k].offsets), k
+
+
+def test_a_step_on_the_packed_batch_gives_the_same_loss():
+    cfg = harness.default_cfg()
+    scenes = [harness.bench_scene(8, room=(2.0, 1.6, 1.2), n_box=2)]
+    losses = []
+    for make in (lambda: harness.to_device(harness.collate(scenes), DEV),
+                 lambda: harness.collate_packed([harness.pack_scene(sc) for sc in scenes], DEV)):
+        model, crit, opt = harness.build_model(cfg, DEV)
+        loss, _ = harness.train_step(model, crit, opt, make(), cfg)
+        losses.append(float(loss))
+    assert losses[0] == losses[1]
+
+
 def test_a_step_on_the_device_collated_batch_gives_the_same_loss():
     cfg = harness.default_cfg()
     scenes = [harness.bench_scene(8, room=(2.0, 1.6, 1.2), n_box=2)]
