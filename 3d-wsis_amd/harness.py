@@ -287,7 +287,10 @@ def pack_scene(sc, pin=True):
     xyz = np.ascontiguousarray(sc["xyz"], dtype=np.float32)
     lo = np.floor(xyz.min(0).astype(np.float64) * SCALE).astype(np.int64)
     hi = np.floor(xyz.max(0).astype(np.float64) * SCALE).astype(np.int64)
-    arrays = dict(sc, xyz=xyz, vmin=lo)
+    # (the log of the voxel counts on the HOST, as the reference's collate_fn takes it, scannetv2_dataset.py:438: the
+    # device's log differs in the last bit)
+    arrays = dict(sc, xyz=xyz, vmin=lo,
+                  sp_voxnum=torch.log(torch.from_numpy(np.ascontiguousarray(sc["sp_voxnum"], dtype=np.float32))).numpy())
     layout, off = {}, 0
     parts = []
     for name, dt, width in _PACK_FIELDS:
@@ -376,7 +379,7 @@ def collate_packed(packs, device, mode=4, n_levels=5):
         "edge_src_rows": edge_src_rows,
         "superpoint_semantic_labels": cat("sp_sem").contiguous(), "superpoint_instance_labels": cat("sp_ins").contiguous(),
         "superpoint_offset_vector": cat("sp_off").contiguous(),
-        "superpoint_instance_voxel_num": torch.log(cat("sp_vox")),
+        "superpoint_instance_voxel_num": cat("sp_vox").contiguous(),
         "superpoint_instance_size": cat("sp_size").contiguous(),
         "scene_list": [f"synthetic_{i}" for i in range(len(packs))],
         "sp_instance_slots": slots,

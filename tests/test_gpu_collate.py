@@ -43,7 +43,8 @@ def test_packed_collate_equals_host_collate(seeds, room):
               "edge_u_list", "edge_v_list", "semantic_labels", "instance_labels", "superpoint_semantic_labels",
               "superpoint_instance_labels", "superpoint_offset_vector", "superpoint_instance_voxel_num",
               "superpoint_instance_size"):
-        assert dev[k].is_cuda and dev[k].dtype == host[k].dtype and torch.equal(dev[k], host[k]), k
+        assert dev[k].is_cuda and dev[k].dtype == host[k].dtype, k
+        assert torch.equal(dev[k], host[k]), k
     for k in ("offsets", "sp_batch_offsets"):
         assert torch.equal(dev[k].cpu(), host[k].cpu()), k
     assert list(dev["level_counts"]) == list(host["level_counts"])
