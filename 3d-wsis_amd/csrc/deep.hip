@@ -230,7 +230,6 @@ __device__ __forceinline__ void deep_conv(const DeepOp& op, unsigned char* lds, 
   unsigned char* base = lds + DEEP_LDS_CTRL + sub * ITEM_BYTES;
   const LateOp late{&op};
   const BnIn bin{};
-  const StatFin fin{};
   const int nwg = (int)gridDim.x;
   if (NW == 16) {
     WgSync sync;
@@ -243,7 +242,7 @@ __device__ __forceinline__ void deep_conv(const DeepOp& op, unsigned char* lds, 
       asm volatile("" : "+v"(t2));
       fwd2_body<1, NW, 2, true, false, false, true>(
           (const float*)op.p[0], (const int32_t*)op.p[1], (const int32_t*)op.p[2], (const float*)op.p[3], late, op.M_out,
-          op.K, op.Cin, op.Cout, op.flip, op.x_bytes, bin, fin, nullptr, bx, r % gy, r / gy, gy, gz, base, t2, sync);
+          op.K, op.Cin, op.Cout, op.flip, op.x_bytes, bin, nullptr, nullptr, bx, r % gy, r / gy, gy, gz, base, t2, sync);
       sync();        // the next work item re-writes the header and the rings
     }
   } else {
@@ -259,7 +258,7 @@ __device__ __forceinline__ void deep_conv(const DeepOp& op, unsigned char* lds, 
       asm volatile("" : "+v"(t2));
       fwd2_body<1, NW, 2, true, false, false, true>(
           (const float*)op.p[0], (const int32_t*)op.p[1], (const int32_t*)op.p[2], (const float*)op.p[3], late, op.M_out,
-          op.K, op.Cin, op.Cout, op.flip, op.x_bytes, bin, fin, nullptr, bx, r % gy, r / gy, gy, gz, base, t2, sync);
+          op.K, op.Cin, op.Cout, op.flip, op.x_bytes, bin, nullptr, nullptr, bx, r % gy, r / gy, gy, gz, base, t2, sync);
       if (NW > 1) sync();
     }
     *sub_epoch = sync.target;

@@ -31,9 +31,59 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   WgSync sync;
   const LateVals late{bias, residual, out, partial, stats, epi};
-  fwd2_body<NB, NW, DA, BD, DIAG, FB, false>(X, nbrS, order, WT, late, M_out, K, Cin, Cout, flip_deal, x_bytes, bin, fin, dbg,
+  fwd2_body<NB, NW, DA, BD, DIAG, FB, false>(X, nbrS, order, WT, late, M_out, K, Cin, Cout, flip_deal, x_bytes, bin, &fin, dbg,
                                             (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.y,
                                             (int)gridDim.z, lds, (int)threadIdx.x, sync);
+}
+
+
+// ---- persistent form for launches of more than one round of work items (levels 0-1 of a scene: 4,803 one-wave items
+// over 3,072 resident waves are 1.56 rounds whose second round runs on 7 of the 12 wave slots of a CU).  gridDim.x
+// workgroups -- as many as are resident at once -- stay on the machine: each starts with work item blockIdx.x and then
+// draws further ones from a ticket counter; the tile order puts the heavy slices first, so the light tail fills the
+// gaps the heavy ones leave and every workgroup finishes at about the same time.  The ticket of the NEXT item is drawn
+// before the current one is computed (its round trip hides behind the item), the counters are sharded eight ways
+// (workgroup % 8; 128 bytes apart in the caller's sync slot) and reset by the last draw of the launch.  A work item is
+// computed by the same code whoever draws it: results bit-identical to spconv_fwd2_kernel.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void spconv_fwd2p_kernel(
+    const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
+    const float* __restrict__ WT, const float* __restrict__ bias, const float* __restrict__ residual,
+    float* __restrict__ out, int64_t M_out, int K, int Cin, int Cout, int flip_deal, uint32_t x_bytes,
+    float* __restrict__ stats, BnEpi epi, unsigned* __restrict__ q_ctr, int total, int gx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  WgSync sync;
+  const int W = (int)gridDim.x, shard = (int)blockIdx.x & 7;
+  const int gy = Cout / 32;
+  // items W + shard + 8 t, t = 0 .. n_sh - 1, are handed out by this shard's counter; every workgroup of the shard draws
+  // until its ticket is past them: n_sh + (workgroups of the shard) draws in all, the last one resets the counter
+  const unsigned n_sh = total > W + shard ? (unsigned)((total - W - shard + 7) / 8) : 0u;
+  const unsigned pullers = (unsigned)((W - shard + 7) / 8);
+  unsigned* const ctr = q_ctr + shard * 32;
+  volatile unsigned* const s_next = reinterpret_cast<volatile unsigned*>(lds + HDR_BYTES + NW * Layout<1, 2, true>::WAVE_BYTES);
+  int item = (int)blockIdx.x;
+  while (item < total) {
+    // (nothing of one work item is kept in registers for the next: see deep.hip)
+    asm volatile("" ::: "memory");
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    unsigned t = 0u;
+    if (tid == 0) t = atomicAdd(ctr, 1u);
+    const int bx = item % gx, by = item / gx;
+    const LateVals late{bias, residual, out, nullptr, stats, epi};      // (built per item: behind the clobber above it
+    const BnIn bin{};                                                   // would have to live in private memory)
+    fwd2_body<1, NW, 2, true, false, false, false>(X, nbrS, order, WT, late, M_out, K, Cin, Cout, flip_deal, x_bytes, bin,
+                                                  nullptr, nullptr, bx, by, 0, gy, 1, lds, tid, sync);
+    if (NW == 1) {
+      t = __builtin_amdgcn_readfirstlane(t);
+    } else {
+      if (tid == 0) *s_next = t;
+      sync();          // also: the next work item re-writes the header and the rings
+      t = *s_next;
+    }
+    if (tid == 0 && t == n_sh + pullers - 1u) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    item = t < n_sh ? W + shard + 8 * (int)t : total;
+  }
 }
 
 // out = sum_z partial[z] (+ bias, + residual)
@@ -188,6 +238,54 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
   // wave -- measured neutral on every level: not kept)
   const int flip_deal = (flip ? 1 : 0) | (((deal_env ? atoi(deal_env) : 0) != 0 && p.ZS == 1) ? 2 : 0);
   ProfScope prof(0, st, /*exact_events=*/true);
+  // persistent form (spconv_fwd2p_kernel): launches of more than one round of resident work items
+  {
+    const char* pe = getenv("WSIS_FWD2P");          // (read per call)
+    const int fwd2p = pe ? atoi(pe) : 1;
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      WSIS_HIP_CHECK(hipGetDevice(&dev));
+      WSIS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int64_t items = ceil_div(M_out, SL) * (Cout / 32);
+    if (fwd2p && !bn_in && n_targets == 0 && d_sync && p.NB == 1 && p.ZS == 1 && p.DA == 2 && p.BD &&
+        (p.NW == 1 || p.NW == 2 || p.NW == 4) && items < ((int64_t)1 << 30)) {
+      const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES * p.NW + 16;
+      int per_cu = (int)((size_t)160 * 1024 / ldsb);
+      const int wave_cap = 12 / p.NW > 0 ? 12 / p.NW : 1;      // 3 waves per SIMD: the occupancy the one-shot kernel runs at
+      if (per_cu > wave_cap) per_cu = wave_cap;
+      const int64_t resident = (int64_t)cus * per_cu;
+      const char* me = getenv("WSIS_FWD2P_MIN");      // rounds (x 100) from which the persistent form is taken
+      const int64_t min_pct = me ? atoi(me) : 110;
+      if (items * 100 >= resident * min_pct) {
+        unsigned* q = static_cast<SyncSlot*>(d_sync)->fin;
+        const int gx = (int)ceil_div(M_out, SL);
+#define WSIS_F2P(nw)                                                                                                   \
+  do {                                                                                                                 \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_fwd2p_kernel<nw>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)ldsb));                                                                  \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    hipExtLaunchKernelGGL((spconv_fwd2p_kernel<nw>), dim3((unsigned)resident), dim3(64 * nw), (uint32_t)ldsb, st,      \
+                          prof.ka(), prof.kb(), 0u, d_X, d_nbr, d_order, d_WT, d_bias, d_residual, d_out, M_out, K, Cin, \
+                          Cout, flip_deal, x_bytes, d_stats, epi, q, (int)items, gx);                                  \
+  } while (0)
+        if (p.NW == 1)
+          WSIS_F2P(1);
+        else if (p.NW == 2)
+          WSIS_F2P(2);
+        else
+          WSIS_F2P(4);
+#undef WSIS_F2P
+        prof.stop();
+        WSIS_LAUNCH_CHECK();
+        return WSIS_OK;
+      }
+    }
+  }
 #define WSIS_F2X(nb, nw, da, bd, fb)                                                                             \
   do {                                                                                                           \
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<nb, da, bd>::WAVE_BYTES * nw + (fb ? (size_t)Cin * 12 : 0); \

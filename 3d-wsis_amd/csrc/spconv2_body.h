@@ -253,8 +253,8 @@ struct LateVals {
 template <int NB, int NW, int DA, bool BD, bool DIAG, bool FB, bool WT, typename Sync, typename Late>
 __device__ __forceinline__ void fwd2_body(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
-    const float* __restrict__ WTp, const Late& late, int64_t M_out, int K, int Cin, int Cout, int flip_deal,
-    uint32_t x_bytes, const BnIn& bin, const StatFin& fin,
+    const float* __restrict__ WTp, const Late late, int64_t M_out, int K, int Cin, int Cout, int flip_deal,
+    uint32_t x_bytes, const BnIn& bin, const StatFin* const finp,      // finp: nullptr = no in-launch statistics finish
     unsigned long long* __restrict__ dbg, const int bx, const int by, const int bz, const int gy, const int gz,
     unsigned char* const lds, const int tid, Sync& sync) {
   static_assert(!FB || (BD && NB == 1), "the fused input BatchNorm is built for the weights-to-registers form");
@@ -784,8 +784,8 @@ __device__ __forceinline__ void fwd2_body(
             st_sc1(stats + ((int64_t)bx * 2 + 0) * Cout + c, sa);
             st_sc1(stats + ((int64_t)bx * 2 + 1) * Cout + c, sb);
           }
-          if (NB == 1 && fin.chunk)
-            stat_finish(fin, stats, M_out, Cout, (int64_t)bx, col0, gy, by,
+          if (NB == 1 && finp && finp->chunk)
+            stat_finish(*finp, stats, M_out, Cout, (int64_t)bx, col0, gy, by,
                         reinterpret_cast<double*>(Aring));
         }
       }
@@ -903,8 +903,8 @@ __device__ __forceinline__ void fwd2_body(
         st_sc1(stats + ((int64_t)bx * 2 + 0) * Cout + c, ta);
         st_sc1(stats + ((int64_t)bx * 2 + 1) * Cout + c, tb);
       }
-      if (NB == 1 && fin.chunk && wave == 0)      // (the partials of a 32-channel block are stored by lanes 0-31 of wave 0)
-        stat_finish(fin, stats, M_out, Cout, (int64_t)bx, col0, gy, by,
+      if (NB == 1 && finp && finp->chunk && wave == 0)      // (the partials of a 32-channel block are stored by lanes 0-31 of wave 0)
+        stat_finish(*finp, stats, M_out, Cout, (int64_t)bx, col0, gy, by,
                     reinterpret_cast<double*>(lds + HDR_BYTES));
     }
   }
