@@ -305,7 +305,7 @@ def pack_scene(sc, pin=True):
     sp_ins, E = sc["sp_ins"], sc["edges"]
     return {"buf": buf, "layout": layout, "N": int(xyz.shape[0]), "S": int(sc["S"]), "E": int(E.shape[0]),
             "n_inst": int(sc["n_inst"]), "extent": (hi - lo + 1), "edge_src_max": int(E[:, 0].max()) if len(E) else -1,
-            "slots": max(int(sp_ins.max()) + 1, 1) if len(sp_ins) else 1}
+            "sp_ins_max": int(sp_ins.max()) if len(sp_ins) else -100}
 
 
 _TORCH_DT = {np.float32: torch.float32, np.int64: torch.int64}
@@ -356,7 +356,8 @@ def collate_packed(packs, device, mode=4, n_levels=5):
         cols["edges_ext"].append(Eb)
         if pk["edge_src_max"] >= 0:
             edge_src_rows = max(edge_src_rows, pk["edge_src_max"] + sp_bias + 1)
-        slots.append(pk["slots"])
+        # bound of the (batch-offset) instance ids of the scene's superpoints: to_device reads it from the label tensor
+        slots.append(pk["sp_ins_max"] + inst_bias + 1 if pk["sp_ins_max"] >= 0 else 1)
         extent = np.maximum(extent, pk["extent"])
         sp_bias += pk["S"]
         inst_bias += pk["n_inst"]
