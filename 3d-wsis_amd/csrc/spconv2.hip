@@ -249,15 +249,21 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
       WSIS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const int64_t items = ceil_div(M_out, SL) * (Cout / 32);
-    if (fwd2p && !bn_in && n_targets == 0 && d_sync && p.NB == 1 && p.ZS == 1 && p.DA == 2 && p.BD &&
-        (p.NW == 1 || p.NW == 2 || p.NW == 4) && items < ((int64_t)1 << 30)) {
+    // measured (tools/conv2p_bench.py): one scene per step (level 0: 1.56 rounds, level 1: 1.6) the hardware's own
+    // dispatch of one-shot workgroups is as good a queue and has no per-item ticket -- 59.8 -> 63.3 us at level 0,
+    // 46.0 -> 52.1 at level 1; four scenes per step (6.4 rounds of one-wave items) 202 -> 180 us for the 3x3x3 layers of
+    // level 0, while the short 2x2x2 items (42 -> 51) and the 4-wave items (139 -> 152) stay slower: the default takes the
+    // persistent form for one-wave items of >= 16 offsets from 4 rounds on (WSIS_FWD2P=2: wherever it applies)
+    const bool p_shape = fwd2p >= 2 ? (p.NW == 1 || p.NW == 2 || p.NW == 4) : (p.NW == 1 && K >= 16);
+    if (fwd2p && !bn_in && n_targets == 0 && d_sync && p.NB == 1 && p.ZS == 1 && p.DA == 2 && p.BD && p_shape &&
+        items < ((int64_t)1 << 30)) {
       const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES * p.NW + 16;
       int per_cu = (int)((size_t)160 * 1024 / ldsb);
       const int wave_cap = 12 / p.NW > 0 ? 12 / p.NW : 1;      // 3 waves per SIMD: the occupancy the one-shot kernel runs at
       if (per_cu > wave_cap) per_cu = wave_cap;
       const int64_t resident = (int64_t)cus * per_cu;
       const char* me = getenv("WSIS_FWD2P_MIN");      // rounds (x 100) from which the persistent form is taken
-      const int64_t min_pct = me ? atoi(me) : 110;
+      const int64_t min_pct = me ? atoi(me) : (fwd2p >= 2 ? 110 : 400);
       if (items * 100 >= resident * min_pct) {
         unsigned* q = static_cast<SyncSlot*>(d_sync)->fin;
         const int gx = (int)ceil_div(M_out, SL);

@@ -29,7 +29,7 @@ def levels():
 
 def _both(monkeypatch, fn):
     res = []
-    for v in ("0", "1"):
+    for v in ("0", "2"):                 # 2: the persistent form wherever it applies (the default takes it from 4 rounds on)
         monkeypatch.setenv("WSIS_FWD2P", v)
         res.append(fn())
     torch.cuda.synchronize()
@@ -57,7 +57,7 @@ def test_persistent_conv_equals_one_shot(monkeypatch, levels, level, cin, cout, 
     assert torch.equal(y0, y1) and torch.equal(s0, s1) and torch.equal(d0, d1)
     assert not _n.sync_block()[:64 * 4096].any(), "ticket counters must be zero again after every launch"
     # three launches in a row through the same slot (the last draw of a launch resets the counter for the next)
-    monkeypatch.setenv("WSIS_FWD2P", "1")
+    monkeypatch.setenv("WSIS_FWD2P", "2")
     for _ in range(3):
         assert torch.equal(ops._conv_t(X, rb.nbr_p, rb.order, WT, 0, None, res, M), y0)
 

@@ -34,7 +34,7 @@ def main():
             WT = ops._weight_t(W, 0)
             st = torch.empty(((Mo + 31) // 32, 2, cout), device=dev)
             row = f"L{l} {name:5s} rows {Mo:6d} {cin:3d}->{cout:3d} items {(Mo + 31) // 32 * (cout // 32):5d}:"
-            for v in ("0", "1"):
+            for v in ("0", "2"):
                 os.environ["WSIS_FWD2P"] = v
                 t = timeit(lambda: ops._conv_t(X, tab.nbr_p, tab.order, WT, 0, None, None, Mo, stats=st))
                 row += f"  FWD2P={v} {t:6.1f} us"
