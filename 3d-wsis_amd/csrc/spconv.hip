@@ -905,6 +905,14 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
   WSIS_REQUIRE(d_X && d_W && d_out, "null pointer");
   WSIS_REQUIRE(d_nbr || (K == 1 && M_in == M_out), "nbr may be null only for the dense 1x1 case");
   WSIS_REQUIRE(M_out < (int64_t)1 << 31 && M_in < (int64_t)1 << 31, "row count exceeds int32");
+  if (d_nbr && spconv_in_supported(K, Cin, Cout) && (reinterpret_cast<uintptr_t>(d_X) & 7) == 0) {
+    // the 6 -> 32 input convolution: im2col on the matrix cores, operands in registers (csrc/spconv_in.hip)
+    hipStream_t st_in = as_stream(stream);
+    ProfScope prof_in(0, st_in, /*exact_events=*/true);
+    const int rc = spconv_in_launch(d_X, d_nbr, d_order, d_W, d_bias, d_residual, d_out, M_out, prof_in.ka(), prof_in.kb(), st_in);
+    prof_in.stop();
+    return rc;
+  }
   const int NB = fwd_nb(M_out, Cout);
   const int ksplit = fwd_ksplit(M_out, K, Cout);
   const int k_per = (K + ksplit - 1) / ksplit;
