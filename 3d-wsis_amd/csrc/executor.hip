@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void weight_transpose_batch_kernel(WtBatch b) 
 // dIn / BatchNorm-backward chain -- at the deep levels neither kernel fills 256 CUs on its own.  dW has its own
 // workspace region.  WSIS_DW_STREAM=0 keeps everything on the caller's stream.
 struct SideStream {
+  bool pending_join = false;      // a part of a pass forked weight gradients and left the join to a later part
   hipStream_t stream = nullptr;
   hipEvent_t join = nullptr;
   hipEvent_t mark_main = nullptr, mark_side = nullptr;   // milestone of wsis_run_ops_marked
@@ -618,7 +619,14 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
 }
 
 static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream,
-                        int32_t mark_op, void* waiter_stream);
+                        int32_t mark_op, void* waiter_stream, bool defer_join = false);
+
+// A pass issued in PARTS (the host does something between two parts: the statistics exchange of a SyncBatchNorm layer,
+// model/unet_native.py): parts with last == 0 leave the weight-gradient side stream un-joined, the part with last != 0
+// (n may be 0) joins everything forked since.  Every part needs its OWN workspace, alive until the last part returns.
+int wsis_run_ops_part(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream, int32_t last) {
+  return run_ops_impl(ops, n, d_ws, ws_bytes, d_sync, stream, -1, nullptr, last == 0);
+}
 
 // WSIS_GRAPH=N (opt-in experiment, default 0): the launches of a pass are recorded into HIP graphs of ~N ops each
 // (N < 4: one graph per pass; the weight-gradient side stream joins the capture through its fork / join events) and
@@ -692,10 +700,10 @@ int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
 }
 
 static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream,
-                        int32_t mark_op, void* waiter_stream) {
-  WSIS_REQUIRE(ops && n >= 0, "bad op list");
+                        int32_t mark_op, void* waiter_stream, bool defer_join) {
+  WSIS_REQUIRE((ops || n == 0) && n >= 0, "bad op list");
   WSIS_REQUIRE(mark_op < n && (mark_op < 0 || waiter_stream), "bad milestone");
-  WSIS_REQUIRE(ws_bytes >= wsis_run_ops_workspace_bytes(ops, n) && (d_ws || n == 0), "workspace too small");
+  WSIS_REQUIRE((n == 0 || ws_bytes >= wsis_run_ops_workspace_bytes(ops, n)) && (d_ws || n == 0), "workspace too small");
   hipStream_t st = as_stream(stream);
   char* ws = static_cast<char*>(d_ws);
   // ---- all transposed weights of the pass, WT_MAX layers per launch; wt_off[i] = offset of op i's W^T
@@ -1091,8 +1099,22 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
     const int wrc = drain_worker();
     if (wrc != WSIS_OK && first_err == WSIS_OK) first_err = wrc;
   }
+  if (defer_join && first_err == WSIS_OK) {
+    if (forked) side->pending_join = true;
+    return WSIS_OK;
+  }
+  if (!forked && !side && dw_stream_enabled()) {      // a part without weight gradients of its own may owe an earlier part's join
+    SideStream* s2 = side_stream_for(st);
+    if (s2 && s2->pending_join) {
+      side = s2;
+      forked = true;
+    }
+  } else if (side && side->pending_join) {
+    forked = true;
+  }
   if (forked) {   // join on EVERY exit path once forked: whatever follows on the caller's stream (optimizer, gradient
                   // all-reduce, the caller's error handling) is ordered behind every dW launch already issued
+    side->pending_join = false;
     const hipError_t e1 = hipEventRecord(side->join, side->stream);
     const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(st, side->join, 0) : e1;
     if (e2 != hipSuccess && first_err == WSIS_OK)

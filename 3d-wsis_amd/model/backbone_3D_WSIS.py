@@ -113,12 +113,19 @@ class Network(nn.Module):
 
         import os
         import wsis_parallel
-        sync_bn = self.training and wsis_parallel.sync_batchnorm_active(self)   # collectives between the layers:
-        if input.features.is_cuda and os.environ.get("WSIS_NATIVE_UNET", "1") != "0" and not sync_bn:   # module walk
+        sync_bn = self.training and wsis_parallel.sync_batchnorm_active(self)
+        # SyncBatchNorm keeps the native executor: the op list is issued in parts around the statistics exchange of every
+        # layer (unet_native._BnSync; WSIS_SYNC_BN_NATIVE=0: the per-module walk with _SyncBatchNormReLU)
+        sync_native = sync_bn and os.environ.get("WSIS_SYNC_BN_NATIVE", "1") != "0"
+        if input.features.is_cuda and os.environ.get("WSIS_NATIVE_UNET", "1") != "0" and (not sync_bn or sync_native):
             # input_conv -> unet -> output_layer recorded as an op list and issued by one native call per pass
             # (model/unet_native.py); WSIS_NATIVE_UNET=0 walks the modules instead (same kernels, same results)
             import unet_native
-            voxel_feats = unet_native.run_unet(self, input)
+            group = None
+            if sync_native:
+                group = next((wsis_ops.sync_group(m) for m in self.unet.modules()
+                              if isinstance(m, nn.BatchNorm1d) and wsis_ops.sync_group(m) is not None), None)
+            voxel_feats = unet_native.run_unet(self, input, sync_group=group)
         else:
             if input.features.is_cuda and os.environ.get("WSIS_PREBUILD", "1") != "0":
                 # all 5 + 4 rulebooks up front: their host syncs happen before the first conv is queued

@@ -208,6 +208,7 @@ class UNetProgram(object):
         self.flat_tail = None        # spare floats behind the gradients (parallel.GradSync packs the other
         self.tail_floats = 0         # parameters' gradients there: ONE collective per step)
         self.overlap = None          # wsis_parallel.GradSync: early all-reduce of the finished first part (see backward)
+        self.bn_sync = None          # _BnSync while the model's BatchNorm layers share their statistics across ranks
         self._cache = {}
 
     # ---- symbolic recording: every helper returns (out_handle, backward_closure) -----------------------------
@@ -547,7 +548,13 @@ class UNetFunction(Function):
         none = fwd_lut[:0]
         luts = {_FWD: fwd_lut, _TBL: table_lut, _EXT: np.array([x.data_ptr(), 0], dtype=np.uint64), _BWD: none,
                 _PAR: none}
-        _run(_n.hip(), c.fwd.instantiate(Mvec, luts), x.device)
+        sy = prog.bn_sync
+        if sy is not None:
+            sy.arenas, sy.counts = [arena], {}
+            _run_synced(_n.hip(), c.fwd.instantiate(Mvec, luts), x.device, sy)
+        else:
+            _run(_n.hip(), c.fwd.instantiate(Mvec, luts), x.device)
+        ctx.sy = sy
         # tables sized from the batch's host-side level counts: the device's own counts are compared inside the SAME
         # pass -- an inference pass right here (its result is used next; the read waits for the rulebook chain on the
         # side stream only), a training pass at the end of its backward pass, i.e. before the optimizer can use a
@@ -576,7 +583,10 @@ class UNetFunction(Function):
         pflat = parena.view(torch.float32)
         first = (pbase - parena.data_ptr()) // 4
         hook = prog.overlap
-        if hook is not None and hook.ready() and len(poffs) > 1:
+        if ctx.sy is not None:
+            ctx.sy.arenas = [ctx.arena, garena, parena]
+            _run_synced(_n.hip(), c.bwd.instantiate(Mvec, luts), dev, ctx.sy)
+        elif hook is not None and hook.ready() and len(poffs) > 1:
             # all-reduce of the first part of the gradient buffer starts while the rest of the pass still runs
             starts = np.append(poffs, ptotal)
             want = ptotal // 2
@@ -606,6 +616,134 @@ class UNetFunction(Function):
         return (dx, None) + tuple(grads)
 
 
+
+class _BnSync(object):
+    """SyncBatchNorm INSIDE the executor's pass (train_scannetv2.py:734-736 converts every BatchNorm when num_gpus > 1):
+    the op list is issued in parts (``wsis_run_ops_part``) that end in front of every training-mode BatchNorm op; the
+    layer itself runs here -- local statistics from the producers' epilogue partials, ONE all-gather of (mean, var,
+    count) combined in fp64 (Chan), apply; backward: local (sum dz, sum dz xhat), ONE all-reduce, dx with the global sums
+    -- and the next part follows.  Convolutions, concatenations and the weight-gradient side stream stay in the native
+    executor; every rank issues the same collectives in the same order (same op list), zero-row ranks included."""
+
+    def __init__(self, prog, group):
+        self.group = group
+        self.by_ptr = {}
+        for bn in prog.bns:
+            for t in (bn.running_mean, bn.running_var):
+                if t is not None:
+                    self.by_ptr[t.data_ptr()] = t
+        self.counts = {}          # mean pointer of a layer -> global row count (fp64 device scalar), forward -> backward
+        self.arenas = []
+
+    def view(self, ptr, numel):
+        ptr = int(ptr)
+        for a in self.arenas:
+            base = a.data_ptr()
+            if base <= ptr < base + a.numel():
+                return a[ptr - base:ptr - base + 4 * numel].view(torch.float32)
+        raise _n.WsisError("synced BatchNorm: pointer outside the pass's arenas")
+
+
+def _bn_fwd_synced(lib, op, sy, dev, st, slot):
+    import torch.distributed as dist
+    M, C, flags = int(op["M_in"]), int(op["Cin"]), int(op["flags"])
+    inp, out = [int(v) for v in op["inp"]], [int(v) for v in op["out"]]
+    mom, eps = float(op["momentum"]), float(op["eps"])
+    mean, var = sy.view(out[1], C), sy.view(out[2], C)
+    if M > 0 and (flags & F_STATS):
+        n_part = (M + 31) // 32
+        C0 = int(op["K"]) if inp[6] else C
+        wsb = lib.wsis_bn_stats_finalize_workspace_bytes(n_part, C)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _n.check(lib.wsis_bn_stats_finalize(inp[5], n_part, M, C0, out[1], out[2], None, None, mom, _n.ptr(ws), wsb, slot, st),
+                 "bn_stats_finalize")
+        if inp[6]:
+            _n.check(lib.wsis_bn_stats_finalize(inp[6], n_part, M, C - C0, out[1] + 4 * C0, out[2] + 4 * C0, None, None, mom,
+                                                _n.ptr(ws), wsb, slot, st), "bn_stats_finalize")
+    elif M > 0:
+        wsb = lib.wsis_bn_workspace_bytes(M, C)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _n.check(lib.wsis_bn_stats(inp[0], M, C, out[1], out[2], None, None, mom, _n.ptr(ws), wsb, st), "bn_stats")
+    else:
+        mean.zero_()
+        var.zero_()
+    t = torch.cat((mean.double(), var.double(), torch.full((1,), float(M), dtype=torch.float64, device=dev)))
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size(sy.group))]
+    dist.all_gather(parts, t, group=sy.group)
+    g = torch.stack(parts)
+    n_i = g[:, 2 * C:2 * C + 1]
+    N = n_i.sum()
+    mean64 = (g[:, :C] * n_i).sum(0) / N
+    dm = g[:, :C] - mean64
+    var64 = ((g[:, C:2 * C] + dm * dm) * n_i).sum(0) / N
+    mean.copy_(mean64.float())
+    var.copy_(var64.float())
+    if flags & F_UPDATE:
+        rm, rv = sy.by_ptr[inp[3]], sy.by_ptr[inp[4]]
+        unb = var64 * (N / (N - 1.0).clamp_min(1.0))
+        rm.mul_(1.0 - mom).add_(mean, alpha=mom)
+        rv.mul_(1.0 - mom).add_(unb.float(), alpha=mom)
+    sy.counts[out[1]] = N
+    if out[0] and M > 0:
+        _n.check(lib.wsis_bn_apply(inp[0], out[1], out[2], inp[1] or None, inp[2] or None, eps, 1 if flags & F_RELU else 0,
+                                   out[0], M, C, st), "bn_apply")
+
+
+def _bn_bwd_synced(lib, op, sy, dev, st):
+    import torch.distributed as dist
+    M, C, flags = int(op["M_in"]), int(op["Cin"]), int(op["flags"])
+    inp, out = [int(v) for v in op["inp"]], [int(v) for v in op["out"]]
+    eps, relu = float(op["eps"]), 1 if flags & F_RELU else 0
+    dg, db = sy.view(out[1], C), sy.view(out[2], C)
+    if M > 0:
+        wsb = lib.wsis_bn_workspace_bytes(M, C)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        _n.check(lib.wsis_bn_bwd(inp[0], inp[1], inp[2], inp[3], inp[4] or None, inp[5] or None, eps, relu, 1, None, out[1],
+                                 out[2], None, M, C, _n.ptr(ws), wsb, st), "bn_bwd")
+    else:
+        dg.zero_()
+        db.zero_()
+    g = torch.cat((dg, db)).double()
+    dist.all_reduce(g, group=sy.group)
+    N = sy.counts[inp[2]]
+    if M > 0:
+        sc = (g * (float(M) / N)).float()      # the kernel divides by the local row count
+        _n.check(lib.wsis_bn_bwd_apply(inp[0], inp[1], inp[2], inp[3], inp[4] or None, inp[5] or None, _n.ptr(sc[:C]),
+                                       _n.ptr(sc[C:]), eps, relu, out[0], inp[6] or None, M, C, st), "bn_bwd_apply")
+
+
+def _run_synced(lib, ops, device, sy):
+    n = len(ops)
+    base, item = ops.ctypes.data, ops.dtype.itemsize
+    kinds, flags = ops["kind"], ops["flags"]
+    is_bn = ((kinds == OP_BN_RELU) | (kinds == OP_BN_RELU_BWD)) & ((flags & F_TRAINING) != 0)
+    sync = _n.ptr(_n.sync_block(device))
+    st = _n.stream_ptr()
+    keep = []                     # every part's workspace stays alive until the weight-gradient side stream is joined
+    i = 0
+    while i < n:
+        j = i
+        while j < n and not is_bn[j]:
+            j += 1
+        if j > i:
+            p = base + i * item
+            wsb = lib.wsis_run_ops_workspace_bytes(p, j - i)
+            if wsb < 0:
+                raise _n.WsisError("run_ops workspace query failed")
+            ws = torch.empty(wsb, dtype=torch.uint8, device=device)
+            keep.append(ws)
+            _n.check(lib.wsis_run_ops_part(p, j - i, _n.ptr(ws), wsb, sync, st, 0), "run_ops_part")
+        if j < n:
+            if int(kinds[j]) == OP_BN_RELU:
+                _bn_fwd_synced(lib, ops[j], sy, device, st, sync)
+            else:
+                _bn_bwd_synced(lib, ops[j], sy, device, st)
+            j += 1
+        i = j
+    _n.check(lib.wsis_run_ops_part(None, 0, None, 0, sync, st, 1), "run_ops_part")
+    return keep
+
+
 def _run(lib, ops, device, mark_op=-1, waiter=None):
     n = len(ops)
     p = ops.ctypes.data
@@ -621,11 +759,16 @@ def _run(lib, ops, device, mark_op=-1, waiter=None):
         _n.check(lib.wsis_run_ops(p, n, _n.ptr(ws), ws_bytes, sync, _n.stream_ptr()), "run_ops")
 
 
-def run_unet(net, input_tensor):
-    """input_conv + unet + output_layer of ``net`` on ``input_tensor`` (SparseConvTensor) -> features [M0, m]"""
+def run_unet(net, input_tensor, sync_group=None):
+    """input_conv + unet + output_layer of ``net`` on ``input_tensor`` (SparseConvTensor) -> features [M0, m].
+    ``sync_group``: the process group the BatchNorm layers take their batch statistics over (None: per rank)"""
     prog = getattr(net, "_native_prog", None)
     if prog is None:
         prog = UNetProgram(net)
         net._native_prog = prog
+    if sync_group is None:
+        prog.bn_sync = None
+    elif prog.bn_sync is None or prog.bn_sync.group is not sync_group:
+        prog.bn_sync = _BnSync(prog, sync_group)
     prog.bind(input_tensor)
     return UNetFunction.apply(input_tensor.features, prog, *prog.params)

@@ -81,6 +81,7 @@ _HIP_SIGS = {
     "wsis_spconv_fwd_f": (I32, [P, P, P, P, P, I32, P, P, P, P, P, I32, I64, I64, I32, I32, I32, P, I64, P, P]),
     "wsis_bn_bwd_from_partials": (I32, [P, I64, P, P, P, P, P, P, F32, I32, P, P, P, P, I64, I32, P, I64, P, P]),
     "wsis_sync_bytes": (I64, []),
+    "wsis_run_ops_part": (I32, [P, I32, P, I64, P, P, I32]),
     "wsis_deep_launches": (I64, []),
     "wsis_deep_phases": (I64, []),
     "wsis_bn_bwd_apply": (I32, [P, P, P, P, P, P, P, P, F32, I32, P, P, I64, I32, P]),

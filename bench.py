@@ -12,7 +12,7 @@ rank, no data-path collective, weak scaling.  `python bench.py --gpus N` without
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      -- dominant kernel family (the forward / dIn launches of the 49 sparse convs: spconv_fwd2_kernel,
-                   its persistent form spconv_fwd3_kernel on the slab-split levels, spconv_fwd_kernel for the
+                   its persistent form spconv_fwd2p_kernel from 4 rounds of work items on, spconv_in_kernel for the
                    6-channel input conv): algorithmic gather/scatter bytes (P*(Cin+Cout)*4 + P*8 per launch,
                    SURVEY 8d) / HIP-event time of those launches, against the 8 TB/s HBM peak.
   cpu_baseline  -- the oracle (torch-CPU restatement mirroring upstream's gather -> mm -> scatter-add) timed on
@@ -606,7 +606,7 @@ def main():
     # ---- roofline of the dominant kernel: event-instrumented extra steps (same inputs, same process) ----
     roof = None
     extra = {}
-    summ = {}
+    summ, summ_ov = {}, {}
     if args.profile_steps > 0:
         # per-kernel durations are only a property of the kernel when it runs alone: the instrumented steps keep the
         # weight-gradient launches on the main stream (in the timed region they overlap the dIn launches of
@@ -625,13 +625,22 @@ def main():
             del os.environ["WSIS_DW_STREAM"]
         else:
             os.environ["WSIS_DW_STREAM"] = prev
+        # the same launches in the TIMED configuration (weight gradients on their side stream, overlapping the dIn
+        # products): what a product takes while it shares the GPU -- reported next to the alone-on-the-GPU figure
+        if rank == 0:
+            sp_ops.PROFILER = sp_ops.KernelProfiler()
+        for _ in range(args.profile_steps):
+            step()
+        if rank == 0:
+            summ_ov = sp_ops.PROFILER.summary()
+            sp_ops.PROFILER = None
     if rank == 0 and summ:
         k = summ.get("spconv_fwd_kernel")
         if k and k["ms"] > 0:
             gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
-            roof = {"kernel": "spconv_fwd2_kernel (+ spconv_fwd3_kernel on slab-split levels, spconv_fwd_kernel for the "
-                              "6-channel input conv) INCLUDING the fixed-order slab sums that finish a product "
-                              "(spconv2_reduce_kernel / spconv2_reduce_stats_kernel)",
+            roof = {"kernel": "spconv_fwd2_kernel (its persistent form spconv_fwd2p_kernel from 4 rounds of work items on; "
+                              "spconv_in_kernel for the 6-channel input conv) INCLUDING the fixed-order slab sums that "
+                              "finish a product (spconv2_reduce_kernel / spconv2_reduce_stats_kernel)",
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
                     "alg_bytes_per_launch": k["bytes"] // k["launches"],
@@ -643,12 +652,17 @@ def main():
                     "tflops": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2),
                     "mfma_frac_fp32": round(k["flops"] / (k["ms"] * 1e-3) / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4),
                     "per_level": per_level(k["per_launch"], args.profile_steps),
+                    "frac_overlapped": None, "avg_launch_us_overlapped": None,
                     "frac_of_binding_ceiling": round(sum(max(r[4] / (HBM_PEAK_GBS * 1e9), r[5] / (MFMA_FP32_PEAK_TFLOPS * 1e12))
                                                          for r in k["per_launch"]) * 1e3 / k["ms"], 4),
                     "measured": "start / stop HIP events of every product's launch on its stream (hipExtLaunchKernelGGL; "
                                 "WSIS_PROF_EXACT=0: events recorded around it; a slab sum, where there is one, is "
                                 "counted with its product) in %d extra steps with the dW side stream off (kernel alone "
                                 "on the GPU); rocprofv3 of WSIS_DW_STREAM=0 agrees, see profiles/" % args.profile_steps}
+            ko = summ_ov.get("spconv_fwd_kernel")
+            if ko and ko["ms"] > 0:      # same products, timed configuration (dW on the side stream beside them)
+                roof["frac_overlapped"] = round(ko["bytes"] / (ko["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                roof["avg_launch_us_overlapped"] = round(ko["ms"] * 1e3 / ko["launches"], 2)
         d = summ.get("spconv_dw_kernel")
         if d and d["ms"] > 0:
             extra["dw_kernel"] = {"achieved_GBs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1),

@@ -634,6 +634,13 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
  * pass still runs (the reference's DDP buckets, train_scannetv2.py:738).  mark_op < 0: no milestone. */
 int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream,
                         int32_t mark_op, void* waiter_stream);
+/* A pass issued in PARTS -- the host does something between two parts (the statistics exchange of a SyncBatchNorm layer:
+ * train_scannetv2.py:734-736 converts every BatchNorm when num_gpus > 1; model/unet_native.py).  Parts with last == 0
+ * leave the weight-gradient side stream un-joined; the part with last != 0 (n may be 0) joins everything forked since.
+ * Every part needs its OWN workspace (wsis_run_ops_workspace_bytes of that part), alive until the last part returns. */
+int wsis_run_ops_part(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream,
+                      int32_t last);
+
 /* A run of consecutive ops whose output tensors have at most WSIS_DEEP_ROWS (8192) rows -- the deep UNet levels of a
  * scene, sparse_unet3d.py:321-350 -- is issued as ONE resident launch (csrc/deep.hip: 256 workgroups walk the ops as
  * phases with grid barriers between them; same kernels' code, same order of additions, results identical to the

@@ -89,7 +89,18 @@ def main():
             loss, _ = harness.train_step(model, crit, opt, batch, cfg, grad_sync=sync)
             losses.append(float(loss))
         torch.cuda.synchronize()
-        info.update(losses=losses, native_prog=getattr(model, "_native_prog", None) is not None)
+        prog = getattr(model, "_native_prog", None)
+        info.update(losses=losses, native_prog=prog is not None and prog.bn_sync is not None)
+        # the same forward pass as the per-module walk with _SyncBatchNormReLU (statistics from a pass over x instead of
+        # the convolution epilogues' partials): the losses agree to rounding
+        both = []
+        for native in ("1", "0"):
+            os.environ["WSIS_SYNC_BN_NATIVE"] = native
+            with torch.no_grad():
+                l2, _ = harness.forward_loss(model, crit, batch, cfg)
+            both.append(float(l2))
+        os.environ["WSIS_SYNC_BN_NATIVE"] = "1"
+        info["loss_native_vs_walk"] = both
         torch.save({"layer": layer, "info": info,
                     "weights": {n: p.detach().cpu() for n, p in model.named_parameters()},
                     "buffers": {n: b.detach().cpu() for n, b in model.named_buffers()}},

@@ -30,7 +30,8 @@ def c2_batch():
 
 @pytest.fixture(scope="module")
 def c3_batch():
-    scenes = [harness.make_scene(s, room=(3.2, 2.6, 2.2), n_box=4) for s in (1, 2, 3, 4)]
+    # BASELINE configs[2] as bench.py runs it (c3_batch4_train): four C2-sized scenes, seeds 1-4, ~625 k voxels
+    scenes = [harness.bench_scene(s) for s in (1, 2, 3, 4)]
     return harness.collate(scenes)
 
 
