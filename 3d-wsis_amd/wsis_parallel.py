@@ -18,6 +18,18 @@ def init_distributed(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force = os.environ.get("WSIS_FORCE_DIST", "0") == "1"    # exercise the collective path with one rank (tests)
     if (world > 1 or force) and not dist.is_initialized():
+        # RCCL's helper threads wait on HSA signals by interrupt unless told otherwise, which costs the launch-bound
+        # issuing thread of this path ~6 %.  The switch only works before the HSA runtime starts,
+        # i.e. before anything in the process touches the GPU: set it here when that is still possible, refuse to go on
+        # silently slow when it is not (WSIS_ALLOW_INTERRUPT_WAITS=1 accepts the slower mode)
+        if os.environ.get("HSA_ENABLE_INTERRUPT") != "0":
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                if os.environ.get("WSIS_ALLOW_INTERRUPT_WAITS", "0") != "1":
+                    raise RuntimeError("wsis_parallel.init_distributed: the GPU runtime is already up without "
+                                       "HSA_ENABLE_INTERRUPT=0; call init_distributed() before the first GPU call, export "
+                                       "HSA_ENABLE_INTERRUPT=0, or set WSIS_ALLOW_INTERRUPT_WAITS=1")
+            else:
+                os.environ["HSA_ENABLE_INTERRUPT"] = "0"
         if backend is None:   # WSIS_DIST_BACKEND=gloo: control-flow tests of N ranks on one GPU (RCCL refuses that)
             backend = os.environ.get("WSIS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
