@@ -277,7 +277,7 @@ _PACK_FIELDS = (("xyz", np.float32, 3), ("rgb", np.float32, 3), ("sem_label", np
                 ("vmin", np.int64, 0))
 
 
-def pack_scene(sc, pin=True):
+def pack_scene(sc, pin=True, buf=None):
     """What a loader worker hands over per sample (the output of ``__getitem__``, scannetv2_dataset.py:96-190): every
     per-scene array in its final dtype, back to back in ONE (pinned) buffer, plus the few numbers the host needs to lay
     out the batch without looking at the data again -- point / superpoint / edge / instance counts, the voxel extent
@@ -298,7 +298,8 @@ def pack_scene(sc, pin=True):
         layout[name] = (off, a.shape, dt)
         parts.append((off, a))
         off = (off + a.nbytes + 15) // 16 * 16
-    buf = torch.empty(off, dtype=torch.uint8, pin_memory=bool(pin and torch.cuda.is_available()))
+    if buf is None or buf.numel() < off:
+        buf = torch.empty(off, dtype=torch.uint8, pin_memory=bool(pin and torch.cuda.is_available()))
     view = buf.numpy()
     for o, a in parts:
         view[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
