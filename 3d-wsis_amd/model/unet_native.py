@@ -715,7 +715,12 @@ def _bn_bwd_synced(lib, op, sy, dev, st):
 def _run_synced(lib, ops, device, sy):
     n = len(ops)
     base, item = ops.ctypes.data, ops.dtype.itemsize
-    kinds, flags = ops["kind"], ops["flags"]
+    kinds = ops["kind"]
+    # backward: the dIn epilogue's partials pair a CONV_BWD op with the BatchNorm op behind it INSIDE one list; the parts
+    # end in front of that op and the synced layer makes its own reduction pass, so the pairing is switched off
+    bwd_pair = (kinds == OP_CONV_BWD) | (kinds == OP_BN_RELU_BWD)
+    ops["flags"] = np.where(bwd_pair, ops["flags"] & ~F_STATS, ops["flags"])
+    flags = ops["flags"]
     is_bn = ((kinds == OP_BN_RELU) | (kinds == OP_BN_RELU_BWD)) & ((flags & F_TRAINING) != 0)
     sync = _n.ptr(_n.sync_block(device))
     st = _n.stream_ptr()
