@@ -18,7 +18,9 @@ struct AdamSeg {
   int64_t n;            // 0: parameter without a gradient this step -> untouched (torch skips it too)
   float step_size;      // lr / (1 - beta1^t), t = number of updates of THIS parameter (torch counts per parameter)
   float inv_sqrt_bc2;   // 1 / sqrt(1 - beta2^t)
-};
+  float g_clamp;        // > 0: the gradient is clamped to [-g_clamp, g_clamp] first AND written back (the reference's
+  float pad_;           //      `p.grad.data.clamp_(-1, 1)` over the ECC parameters, train_scannetv2.py:247-249, without
+};                      //      its 20 small launches in front of the optimizer)
 
 // decay = 1 - lr * weight_decay, omb1 = 1 - beta1, omb2 = 1 - beta2: formed in double on the host and rounded once,
 // as torch does (1.0f - 0.999f is off by 5e-5 relative)
@@ -37,13 +39,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamSeg* __restrict__ 
   const int s = blocks[2 * blockIdx.x], chunk = blocks[2 * blockIdx.x + 1];
   const AdamSeg sg = segs[s];
   const float step_size = sg.step_size, inv_sqrt_bc2 = sg.inv_sqrt_bc2;
+  const float gc = sg.g_clamp;
+  float* const gw = const_cast<float*>(sg.g);
   const int64_t i0 = (int64_t)chunk * AD_CHUNK + (int64_t)threadIdx.x * 4;
   if (i0 >= sg.n) return;
   const bool vec = i0 + 4 <= sg.n && ((reinterpret_cast<uintptr_t>(sg.p + i0) | reinterpret_cast<uintptr_t>(sg.g + i0) |
                                        reinterpret_cast<uintptr_t>(sg.m + i0) | reinterpret_cast<uintptr_t>(sg.v + i0)) & 15) == 0;
   if (vec) {
     float4 p = *reinterpret_cast<float4*>(sg.p + i0);
-    const float4 g = *reinterpret_cast<const float4*>(sg.g + i0);
+    float4 g = *reinterpret_cast<const float4*>(sg.g + i0);
+    if (gc > 0.0f) {
+      g.x = fminf(fmaxf(g.x, -gc), gc);
+      g.y = fminf(fmaxf(g.y, -gc), gc);
+      g.z = fminf(fmaxf(g.z, -gc), gc);
+      g.w = fminf(fmaxf(g.w, -gc), gc);
+      *reinterpret_cast<float4*>(gw + i0) = g;
+    }
     float4 m = *reinterpret_cast<float4*>(sg.m + i0);
     float4 v = *reinterpret_cast<float4*>(sg.v + i0);
     adam_one(p.x, g.x, m.x, v.x, lr, b1, b2, eps, wd, step_size, inv_sqrt_bc2);
@@ -56,7 +67,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamSeg* __restrict__ 
   } else {
     for (int64_t i = i0; i < i0 + 4 && i < sg.n; ++i) {
       float p = sg.p[i], m = sg.m[i], v = sg.v[i];
-      adam_one(p, sg.g[i], m, v, lr, b1, b2, eps, wd, step_size, inv_sqrt_bc2);
+      float g = sg.g[i];
+      if (gc > 0.0f) {
+        g = fminf(fmaxf(g, -gc), gc);
+        gw[i] = g;
+      }
+      adam_one(p, g, m, v, lr, b1, b2, eps, wd, step_size, inv_sqrt_bc2);
       sg.p[i] = p;
       sg.m[i] = m;
       sg.v[i] = v;

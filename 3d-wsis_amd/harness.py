@@ -545,10 +545,17 @@ def train_step(model, criterion, optimizer, batch, cfg, epoch=5, grad_sync=None,
         pipeline.pump()
     if grad_sync is not None:
         grad_sync(model)
-    grads = [p.grad for p in model.ecc.parameters() if p.grad is not None]
-    if grads:   # train_scannetv2.py:247-249 as two multi-tensor launches instead of one per parameter
-        torch._foreach_clamp_min_(grads, -1.0)
-        torch._foreach_clamp_max_(grads, 1.0)
+    # train_scannetv2.py:247-249: the ECC gradients clamped to [-1, 1] -- inside the one-launch AdamW (the foreach forms
+    # still ran one kernel per tensor: 20 launches in front of the optimizer), or as multi-tensor ops for another optimizer
+    if hasattr(optimizer, "set_grad_clamp"):
+        if getattr(optimizer, "_ecc_clamp_of", None) is not model:
+            optimizer.set_grad_clamp(list(model.ecc.parameters()), 1.0)
+            optimizer._ecc_clamp_of = model
+    else:
+        grads = [p.grad for p in model.ecc.parameters() if p.grad is not None]
+        if grads:
+            torch._foreach_clamp_min_(grads, -1.0)
+            torch._foreach_clamp_max_(grads, 1.0)
     optimizer.step()
     if pipeline is not None:
         pipeline.pump()

@@ -47,10 +47,10 @@ class FlatAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         seg_bytes = lib.wsis_adamw_segment_bytes()
-        assert seg_bytes == 48
+        assert seg_bytes == 56
         chunk = lib.wsis_adamw_chunk()
         n = len(self.params)
-        self._table = np.zeros((n, 6), dtype=np.int64)            # p, g, m, v, numel, (step_size, inv_sqrt_bc2) as 2 x fp32
+        self._table = np.zeros((n, 7), dtype=np.int64)            # p, g, m, v, numel, (step_size, inv_sqrt_bc2), (g_clamp, 0) as 2 x fp32
         self._table[:, 0] = [p.data_ptr() for p in self.params]
         self._table[:, 2] = [self.exp_avg.data_ptr() + 4 * s for s in starts]
         self._table[:, 3] = [self.exp_avg_sq.data_ptr() + 4 * s for s in starts]
@@ -60,8 +60,8 @@ class FlatAdamW(torch.optim.Optimizer):
                                  for i, k in enumerate(numel)])
         self._blocks = torch.from_numpy(np.ascontiguousarray(blocks)).to(dev)
         self._n_blocks = int(blocks.shape[0])
-        self._host = [torch.empty((n, 6), dtype=torch.int64).pin_memory() for _ in range(_RING)]
-        self._dev = [torch.empty((n, 6), dtype=torch.int64, device=dev) for _ in range(_RING)]
+        self._host = [torch.empty((n, 7), dtype=torch.int64).pin_memory() for _ in range(_RING)]
+        self._dev = [torch.empty((n, 7), dtype=torch.int64, device=dev) for _ in range(_RING)]
         self._done = [None] * _RING
         self._slot = 0
 
@@ -71,6 +71,18 @@ class FlatAdamW(torch.optim.Optimizer):
     betas = property(lambda self: tuple(float(b) for b in self.param_groups[0]["betas"]))
     eps = property(lambda self: float(self.param_groups[0]["eps"]))
     weight_decay = property(lambda self: float(self.param_groups[0]["weight_decay"]))
+
+    def set_grad_clamp(self, params, bound):
+        """gradients of ``params`` are clamped to [-bound, bound] inside the step's ONE launch (and written back, like the
+        reference's ``p.grad.data.clamp_(-1, 1)`` over the ECC parameters, train_scannetv2.py:247-249); bound <= 0: off"""
+        ids = {id(p) for p in params}
+        pair = np.array([max(float(bound), 0.0), 0.0], dtype=np.float32).view(np.int64)[0]
+        n = 0
+        for i, p in enumerate(self.params):
+            if id(p) in ids:
+                self._table[i, 6] = pair
+                n += 1
+        return n
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:

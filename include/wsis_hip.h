@@ -574,7 +574,8 @@ int wsis_disc_loss_bwd(const float* d_x, const int64_t* d_ins_label, const int64
 
 /* ---- optimizer step (train_scannetv2.py:251; AdamW of config/ScanNet_v2_3D_WSIS.yaml:58-61) in one launch.
  * d_segments: device array of {float* p; const float* g; float* m; float* v; int64_t n; float step_size;
- * float inv_sqrt_bc2;} (wsis_adamw_segment_bytes() bytes each; n == 0 skips the parameter; step_size =
+ * float inv_sqrt_bc2; float g_clamp; float pad;} (wsis_adamw_segment_bytes() bytes each; n == 0 skips the parameter;
+ * g_clamp > 0 clamps the gradient to [-g_clamp, g_clamp] first and writes it back: train_scannetv2.py:247-249; step_size =
  * lr / (1 - beta1^t), inv_sqrt_bc2 = 1 / sqrt(1 - beta2^t) with t = updates of that parameter so far, this one
  * included); d_blocks int32 [n_blocks,2] = (segment, chunk of wsis_adamw_chunk() elements) for every chunk of every
  * segment.  Update rule of torch.optim.AdamW (decoupled weight decay), fp32. */

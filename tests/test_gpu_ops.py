@@ -885,6 +885,38 @@ def test_flat_adamw_matches_torch_adamw_step_by_step():
 
 
 @pytest.mark.gpu
+def test_flat_adamw_gradient_clamp_inside_the_step():
+    """FlatAdamW.set_grad_clamp: the clamp of train_scannetv2.py:247-249 (``p.grad.data.clamp_(-1, 1)`` over the ECC
+    parameters) inside the optimizer's one launch -- parameters equal torch's AdamW on clamped gradients, the clamped
+    gradients are written back, unclamped tensors untouched; odd sizes and an unaligned view included"""
+    import wsis_optim as optim
+    g = torch.Generator().manual_seed(5)
+    shapes = [(96, 32), (33,), (1025,), (7, 5)]
+    a = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    mine = optim.FlatAdamW(a, lr=1e-3, weight_decay=1e-4)
+    assert mine.set_grad_clamp([a[0], a[2], a[3]], 1.0) == 3
+    ref = torch.optim.AdamW(b, lr=1e-3, weight_decay=1e-4, foreach=False, fused=False)
+    flat = torch.empty(sum(t.numel() for t in a) + 3, device="cuda")
+    for step in range(3):
+        off = 1
+        raw = []
+        for i, (p, q) in enumerate(zip(a, b)):
+            gr = torch.randn(p.shape, generator=g).cuda() * 3.0
+            view = flat[off:off + p.numel()].view(p.shape)
+            view.copy_(gr)
+            off += p.numel()
+            p.grad = view
+            q.grad = gr.clamp(-1.0, 1.0) if i != 1 else gr.clone()
+            raw.append(gr)
+        mine.step()
+        ref.step()
+        for i, (p, q) in enumerate(zip(a, b)):
+            assert float((p - q).abs().max()) <= 2e-6 * float(q.abs().max()) + 1e-9, (step, i)
+            assert torch.equal(p.grad, q.grad), (step, i)          # written back clamped / left alone
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("S", [1190, 5, 3000])
 def test_fused_superpoint_regression_losses_match_torch_formulation(S):
     """wsis_sp_regression_loss_fwd/bwd against the torch evaluation of losses_3D_WSIS.py:79-96,113-127 in fp64
