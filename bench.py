@@ -91,8 +91,8 @@ def parse():
                          "instead of inside every timed step")
     ap.add_argument("--small", action="store_true", help="debug: a small room instead of the C2 scene")
     ap.add_argument("--sync-bn", action="store_true",
-                    help="N > 1: BatchNorm statistics over all ranks (the reference's SyncBatchNorm conversion); the UNet "
-                         "then runs as the per-module walk with two small collectives per BatchNorm layer and pass")
+                    help="N > 1: BatchNorm statistics over all ranks (the reference's SyncBatchNorm conversion): one small "
+                         "collective per BatchNorm layer and pass, issued between two parts of the executor's op list")
     return ap.parse_args()
 
 
@@ -709,8 +709,9 @@ def main():
                        "global_batch": spg * world, "scene_seeds_rank0": seeds,
                        "untimed_setup_steps": args.setup_steps,
                        "parallelism": f"scene-sharded dp{world}",
-                       "batchnorm": ("statistics shared across the ranks (--sync-bn: wsis_parallel.convert_sync_batchnorm, "
-                                     "UNet as the module walk)" if sync_bn else
+                       "batchnorm": ("statistics shared across the ranks (--sync-bn: wsis_parallel.convert_sync_batchnorm; the UNet "
+                                     "keeps the native executor, its op list issued in parts around every layer's "
+                                     "statistics exchange)" if sync_bn else
                                      "per-rank batch statistics (the reference converts to SyncBatchNorm when num_gpus > 1: "
                                      "--sync-bn)"),
                        "loss": float(loss)},
