@@ -39,6 +39,18 @@ __device__ __forceinline__ f4 ld4(const float* p, bool vec) {
 
 // Thread layout of the reductions: channels are handled in groups of 4 (one 16-byte load per row);
 // 256 threads = G channel groups x R row lanes.  C is padded to C4*4 logically; tail channels are masked.
+// pivot of channel c: the mean of its first (up to) 8 rows, fp32, fixed order.  Every sum of the statistics pass is
+// taken of x - K: fp32 sums of the raw x and x^2 cancel in var = E[x^2] - mean^2 when |mean| >> sigma (|mean| = 1000
+// sigma: 10 % off); a pivot within sigma / sqrt(8) of the mean keeps sum (x - K)^2 within 12 % of the centred sum (a
+// one-row pivot doubles it, and with it the rounding error: median gradient error against the fp64 oracle 3.7e-4 ->
+// 6.6e-4)
+__device__ __forceinline__ float bn_pivot(const float* __restrict__ x, int64_t M, int C, int c) {
+  const int n = M < 8 ? (int)M : 8;
+  float s = 0.0f;
+  for (int r = 0; r < n; ++r) s += x[(int64_t)r * C + c];
+  return s / (float)n;
+}
+
 // pass 1 (forward): per-workgroup (sum, sumsq) per channel from ONE read of x.  partial [nblk][2][Cp].
 // Both sums are taken of x - K with the pivot K[c] = x[0][c] (one sample of the channel): fp32 sums of the raw x and x^2
 // cancel in var = E[x^2] - mean^2 when |mean| >> sigma (|mean| = 1000 sigma: 10 % off), the shifted ones do not.
@@ -59,7 +71,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_partial_kernel(const floa
       const int c = g * 4;
       float K[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) K[e] = (c + e < C) ? x[c + e] : 0.0f;
+      for (int e = 0; e < 4; ++e) K[e] = (c + e < C) ? bn_pivot(x, M, C, c + e) : 0.0f;
 #pragma unroll 8
       for (int64_t r = r0 + rl; r < r1; r += R) {
         float v[4];
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(64) void bn_stats_final_kernel(const float* __restr
   if (threadIdx.x == 0) {
     const double n = (double)M;
     const double ms = S / n;              // mean of x - K, K = x0[c] (bn_stats_partial_kernel)
-    const double mu = (double)x0[c] + ms;
+    const double mu = (double)bn_pivot(x0, M, C, c) + ms;
     double v = Q / n - ms * ms;
     if (v < 0.0) v = 0.0;
     mean[c] = (float)mu;
@@ -954,7 +966,7 @@ __global__ __launch_bounds__(BN_SMALL_THREADS) void bn_stats_small_kernel(const 
   float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
   float K[4];                                 // pivot: sums of x - x[0][c] (see bn_stats_partial_kernel)
 #pragma unroll
-  for (int e = 0; e < 4; ++e) K[e] = (c0 + e < C) ? x[c0 + e] : 0.0f;
+  for (int e = 0; e < 4; ++e) K[e] = (c0 + e < C) ? bn_pivot(x, M, C, c0 + e) : 0.0f;
 #pragma unroll 8
   for (int64_t r = threadIdx.x; r < M; r += BN_SMALL_THREADS) {
     float v[4];
@@ -983,7 +995,7 @@ __global__ __launch_bounds__(BN_SMALL_THREADS) void bn_stats_small_kernel(const 
     const int e = threadIdx.x, c = c0 + e;
     const double n = (double)M;
     const double ms = a[e] / n;
-    const double mu = (double)x[c] + ms;
+    const double mu = (double)K[e] + ms;
     double v = b[e] / n - ms * ms;
     if (v < 0.0) v = 0.0;
     mean[c] = (float)mu;
