@@ -279,8 +279,11 @@ def side_measurements(harness, optimizer, device, args):
             fn()
             torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
-    ms_host_collate = _wall(lambda: harness.collate([sc]))
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)                   # a DataLoader worker runs torch with ONE thread (with the parent's pool a
+    ms_host_collate = _wall(lambda: harness.collate([sc]))      # small CPU op costs milliseconds of wake-up)
     ms_host_total = _wall(lambda: harness.to_device(harness.collate([sc]), device))
+    torch.set_num_threads(nt)
     ms_dev_total = _wall(lambda: harness.collate_device([sc], device))
     pk = harness.pack_scene(sc)
     t0 = time.perf_counter()
@@ -299,7 +302,8 @@ def side_measurements(harness, optimizer, device, args):
         torch.cuda.synchronize()
         return dt
     ms_packed_host = _host_only(lambda: harness.collate_packed([pk], device))
-    out["batch_assembly"] = {"workload": "one C2 scene: collate (+ H2D, per-batch CSRs) by one host thread vs on the device",
+    out["batch_assembly"] = {"workload": "one C2 scene: collate (+ H2D, per-batch CSRs) by one host thread (torch.set_num_threads(1), "
+                                         "as in a DataLoader worker) vs on the device",
                              "host_collate_ms_per_scene": round(ms_host_collate, 2),
                              "host_collate_plus_to_device_ms_per_scene": round(ms_host_total, 2),
                              "device_collate_ms_per_scene": round(ms_packed, 2),
