@@ -16,6 +16,8 @@
 #include <utility>
 #include <vector>
 
+#include <unistd.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -167,6 +169,7 @@ hipEvent_t next_fork_event(SideStream* s) {
 // stream wait for the event and launches the dW product; the caller waits for the worker to drain before it records a
 // milestone or the join event.  One worker per process (lazily started); WSIS_DW_THREAD=0: everything from the caller.
 struct DwTask {
+  std::thread::id owner;      // the host thread that pushed it (set by DwWorker::push)
   wsis_op op;
   hipEvent_t ev;
   int dev;
@@ -185,28 +188,43 @@ int issue_dw(const wsis_op& op, char* dw_ws, int64_t dw_bytes, void* dw_stream) 
 }
 class DwWorker {
  public:
-  void push(const DwTask& t) {
+  void push(DwTask t) {
     std::lock_guard<std::mutex> lock(mu_);
+    const long pid = (long)getpid();
+    if (started_ && pid_ != pid) {      // a forked child inherits the flag but not the thread: start over
+      started_ = false;
+      q_.clear();
+      st_.clear();
+    }
     if (!started_) {
       started_ = true;
+      pid_ = pid;
       std::thread(&DwWorker::run, this).detach();
     }
+    t.owner = std::this_thread::get_id();
     q_.push_back(t);
-    ++pending_;
+    ++st_[t.owner].pending;
     cv_.notify_one();
   }
-  // waits until every task pushed so far has been issued; returns the first error of the batch (and its message)
+  // waits until every task THIS thread pushed has been issued; returns the first error among them (and its message):
+  // two host threads driving passes on different streams neither wait for nor see each other's tasks
   int drain(std::string* msg) {
+    const std::thread::id me = std::this_thread::get_id();
     std::unique_lock<std::mutex> lock(mu_);
-    done_.wait(lock, [this] { return pending_ == 0; });
-    const int rc = err_;
-    if (rc != WSIS_OK && msg) *msg = err_msg_;
-    err_ = WSIS_OK;
-    err_msg_.clear();
+    done_.wait(lock, [&] { return st_[me].pending == 0; });
+    State& s = st_[me];
+    const int rc = s.err;
+    if (rc != WSIS_OK && msg) *msg = s.msg;
+    s.err = WSIS_OK;
+    s.msg.clear();
     return rc;
   }
 
  private:
+  struct State {
+    int pending = 0, err = WSIS_OK;
+    std::string msg;
+  };
   void run() {
     for (;;) {
       DwTask t;
@@ -228,19 +246,20 @@ class DwWorker {
         if (rc != WSIS_OK) msg = wsis_last_error();
       }
       std::lock_guard<std::mutex> lock(mu_);
-      if (rc != WSIS_OK && err_ == WSIS_OK) {
-        err_ = rc;
-        err_msg_ = msg;
+      State& s = st_[t.owner];
+      if (rc != WSIS_OK && s.err == WSIS_OK) {
+        s.err = rc;
+        s.msg = msg;
       }
-      if (--pending_ == 0) done_.notify_all();
+      if (--s.pending == 0) done_.notify_all();
     }
   }
   std::mutex mu_;
   std::condition_variable cv_, done_;
   std::deque<DwTask> q_;
-  int pending_ = 0, err_ = WSIS_OK;
-  std::string err_msg_;
+  std::map<std::thread::id, State> st_;
   bool started_ = false;
+  long pid_ = 0;
 };
 DwWorker& dw_worker() {
   static DwWorker* w = new DwWorker();      // never destroyed: its thread may outlive static destruction

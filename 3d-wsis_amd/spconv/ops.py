@@ -266,11 +266,17 @@ def verify_pending_counts():
     if chk is None:
         chk = _CHECK_STREAMS[key] = torch.cuda.Stream(device=dev)
     chk.wait_event(pend[-1][2])          # recorded on the building stream behind the last count (stream order)
+    # the error words of the device's sync blocks ride in the same copy: a bounded wait inside a launch that ran out
+    # (csrc/common.h SyncSlot::err, word 19 of a slot) would otherwise be wrong numerics nobody looks at
+    errs = _n.sync_err_words(dev)
     with torch.cuda.stream(chk):
-        both = torch.cat([c for c, _, _ in pend])
+        both = torch.cat([c.to(torch.int64).reshape(-1) for c, _, _ in pend] + [e.to(torch.int64).reshape(-1) for e in errs])
         got = both.tolist()
     for c, _, _ in pend:
         c.record_stream(chk)
+    if any(int(v) != 0 for v in got[len(pend):]):
+        raise _n.WsisError("a bounded wait inside a launch ran out (sync slots %s): results of that launch are invalid"
+                           % (_n.sync_errors(),))
     for g, (_, want, _) in zip(got, pend):
         if int(g) != int(want):
             raise _n.WsisError("strided rulebook: the device found %d output voxels, the batch's level_counts said %d"

@@ -226,6 +226,13 @@ def sync_block(device=None):
     return t
 
 
+def sync_err_words(device):
+    """views of the error words (word 19 of every slot) of the sync blocks of ``device`` -- device tensors, not read here"""
+    import torch
+    dev = torch.device(device)
+    return [t.view(torch.int32).view(-1, 1024)[:, 19] for (d, _), t in _SYNC.items() if d == dev.index]
+
+
 def sync_errors():
     """slots whose bounded wait ran out (word 19 of a slot): a list of (device, stream, slot); reads the device"""
     bad = []
