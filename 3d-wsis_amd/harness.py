@@ -233,8 +233,8 @@ def _assemble_host(scenes):
         "superpoint_semantic_labels": torch.cat(sp_sem, 0).long(),
         "superpoint_instance_labels": torch.cat(sp_ins, 0).long(),
         "superpoint_offset_vector": torch.cat(sp_off, 0).float(),
-        # (numpy's log: a torch CPU op costs tens of milliseconds of thread-pool wake-up on a many-core host)
-        "superpoint_instance_voxel_num": torch.from_numpy(np.log(torch.cat(sp_vox, 0).float().numpy())),
+        # (torch's CPU log, as the reference's collate_fn, scannetv2_dataset.py:438: numpy's differs in the last bit)
+        "superpoint_instance_voxel_num": torch.log(torch.cat(sp_vox, 0).float()),
         "superpoint_instance_size": torch.cat(sp_size, 0).float(),
         "scene_list": [f"synthetic_{i}" for i in range(len(scenes))],
     }
@@ -289,9 +289,11 @@ def pack_scene(sc, pin=True, buf=None):
     # (column by column: numpy's reduction along axis 0 of an [N, 3] array is ten times slower)
     lo = np.floor(np.array([xyz[:, j].min() for j in range(3)], dtype=np.float64) * SCALE).astype(np.int64)
     hi = np.floor(np.array([xyz[:, j].max() for j in range(3)], dtype=np.float64) * SCALE).astype(np.int64)
-    # (the log of the voxel counts on the HOST with numpy, exactly as ``_assemble_host`` takes it -- the reference's
-    # collate_fn does it on the host too, scannetv2_dataset.py:438; the device's log differs in the last bit)
-    arrays = dict(sc, xyz=xyz, vmin=lo, sp_voxnum=np.log(np.ascontiguousarray(sc["sp_voxnum"], dtype=np.float32)))
+    # (the log of the voxel counts with torch's CPU log, exactly as ``_assemble_host`` and the reference's collate_fn,
+    # scannetv2_dataset.py:438, take it: numpy's and the device's log differ in the last bit.  A few thousand values:
+    # below the size at which a torch CPU op wakes its thread pool)
+    voxnum = torch.from_numpy(np.ascontiguousarray(sc["sp_voxnum"], dtype=np.float32))
+    arrays = dict(sc, xyz=xyz, vmin=lo, sp_voxnum=torch.log(voxnum).numpy())
     layout, off = {}, 0
     parts = []
     for name, dt, width in _PACK_FIELDS:
