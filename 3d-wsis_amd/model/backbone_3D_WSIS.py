@@ -150,15 +150,24 @@ class Network(nn.Module):
         self.ecc.set_info(extra_data["GIs"], cuda=True)
         ecc_outputs = self.ecc(embeddings)
 
-        ret["sp_semantic_scores"] = self.sp_sem_seg(ecc_outputs)
-        ret["pred_sp_offset_vectors"] = self.sp_offset_vector_head(ecc_outputs)
-        ret["pred_sp_occupancy"] = self.sp_occupancy_head(ecc_outputs).squeeze(-1)
-        ret["pred_sp_ins_size"] = self.sp_ins_size_head(ecc_outputs).squeeze(-1)
+        # the four heads and the q / k / v layers read the same rows: ONE operator (2 launches forward, 3 backward,
+        # csrc/heads.hip) where it applies, else module by module
+        fused = wsis_ops.sp_heads(ecc_outputs, [self.sp_sem_seg, self.sp_offset_vector_head, self.sp_occupancy_head,
+                                                self.sp_ins_size_head], [self.w_qs, self.w_ks, self.w_vs])
+        if fused is not None:
+            (sem, off, occ, size), (q, k, v) = fused
+        else:
+            sem, off = self.sp_sem_seg(ecc_outputs), self.sp_offset_vector_head(ecc_outputs)
+            occ, size = self.sp_occupancy_head(ecc_outputs), self.sp_ins_size_head(ecc_outputs)
+            q, k, v = (wsis_ops.tall_linear(ecc_outputs, m) if ecc_outputs.is_cuda else m(ecc_outputs)
+                       for m in (self.w_qs, self.w_ks, self.w_vs))
+        ret["sp_semantic_scores"] = sem
+        ret["pred_sp_offset_vectors"] = off
+        ret["pred_sp_occupancy"] = occ.squeeze(-1)
+        ret["pred_sp_ins_size"] = size.squeeze(-1)
 
         # ---- affinity between adjacent superpoints (backbone_3D_WSIS.py:207-253) ----
         centre = extra_data["superpoint_cenetr_xyz"]
-        q, k, v = (wsis_ops.tall_linear(ecc_outputs, m) if ecc_outputs.is_cuda else m(ecc_outputs)
-                   for m in (self.w_qs, self.w_ks, self.w_vs))
         edge_u, edge_v = extra_data["edge_u_list"], extra_data["edge_v_list"]
         graph = extra_data.get("edge_graph")
         if graph is None:
@@ -173,5 +182,6 @@ class Network(nn.Module):
             pad = torch.zeros((ecc_outputs.shape[0] - res.shape[0], res.shape[1]), dtype=res.dtype,
                               device=res.device)
             sp_feat = ecc_outputs + torch.cat((res, pad), 0)
-        ret["sp_discriminative_feats"] = self.feature_term(sp_feat)
+        fused = wsis_ops.sp_heads(sp_feat, [self.feature_term])
+        ret["sp_discriminative_feats"] = fused[0][0] if fused is not None else self.feature_term(sp_feat)
         return ret

@@ -125,6 +125,9 @@ _HIP_SIGS = {
     "wsis_gru_cell_bwd": (I32, [P] * 17 + [I64, I32, P, I64, P]),
     "wsis_colsum_workspace_bytes": (I64, [I64, I32]),
     "wsis_colsum": (I32, [P, I64, I32, P, P, I64, P, P]),
+    "wsis_heads_workspace_bytes": (I64, [I64, I32, I32]),
+    "wsis_heads_fwd": (I32, [P, P, I64, F32, F32, I32, P, P, I64, P]),
+    "wsis_heads_bwd": (I32, [P, P, I64, I32, P, P, P, I64, P]),
     "wsis_gru_cell_bwd_seq": (I32, [P] * 17 + [I64, I32, I32, I32, I32, P, I64, P]),
     "wsis_affinity_dense_build": (I32, [P, P, P, I64, P, I64, P]),
     "wsis_affinity_transition": (I32, [P, P, P, P, P, I32, F32, P, I64, P]),
@@ -241,6 +244,17 @@ def sync_errors():
         for i in w.nonzero().flatten().tolist():
             bad.append((dev, st, int(i)))
     return bad
+
+
+HEADS_MAX = 8          # WSIS_HEADS_MAX of include/wsis_hip.h
+
+
+class Heads(ctypes.Structure):
+    """``wsis_heads`` of include/wsis_hip.h: the pointer tables of wsis_heads_fwd / wsis_heads_bwd (host memory)"""
+    _fields_ = [("n_heads", c_int32), ("n_lin", c_int32), ("cout", c_int32 * HEADS_MAX)] + \
+               [(name, c_void_p * HEADS_MAX) for name in
+                ("W1", "b1", "gamma", "beta", "W2", "b2", "running_mean", "running_var", "hidden", "out", "dout",
+                 "dW1", "db1", "dgamma", "dbeta", "dW2", "db2")]
 
 
 def require_cuda(*tensors):

@@ -5,6 +5,7 @@
 * ``affinity_matrix`` / ``propagate_class`` / ``weak_label_propagation`` -- the dense S x S fp64 affinity
   product of train_scannetv2.py:562-570 and modules/datasets/scannetv2_dataset.py:664-736 on the f64 MFMA.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -665,6 +666,142 @@ def tall_sequential(seq, x):
     for m in seq:
         x = tall_linear(x, m) if type(m) is torch.nn.Linear else m(x)
     return x
+
+
+# ---- the superpoint-level heads as one operator ----------------------------------------------------------------------
+
+class _SpHeads(Function):
+    """All heads Linear(64,64) -> BatchNorm1d -> ReLU -> Linear(64,cout) and bias-free Linear(64,64) layers that read the
+    same [S,64] rows (backbone_3D_WSIS.py:59-64, 195-216, 253) as ONE autograd node: two launches forward, three
+    backward (csrc/heads.hip) instead of a module chain per head (4 launches forward and ~12 backward each, plus the
+    gradient accumulation of the shared input)."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *tensors):
+        n_heads, n_lin, couts, eps, momentum, training, running = meta
+        _n.require_cuda(x, *tensors)
+        ctx.set_materialize_grads(False)       # an output nobody consumed arrives as None (NULL = zero in the library)
+        lib = _n.hip()
+        x = x.contiguous().float()
+        S = x.shape[0]
+        nb = n_heads + n_lin
+        hidden = torch.empty((nb, S, 64), dtype=torch.float32, device=x.device)
+        saved = torch.empty((max(n_heads, 1), 2, 64), dtype=torch.float32, device=x.device)
+        outs = [torch.empty((S, couts[p]), dtype=torch.float32, device=x.device) for p in range(n_heads)]
+        h = _n.Heads()
+        h.n_heads, h.n_lin = n_heads, n_lin
+        for p in range(n_heads):
+            W1, b1, g, b, W2, b2 = tensors[6 * p:6 * p + 6]
+            h.cout[p] = couts[p]
+            h.W1[p], h.b1[p], h.gamma[p], h.beta[p] = _n.ptr(W1), _n.ptr(b1), _n.ptr(g), _n.ptr(b)
+            h.W2[p], h.b2[p] = _n.ptr(W2), _n.ptr(b2)
+            rm, rv = running[p]
+            h.running_mean[p], h.running_var[p] = _n.ptr(rm), _n.ptr(rv)
+            h.out[p] = _n.ptr(outs[p])
+        for q in range(n_lin):
+            h.W1[n_heads + q] = _n.ptr(tensors[6 * n_heads + q])
+        for p in range(nb):
+            h.hidden[p] = hidden[p].data_ptr()
+        ws_bytes = lib.wsis_heads_workspace_bytes(S, n_heads, n_lin)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        _n.check(lib.wsis_heads_fwd(ctypes.byref(h), _n.ptr(x), S, float(eps), float(momentum), int(training),
+                                    _n.ptr(saved), _n.ptr(ws), ws_bytes, _n.stream_ptr()), "heads_fwd")
+        ctx.save_for_backward(x, hidden, saved, *tensors)
+        ctx.meta = (n_heads, n_lin, couts, training)
+        return tuple(outs) + tuple(hidden[n_heads + q] for q in range(n_lin))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n_heads, n_lin, couts, training = ctx.meta
+        x, hidden, saved = ctx.saved_tensors[:3]
+        tensors = ctx.saved_tensors[3:]
+        lib = _n.hip()
+        S = x.shape[0]
+        nb = n_heads + n_lin
+        keep = []
+        h = _n.Heads()
+        h.n_heads, h.n_lin = n_heads, n_lin
+        out_grads = [None] * len(tensors)
+
+        def want(i):
+            if not ctx.needs_input_grad[2 + i]:
+                return None
+            out_grads[i] = torch.empty_like(tensors[i], memory_format=torch.contiguous_format)
+            return out_grads[i].data_ptr()
+
+        for p in range(nb):
+            g = grads[p]
+            if g is not None:
+                g = g.contiguous().float()
+                keep.append(g)
+            h.dout[p] = _n.ptr(g)
+            h.hidden[p] = hidden[p].data_ptr()
+        for p in range(n_heads):
+            W1, b1, gam, bet, W2, b2 = tensors[6 * p:6 * p + 6]
+            h.cout[p] = couts[p]
+            h.W1[p], h.b1[p], h.gamma[p], h.beta[p] = _n.ptr(W1), _n.ptr(b1), _n.ptr(gam), _n.ptr(bet)
+            h.W2[p], h.b2[p] = _n.ptr(W2), _n.ptr(b2)
+            h.dW1[p], h.db1[p], h.dgamma[p] = want(6 * p), want(6 * p + 1), want(6 * p + 2)
+            h.dbeta[p], h.dW2[p], h.db2[p] = want(6 * p + 3), want(6 * p + 4), want(6 * p + 5)
+        for q in range(n_lin):
+            h.W1[n_heads + q] = _n.ptr(tensors[6 * n_heads + q])
+            h.dW1[n_heads + q] = want(6 * n_heads + q)
+        dx = torch.empty_like(x)
+        ws_bytes = lib.wsis_heads_workspace_bytes(S, n_heads, n_lin)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        _n.check(lib.wsis_heads_bwd(ctypes.byref(h), _n.ptr(x), S, int(training), _n.ptr(saved), _n.ptr(dx), _n.ptr(ws),
+                                    ws_bytes, _n.stream_ptr()), "heads_bwd")
+        return (dx if ctx.needs_input_grad[0] else None, None) + tuple(out_grads)
+
+
+def _head_parts(head):
+    """(Linear, BatchNorm1d, Linear) of a ``head(cin, cout)`` Sequential that the fused operator covers, else None"""
+    if len(head) != 4:
+        return None
+    l1, bn, act, l2 = head[0], head[1], head[2], head[3]
+    if not (type(l1) is torch.nn.Linear and type(l2) is torch.nn.Linear and isinstance(bn, torch.nn.BatchNorm1d)
+            and isinstance(act, torch.nn.ReLU)):
+        return None
+    if l1.in_features != 64 or l1.out_features != 64 or l1.bias is None or l2.in_features != 64 or l2.out_features > 32:
+        return None
+    if not bn.affine or bn.num_features != 64 or bn.momentum is None or sync_group(bn) is not None:
+        return None
+    if not bn.training and not bn.track_running_stats:
+        return None
+    return l1, bn, l2
+
+
+def sp_heads(x, heads, linears=()):
+    """outputs of the ``head`` Sequentials and of the bias-free Linear(64,64) layers over x [S,64]; None where the fused
+    operator does not apply (CPU tensors, other widths, SyncBatchNorm, mixed train / eval heads, WSIS_FUSE_HEADS=0): the
+    caller then runs the modules one by one"""
+    import os
+    if (not x.is_cuda or x.dim() != 2 or x.shape[1] != 64 or x.dtype != torch.float32 or x.shape[0] < 1
+            or len(heads) + len(linears) > _n.HEADS_MAX or os.environ.get("WSIS_FUSE_HEADS", "1") == "0"):
+        return None
+    parts = [_head_parts(hd) for hd in heads]
+    if any(p is None for p in parts):
+        return None
+    if any(type(l) is not torch.nn.Linear or l.bias is not None or l.in_features != 64 or l.out_features != 64
+           for l in linears):
+        return None
+    modes = {bn.training for _, bn, _ in parts}
+    if len(modes) > 1 or len({(bn.eps, bn.momentum) for _, bn, _ in parts}) > 1:
+        return None
+    training = bool(modes.pop()) if modes else False
+    eps, momentum = (parts[0][1].eps, parts[0][1].momentum) if parts else (1e-5, 0.1)
+    tensors, running, couts = [], [], []
+    for l1, bn, l2 in parts:
+        tensors += [l1.weight, l1.bias, bn.weight, bn.bias, l2.weight, l2.bias]
+        couts.append(l2.out_features)
+        track = bn.track_running_stats and bn.running_mean is not None
+        running.append((bn.running_mean, bn.running_var) if track else (None, None))
+        if training and track and bn.num_batches_tracked is not None:
+            _defer_batch_count(bn)
+    tensors += [l.weight for l in linears]
+    meta = (len(parts), len(linears), tuple(couts), eps, momentum, training, tuple(running))
+    outs = _SpHeads.apply(x, meta, *tensors)
+    return list(outs[:len(parts)]), list(outs[len(parts):])
 
 
 # ---- a14: voxel -> point gather with a deterministic backward ---------------------------------------------------

@@ -452,6 +452,46 @@ int64_t wsis_colsum_workspace_bytes(int64_t M, int32_t C);
 int wsis_colsum(const float* d_x, int64_t M, int32_t C, float* d_out, void* d_ws, int64_t ws_bytes, void* d_sync,
                 void* stream);
 
+/* Prediction heads over the superpoint rows: replaces the per-layer module chains of
+ * modules/model/backbone_3D_WSIS.py:59-64 (`head(cin, cout)` = Linear(cin,cin) -> BatchNorm1d -> ReLU -> Linear(cin,cout)),
+ * :195-204 (sp_sem_seg / sp_offset_vector_head / sp_occupancy_head / sp_ins_size_head on the GNN output), :210-216 (the
+ * bias-free w_qs / w_ks / w_vs on the same rows) and :253 (feature_term), cin == 64.  All blocks of one call read the same
+ * input x [S,64]: blocks 0 .. n_heads-1 are heads (cout <= 32), blocks n_heads .. n_heads+n_lin-1 plain Linear(64,64)
+ * layers without bias.  Forward = 2 launches, backward = 3 (csrc/heads.hip), fixed summation orders, exact fp32.
+ * The tables hold DEVICE pointers in torch's layouts (Linear weight [out,in]); the struct itself is host memory.
+ *   forward   reads W1,b1,gamma,beta,W2,b2 (+ running_* in eval mode), writes hidden[p] [S,64] (heads: the pre-BatchNorm
+ *             activations, kept for backward; plain layers: their OUTPUT), out[p] [S,cout[p]], d_saved [n_heads,2,64]
+ *             (mean, 1/sqrt(var+eps)); training != 0 uses batch statistics and updates running_* (NULL: not tracked)
+ *   backward  reads dout[p] (heads: [S,cout[p]]; plain layers: [S,64]; NULL = zero), hidden, d_saved; writes d_dx [S,64]
+ *             and every non-NULL dW1 [64,64] / db1 [64] / dgamma / dbeta [64] / dW2 [cout,64] / db2 [cout] (overwritten) */
+#define WSIS_HEADS_MAX 8
+typedef struct wsis_heads {
+  int32_t n_heads, n_lin;
+  int32_t cout[WSIS_HEADS_MAX];
+  const float* W1[WSIS_HEADS_MAX];
+  const float* b1[WSIS_HEADS_MAX];
+  const float* gamma[WSIS_HEADS_MAX];
+  const float* beta[WSIS_HEADS_MAX];
+  const float* W2[WSIS_HEADS_MAX];
+  const float* b2[WSIS_HEADS_MAX];
+  float* running_mean[WSIS_HEADS_MAX];
+  float* running_var[WSIS_HEADS_MAX];
+  float* hidden[WSIS_HEADS_MAX];
+  float* out[WSIS_HEADS_MAX];
+  const float* dout[WSIS_HEADS_MAX];
+  float* dW1[WSIS_HEADS_MAX];
+  float* db1[WSIS_HEADS_MAX];
+  float* dgamma[WSIS_HEADS_MAX];
+  float* dbeta[WSIS_HEADS_MAX];
+  float* dW2[WSIS_HEADS_MAX];
+  float* db2[WSIS_HEADS_MAX];
+} wsis_heads;
+int64_t wsis_heads_workspace_bytes(int64_t S, int32_t n_heads, int32_t n_lin);
+int wsis_heads_fwd(const wsis_heads* h, const float* d_x, int64_t S, float eps, float momentum, int32_t training,
+                   float* d_saved, void* d_ws, int64_t ws_bytes, void* stream);
+int wsis_heads_bwd(const wsis_heads* h, const float* d_x, int64_t S, int32_t training, const float* d_saved, float* d_dx,
+                   void* d_ws, int64_t ws_bytes, void* stream);
+
 /* GRUCellEx of the superpoint GNN (modules/model/spg_modules.py:207-253: GRU cell + input gate + per-row
  * normalisation of the gate pre-activations), C == 32: one kernel forward, one backward + a fixed-order reduce of
  * the parameter gradients.  Weights in torch.nn.GRUCell layout: Wih/Whh [3C,C] (r,z,n blocks), Wig [C,C]. */
