@@ -569,6 +569,104 @@ int waves_grid(int64_t segments) {
   return (int)g;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Position encoding of the edge affinity (backbone_3D_WSIS.py:54-58, 222-224): pos_e = fc_position(centre[u_e] - centre[v_e])
+// with fc_position = Linear(3,16) -> ReLU -> Linear(16,1).  The reference runs two gathers, a subtraction and three
+// module launches forward and a dozen small launches backward (two of them [E,16] x [16,3] weight gradients) over
+// E ~ 20 k rows; here one thread per edge does the whole chain, and the backward leaves the 81 parameter-gradient sums
+// of a workgroup (butterfly inside the wave, waves added in order) as one partial row, summed by a second tiny launch.
+constexpr int PE_H = 16;                           // hidden width
+constexpr int PE_G = PE_H * 3 + PE_H + PE_H + 1;   // dW1 [16,3], db1 [16], dW2 [16], db2
+
+__device__ __forceinline__ void pe_hidden(const float* __restrict__ centre, int64_t u, int64_t v, const float* __restrict__ W1,
+                                          const float* __restrict__ b1, float (&d)[3], float (&hid)[PE_H]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) d[k] = centre[u * 3 + k] - centre[v * 3 + k];
+#pragma unroll
+  for (int j = 0; j < PE_H; ++j) {
+    float a = b1[j];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a += d[k] * W1[j * 3 + k];
+    hid[j] = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void pos_enc_fwd_kernel(const float* __restrict__ centre, const int64_t* __restrict__ eu,
+                                                          const int64_t* __restrict__ ev, const float* __restrict__ W1,
+                                                          const float* __restrict__ b1, const float* __restrict__ W2,
+                                                          const float* __restrict__ b2, float* __restrict__ pos, int64_t E) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  float d[3], hid[PE_H];
+  pe_hidden(centre, eu[e], ev[e], W1, b1, d, hid);
+  float p = b2[0];
+#pragma unroll
+  for (int j = 0; j < PE_H; ++j) p += fmaxf(hid[j], 0.0f) * W2[j];
+  pos[e] = p;
+}
+
+__global__ __launch_bounds__(256) void pos_enc_bwd_kernel(const float* __restrict__ centre, const int64_t* __restrict__ eu,
+                                                          const int64_t* __restrict__ ev, const float* __restrict__ W1,
+                                                          const float* __restrict__ b1, const float* __restrict__ W2,
+                                                          const float* __restrict__ dpos, float* __restrict__ partial,
+                                                          int64_t E) {
+  __shared__ float red[4][PE_G];
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float g[PE_G];
+#pragma unroll
+  for (int i = 0; i < PE_G; ++i) g[i] = 0.0f;
+  if (e < E) {
+    float d[3], hid[PE_H];
+    pe_hidden(centre, eu[e], ev[e], W1, b1, d, hid);
+    const float gp = dpos[e];
+#pragma unroll
+    for (int j = 0; j < PE_H; ++j) {
+      const float dh = hid[j] > 0.0f ? gp * W2[j] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) g[j * 3 + k] = dh * d[k];
+      g[PE_H * 3 + j] = dh;
+      g[PE_H * 4 + j] = gp * fmaxf(hid[j], 0.0f);
+    }
+    g[PE_G - 1] = gp;
+  }
+#pragma unroll
+  for (int i = 0; i < PE_G; ++i) {
+    float v = g[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < PE_G)
+    partial[(int64_t)blockIdx.x * PE_G + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// workgroup partials added in workgroup order: eight lanes per sum split the rows, added in lane order
+__global__ __launch_bounds__(PE_G * 8) void pos_enc_bwd_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ dW1,
+                                                                      float* __restrict__ db1, float* __restrict__ dW2,
+                                                                      float* __restrict__ db2) {
+  __shared__ float red[8][PE_G];
+  const int i = threadIdx.x % PE_G, l = threadIdx.x / PE_G;
+  float s = 0.0f;
+  for (int r = l; r < n; r += 8) s += partial[(int64_t)r * PE_G + i];
+  red[l][i] = s;
+  __syncthreads();
+  if (l != 0) return;
+#pragma unroll
+  for (int q = 1; q < 8; ++q) s += red[q][i];
+  if (i < PE_H * 3) {
+    if (dW1) dW1[i] = s;
+  } else if (i < PE_H * 4) {
+    if (db1) db1[i - PE_H * 3] = s;
+  } else if (i < PE_H * 5) {
+    if (dW2) dW2[i - PE_H * 4] = s;
+  } else if (db2) {
+    db2[0] = s;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -705,6 +803,39 @@ int wsis_affinity_propagate_sparse(const double* d_A, const uint8_t* d_adj, cons
   WSIS_LAUNCH_CHECK();
   hipLaunchKernelGGL(prop_colmax_kernel, dim3((unsigned)ceil_div(S, 64), (unsigned)n_present), dim3(64), 0, st, X, d_label,
                      d_cls_of, d_scores, d_arg, S);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int64_t wsis_pos_enc_workspace_bytes(int64_t E) {
+  if (E < 0) return -1;
+  return ceil_div(E > 0 ? E : 1, 256) * PE_G * (int64_t)sizeof(float) + 256;
+}
+
+int wsis_pos_enc_fwd(const float* d_centre, const int64_t* d_eu, const int64_t* d_ev, const float* d_W1, const float* d_b1,
+                     const float* d_W2, const float* d_b2, float* d_pos, int64_t E, void* stream) {
+  WSIS_REQUIRE(E >= 0, "bad sizes");
+  if (E == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_centre && d_eu && d_ev && d_W1 && d_b1 && d_W2 && d_b2 && d_pos, "null pointer");
+  hipLaunchKernelGGL(pos_enc_fwd_kernel, dim3((unsigned)ceil_div(E, 256)), dim3(256), 0, as_stream(stream), d_centre, d_eu, d_ev,
+                     d_W1, d_b1, d_W2, d_b2, d_pos, E);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_pos_enc_bwd(const float* d_centre, const int64_t* d_eu, const int64_t* d_ev, const float* d_W1, const float* d_b1,
+                     const float* d_W2, const float* d_dpos, float* d_dW1, float* d_db1, float* d_dW2, float* d_db2, int64_t E,
+                     void* d_ws, int64_t ws_bytes, void* stream) {
+  WSIS_REQUIRE(E >= 1, "bad sizes");
+  WSIS_REQUIRE(d_centre && d_eu && d_ev && d_W1 && d_b1 && d_W2 && d_dpos && d_ws, "null pointer");
+  WSIS_REQUIRE(ws_bytes >= wsis_pos_enc_workspace_bytes(E), "workspace too small");
+  const int n = (int)ceil_div(E, 256);
+  float* partial = static_cast<float*>(d_ws);
+  hipLaunchKernelGGL(pos_enc_bwd_kernel, dim3((unsigned)n), dim3(256), 0, as_stream(stream), d_centre, d_eu, d_ev, d_W1, d_b1, d_W2,
+                     d_dpos, partial, E);
+  WSIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pos_enc_bwd_final_kernel, dim3(1), dim3(PE_G * 8), 0, as_stream(stream), partial, n, d_dW1, d_db1, d_dW2,
+                     d_db2);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

@@ -5,6 +5,8 @@
 // bmm + scatter-mean (and three more launches in backward); here it is one kernel forward and one backward,
 // each reading the [E,C,C] filter tensor exactly once.  One wavefront per source node (forward) / per target
 // node (backward), fixed summation order => deterministic.  C <= 32 (the model uses 32).
+#include <type_traits>
+
 #include "common.h"
 
 using namespace wsis;
@@ -210,8 +212,13 @@ __global__ __launch_bounds__(256) void ecc_contract_fwd_kernel(const float* __re
 }
 
 // dU[t,c,b] = sum_{e in in(t)} haug[e,c] dm[e,b] (haug[e,64] = 1);  dh[e,c] = sum_b dm[e,b] U[t,c,b]
+// MEAN: dm is not materialised -- dm[e,:] = d_inp[src_e,:] / out-degree(src_e), the backward of the segmented mean that
+// follows the messages (the expression of segment_bwd_kernel: the same values)
+template <bool MEAN>
 __global__ __launch_bounds__(256) void ecc_contract_bwd_kernel(const float* __restrict__ h, const float* __restrict__ U,
                                                                const float* __restrict__ dm,
+                                                               const int64_t* __restrict__ src_index,
+                                                               const int32_t* __restrict__ off_src,
                                                                const int32_t* __restrict__ perm_dst,
                                                                const int32_t* __restrict__ off_dst,
                                                                float* __restrict__ dU, float* __restrict__ dh, int64_t S,
@@ -249,7 +256,13 @@ __global__ __launch_bounds__(256) void ecc_contract_bwd_kernel(const float* __re
 #pragma unroll
       for (int i = 0; i < EBATCH; ++i) {
         hv[i] = h[(int64_t)eid[i] * EH + lane];
-        dv[i] = dm[(int64_t)eid[i] * EC + b];
+        if (MEAN) {
+          const int64_t sn = src_index[eid[i]];
+          const int cnt = off_src[sn + 1] - off_src[sn];
+          dv[i] = dm[sn * EC + b] / (float)(cnt > 0 ? cnt : 1);
+        } else {
+          dv[i] = dm[(int64_t)eid[i] * EC + b];
+        }
       }
 #pragma unroll
       for (int i = 0; i < EBATCH; ++i) {
@@ -287,6 +300,113 @@ __global__ __launch_bounds__(256) void ecc_contract_bwd_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < 32; ++j) dUt[(half * 32 + j) * EC + b] = du[j];
     if (half == 0) dUt[EH * EC + b] = dub;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// The two dense products of a GRU step around the contraction, K or N = 32 (hipBLASLt takes 13.6 / 15.4 us for them on
+// 2,289 rows: 19 MB written / read at 1.3 TB/s):
+//   U  [S, 2080] = hx [S,32] @ W' [32, 2080]                     one wave per (32-row slice, 5 of the 65 column blocks)
+//   out [S, 32]  = base (+ extra) + dU [S, 2080] @ W'^T          one workgroup per slice, 8 waves split the 65 k-chunks,
+//                                                                added through LDS in wave order
+// exact fp32 (v_mfma_f32_32x32x2_f32), fixed order.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int UB = EU / 32;      // 65 column blocks
+constexpr int UC = 5;            // column blocks per wave of the forward product (65 = 13 x 5)
+
+__device__ __forceinline__ int mrow(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+__global__ __launch_bounds__(256) void ecc_u_fwd_kernel(const float* __restrict__ hx, const float* __restrict__ W,
+                                                        float* __restrict__ U, int64_t S) {
+  // wave = one 32-row slice x UC consecutive column blocks: all weight loads of the wave in flight together
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r31 = lane & 31, half = lane >> 5;
+  const int64_t s = (int64_t)blockIdx.x * 4 + wave, row = s * 32 + r31;
+  if (s * 32 >= S) return;
+  float a[16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < S) v = *reinterpret_cast<const float4*>(hx + row * EC + half * 16 + q * 4);
+    a[q * 4 + 0] = v.x; a[q * 4 + 1] = v.y; a[q * 4 + 2] = v.z; a[q * 4 + 3] = v.w;
+  }
+  const int cb0 = blockIdx.y * UC;
+  float b[UC][16];
+#pragma unroll
+  for (int u = 0; u < UC; ++u)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[u][i] = W[(half * 16 + i) * EU + (cb0 + u) * 32 + r31];
+#pragma unroll
+  for (int u = 0; u < UC; ++u) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[u][i], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t g = s * 32 + mrow(i, half);
+      if (g < S) U[g * EU + (cb0 + u) * 32 + r31] = acc[i];
+    }
+  }
+}
+
+constexpr int UW = 8;                        // waves of a slice in the backward product
+constexpr int UK = (UB + UW - 1) / UW;       // k-chunks per wave (9)
+
+__global__ __launch_bounds__(64 * UW) void ecc_u_bwd_kernel(const float* __restrict__ dU, const float* __restrict__ W,
+                                                            const float* __restrict__ base, const float* __restrict__ extra,
+                                                            int64_t extra_pitch, float* __restrict__ out, int64_t S) {
+  __shared__ float red[UW][32][32];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r31 = lane & 31, half = lane >> 5;
+  const int64_t s = blockIdx.x, row = s * 32 + r31;
+  // wave w owns chunks w, w + 8, ...; two batches (5 + 4 chunks), the loads of a batch in flight together (16 waves per
+  // slice with 3 + 2 chunks measured slower: 28 us against 18 for the chunk-by-chunk loop)
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+  auto batch = [&](auto u0c, auto nuc) {
+    constexpr int U0 = decltype(u0c)::value, NU = decltype(nuc)::value;
+    float4 av[NU][4], bv[NU][4];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int ch = wave + (U0 + u) * UW;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        av[u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ch < UB) {
+          if (row < S) av[u][q] = *reinterpret_cast<const float4*>(dU + row * EU + ch * 32 + half * 16 + q * 4);
+          bv[u][q] = *reinterpret_cast<const float4*>(W + (int64_t)r31 * EU + ch * 32 + half * 16 + q * 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q].x, bv[u][q].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q].y, bv[u][q].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q].z, bv[u][q].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q].w, bv[u][q].w, acc, 0, 0, 0);
+      }
+  };
+  static_assert(UK == 9, "two batches of 5 + 4 chunks");
+  batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+  batch(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
+#pragma unroll
+  for (int i = 0; i < 16; ++i) red[wave][mrow(i, half)][r31] = acc[i];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * 32; e += 64 * UW) {
+    const int rr = e >> 5, c = e & 31;
+    const int64_t g = s * 32 + rr;
+    if (g < S) {
+      float v = base ? base[g * EC + c] : 0.0f;
+#pragma unroll
+      for (int w = 0; w < UW; ++w) v += red[w][rr][c];
+      if (extra) v += extra[g * extra_pitch + c];
+      out[g * EC + c] = v;
+    }
   }
 }
 
@@ -337,28 +457,65 @@ int wsis_ecc_contract_fwd(const float* d_h, const float* d_U, const int32_t* d_p
   return WSIS_OK;
 }
 
-static int ecc_contract_bwd_impl(const float* d_h, const float* d_U, const float* d_dm, const int32_t* d_perm_dst,
-                                 const int32_t* d_off_dst, float* d_dU, float* d_dh, int64_t S, int64_t E,
-                                 int accumulate, void* stream) {
+static int ecc_contract_bwd_impl(const float* d_h, const float* d_U, const float* d_dm, const int64_t* d_src_index,
+                                 const int32_t* d_off_src, const int32_t* d_perm_dst, const int32_t* d_off_dst, float* d_dU,
+                                 float* d_dh, int64_t S, int64_t E, int accumulate, void* stream) {
   WSIS_REQUIRE(S >= 0 && E >= 0, "bad sizes");
   if (S == 0) return WSIS_OK;
   WSIS_REQUIRE(d_U && d_off_dst && d_dU && (E == 0 || (d_h && d_dm && d_perm_dst && d_dh)), "null pointer");
   WSIS_REQUIRE(((reinterpret_cast<uintptr_t>(d_U) | reinterpret_cast<uintptr_t>(d_h)) & 15) == 0, "16-byte alignment");
-  hipLaunchKernelGGL(ecc_contract_bwd_kernel, dim3(waves_grid(S)), dim3(256), 0, as_stream(stream), d_h, d_U, d_dm,
-                     d_perm_dst, d_off_dst, d_dU, d_dh, S, accumulate);
+  if (d_src_index)
+    hipLaunchKernelGGL(ecc_contract_bwd_kernel<true>, dim3(waves_grid(S)), dim3(256), 0, as_stream(stream), d_h, d_U, d_dm,
+                       d_src_index, d_off_src, d_perm_dst, d_off_dst, d_dU, d_dh, S, accumulate);
+  else
+    hipLaunchKernelGGL(ecc_contract_bwd_kernel<false>, dim3(waves_grid(S)), dim3(256), 0, as_stream(stream), d_h, d_U, d_dm,
+                       d_src_index, d_off_src, d_perm_dst, d_off_dst, d_dU, d_dh, S, accumulate);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }
 
 int wsis_ecc_contract_bwd(const float* d_h, const float* d_U, const float* d_dm, const int32_t* d_perm_dst,
                           const int32_t* d_off_dst, float* d_dU, float* d_dh, int64_t S, int64_t E, void* stream) {
-  return ecc_contract_bwd_impl(d_h, d_U, d_dm, d_perm_dst, d_off_dst, d_dU, d_dh, S, E, 0, stream);
+  return ecc_contract_bwd_impl(d_h, d_U, d_dm, nullptr, nullptr, d_perm_dst, d_off_dst, d_dU, d_dh, S, E, 0, stream);
 }
 
 int wsis_ecc_contract_bwd_acc(const float* d_h, const float* d_U, const float* d_dm, const int32_t* d_perm_dst,
                               const int32_t* d_off_dst, float* d_dU, float* d_dh, int64_t S, int64_t E,
                               int32_t accumulate, void* stream) {
-  return ecc_contract_bwd_impl(d_h, d_U, d_dm, d_perm_dst, d_off_dst, d_dU, d_dh, S, E, accumulate ? 1 : 0, stream);
+  return ecc_contract_bwd_impl(d_h, d_U, d_dm, nullptr, nullptr, d_perm_dst, d_off_dst, d_dU, d_dh, S, E, accumulate ? 1 : 0,
+                               stream);
+}
+
+int wsis_ecc_contract_bwd_mean(const float* d_h, const float* d_U, const float* d_dinp, const int64_t* d_src_index,
+                               const int32_t* d_off_src, const int32_t* d_perm_dst, const int32_t* d_off_dst, float* d_dU,
+                               float* d_dh, int64_t S, int64_t E, int32_t accumulate, void* stream) {
+  WSIS_REQUIRE(E == 0 || (d_src_index && d_off_src), "source index / offsets missing");
+  if (E == 0) return ecc_contract_bwd_impl(d_h, d_U, d_dinp, nullptr, nullptr, d_perm_dst, d_off_dst, d_dU, d_dh, S, E, 0, stream);
+  return ecc_contract_bwd_impl(d_h, d_U, d_dinp, d_src_index, d_off_src, d_perm_dst, d_off_dst, d_dU, d_dh, S, E,
+                               accumulate ? 1 : 0, stream);
+}
+
+int wsis_ecc_u_fwd(const float* d_hx, const float* d_W, float* d_U, int64_t S, void* stream) {
+  WSIS_REQUIRE(S >= 0, "bad sizes");
+  if (S == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_hx && d_W && d_U, "null pointer");
+  WSIS_REQUIRE((reinterpret_cast<uintptr_t>(d_hx) & 15) == 0, "16-byte alignment");
+  hipLaunchKernelGGL(ecc_u_fwd_kernel, dim3((unsigned)ceil_div(S, 128), UB / UC), dim3(256), 0, as_stream(stream), d_hx, d_W, d_U,
+                     S);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_ecc_u_bwd(const float* d_dU, const float* d_W, const float* d_base, const float* d_extra, int64_t extra_pitch,
+                   float* d_out, int64_t S, void* stream) {
+  WSIS_REQUIRE(S >= 0, "bad sizes");
+  if (S == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_dU && d_W && d_out, "null pointer");
+  WSIS_REQUIRE(((reinterpret_cast<uintptr_t>(d_dU) | reinterpret_cast<uintptr_t>(d_W)) & 15) == 0, "16-byte alignment");
+  hipLaunchKernelGGL(ecc_u_bwd_kernel, dim3((unsigned)ceil_div(S, 32)), dim3(64 * UW), 0, as_stream(stream), d_dU, d_W, d_base,
+                     d_extra, extra_pitch, d_out, S);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
 }
 
 }  // extern "C"

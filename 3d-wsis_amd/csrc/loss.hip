@@ -285,6 +285,89 @@ __global__ void sp_reg_bwd_kernel(const float* __restrict__ p_off, const float* 
   }
 }
 
+// ---- superpoint semantic term (losses_3D_WSIS.py:72-74: CrossEntropyLoss(ignore_index) on the [S, C] superpoint scores,
+// logged with scores.sum()) and the weighted sum of all terms (:130-151).  torch runs log_softmax + nll_loss + sum forward
+// and two launches backward on 2,289 rows, and one launch per `loss = loss + term`; here one workgroup walks the rows
+// (fp32 per row, folded in fp64 in a fixed order) and one thread adds the terms in the reference's order.
+//   out[0] = sum_kept (logsumexp(row) - row[label]) / n_kept     out[1] = sum of all scores     out[2] = n_kept
+__global__ __launch_bounds__(SR_THREADS) void sp_ce_fwd_kernel(const float* __restrict__ scores, const int64_t* __restrict__ labels,
+                                                                int64_t S, int C, int64_t ignore, float* __restrict__ out) {
+  __shared__ double sh[SR_THREADS / 64][3];
+  float a[3] = {0.f, 0.f, 0.f};
+  for (int64_t r = threadIdx.x; r < S; r += SR_THREADS) {
+    const float* row = scores + r * C;
+    float mx = row[0], sum = 0.f;
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) {
+      se += expf(row[c] - mx);
+      sum += row[c];
+    }
+    a[1] += sum;
+    const int64_t lab = labels[r];
+    if (lab != ignore && lab >= 0 && lab < C) {
+      a[0] += (logf(se) + mx) - row[lab];
+      a[2] += 1.0f;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    double v = (double)a[q];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) sh[wave][q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[3] = {0, 0, 0};
+    for (int w = 0; w < SR_THREADS / 64; ++w)
+      for (int q = 0; q < 3; ++q) t[q] += sh[w][q];
+    out[0] = (float)(t[0] / t[2]);        // n_kept == 0 -> nan, as torch
+    out[1] = (float)t[1];
+    out[2] = (float)t[2];
+  }
+}
+
+// d scores[r, c] = g * (softmax(row)[c] - [c == label]) / n_kept for kept rows, 0 for the others
+__global__ void sp_ce_bwd_kernel(const float* __restrict__ scores, const int64_t* __restrict__ labels, int64_t S, int C,
+                                 int64_t ignore, const float* __restrict__ out, const float* __restrict__ g,
+                                 float* __restrict__ d) {
+  const float w = g[0] / out[2];
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < S; r += (int64_t)gridDim.x * blockDim.x) {
+    const float* row = scores + r * C;
+    const int64_t lab = labels[r];
+    if (lab == ignore || lab < 0 || lab >= C) {
+      for (int c = 0; c < C; ++c) d[r * C + c] = 0.f;
+      continue;
+    }
+    float mx = row[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
+    const float inv = 1.0f / se;
+    for (int c = 0; c < C; ++c) d[r * C + c] = w * (expf(row[c] - mx) * inv - ((int64_t)c == lab ? 1.0f : 0.0f));
+  }
+}
+
+// loss = t0 + t1 + ... in order; a term with `paired` bit i set is first added to its successor: (t_i + t_{i+1})
+__global__ void loss_sum_kernel(const float* t0, const float* t1, const float* t2, const float* t3, const float* t4,
+                                const float* t5, const float* t6, const float* t7, int n, unsigned paired, float* out) {
+  const float* t[8] = {t0, t1, t2, t3, t4, t5, t6, t7};
+  float acc = 0.0f;
+  bool first = true;
+  for (int i = 0; i < n; ++i) {
+    float v = t[i][0];
+    if ((paired >> i) & 1u) {
+      v = v + t[i + 1][0];
+      ++i;
+    }
+    acc = first ? v : acc + v;
+    first = false;
+  }
+  out[0] = acc;
+}
+
 // ---- discriminative (pull / push / regularisation) loss of one scene's superpoint embeddings
 // (losses_3D_WSIS.py:157-230): instances in n_slots <= 64 fixed slots (slot = instance id, bound known on the host),
 // S <= 4096 rows of D = 7 features, everything in one workgroup: rows and slots staged in LDS, instance sums by
@@ -579,6 +662,41 @@ int wsis_sp_regression_loss_bwd(const float* d_pred_off, const float* d_gt_off, 
   hipLaunchKernelGGL(sp_reg_bwd_kernel, dim3(grid_for(S, 256)), dim3(256), 0, as_stream(stream), d_pred_off, d_gt_off,
                      d_pred_occ, d_gt_occ, d_pred_size, d_gt_size, d_sem_label, d_ins_label, S, ignore_label, d_out5,
                      d_g_norm, d_g_dir, d_g_occ, d_g_size, d_doff, d_docc, d_dsize);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_sp_ce_loss_fwd(const float* d_scores, const int64_t* d_labels, int64_t S, int32_t C, int64_t ignore_label,
+                        float* d_out3, void* stream) {
+  WSIS_REQUIRE(S >= 0 && C >= 1 && d_out3, "bad args");
+  WSIS_REQUIRE(S == 0 || (d_scores && d_labels), "null pointer");
+  hipLaunchKernelGGL(sp_ce_fwd_kernel, dim3(1), dim3(SR_THREADS), 0, as_stream(stream), d_scores, d_labels, S, (int)C, ignore_label,
+                     d_out3);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_sp_ce_loss_bwd(const float* d_scores, const int64_t* d_labels, int64_t S, int32_t C, int64_t ignore_label,
+                        const float* d_out3, const float* d_grad_loss, float* d_dscores, void* stream) {
+  WSIS_REQUIRE(S >= 0 && C >= 1, "bad args");
+  if (S == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_scores && d_labels && d_out3 && d_grad_loss && d_dscores, "null pointer");
+  hipLaunchKernelGGL(sp_ce_bwd_kernel, dim3(grid_for(S, 256)), dim3(256), 0, as_stream(stream), d_scores, d_labels, S, (int)C,
+                     ignore_label, d_out3, d_grad_loss, d_dscores);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
+int wsis_loss_sum(const float* const* d_terms, int32_t n, uint32_t paired, float* d_out, void* stream) {
+  WSIS_REQUIRE(d_terms && d_out && n >= 1 && n <= 8, "1..8 terms");
+  const float* t[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < n; ++i) {
+    WSIS_REQUIRE(d_terms[i], "null term");
+    t[i] = d_terms[i];
+  }
+  WSIS_REQUIRE((paired >> (n - 1)) == 0, "a paired term needs a successor");
+  hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1), 0, as_stream(stream), t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], (int)n,
+                     (unsigned)paired, d_out);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

@@ -172,7 +172,9 @@ class Network(nn.Module):
         graph = extra_data.get("edge_graph")
         if graph is None:
             graph = wsis_ops.EdgeGraph(edge_u, edge_v, ecc_outputs.shape[0], num_src=extra_data.get("edge_src_rows"))
-        pos_enc = wsis_ops.tall_sequential(self.fc_position, centre[edge_u] - centre[edge_v]).reshape(-1)
+        pos_enc = wsis_ops.edge_position_encoding(self.fc_position, centre, edge_u, edge_v)      # one launch each way
+        if pos_enc is None:
+            pos_enc = wsis_ops.tall_sequential(self.fc_position, centre[edge_u] - centre[edge_v]).reshape(-1)
         affinity, res = wsis_ops.edge_affinity(q, k, v, pos_enc, graph, 1.0 / math.sqrt(k.size(-1)))
         ret["edge_affinity"] = affinity
 

@@ -88,8 +88,15 @@ class MultiTaskLoss(nn.Module):
                 return _mask
 
             sp_semantic_scores = loss_inp["sp_semantic"]
-            superpoint_semantic_loss = self.superpoint_semantic_criterion(sp_semantic_scores, sp_sem_labels)
-            loss_out["superpoint_semantic_loss"] = (superpoint_semantic_loss, sp_semantic_scores.sum())
+            if (not indexed and sp_semantic_scores.is_cuda and sp_semantic_scores.dim() == 2
+                    and os.environ.get("WSIS_FUSE_SP_CE", "1") != "0"):
+                import wsis_ops      # cross entropy + the logged sum of the scores: one launch each way (csrc/loss.hip)
+                superpoint_semantic_loss, sp_score_sum = wsis_ops.superpoint_cross_entropy(
+                    sp_semantic_scores, sp_sem_labels, self.ignore_label)
+            else:
+                superpoint_semantic_loss = self.superpoint_semantic_criterion(sp_semantic_scores, sp_sem_labels)
+                sp_score_sum = sp_semantic_scores.sum()
+            loss_out["superpoint_semantic_loss"] = (superpoint_semantic_loss, sp_score_sum)
 
             fused_reg = (not indexed and self.supervise_sp_offset and self.supervise_instance_size
                          and loss_inp["sp_offset_vector"][0].is_cuda
@@ -161,21 +168,37 @@ class MultiTaskLoss(nn.Module):
         # losses_3D_WSIS.py:130-151: loss = 0.0 + 1.0 * term + ...  All weights are 1.0 there, and 0.0 + x and 1.0 * x are
         # exact in floating point: the same sum in the same order without the seven scalar multiplications (each one a
         # launch forward and one backward)
-        loss = semantic_loss
+        # (the terms and the pairs of the reference's expression; summed left to right)
+        terms, paired = [semantic_loss], 0
         self._log("point semantic loss", semantic_loss)
         if joint:
-            loss = loss + superpoint_semantic_loss
+            terms.append(superpoint_semantic_loss)
             self._log("sp semantic loss", superpoint_semantic_loss)
             if self.supervise_sp_offset:
-                loss = loss + (offset_norm_loss + offset_dir_loss)
+                paired |= 1 << len(terms)                  # loss + (offset_norm_loss + offset_dir_loss)
+                terms += [offset_norm_loss, offset_dir_loss]
                 self._log("sp offset norm loss", offset_norm_loss)
                 self._log("sp offset dir loss", offset_dir_loss)
-            loss = loss + sp_d_loss
+            terms.append(sp_d_loss)
             self._log("sp discriminative loss", sp_d_loss)
             if self.supervise_instance_size:
-                loss = loss + occupancy_loss + instance_size_loss
+                terms += [occupancy_loss, instance_size_loss]
                 self._log("sp occupancy loss", occupancy_loss)
                 self._log("sp instance size loss", instance_size_loss)
+        if (len(terms) > 1 and len(terms) <= 8 and all(torch.is_tensor(t) and t.is_cuda and t.numel() == 1 for t in terms)
+                and os.environ.get("WSIS_FUSE_LOSS_SUM", "1") != "0"):
+            import wsis_ops
+            loss = wsis_ops.loss_sum(terms, paired)      # one launch instead of one per `loss = loss + term`
+        else:
+            loss = terms[0]
+            i = 1
+            while i < len(terms):
+                if (paired >> i) & 1:
+                    loss = loss + (terms[i] + terms[i + 1])
+                    i += 2
+                else:
+                    loss = loss + terms[i]
+                    i += 1
         return loss, loss_out
 
     def discriminative_loss(self, prediction, correct_label):

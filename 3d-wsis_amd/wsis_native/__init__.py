@@ -120,11 +120,17 @@ _HIP_SIGS = {
     "wsis_ecc_contract_fwd": (I32, [P, P, P, P, P, I64, I64, P]),
     "wsis_ecc_contract_bwd": (I32, [P, P, P, P, P, P, P, I64, I64, P]),
     "wsis_ecc_contract_bwd_acc": (I32, [P, P, P, P, P, P, P, I64, I64, I32, P]),
+    "wsis_ecc_contract_bwd_mean": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I32, P]),
+    "wsis_ecc_u_fwd": (I32, [P, P, P, I64, P]),
+    "wsis_ecc_u_bwd": (I32, [P, P, P, P, I64, P, I64, P]),
     "wsis_gru_cell_workspace_bytes": (I64, [I64]),
     "wsis_gru_cell_fwd": (I32, [P] * 9 + [I64, I32, P]),
     "wsis_gru_cell_bwd": (I32, [P] * 17 + [I64, I32, P, I64, P]),
     "wsis_colsum_workspace_bytes": (I64, [I64, I32]),
     "wsis_colsum": (I32, [P, I64, I32, P, P, I64, P, P]),
+    "wsis_pos_enc_workspace_bytes": (I64, [I64]),
+    "wsis_pos_enc_fwd": (I32, [P, P, P, P, P, P, P, P, I64, P]),
+    "wsis_pos_enc_bwd": (I32, [P, P, P, P, P, P, P, P, P, P, P, I64, P, I64, P]),
     "wsis_heads_workspace_bytes": (I64, [I64, I32, I32]),
     "wsis_heads_fwd": (I32, [P, P, I64, F32, F32, I32, P, P, I64, P]),
     "wsis_heads_bwd": (I32, [P, P, I64, I32, P, P, P, I64, P]),
@@ -143,6 +149,9 @@ _HIP_SIGS = {
     "wsis_semantic_loss_workspace_bytes": (I64, [I64]),
     "wsis_semantic_loss_fwd": (I32, [P, P, I64, I32, I64, P, P, P, I64, P]),
     "wsis_semantic_loss_bwd": (I32, [P, P, I64, I32, I64, P, P, P, P]),
+    "wsis_sp_ce_loss_fwd": (I32, [P, P, I64, I32, I64, P, P]),
+    "wsis_sp_ce_loss_bwd": (I32, [P, P, I64, I32, I64, P, P, P, P]),
+    "wsis_loss_sum": (I32, [P, I32, ctypes.c_uint32, P, P]),
     "wsis_sp_regression_loss_fwd": (I32, [P] * 8 + [I64, I64, P, P]),
     "wsis_sp_regression_loss_bwd": (I32, [P] * 8 + [I64, I64] + [P] * 8 + [P]),
     "wsis_disc_loss_saved_floats": (I32, []),

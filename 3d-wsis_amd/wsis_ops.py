@@ -85,6 +85,55 @@ def edge_affinity(q, k, v, pos_enc, graph, scale):
     return _EdgeAffinity.apply(q, k, v, pos_enc, graph, scale)
 
 
+class _PosEnc(Function):
+    """pos_e = fc_position(centre[u_e] - centre[v_e]) (backbone_3D_WSIS.py:54-58, 222-224) as one launch forward, two
+    backward (csrc/affinity.hip); the centres are data (no gradient)"""
+
+    @staticmethod
+    def forward(ctx, centre, eu, ev, W1, b1, W2, b2):
+        _n.require_cuda(centre, eu, ev, W1)
+        centre = centre.contiguous().float()
+        E = eu.numel()
+        pos = torch.empty(E, dtype=torch.float32, device=centre.device)
+        _n.check(_n.hip().wsis_pos_enc_fwd(_n.ptr(centre), _n.ptr(eu), _n.ptr(ev), _n.ptr(W1), _n.ptr(b1), _n.ptr(W2),
+                                           _n.ptr(b2), _n.ptr(pos), E, _n.stream_ptr()), "pos_enc_fwd")
+        ctx.save_for_backward(centre, eu, ev, W1, b1, W2)
+        return pos
+
+    @staticmethod
+    def backward(ctx, dpos):
+        centre, eu, ev, W1, b1, W2 = ctx.saved_tensors
+        E = eu.numel()
+        need = ctx.needs_input_grad
+        dW1 = torch.empty_like(W1) if need[3] else None
+        db1 = torch.empty_like(b1) if need[4] else None
+        dW2 = torch.empty_like(W2) if need[5] else None
+        db2 = torch.empty(1, dtype=torch.float32, device=W1.device) if need[6] else None
+        if E == 0:
+            return (None, None, None) + tuple(None if t is None else t.zero_() for t in (dW1, db1, dW2, db2))
+        lib = _n.hip()
+        ws_bytes = lib.wsis_pos_enc_workspace_bytes(E)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=W1.device)
+        _n.check(lib.wsis_pos_enc_bwd(_n.ptr(centre), _n.ptr(eu), _n.ptr(ev), _n.ptr(W1), _n.ptr(b1), _n.ptr(W2),
+                                      _n.ptr(dpos.contiguous().float()), _n.ptr(dW1), _n.ptr(db1), _n.ptr(dW2), _n.ptr(db2),
+                                      E, _n.ptr(ws), ws_bytes, _n.stream_ptr()), "pos_enc_bwd")
+        return None, None, None, dW1, db1, dW2, db2
+
+
+def edge_position_encoding(fc_position, centre, edge_u, edge_v):
+    """[E] position encodings, or None where the fused form does not apply (the caller runs the modules)"""
+    if (not centre.is_cuda or centre.requires_grad or len(fc_position) != 3 or centre.dim() != 2 or centre.shape[1] != 3
+            or os.environ.get("WSIS_FUSE_POS_ENC", "1") == "0"):
+        return None
+    l1, act, l2 = fc_position[0], fc_position[1], fc_position[2]
+    if not (type(l1) is torch.nn.Linear and type(l2) is torch.nn.Linear and isinstance(act, torch.nn.ReLU)
+            and l1.in_features == 3 and l1.out_features == 16 and l2.in_features == 16 and l2.out_features == 1
+            and l1.bias is not None and l2.bias is not None):
+        return None
+    eu, ev = edge_u.contiguous().long(), edge_v.contiguous().long()
+    return _PosEnc.apply(centre, eu, ev, l1.weight, l1.bias, l2.weight, l2.bias)
+
+
 # ---- a17: dense affinity matrix + label propagation -------------------------------------------------
 
 def affinity_matrix(edge_u, edge_v, edge_affinity_vals, S):
@@ -529,8 +578,13 @@ class _EccGruLoop(Function):
         hxs = [hx_all[i * S:(i + 1) * S] for i in range(repeats + 1)]
         hxs[0].copy_(hx)
         inps, Us = [], []
+        own = os.environ.get("WSIS_ECC_OWN_GEMM", "1") != "0"     # the two K / N = 32 products on csrc/ecc.hip's kernels
         for i in range(repeats):
-            U = hxs[i] @ Waug
+            if own:
+                U = torch.empty((S, Waug.shape[1]), dtype=torch.float32, device=hx.device)
+                _n.check(lib.wsis_ecc_u_fwd(_n.ptr(hxs[i]), _n.ptr(Waug), _n.ptr(U), S, st), "ecc_u_fwd")
+            else:
+                U = hxs[i] @ Waug
             m = torch.empty((E, 32), dtype=torch.float32, device=hx.device)
             _n.check(lib.wsis_ecc_contract_fwd(_n.ptr(h), _n.ptr(U), _n.ptr(csr_dst.perm), _n.ptr(csr_dst.offsets),
                                                _n.ptr(m), S, E, st), "ecc_contract_fwd")
@@ -569,16 +623,29 @@ class _EccGruLoop(Function):
         # row-split MFMA reduction (the sparse-conv dW kernel, K = 1, dense rows) instead of R one-workgroup GEMMs
         dU_all = torch.empty((R * S, Waug.shape[1]), dtype=torch.float32, device=dev)
         WaugT = Waug.t()
+        own = os.environ.get("WSIS_ECC_OWN_GEMM", "1") != "0"
         for i in reversed(range(R)):
             d_inp, d_hprev = torch.empty_like(d_hx), torch.empty_like(d_hx)
             _n.check(lib.wsis_gru_cell_bwd_seq(_n.ptr(inps[i]), _n.ptr(hxs[i]), *[_n.ptr(t) for t in gp], _n.ptr(d_hx),
                                                _n.ptr(d_inp), _n.ptr(d_hprev), *[_n.ptr(t) for t in dgp], S, 32,
                                                R - 1 - i, R, 1 if i == 0 else 0, _n.ptr(ws), ws_bytes, st),
                      "gru_cell_bwd_seq")
+            dU = dU_all[i * S:(i + 1) * S]
+            if own:
+                # the mean's backward (d_m[e] = d_inp[src_e] / out-degree) is formed inside the contraction's backward,
+                # and d_hx = d_hprev + dU @ W'^T + the output gradient of hx_i is ONE launch
+                _n.check(lib.wsis_ecc_contract_bwd_mean(_n.ptr(h), _n.ptr(Us[i]), _n.ptr(d_inp), _n.ptr(csr_src.index),
+                                                        _n.ptr(csr_src.offsets), _n.ptr(csr_dst.perm),
+                                                        _n.ptr(csr_dst.offsets), _n.ptr(dU), _n.ptr(dh), S, E,
+                                                        0 if i == R - 1 else 1, st), "ecc_contract_bwd_mean")
+                extra = (dout.data_ptr() + 4 * 32 * i) if cat_all else None
+                _n.check(lib.wsis_ecc_u_bwd(_n.ptr(dU), _n.ptr(Waug), _n.ptr(d_hprev), extra, dout.shape[1],
+                                            _n.ptr(d_hprev), S, st), "ecc_u_bwd")
+                d_hx = d_hprev
+                continue
             d_m = torch.empty((E, 32), dtype=torch.float32, device=dev)
             _n.check(lib.wsis_segment_reduce_bwd(_n.ptr(d_inp), _n.ptr(csr_src.index), _n.ptr(csr_src.offsets), None,
                                                  _n.ptr(d_m), E, S, 32, 1, st), "segment_reduce_bwd")
-            dU = dU_all[i * S:(i + 1) * S]
             _n.check(lib.wsis_ecc_contract_bwd_acc(_n.ptr(h), _n.ptr(Us[i]), _n.ptr(d_m), _n.ptr(csr_dst.perm),
                                                    _n.ptr(csr_dst.offsets), _n.ptr(dU), _n.ptr(dh), S, E,
                                                    0 if i == R - 1 else 1, st), "ecc_contract_bwd")
@@ -882,6 +949,64 @@ class _SemanticPointLoss(Function):
 
 def semantic_point_loss(scores, labels, ignore_label=-100):
     return _SemanticPointLoss.apply(scores, labels, ignore_label)
+
+
+class _SpCrossEntropy(Function):
+    """CrossEntropyLoss(ignore_index) of the superpoint scores + the logged scores.sum() in one launch each way
+    (csrc/loss.hip; reference losses_3D_WSIS.py:72-74).  Returns (loss, sum of the scores)."""
+
+    @staticmethod
+    def forward(ctx, scores, labels, ignore_label):
+        _n.require_cuda(scores, labels)
+        scores = scores.contiguous().float()
+        labels = labels.contiguous().long()
+        S, C = scores.shape
+        out = torch.empty(3, dtype=torch.float32, device=scores.device)
+        _n.check(_n.hip().wsis_sp_ce_loss_fwd(_n.ptr(scores), _n.ptr(labels), S, C, int(ignore_label), _n.ptr(out),
+                                              _n.stream_ptr()), "sp_ce_loss_fwd")
+        ctx.save_for_backward(scores, labels, out)
+        ctx.ignore_label = int(ignore_label)
+        loss, total = out[0], out[1]
+        ctx.mark_non_differentiable(total)
+        return loss, total
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_total):
+        scores, labels, out = ctx.saved_tensors
+        S, C = scores.shape
+        d = torch.empty_like(scores)
+        _n.check(_n.hip().wsis_sp_ce_loss_bwd(_n.ptr(scores), _n.ptr(labels), S, C, ctx.ignore_label, _n.ptr(out),
+                                              _n.ptr(g_loss.contiguous().float()), _n.ptr(d), _n.stream_ptr()),
+                 "sp_ce_loss_bwd")
+        return d, None, None
+
+
+def superpoint_cross_entropy(scores, labels, ignore_label=-100):
+    return _SpCrossEntropy.apply(scores, labels, ignore_label)
+
+
+class _LossSum(Function):
+    """t_0 + t_1 + ... of device scalars in order, one launch (each `loss = loss + term` is a launch otherwise); the
+    gradient of a sum is the upstream scalar for every term"""
+
+    @staticmethod
+    def forward(ctx, paired, *terms):
+        ts = [t.reshape(()).float() for t in terms]
+        _n.require_cuda(*ts)
+        out = torch.empty((), dtype=torch.float32, device=ts[0].device)
+        arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        _n.check(_n.hip().wsis_loss_sum(arr, len(ts), int(paired), _n.ptr(out), _n.stream_ptr()), "loss_sum")
+        ctx.n = len(ts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + (g,) * ctx.n
+
+
+def loss_sum(terms, paired=0):
+    """sum of 1..8 device scalars in list order; bit i of ``paired`` groups (t_i + t_{i+1}) first"""
+    return _LossSum.apply(paired, *terms)
 
 
 class _SpRegressionLoss(Function):

@@ -401,6 +401,16 @@ int wsis_segment_reduce_bwd(const float* d_dout, const int64_t* d_index, const i
 int wsis_gather_rows(const float* d_src, const void* d_idx, int32_t idx_is_64, float* d_out, int64_t N,
                      int32_t C, void* stream);
 
+/* Position encoding of the edge affinity (backbone_3D_WSIS.py:54-58 fc_position = Linear(3,16) -> ReLU -> Linear(16,1),
+ * :222-224 applied to centre[u_e] - centre[v_e]): pos [E] in one launch; backward (no gradient for the centres: they are
+ * data) writes every non-NULL dW1 [16,3] / db1 [16] / dW2 [1,16] / db2 [1] in two launches, fixed summation order. */
+int64_t wsis_pos_enc_workspace_bytes(int64_t E);
+int wsis_pos_enc_fwd(const float* d_centre, const int64_t* d_eu, const int64_t* d_ev, const float* d_W1, const float* d_b1,
+                     const float* d_W2, const float* d_b2, float* d_pos, int64_t E, void* stream);
+int wsis_pos_enc_bwd(const float* d_centre, const int64_t* d_eu, const int64_t* d_ev, const float* d_W1, const float* d_b1,
+                     const float* d_W2, const float* d_dpos, float* d_dW1, float* d_db1, float* d_dW2, float* d_db2, int64_t E,
+                     void* d_ws, int64_t ws_bytes, void* stream);
+
 /* ---- a16: edge affinity attention  backbone_3D_WSIS.py:218-249 ------------------------------
  * logit_e = (q[u_e].k[v_e]) * scale * pos_enc_e ; a = segment softmax over edges sharing u ;
  * res[u,:] = sum_e a_e v[v_e,:].  CSR over u: d_perm_u/d_off_u from wsis_segment_csr(edge_u).
@@ -438,6 +448,18 @@ int wsis_ecc_contract_bwd(const float* d_h, const float* d_U, const float* d_dm,
 int wsis_ecc_contract_bwd_acc(const float* d_h, const float* d_U, const float* d_dm, const int32_t* d_perm_dst,
                               const int32_t* d_off_dst, float* d_dU, float* d_dh, int64_t S, int64_t E,
                               int32_t accumulate, void* stream);
+/* the same with the backward of the segmented mean that follows the messages folded in (spg_modules.py:97-121,
+ * aggr='mean'): dm[e,:] = d_dinp[src_e,:] / out-degree(src_e) is formed on the fly from the source index / CSR offsets */
+int wsis_ecc_contract_bwd_mean(const float* d_h, const float* d_U, const float* d_dinp, const int64_t* d_src_index,
+                               const int32_t* d_off_src, const int32_t* d_perm_dst, const int32_t* d_off_dst, float* d_dU,
+                               float* d_dh, int64_t S, int64_t E, int32_t accumulate, void* stream);
+/* the dense products of a GRU step around the contraction (graphnet.py:19-36 folded as above):
+ *   wsis_ecc_u_fwd   U [S,65*32] = hx [S,32] @ W' [32,65*32]
+ *   wsis_ecc_u_bwd   out [S,32] = base [S,32] (NULL: 0) + dU [S,65*32] @ W'^T (+ extra[:, 0:32] with row pitch extra_pitch
+ *                    floats, NULL: none): the hidden-state gradient of the previous step, accumulated in the same launch */
+int wsis_ecc_u_fwd(const float* d_hx, const float* d_W, float* d_U, int64_t S, void* stream);
+int wsis_ecc_u_bwd(const float* d_dU, const float* d_W, const float* d_base, const float* d_extra, int64_t extra_pitch,
+                   float* d_out, int64_t S, void* stream);
 int wsis_ecc_message_fwd(const float* d_x, const float* d_w, const int64_t* d_dst, const int32_t* d_perm_src,
                          const int32_t* d_off_src, float* d_out, int64_t S, int64_t E, int32_t C, void* stream);
 int wsis_ecc_message_bwd(const float* d_x, const float* d_w, const float* d_dout, const int64_t* d_src,
@@ -584,6 +606,17 @@ int wsis_semantic_loss_fwd(const float* d_scores, const int64_t* d_labels, int64
                            float* d_out2, float* d_saved, void* d_ws, int64_t ws_bytes, void* stream);
 int wsis_semantic_loss_bwd(const float* d_scores, const int64_t* d_labels, int64_t N, int32_t C, int64_t ignore_label,
                            const float* d_saved, const float* d_grad_loss, float* d_dscores, void* stream);
+
+/* Superpoint semantic term (losses_3D_WSIS.py:72-74: CrossEntropyLoss(ignore_index) on the [S,C] superpoint scores, mean
+ * over the kept rows) with the logged scores.sum(): d_out3 = {loss, sum of all scores, n_kept}; one launch each way.
+ * wsis_loss_sum: out = t_0 + t_1 + ... in order (the weighted sum of losses_3D_WSIS.py:130-151, all weights 1); bit i of
+ * `paired` adds term i to term i+1 first (the reference's `offset_norm_loss + offset_dir_loss`).  d_terms is a HOST array
+ * of n <= 8 device scalars. */
+int wsis_sp_ce_loss_fwd(const float* d_scores, const int64_t* d_labels, int64_t S, int32_t C, int64_t ignore_label,
+                        float* d_out3, void* stream);
+int wsis_sp_ce_loss_bwd(const float* d_scores, const int64_t* d_labels, int64_t S, int32_t C, int64_t ignore_label,
+                        const float* d_out3, const float* d_grad_loss, float* d_dscores, void* stream);
+int wsis_loss_sum(const float* const* d_terms, int32_t n, uint32_t paired, float* d_out, void* stream);
 
 /* Superpoint regression terms of the same loss (losses_3D_WSIS.py:79-96 offset L1 + cosine, :113-127 occupancy and
  * instance-size L1) over the rows whose two labels both differ from ignore_label: d_out5 = {offset_norm, offset_dir,

@@ -143,3 +143,26 @@ def test_fallback_conditions():
     hg = [h.cuda() for h in heads]
     hg[0].eval()
     assert wsis_ops.sp_heads(x.cuda(), hg) is None                        # mixed train / eval
+
+
+@pytest.mark.parametrize("E", [20054, 1, 300])
+def test_position_encoding_matches_modules_in_float64(E):
+    """fc_position(centre[u] - centre[v]) (backbone_3D_WSIS.py:54-58, 222-224) as one operator"""
+    torch.manual_seed(3)
+    S = 500
+    fc = nn.Sequential(nn.Linear(3, 16), nn.ReLU(), nn.Linear(16, 1))
+    centre = torch.randn(S, 3) * 2
+    eu, ev = torch.randint(0, S, (E,)), torch.randint(0, S, (E,))
+    w = torch.randn(E)
+    f64 = copy.deepcopy(fc).double()
+    ref = f64(centre.double()[eu] - centre.double()[ev]).reshape(-1)
+    (ref * w.double()).sum().backward()
+    g = copy.deepcopy(fc).cuda()
+    pos = wsis_ops.edge_position_encoding(g, centre.cuda(), eu.cuda(), ev.cuda())
+    assert pos is not None and pos.shape == (E,)
+    (pos * w.cuda()).sum().backward()
+    _close(pos, ref)
+    for pg, pr in zip(g.parameters(), f64.parameters()):
+        _close(pg.grad, pr.grad, 1e-4)
+    pos2 = wsis_ops.edge_position_encoding(copy.deepcopy(fc).cuda(), centre.cuda(), eu.cuda(), ev.cuda())
+    assert torch.equal(pos, pos2)

@@ -959,6 +959,41 @@ def test_fused_superpoint_regression_losses_match_torch_formulation(S):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("S,C,frac", [(2289, 20, 0.3), (7, 13, 0.0), (3000, 20, 0.95)])
+def test_fused_superpoint_cross_entropy_matches_torch(S, C, frac):
+    """wsis_sp_ce_loss_fwd/bwd against nn.CrossEntropyLoss(ignore_index) in fp64 (losses_3D_WSIS.py:72-74) and the logged
+    scores.sum()"""
+    g = torch.Generator().manual_seed(S + C)
+    scores = torch.randn(S, C, generator=g) * 3
+    labels = torch.randint(0, C, (S,), generator=g)
+    labels[torch.rand(S, generator=g) < frac] = -100
+    labels[0] = 1                                             # at least one kept row
+    leaf = scores.cuda().requires_grad_(True)
+    loss, total = wsis_ops.superpoint_cross_entropy(leaf, labels.cuda(), -100)
+    (1.7 * loss).backward()
+    ref = scores.double().requires_grad_(True)
+    want = torch.nn.functional.cross_entropy(ref, labels, ignore_index=-100)
+    (1.7 * want).backward()
+    assert abs(float(loss) - float(want)) <= 2e-6 * abs(float(want))
+    assert abs(float(total) - float(scores.double().sum())) <= 1e-5 * float(scores.double().abs().sum())
+    assert float((leaf.grad.double().cpu() - ref.grad).abs().max()) <= 1e-5 * float(ref.grad.abs().max())
+    assert bool((leaf.grad[labels.cuda() == -100] == 0).all())
+
+
+@pytest.mark.gpu
+def test_loss_sum_adds_in_the_reference_order():
+    """wsis_loss_sum: ((((t0 + t1) + (t2 + t3)) + t4) + t5) + t6 bit for bit, gradient = upstream scalar for every term"""
+    vals = [0.1234567, 3.7654321e-3, -0.91234, 0.3333333, 2.25e-5, 1.0101, 0.77]
+    terms = [torch.tensor(v, dtype=torch.float32, device="cuda", requires_grad=True) for v in vals]
+    got = wsis_ops.loss_sum(terms, paired=1 << 2)
+    (2.0 * got).backward()
+    t = [torch.tensor(v, dtype=torch.float32) for v in vals]
+    want = ((((t[0] + t[1]) + (t[2] + t[3])) + t[4]) + t[5]) + t[6]
+    assert float(got) == float(want)
+    assert all(float(x.grad) == 2.0 for x in terms)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("S,I,keep", [(1190, 12, 0.6), (1536, 64, 0.9), (40, 1, 1.0), (9, 5, 0.5), (300, 33, 0.05)])
 def test_fused_discriminative_loss_matches_torch_formulation(S, I, keep):
     """wsis_disc_loss_fwd/bwd against MultiTaskLoss.discriminative_loss_slots (itself pinned by the reference's

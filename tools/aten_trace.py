@@ -71,13 +71,16 @@ print("total", tot)
 # ---- phase stamps of un-profiled steps
 import unet_native  # noqa: E402
 
-marks = {}
+import time  # noqa: E402
+
+marks, host_t = {}, {}
 
 
 def mark(name):
     e = torch.cuda.Event(enable_timing=True)
     e.record()
     marks.setdefault(name, []).append(e)
+    host_t.setdefault(name, []).append(time.perf_counter())
 
 
 orig_run = unet_native.run_unet
@@ -116,6 +119,8 @@ def step_opt(*a, **k):
 
 opt.step = step_opt
 N = 20
+torch.cuda.synchronize()
+mark("origin")
 for _ in range(N):
     mark("step_begin")
     harness.build_batch_graphs(batch)
@@ -131,3 +136,15 @@ d = [marks["opt_end"][i].elapsed_time(marks["step_begin"][i + 1]) * 1e3 for i in
 print("%-16s -> %-16s %8.1f" % ("opt_end", "next step_begin", sum(d) / len(d)))
 d = [marks["step_begin"][i].elapsed_time(marks["step_begin"][i + 1]) * 1e3 for i in range(2, N)]
 print("step %8.1f" % (sum(d) / len(d)))
+
+# how far the host is ahead of the GPU at every mark (GPU time of the mark - host time of the mark, same origin): ~0 means
+# the GPU reached the mark as soon as the host issued it, i.e. it was waiting for the host
+print("== host lead at the marks, steps %d..%d (us): GPU reaches the mark this long after the host issued it ==" % (N - 4, N - 1))
+e0, h0 = marks["origin"][0], host_t["origin"][0]
+for name in order:
+    lead = []
+    for i in range(N - 4, N):
+        g = e0.elapsed_time(marks[name][i]) * 1e3
+        hh = (host_t[name][i] - h0) * 1e6
+        lead.append(g - hh)
+    print("%-16s %s" % (name, " ".join("%8.0f" % v for v in lead)))
