@@ -5,8 +5,6 @@
 // bmm + scatter-mean (and three more launches in backward); here it is one kernel forward and one backward,
 // each reading the [E,C,C] filter tensor exactly once.  One wavefront per source node (forward) / per target
 // node (backward), fixed summation order => deterministic.  C <= 32 (the model uses 32).
-#include <type_traits>
-
 #include "common.h"
 
 using namespace wsis;
@@ -305,12 +303,10 @@ __global__ __launch_bounds__(256) void ecc_contract_bwd_kernel(const float* __re
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// The two dense products of a GRU step around the contraction, K or N = 32 (hipBLASLt takes 13.6 / 15.4 us for them on
-// 2,289 rows: 19 MB written / read at 1.3 TB/s):
-//   U  [S, 2080] = hx [S,32] @ W' [32, 2080]                     one wave per (32-row slice, 5 of the 65 column blocks)
-//   out [S, 32]  = base (+ extra) + dU [S, 2080] @ W'^T          one workgroup per slice, 8 waves split the 65 k-chunks,
-//                                                                added through LDS in wave order
-// exact fp32 (v_mfma_f32_32x32x2_f32), fixed order.
+// The dense product in front of the contraction, K = 32 (hipBLASLt: 12.9 us on 2,289 rows for 19 MB written):
+//   U  [S, 2080] = hx [S,32] @ W' [32, 2080]       one wave per (32-row slice, 5 of the 65 column blocks): 9.5 us
+// exact fp32 (v_mfma_f32_32x32x2_f32), fixed order.  (The backward product dU @ W'^T stays on hipBLASLt: one workgroup
+// per 32-row slice with the 65 k-chunks on 8 or 16 waves measured 18-30 us against 13.)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int UB = EU / 32;      // 65 column blocks
 constexpr int UC = 5;            // column blocks per wave of the forward product (65 = 13 x 5)
@@ -347,65 +343,6 @@ __global__ __launch_bounds__(256) void ecc_u_fwd_kernel(const float* __restrict_
     for (int i = 0; i < 16; ++i) {
       const int64_t g = s * 32 + mrow(i, half);
       if (g < S) U[g * EU + (cb0 + u) * 32 + r31] = acc[i];
-    }
-  }
-}
-
-constexpr int UW = 8;                        // waves of a slice in the backward product
-constexpr int UK = (UB + UW - 1) / UW;       // k-chunks per wave (9)
-
-__global__ __launch_bounds__(64 * UW) void ecc_u_bwd_kernel(const float* __restrict__ dU, const float* __restrict__ W,
-                                                            const float* __restrict__ base, const float* __restrict__ extra,
-                                                            int64_t extra_pitch, float* __restrict__ out, int64_t S) {
-  __shared__ float red[UW][32][32];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r31 = lane & 31, half = lane >> 5;
-  const int64_t s = blockIdx.x, row = s * 32 + r31;
-  // wave w owns chunks w, w + 8, ...; two batches (5 + 4 chunks), the loads of a batch in flight together (16 waves per
-  // slice with 3 + 2 chunks measured slower: 28 us against 18 for the chunk-by-chunk loop)
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-  auto batch = [&](auto u0c, auto nuc) {
-    constexpr int U0 = decltype(u0c)::value, NU = decltype(nuc)::value;
-    float4 av[NU][4], bv[NU][4];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int ch = wave + (U0 + u) * UW;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        av[u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        bv[u][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ch < UB) {
-          if (row < S) av[u][q] = *reinterpret_cast<const float4*>(dU + row * EU + ch * 32 + half * 16 + q * 4);
-          bv[u][q] = *reinterpret_cast<const float4*>(W + (int64_t)r31 * EU + ch * 32 + half * 16 + q * 4);
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < NU; ++u)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q].x, bv[u][q].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q].y, bv[u][q].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q].z, bv[u][q].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][q].w, bv[u][q].w, acc, 0, 0, 0);
-      }
-  };
-  static_assert(UK == 9, "two batches of 5 + 4 chunks");
-  batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
-  batch(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
-#pragma unroll
-  for (int i = 0; i < 16; ++i) red[wave][mrow(i, half)][r31] = acc[i];
-  __syncthreads();
-  for (int e = threadIdx.x; e < 32 * 32; e += 64 * UW) {
-    const int rr = e >> 5, c = e & 31;
-    const int64_t g = s * 32 + rr;
-    if (g < S) {
-      float v = base ? base[g * EC + c] : 0.0f;
-#pragma unroll
-      for (int w = 0; w < UW; ++w) v += red[w][rr][c];
-      if (extra) v += extra[g * extra_pitch + c];
-      out[g * EC + c] = v;
     }
   }
 }
@@ -502,18 +439,6 @@ int wsis_ecc_u_fwd(const float* d_hx, const float* d_W, float* d_U, int64_t S, v
   WSIS_REQUIRE((reinterpret_cast<uintptr_t>(d_hx) & 15) == 0, "16-byte alignment");
   hipLaunchKernelGGL(ecc_u_fwd_kernel, dim3((unsigned)ceil_div(S, 128), UB / UC), dim3(256), 0, as_stream(stream), d_hx, d_W, d_U,
                      S);
-  WSIS_LAUNCH_CHECK();
-  return WSIS_OK;
-}
-
-int wsis_ecc_u_bwd(const float* d_dU, const float* d_W, const float* d_base, const float* d_extra, int64_t extra_pitch,
-                   float* d_out, int64_t S, void* stream) {
-  WSIS_REQUIRE(S >= 0, "bad sizes");
-  if (S == 0) return WSIS_OK;
-  WSIS_REQUIRE(d_dU && d_W && d_out, "null pointer");
-  WSIS_REQUIRE(((reinterpret_cast<uintptr_t>(d_dU) | reinterpret_cast<uintptr_t>(d_W)) & 15) == 0, "16-byte alignment");
-  hipLaunchKernelGGL(ecc_u_bwd_kernel, dim3((unsigned)ceil_div(S, 32)), dim3(64 * UW), 0, as_stream(stream), d_dU, d_W, d_base,
-                     d_extra, extra_pitch, d_out, S);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }

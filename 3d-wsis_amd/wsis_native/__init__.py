@@ -122,7 +122,6 @@ _HIP_SIGS = {
     "wsis_ecc_contract_bwd_acc": (I32, [P, P, P, P, P, P, P, I64, I64, I32, P]),
     "wsis_ecc_contract_bwd_mean": (I32, [P, P, P, P, P, P, P, P, P, I64, I64, I32, P]),
     "wsis_ecc_u_fwd": (I32, [P, P, P, I64, P]),
-    "wsis_ecc_u_bwd": (I32, [P, P, P, P, I64, P, I64, P]),
     "wsis_gru_cell_workspace_bytes": (I64, [I64]),
     "wsis_gru_cell_fwd": (I32, [P] * 9 + [I64, I32, P]),
     "wsis_gru_cell_bwd": (I32, [P] * 17 + [I64, I32, P, I64, P]),

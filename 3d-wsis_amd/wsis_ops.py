@@ -632,16 +632,14 @@ class _EccGruLoop(Function):
                      "gru_cell_bwd_seq")
             dU = dU_all[i * S:(i + 1) * S]
             if own:
-                # the mean's backward (d_m[e] = d_inp[src_e] / out-degree) is formed inside the contraction's backward,
-                # and d_hx = d_hprev + dU @ W'^T + the output gradient of hx_i is ONE launch
+                # the mean's backward (d_m[e] = d_inp[src_e] / out-degree) is formed inside the contraction's backward
                 _n.check(lib.wsis_ecc_contract_bwd_mean(_n.ptr(h), _n.ptr(Us[i]), _n.ptr(d_inp), _n.ptr(csr_src.index),
                                                         _n.ptr(csr_src.offsets), _n.ptr(csr_dst.perm),
                                                         _n.ptr(csr_dst.offsets), _n.ptr(dU), _n.ptr(dh), S, E,
                                                         0 if i == R - 1 else 1, st), "ecc_contract_bwd_mean")
-                extra = (dout.data_ptr() + 4 * 32 * i) if cat_all else None
-                _n.check(lib.wsis_ecc_u_bwd(_n.ptr(dU), _n.ptr(Waug), _n.ptr(d_hprev), extra, dout.shape[1],
-                                            _n.ptr(d_hprev), S, st), "ecc_u_bwd")
-                d_hx = d_hprev
+                d_hx = d_hprev.addmm_(dU, WaugT)
+                if cat_all:
+                    d_hx += d_slices[i]
                 continue
             d_m = torch.empty((E, 32), dtype=torch.float32, device=dev)
             _n.check(lib.wsis_segment_reduce_bwd(_n.ptr(d_inp), _n.ptr(csr_src.index), _n.ptr(csr_src.offsets), None,

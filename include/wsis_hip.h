@@ -453,13 +453,8 @@ int wsis_ecc_contract_bwd_acc(const float* d_h, const float* d_U, const float* d
 int wsis_ecc_contract_bwd_mean(const float* d_h, const float* d_U, const float* d_dinp, const int64_t* d_src_index,
                                const int32_t* d_off_src, const int32_t* d_perm_dst, const int32_t* d_off_dst, float* d_dU,
                                float* d_dh, int64_t S, int64_t E, int32_t accumulate, void* stream);
-/* the dense products of a GRU step around the contraction (graphnet.py:19-36 folded as above):
- *   wsis_ecc_u_fwd   U [S,65*32] = hx [S,32] @ W' [32,65*32]
- *   wsis_ecc_u_bwd   out [S,32] = base [S,32] (NULL: 0) + dU [S,65*32] @ W'^T (+ extra[:, 0:32] with row pitch extra_pitch
- *                    floats, NULL: none): the hidden-state gradient of the previous step, accumulated in the same launch */
+/* the dense product in front of the contraction (graphnet.py:19-36 folded as above): U [S,65*32] = hx [S,32] @ W' [32,65*32] */
 int wsis_ecc_u_fwd(const float* d_hx, const float* d_W, float* d_U, int64_t S, void* stream);
-int wsis_ecc_u_bwd(const float* d_dU, const float* d_W, const float* d_base, const float* d_extra, int64_t extra_pitch,
-                   float* d_out, int64_t S, void* stream);
 int wsis_ecc_message_fwd(const float* d_x, const float* d_w, const int64_t* d_dst, const int32_t* d_perm_src,
                          const int32_t* d_off_src, float* d_out, int64_t S, int64_t E, int32_t C, void* stream);
 int wsis_ecc_message_bwd(const float* d_x, const float* d_w, const float* d_dout, const int64_t* d_src,

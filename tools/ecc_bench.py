@@ -39,24 +39,6 @@ print("U = hx @ W     torch %.1f us   own %.1f us" % (
 U2 = torch.empty_like(U)
 lib.wsis_ecc_u_fwd(_n.ptr(hx), _n.ptr(W), _n.ptr(U2), S, st)
 print("   max diff", float((U2 - hx @ W).abs().max()))
-dU = torch.randn(S, 2080, device=dev)
-base = torch.randn(S, 32, device=dev)
-extra = torch.randn(S, 256, device=dev)
-out = torch.empty(S, 32, device=dev)
-WT = W.t()
-
-
-def ref():
-    o = base.clone()
-    o.addmm_(dU, WT)
-    o += extra[:, 32:64]
-    return o
-
-
-print("dhx             torch %.1f us   own %.1f us" % (
-    t(ref), t(lambda: lib.wsis_ecc_u_bwd(_n.ptr(dU), _n.ptr(W), _n.ptr(base), extra.data_ptr() + 128, 256, _n.ptr(out), S, st))))
-lib.wsis_ecc_u_bwd(_n.ptr(dU), _n.ptr(W), _n.ptr(base), extra.data_ptr() + 128, 256, _n.ptr(out), S, st)
-print("   max rel diff", float((out - ref()).abs().max() / ref().abs().max()))
 d_inp = torch.randn(S, 32, device=dev)
 d_m = torch.empty(E, 32, device=dev)
 dUo, dh = torch.empty(S, 2080, device=dev), torch.empty(E, 64, device=dev)
