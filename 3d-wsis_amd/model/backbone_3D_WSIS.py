@@ -114,6 +114,15 @@ class Network(nn.Module):
         import os
         import wsis_parallel
         sync_bn = self.training and wsis_parallel.sync_batchnorm_active(self)
+        # work that does not depend on the UNet goes to branch streams (WSIS_BRANCH=0: one stream): the filter net of the
+        # superpoint graph here, the point-level head below.  Not with shared BatchNorm statistics: the ranks' collectives
+        # must be issued in one order.
+        self.ecc.set_info(extra_data["GIs"], cuda=True)
+        branch = None if sync_bn else (wsis_ops.branch_stream(input.features.device, 0)
+                                       if input.features.is_cuda else None)
+        if branch is not None:
+            for gconv in self.ecc.gconvs:
+                gconv.prefetch_filter_state(branch)
         # SyncBatchNorm keeps the native executor: the op list is issued in parts around the statistics exchange of every
         # layer (unet_native._BnSync; WSIS_SYNC_BN_NATIVE=0: the per-module walk with _SyncBatchNormReLU)
         sync_native = sync_bn and os.environ.get("WSIS_SYNC_BN_NATIVE", "1") != "0"
@@ -141,13 +150,23 @@ class Network(nn.Module):
         else:
             output_feats = voxel_feats[input_map.long()]
 
-        ret["semantic_scores"] = self.linear(output_feats)          # [N, nClass]
+        head_branch = None if sync_bn else (wsis_ops.branch_stream(output_feats.device, 1)
+                                            if output_feats.is_cuda else None)
+        if head_branch is not None:
+            # the point-level head (4 launches forward, ~14 backward over N ~ 2*10^5 rows) beside the superpoint chain
+            # (~60 launches over S ~ 2*10^3 rows each way); joined at the end of this forward
+            main = torch.cuda.current_stream()
+            head_branch.wait_stream(main)
+            with torch.cuda.stream(head_branch):
+                ret["semantic_scores"] = self.linear(output_feats)  # [N, nClass]
+            output_feats.record_stream(head_branch)
+        else:
+            ret["semantic_scores"] = self.linear(output_feats)      # [N, nClass]
 
         superpoint = extra_data["superpoint"].long()
         sp_csr = extra_data.get("superpoint_csr")                   # optional reuse (extension)
         embeddings = scatter(output_feats, superpoint, dim=0, reduce="mean", csr=sp_csr)
 
-        self.ecc.set_info(extra_data["GIs"], cuda=True)
         ecc_outputs = self.ecc(embeddings)
 
         # the four heads and the q / k / v layers read the same rows: ONE operator (2 launches forward, 3 backward,
@@ -186,4 +205,7 @@ class Network(nn.Module):
             sp_feat = ecc_outputs + torch.cat((res, pad), 0)
         fused = wsis_ops.sp_heads(sp_feat, [self.feature_term])
         ret["sp_discriminative_feats"] = fused[0][0] if fused is not None else self.feature_term(sp_feat)
+        if head_branch is not None:
+            torch.cuda.current_stream().wait_stream(head_branch)
+            ret["semantic_scores"].record_stream(torch.cuda.current_stream())
         return ret

@@ -163,13 +163,41 @@ class RNNGraphConvModule(nn.Module):
 
     def set_info(self, gc_info):
         self._gci = gc_info
+        self._pre = None
+
+    def _filter_state(self):
+        """(h [E,64], W' [32, 65*32]) of the filter-free evaluation: the fnet hidden state of every edge and the last
+        Linear folded per node channel -- functions of the edge features and the parameters alone"""
+        last = self._fnet[-1]
+        h = _run_modules(list(self._fnet[:-1]), self._gci.get_buffers())     # fnet hidden state [E, 64]
+        # W'[a, c*32 + b] = Wl[a*32 + b, c];  W'[a, 64*32 + b] = bl[a*32 + b]
+        Waug = torch.cat([last.weight.view(32, 32, 64).permute(0, 2, 1).reshape(32, 64 * 32),
+                          last.bias.view(32, 32)], 1)
+        return h, Waug
+
+    def prefetch_filter_state(self, stream):
+        """run the filter net on ``stream`` now (it does not depend on the node features): its five launches run beside
+        the sparse UNet instead of between UNet and recurrence, and -- autograd runs a node's backward on the stream of
+        its forward -- its ~20 backward launches beside the UNet's backward pass instead of in front of it.  The state is
+        handed to the next ``forward`` (which makes the current stream wait for ``stream``)."""
+        if self._gci is None or not self._contract_ok(None):
+            return
+        main = torch.cuda.current_stream()
+        stream.wait_stream(main)             # the parameters: everything queued so far (the previous optimizer step)
+        with torch.cuda.stream(stream):
+            h, Waug = self._filter_state()
+        self._pre = (h, Waug, stream)
 
     def _contract_ok(self, hx):
         """the filter-free evaluation applies to the model's configuration: 32 node channels, a filter net that ends
         in Linear(64 -> 32*32) with bias (graphnet.py:77-92), on the GPU; WSIS_ECC_CONTRACT=0 keeps the [E,1024] path"""
         import os
         last = self._fnet[-1]
-        return (hx.is_cuda and hx.size(1) == 32 and isinstance(last, nn.Linear) and last.in_features == 64
+        if hx is None:       # asked before the node features exist (prefetch): the model's width
+            node_ok = self._cell.hidden_size == 32 and self._gci.get_buffers().is_cuda
+        else:
+            node_ok = hx.is_cuda and hx.size(1) == 32
+        return (node_ok and isinstance(last, nn.Linear) and last.in_features == 64
                 and last.out_features == 1024 and last.bias is not None and len(self._fnet) >= 2
                 and os.environ.get("WSIS_ECC_CONTRACT", "1") != "0")
 
@@ -180,11 +208,15 @@ class RNNGraphConvModule(nn.Module):
         import wsis_ops
         edge_indexes = self._gci.get_pyg_buffers()
         tgt = edge_indexes[1]                      # messages are aggregated at the edge's target
-        last = self._fnet[-1]
-        h = _run_modules(list(self._fnet[:-1]), self._gci.get_buffers())     # fnet hidden state [E, 64]
-        # W'[a, c*32 + b] = Wl[a*32 + b, c];  W'[a, 64*32 + b] = bl[a*32 + b]
-        Waug = torch.cat([last.weight.view(32, 32, 64).permute(0, 2, 1).reshape(32, 64 * 32),
-                          last.bias.view(32, 32)], 1)
+        pre, self._pre = getattr(self, "_pre", None), None
+        if pre is not None:          # computed ahead on a branch stream (prefetch_filter_state)
+            h, Waug, side = pre
+            main = torch.cuda.current_stream()
+            main.wait_stream(side)
+            h.record_stream(main)
+            Waug.record_stream(main)
+        else:
+            h, Waug = self._filter_state()
         csr_gat, csr_agg = self._gci.csr(), self._gci.csr_dst()      # gather side = sources, aggregation side = targets
         cell = self._cell
         if (os.environ.get("WSIS_GNN_LOOP", "1") != "0" and os.environ.get("WSIS_FUSE_GRU", "1") != "0"

@@ -270,8 +270,10 @@ def verify_pending_counts():
     # (csrc/common.h SyncSlot::err, word 19 of a slot) would otherwise be wrong numerics nobody looks at
     errs = _n.sync_err_words(dev)
     with torch.cuda.stream(chk):
-        both = torch.cat([c.to(torch.int64).reshape(-1) for c, _, _ in pend] + [e.to(torch.int64).reshape(-1) for e in errs])
-        got = both.tolist()
+        # (one cat + one copy: the counts and the error words are int32 views already)
+        parts = [c.reshape(-1) for c, _, _ in pend] + [e.reshape(-1) for e in errs]
+        parts = [t if t.dtype == torch.int32 else t.to(torch.int32) for t in parts]
+        got = torch.cat(parts).tolist()
     for c, _, _ in pend:
         c.record_stream(chk)
     if any(int(v) != 0 for v in got[len(pend):]):

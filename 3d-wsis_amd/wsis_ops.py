@@ -16,6 +16,22 @@ import wsis_native as _n
 from torch_scatter import SegmentCSR
 
 
+_BRANCH_STREAMS = {}
+
+
+def branch_stream(device, i=0):
+    """stream ``i`` for work that is independent of the main chain of a step (the filter net beside the UNet, the
+    point-level head beside the superpoint recurrence); autograd runs the backward of such work on the same stream.
+    WSIS_BRANCH=0: None (everything on the current stream)."""
+    if os.environ.get("WSIS_BRANCH", "1") == "0" or device.type != "cuda":
+        return None
+    key = (device.index, i)
+    st = _BRANCH_STREAMS.get(key)
+    if st is None:
+        st = _BRANCH_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class EdgeGraph(object):
     """CSR over sources and over targets of a directed edge list (built once per batch)."""
 
@@ -709,10 +725,15 @@ class _TallLinear(Function):
             # 13-wide first layer of the filter net over the edge rows) are zero-padded for this product only --
             # hipBLASLt runs their [Cin x rows] @ [rows x Cout] gradient as one 16x16 tile per workgroup (43-87 us)
             cout, cin = weight.shape
-            cin_p, cout_p = (cin + 31) // 32 * 32, (cout + 3) // 4 * 4
-            xp = x.contiguous() if cin_p == cin else torch.nn.functional.pad(x, (0, cin_p - cin))
-            dyp = dy if cout_p == cout else torch.nn.functional.pad(dy, (0, cout_p - cout))
-            dw = sp_ops._dw(xp, None, None, dyp, 1, cin_p, cout_p).view(cin_p, cout_p)[:cin, :cout].t()
+            if cout % 32 == 0 and cin % 4 == 0:
+                # dW in the weight's own [out, in] layout straight from the kernel (dy as the "input" side): no transposed
+                # view for autograd to copy into the .grad tensor
+                dw = sp_ops._dw(dy, None, None, x.contiguous(), 1, cout, cin).view(cout, cin)
+            else:
+                cin_p, cout_p = (cin + 31) // 32 * 32, (cout + 3) // 4 * 4
+                xp = x.contiguous() if cin_p == cin else torch.nn.functional.pad(x, (0, cin_p - cin))
+                dyp = dy if cout_p == cout else torch.nn.functional.pad(dy, (0, cout_p - cout))
+                dw = sp_ops._dw(xp, None, None, dyp, 1, cin_p, cout_p).view(cin_p, cout_p)[:cin, :cout].t()
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy)
