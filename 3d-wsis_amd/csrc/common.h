@@ -167,6 +167,10 @@ bool spconv_in_supported(int K, int Cin, int Cout);
 int spconv_in_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_W, const float* d_bias,
                      const float* d_residual, float* d_out, int64_t M_out, hipEvent_t ka, hipEvent_t kb, hipStream_t st);
 
+int64_t spconv_in_dw_workspace_bytes(int64_t M_out);
+int spconv_in_dw_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY, float* d_dW,
+                        int64_t M_out, void* d_ws, hipEvent_t ka, hipEvent_t kb, hipStream_t st);
+
 // wave-autonomous weight-gradient kernel (csrc/spconv_dw2.hip), dispatched from wsis_spconv_dw
 bool dw2_supported(int K, int Cin, int Cout);
 bool dw2_fits(int64_t M_in, int64_t M_out, int K, int Cin, int Cout);   // 32-bit buffer offsets

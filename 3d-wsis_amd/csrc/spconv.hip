@@ -1120,6 +1120,7 @@ int64_t wsis_spconv_dw_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, in
   const int64_t ci_pad = ceil_div(Cin, 32) * 32;
   const int64_t old_bytes = (int64_t)plan.begin[K] * ci_pad * Cout * (int64_t)sizeof(float) + 256;
   if (dw2_supported(K, Cin, Cout)) return std::max(old_bytes, dw2_workspace_bytes(M_out, K, Cin, Cout));
+  if (spconv_in_supported(K, Cin, Cout)) return std::max(old_bytes, spconv_in_dw_workspace_bytes(M_out));
   return old_bytes;
 }
 
@@ -1172,6 +1173,15 @@ int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_orde
       ((d_nbr && d_order) || (!d_nbr && K == 1 && M_in == M_out)) && ((reinterpret_cast<uintptr_t>(d_X) | reinterpret_cast<uintptr_t>(d_dY) |
                                        reinterpret_cast<uintptr_t>(d_dW) | reinterpret_cast<uintptr_t>(d_ws)) & 15) == 0)
     return dw2_launch(d_X, d_nbr, d_order, d_dY, d_dW, M_in, M_out, K, Cin, Cout, d_ws, st);
+  if (d_nbr && spconv_in_supported(K, Cin, Cout) &&
+      ((reinterpret_cast<uintptr_t>(d_X) & 7) | (reinterpret_cast<uintptr_t>(d_dW) & 15) | (reinterpret_cast<uintptr_t>(d_ws) & 15)) == 0) {
+    // the 6-channel input convolution: im2col on the matrix cores (csrc/spconv_in.hip)
+    ProfScope prof_in(1, st, true);
+    const int rc = spconv_in_dw_launch(d_X, d_nbr, d_order, d_dY, d_dW, M_out, d_ws, prof_in.ka(), prof_in.kb(), st);
+    prof_in.stop();
+    prof_in.tail();
+    return rc;
+  }
   DwPlan plan;
   dw_make_plan(M_out, K, plan);
   const int n_cib = (int)ceil_div(Cin, 32);

@@ -57,7 +57,21 @@ class MultiTaskLoss(nn.Module):
                  and os.environ.get("WSIS_FUSE_SEM_LOSS", "1") != "0")
         if fused:       # CE + dice in two passes over [N, C] (csrc/loss.hip) instead of ~40 torch launches
             import wsis_ops
-            semantic_loss, n_kept = wsis_ops.semantic_point_loss(semantic_scores, semantic_labels, self.ignore_label)
+            # on the point-level head's branch stream (backbone_3D_WSIS.py): the two passes over [N, C] and their backward
+            # run beside the superpoint terms instead of in front of them
+            side = wsis_ops.branch_stream(semantic_scores.device, 1)
+            if side is not None and os.environ.get("WSIS_BRANCH_LOSS", "0") != "0":      # (measured: within the noise)
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    semantic_loss, n_kept = wsis_ops.semantic_point_loss(semantic_scores, semantic_labels,
+                                                                         self.ignore_label)
+                semantic_scores.record_stream(side)
+                semantic_labels.record_stream(side)
+                loss_join = (main, side, (semantic_loss, n_kept))
+            else:
+                semantic_loss, n_kept = wsis_ops.semantic_point_loss(semantic_scores, semantic_labels, self.ignore_label)
+                loss_join = None
             loss_out["semantic_loss"] = (semantic_loss, n_kept)
         else:
             semantic_loss = self.semantic_criterion(semantic_scores, semantic_labels)
@@ -168,6 +182,11 @@ class MultiTaskLoss(nn.Module):
         # losses_3D_WSIS.py:130-151: loss = 0.0 + 1.0 * term + ...  All weights are 1.0 there, and 0.0 + x and 1.0 * x are
         # exact in floating point: the same sum in the same order without the seven scalar multiplications (each one a
         # launch forward and one backward)
+        if fused and loss_join is not None:       # the point term joins the others here
+            main, side, made = loss_join
+            main.wait_stream(side)
+            for t in made:
+                t.record_stream(main)
         # (the terms and the pairs of the reference's expression; summed left to right)
         terms, paired = [semantic_loss], 0
         self._log("point semantic loss", semantic_loss)

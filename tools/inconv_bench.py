@@ -1,5 +1,5 @@
 import importlib, os, sys
-sys.path.insert(0, "."); importlib.import_module("3d-wsis_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")); importlib.import_module("3d-wsis_amd")
 import torch, harness
 from spconv import ops
 dev="cuda:0"
@@ -17,3 +17,7 @@ def timeit(f,n=50):
 for v in ("0","1"):
     os.environ["WSIS_IN_CONV"]=v
     print("WSIS_IN_CONV",v, timeit(lambda: ops._conv(X, rb.nbr_p, rb.order, W, None, None, M)), "us")
+dY = torch.randn(M, 32, device=dev)
+for v in ("0", "1"):
+    os.environ["WSIS_IN_CONV"] = v
+    print("dW WSIS_IN_CONV", v, timeit(lambda: ops._dw(X, rb.nbr_p, rb.order, dY, 27, 6, 32)), "us (kernel + slab sum + host)")
