@@ -120,9 +120,10 @@ class Network(nn.Module):
         self.ecc.set_info(extra_data["GIs"], cuda=True)
         branch = None if sync_bn else (wsis_ops.branch_stream(input.features.device, 0)
                                        if input.features.is_cuda else None)
+        params_ready = None
         if branch is not None:
-            for gconv in self.ecc.gconvs:
-                gconv.prefetch_filter_state(branch)
+            params_ready = torch.cuda.Event()
+            params_ready.record()            # behind the previous optimizer step, in front of this forward pass
         # SyncBatchNorm keeps the native executor: the op list is issued in parts around the statistics exchange of every
         # layer (unet_native._BnSync; WSIS_SYNC_BN_NATIVE=0: the per-module walk with _SyncBatchNormReLU)
         sync_native = sync_bn and os.environ.get("WSIS_SYNC_BN_NATIVE", "1") != "0"
@@ -135,6 +136,10 @@ class Network(nn.Module):
                 group = next((wsis_ops.sync_group(m) for m in self.unet.modules()
                               if isinstance(m, nn.BatchNorm1d) and wsis_ops.sync_group(m) is not None), None)
             voxel_feats = unet_native.run_unet(self, input, sync_group=group)
+            if branch is not None:
+                # issued behind the rulebook build of this pass on the same stream: runs while the UNet does
+                for gconv in self.ecc.gconvs:
+                    gconv.prefetch_filter_state(branch, params_ready)
         else:
             if input.features.is_cuda and os.environ.get("WSIS_PREBUILD", "1") != "0":
                 # all 5 + 4 rulebooks up front: their host syncs happen before the first conv is queued

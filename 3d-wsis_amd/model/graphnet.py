@@ -175,18 +175,24 @@ class RNNGraphConvModule(nn.Module):
                           last.bias.view(32, 32)], 1)
         return h, Waug
 
-    def prefetch_filter_state(self, stream):
+    def prefetch_filter_state(self, stream, ready=None):
         """run the filter net on ``stream`` now (it does not depend on the node features): its five launches run beside
         the sparse UNet instead of between UNet and recurrence, and -- autograd runs a node's backward on the stream of
         its forward -- its ~20 backward launches beside the UNet's backward pass instead of in front of it.  The state is
         handed to the next ``forward`` (which makes the current stream wait for ``stream``)."""
         if self._gci is None or not self._contract_ok(None):
             return
-        main = torch.cuda.current_stream()
-        stream.wait_stream(main)             # the parameters: everything queued so far (the previous optimizer step)
+        # the parameters must be final: ``ready`` = an event recorded on the main stream behind the previous optimizer step
+        # (None: everything queued so far)
+        if ready is not None:
+            stream.wait_event(ready)
+        else:
+            stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             h, Waug = self._filter_state()
-        self._pre = (h, Waug, stream)
+            done = torch.cuda.Event()
+            done.record(stream)              # (the consumer waits for this, not for what else the stream gets later)
+        self._pre = (h, Waug, done)
 
     def _contract_ok(self, hx):
         """the filter-free evaluation applies to the model's configuration: 32 node channels, a filter net that ends
@@ -210,9 +216,9 @@ class RNNGraphConvModule(nn.Module):
         tgt = edge_indexes[1]                      # messages are aggregated at the edge's target
         pre, self._pre = getattr(self, "_pre", None), None
         if pre is not None:          # computed ahead on a branch stream (prefetch_filter_state)
-            h, Waug, side = pre
+            h, Waug, done = pre
             main = torch.cuda.current_stream()
-            main.wait_stream(side)
+            main.wait_event(done)
             h.record_stream(main)
             Waug.record_stream(main)
         else:

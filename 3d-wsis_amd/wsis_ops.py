@@ -16,20 +16,17 @@ import wsis_native as _n
 from torch_scatter import SegmentCSR
 
 
-_BRANCH_STREAMS = {}
-
-
 def branch_stream(device, i=0):
-    """stream ``i`` for work that is independent of the main chain of a step (the filter net beside the UNet, the
-    point-level head beside the superpoint recurrence); autograd runs the backward of such work on the same stream.
+    """the stream for work that is independent of the main chain of a step (the filter net beside the UNet, the point-level
+    head beside the superpoint recurrence); autograd runs the backward of such work on the same stream.  It is the
+    rulebook side stream of spconv.ops (idle once the pyramid of the step is built): a process keeps to four streams
+    -- main, this one, the weight-gradient stream, the count check -- because HIP maps streams onto four hardware queues
+    and a fifth stream shares its queue with one of the others (measured: 8.52 or 8.74 ms per step depending on which).
     WSIS_BRANCH=0: None (everything on the current stream)."""
     if os.environ.get("WSIS_BRANCH", "1") == "0" or device.type != "cuda":
         return None
-    key = (device.index, i)
-    st = _BRANCH_STREAMS.get(key)
-    if st is None:
-        st = _BRANCH_STREAMS[key] = torch.cuda.Stream(device=device)
-    return st
+    from spconv import ops as sp_ops
+    return sp_ops._side_stream(device)
 
 
 class EdgeGraph(object):
