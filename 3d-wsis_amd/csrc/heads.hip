@@ -119,24 +119,25 @@ __device__ __forceinline__ void head_stats(const float* __restrict__ part, int n
                                            double& mu, double& var) {
   const int64_t n_slices = (S + 31) / 32;
   double s = 0.0, q = 0.0, w = 0.0;
-  for (int64_t j0 = 0; j0 < n_slices; j0 += 8) {
-    float a[8], b[8];
+  const double inv_last = 1.0 / (double)(S - (n_slices - 1) * 32);
+  constexpr int NB = 24;                  // slices whose partials are in flight together
+  for (int64_t j0 = 0; j0 < n_slices; j0 += NB) {
+    float a[NB], b[NB];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < NB; ++u) {
       const int64_t j = j0 + u;
       const float* src = part + ((j * n_heads + p) * 2) * HC + c;
       a[u] = j < n_slices ? src[0] : 0.0f;
       b[u] = j < n_slices ? src[HC] : 0.0f;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < NB; ++u) {
       const int64_t j = j0 + u;
       if (j < n_slices) {
-        const int64_t left = S - j * 32;
-        const double nj = (double)(left < 32 ? left : 32);
         s += (double)a[u];
         q += (double)b[u];
-        w += (double)a[u] * (double)a[u] / nj;
+        // S_i^2 / n_i: n_i = 32 for every slice but the last (no fp64 division inside the loop)
+        w += (double)a[u] * (double)a[u] * (j + 1 < n_slices ? 1.0 / 32.0 : inv_last);
       }
     }
   }
@@ -314,17 +315,18 @@ __global__ __launch_bounds__(64 * HB) void heads_bwd2_kernel(const wsis_heads h,
   for (int t = threadIdx.x; t < h.n_heads * HC; t += blockDim.x) {
     const int p = t / HC, c = t % HC;
     double a = 0.0, b = 0.0;
-    for (int64_t j0 = 0; j0 < n_slices; j0 += 8) {
-      float va[8], vb[8];
+    constexpr int NB = 24;
+    for (int64_t j0 = 0; j0 < n_slices; j0 += NB) {
+      float va[NB], vb[NB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int64_t j = j0 + u;
         const float* src = partb + ((j * h.n_heads + p) * 2) * HC + c;
         va[u] = j < n_slices ? src[0] : 0.0f;
         vb[u] = j < n_slices ? src[HC] : 0.0f;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < NB; ++u) {
         a += (double)va[u];
         b += (double)vb[u];
       }

@@ -296,12 +296,17 @@ __global__ __launch_bounds__(SR_THREADS) void sp_ce_fwd_kernel(const float* __re
   float a[3] = {0.f, 0.f, 0.f};
   for (int64_t r = threadIdx.x; r < S; r += SR_THREADS) {
     const float* row = scores + r * C;
-    float mx = row[0], sum = 0.f;
-    for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+    float v[32];                           // the row once, all loads in flight (C <= 32: checked by the host)
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v[c] = c < C ? row[c] : -INFINITY;
+    float mx = v[0], sum = 0.f;
+#pragma unroll
+    for (int c = 1; c < 32; ++c) mx = fmaxf(mx, v[c]);
     float se = 0.f;
-    for (int c = 0; c < C; ++c) {
-      se += expf(row[c] - mx);
-      sum += row[c];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      se += c < C ? expf(v[c] - mx) : 0.0f;
+      sum += c < C ? v[c] : 0.0f;
     }
     a[1] += sum;
     const int64_t lab = labels[r];
@@ -668,7 +673,7 @@ int wsis_sp_regression_loss_bwd(const float* d_pred_off, const float* d_gt_off, 
 
 int wsis_sp_ce_loss_fwd(const float* d_scores, const int64_t* d_labels, int64_t S, int32_t C, int64_t ignore_label,
                         float* d_out3, void* stream) {
-  WSIS_REQUIRE(S >= 0 && C >= 1 && d_out3, "bad args");
+  WSIS_REQUIRE(S >= 0 && C >= 1 && C <= 32 && d_out3, "bad args (C <= 32)");
   WSIS_REQUIRE(S == 0 || (d_scores && d_labels), "null pointer");
   hipLaunchKernelGGL(sp_ce_fwd_kernel, dim3(1), dim3(SR_THREADS), 0, as_stream(stream), d_scores, d_labels, S, (int)C, ignore_label,
                      d_out3);
