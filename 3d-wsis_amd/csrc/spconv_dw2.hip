@@ -482,8 +482,7 @@ int dw2_env(const char* name, int dflt) {
 
 // workgroups per combination (= slabs): ~target waves over the launch, never more than there are slices
 int dw2_P(int64_t M_out, int K, int Cin, int Cout) {
-  static int target = -1;
-  if (target < 0) target = dw2_env("WSIS_DW2_WAVES", 2048);
+  const int target = dw2_env("WSIS_DW2_WAVES", 1024);      // (read per call) one 4-wave workgroup per CU: the launches share the GPU with the dIn products of the main stream (2048: +1.5 % per step)
   const int NOG = (K + GS - 1) / GS;
   const int64_t combos = (int64_t)NOG * (Cin / 32) * ((Cout + 31) / 32);
   const int64_t n_slices = (M_out + 31) / 32;
