@@ -18,10 +18,11 @@
 //   * slab sums (levels with <= 96 work items keep their offset slabs), concat / split copies: phases of their own.
 //
 // Hand-off between phases (cdna_hip_programming.md Guideline 16): every byte another workgroup reads in a later phase is
-// stored write-through (sc1), every storing wave drains (s_waitcnt vmcnt(0)), then the grid barrier: XCD-style
-// hierarchy of agent-scope counters (8 group counters -> top counter -> 8 generation words), one acquire per workgroup
-// behind it.  Every buffer written inside the launch is written ONCE and only read in later phases (private workspace
-// per phase), so no line can be resident anywhere before it is final.  All waits are bounded (2 s) and set an error
+// stored write-through (sc1), every storing wave drains (s_waitcnt vmcnt(0)), then the grid barrier: eight agent-scope
+// arrival counters (one per blockIdx.x % 8) that eight lanes of every workgroup poll together; WSIS_DEEP_FENCE bit 2
+// selects the XCC-aware variant (L2-local counter + generation word per XCC, one fabric hop by the XCC's last arriver),
+// which measures the same.  Every buffer written inside the launch is written ONCE and only read in later phases
+// (private workspace per phase), so no line can be resident anywhere before it is final.  All waits are bounded (2 s) and set an error
 // word the host checks.
 #include <mutex>
 #include <vector>
@@ -70,7 +71,6 @@ __device__ __forceinline__ unsigned ld_u32_sc1(const unsigned* p) {
 // (blockIdx.x % 8: eight counters on lines of their own, so the 256 arrivals serialise 32 deep instead of 256 deep) with
 // an atomic that returns nothing, then eight lanes of its first wave poll the eight counters together (sc1 loads) until
 // all have reached epoch x group size: one one-way trip + one poll round trip, no top-level counter, no second hop.
-// mode 0: the hierarchical form of the first version (group counter -> top counter -> generation word) for A/B runs.
 // fence bit 0: agent-scope acquire behind the barrier, bit 1: release in front (the payload is stored write-through and
 // every buffer is written once per launch, so neither is needed: see the file header; kept as switches)
 __device__ __forceinline__ void deep_grid_barrier(DeepSync* s, unsigned epoch, int fence) {
