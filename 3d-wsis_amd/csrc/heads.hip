@@ -4,13 +4,14 @@
 // 4 per head, backward ~12 with the bias / weight gradients and the gradient accumulation of the shared input); on
 // S ~ 2,300 rows each of those is pure launch latency.  Here ALL blocks that read the same input x [S,64] are
 //
-//   forward  2 launches   lin1: one wave per (32-row slice, block): H_p = x W1_p^T + b1_p on the fp32 matrix cores
+//   forward  3 launches   lin1: one wave per (32-row slice, block): H_p = x W1_p^T + b1_p on the fp32 matrix cores
 //                               (32 v_mfma_f32_32x32x2_f32 per 32-column half, operands straight from global in
 //                               64-byte pieces) + the BatchNorm partials of the slice (sum, centred sum of squares);
-//                         lin2: every wave combines the slice partials of its head (fp64, Chan's form as bn.hip),
-//                               applies BatchNorm + ReLU on its fragment and multiplies by W2_p^T
-//   backward 3 launches   bwd1: dA = dY_p W2_p, dz = dA * [relu'], slice partials (sum dz, sum dz x^), dW2 / db2 partials
-//                         bwd2: BatchNorm backward (global sums from the partials), dx = sum_p dH_p W1_p (blocks of a
+//                         fin:  the slice partials of a head combined by one workgroup (fp64, Chan's form as bn.hip)
+//                         lin2: BatchNorm + ReLU on the wave's fragment, then times W2_p^T
+//   backward 4 launches   bwd1: dA = dY_p W2_p, dz = dA * [relu'], slice partials (sum dz, sum dz x^), dW2 / db2 partials
+//                         fin:  the global sums of the BatchNorm backward (+ d gamma, d beta)
+//                         bwd2: BatchNorm backward, dx = sum_p dH_p W1_p (blocks of a
 //                               slice on 8 waves, added through LDS in block order), dW1 / db1 partials
 //                         bwd3: fixed-order sum of the partials into the caller's gradient tensors
 //
@@ -113,43 +114,99 @@ __global__ __launch_bounds__(256) void heads_lin1_kernel(const wsis_heads h, con
   }
 }
 
-// statistics of column `c` of head p from the slice partials: S = sum of slice sums, Q = sum of centred squares,
-// W = sum S_i^2 / n_i in slice order (fp64): mean, biased variance (bn.hip: bn_finish_centred)
-__device__ __forceinline__ void head_stats(const float* __restrict__ part, int n_heads, int p, int c, int64_t S,
-                                           double& mu, double& var) {
+// ---- statistics finish: one workgroup per head, thread (g, c) adds the slice partials g, g + 16, ... of column c (8 in
+// flight), the sixteen group sums are added in group order (fp64).  Forward: S = sum of slice sums, Q = sum of centred
+// squares, W = sum S_i^2 / n_i -> mean, biased variance (Chan's combination, bn.hip: bn_finish_centred), running
+// statistics; backward: sum dz, sum dz x^.  (The first version had every wave of lin2 / bwd2 combine the partials itself:
+// n_slices^2 loads of the same lines -- 31 us at 72 slices, 99 us at 287.)
+constexpr int FIN_G = 16;
+
+template <int NV>
+__device__ __forceinline__ void fin_sums(const float* __restrict__ part, int n_heads, int p, int64_t S, double (&out)[NV],
+                                         double (*red)[NV][HC]) {
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t n_slices = (S + 31) / 32;
-  double s = 0.0, q = 0.0, w = 0.0;
   const double inv_last = 1.0 / (double)(S - (n_slices - 1) * 32);
-  constexpr int NB = 24;                  // slices whose partials are in flight together
-  for (int64_t j0 = 0; j0 < n_slices; j0 += NB) {
+  double acc[3] = {0.0, 0.0, 0.0};
+  constexpr int NB = 8;
+  for (int64_t j0 = g; j0 < n_slices; j0 += FIN_G * NB) {
     float a[NB], b[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-      const int64_t j = j0 + u;
+      const int64_t j = j0 + (int64_t)u * FIN_G;
       const float* src = part + ((j * n_heads + p) * 2) * HC + c;
       a[u] = j < n_slices ? src[0] : 0.0f;
       b[u] = j < n_slices ? src[HC] : 0.0f;
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-      const int64_t j = j0 + u;
+      const int64_t j = j0 + (int64_t)u * FIN_G;
       if (j < n_slices) {
-        s += (double)a[u];
-        q += (double)b[u];
-        // S_i^2 / n_i: n_i = 32 for every slice but the last (no fp64 division inside the loop)
-        w += (double)a[u] * (double)a[u] * (j + 1 < n_slices ? 1.0 / 32.0 : inv_last);
+        acc[0] += (double)a[u];
+        acc[1] += (double)b[u];
+        if (NV == 3) acc[2] += (double)a[u] * (double)a[u] * (j + 1 < n_slices ? 1.0 / 32.0 : inv_last);
       }
     }
   }
-  const double n = (double)S;
-  mu = s / n;
-  var = (q + (w - n * mu * mu)) / n;
-  if (var < 0.0) var = 0.0;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) red[g][q][c] = acc[q];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    double t = red[0][q][c];
+#pragma unroll
+    for (int w = 1; w < FIN_G; ++w) t += red[w][q][c];
+    out[q] = t;
+  }
+}
+
+__global__ __launch_bounds__(64 * FIN_G) void heads_fin_fwd_kernel(const wsis_heads h, int64_t S, const float* __restrict__ part,
+                                                                    float* __restrict__ saved, float eps, float momentum,
+                                                                    int training) {
+  __shared__ double red[FIN_G][3][HC];
+  const int p = blockIdx.x, c = threadIdx.x & 63;
+  float mean, var;
+  if (training) {
+    double t[3];
+    fin_sums<3>(part, h.n_heads, p, S, t, red);
+    const double n = (double)S, mu = t[0] / n;
+    double v = (t[1] + (t[2] - n * mu * mu)) / n;
+    if (v < 0.0) v = 0.0;
+    mean = (float)mu;
+    var = (float)v;
+    if (threadIdx.x < HC && h.running_mean[p]) {
+      const double unb = n > 1 ? v * n / (n - 1) : v;
+      h.running_mean[p][c] = (float)((1.0 - momentum) * h.running_mean[p][c] + momentum * mu);
+      h.running_var[p][c] = (float)((1.0 - momentum) * h.running_var[p][c] + momentum * unb);
+    }
+  } else {
+    mean = h.running_mean[p][c];
+    var = h.running_var[p][c];
+  }
+  if (threadIdx.x < HC) {
+    saved[(p * 2 + 0) * HC + c] = mean;
+    saved[(p * 2 + 1) * HC + c] = 1.0f / sqrtf(var + eps);
+  }
+}
+
+// sums[p][0][c] = mean of dz, sums[p][1][c] = mean of dz x^ (zeros in eval mode: running statistics are constants);
+// d beta = sum dz, d gamma = sum dz x^ in both modes
+__global__ __launch_bounds__(64 * FIN_G) void heads_fin_bwd_kernel(const wsis_heads h, int64_t S, const float* __restrict__ partb,
+                                                                    float* __restrict__ sums, int training) {
+  __shared__ double red[FIN_G][2][HC];
+  const int p = blockIdx.x, c = threadIdx.x & 63;
+  double t[2];
+  fin_sums<2>(partb, h.n_heads, p, S, t, red);
+  if (threadIdx.x < HC) {
+    if (h.dbeta[p]) h.dbeta[p][c] = (float)t[0];
+    if (h.dgamma[p]) h.dgamma[p][c] = (float)t[1];
+    sums[(p * 2 + 0) * HC + c] = training ? (float)(t[0] / (double)S) : 0.0f;
+    sums[(p * 2 + 1) * HC + c] = training ? (float)(t[1] / (double)S) : 0.0f;
+  }
 }
 
 // ---- forward 2: BatchNorm (+ running statistics) + ReLU + second Linear -------------------------------------------
-__global__ __launch_bounds__(256) void heads_lin2_kernel(const wsis_heads h, int64_t S, const float* __restrict__ part,
-                                                         float* __restrict__ saved, float eps, float momentum, int training) {
+__global__ __launch_bounds__(256) void heads_lin2_kernel(const wsis_heads h, int64_t S, const float* __restrict__ saved) {
   __shared__ float coef[4][3][HC];      // mean, gamma * rstd, beta per wave
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r31 = lane & 31, half = lane >> 5;
   const int p = blockIdx.y * 4 + wave;
@@ -157,28 +214,8 @@ __global__ __launch_bounds__(256) void heads_lin2_kernel(const wsis_heads h, int
   const int64_t s = blockIdx.x;
   {   // lane = column
     const int c = lane;
-    float mean, var;
-    if (training) {
-      double mu, v;
-      head_stats(part, h.n_heads, p, c, S, mu, v);
-      mean = (float)mu;
-      var = (float)v;
-      if (s == 0 && h.running_mean[p]) {
-        const double n = (double)S, unb = n > 1 ? v * n / (n - 1) : v;
-        h.running_mean[p][c] = (float)((1.0 - momentum) * h.running_mean[p][c] + momentum * mu);
-        h.running_var[p][c] = (float)((1.0 - momentum) * h.running_var[p][c] + momentum * unb);
-      }
-    } else {
-      mean = h.running_mean[p][c];
-      var = h.running_var[p][c];
-    }
-    const float rstd = 1.0f / sqrtf(var + eps);
-    if (s == 0) {
-      saved[(p * 2 + 0) * HC + c] = mean;
-      saved[(p * 2 + 1) * HC + c] = rstd;
-    }
-    coef[wave][0][c] = mean;
-    coef[wave][1][c] = h.gamma[p][c] * rstd;
+    coef[wave][0][c] = saved[(p * 2 + 0) * HC + c];
+    coef[wave][1][c] = h.gamma[p][c] * saved[(p * 2 + 1) * HC + c];
     coef[wave][2][c] = h.beta[p][c];
   }
   __builtin_amdgcn_wave_barrier();
@@ -298,47 +335,18 @@ __global__ __launch_bounds__(256) void heads_bwd1_kernel(const wsis_heads h, int
 // ---- backward 2: BatchNorm backward, dx, dW1 / db1 partials -------------------------------------------------------------
 constexpr int TP = HC + 4;       // row pitch of the LDS tiles (floats)
 struct Bwd2Lds {
-  float m1[4][HC], m2[4][HC];    // mean of dz, mean of dz * x^ per head column
   float tile[HB][32][TP];        // dH of a block (column layout in, row layout out), then its dx partial
 };
 
 __global__ __launch_bounds__(64 * HB) void heads_bwd2_kernel(const wsis_heads h, const float* __restrict__ X, int64_t S,
                                                               const float* __restrict__ saved, const float* __restrict__ dZ,
-                                                              const float* __restrict__ partb, float* __restrict__ dX,
-                                                              float* __restrict__ partW1, int n_part, int training) {
+                                                              const float* __restrict__ sums, float* __restrict__ dX,
+                                                              float* __restrict__ partW1, int n_part) {
   extern __shared__ unsigned char lds_raw[];
   Bwd2Lds& L = *reinterpret_cast<Bwd2Lds*>(lds_raw);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r31 = lane & 31, half = lane >> 5;
   const int nb = h.n_heads + h.n_lin;
   const int64_t n_slices = (S + 31) / 32;
-  // global sums of the BatchNorm backward, one thread per (head, column), slice order, fp64
-  for (int t = threadIdx.x; t < h.n_heads * HC; t += blockDim.x) {
-    const int p = t / HC, c = t % HC;
-    double a = 0.0, b = 0.0;
-    constexpr int NB = 24;
-    for (int64_t j0 = 0; j0 < n_slices; j0 += NB) {
-      float va[NB], vb[NB];
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int64_t j = j0 + u;
-        const float* src = partb + ((j * h.n_heads + p) * 2) * HC + c;
-        va[u] = j < n_slices ? src[0] : 0.0f;
-        vb[u] = j < n_slices ? src[HC] : 0.0f;
-      }
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        a += (double)va[u];
-        b += (double)vb[u];
-      }
-    }
-    if (blockIdx.x == 0) {       // d beta = sum dz, d gamma = sum dz x^ (batch or running statistics alike)
-      if (h.dbeta[p]) h.dbeta[p][c] = (float)a;
-      if (h.dgamma[p]) h.dgamma[p][c] = (float)b;
-    }
-    L.m1[p][c] = (float)(a / (double)S);
-    L.m2[p][c] = (float)(b / (double)S);
-  }
-  __syncthreads();
   const int p = wave;                       // one block per wave
   const bool live = p < nb, is_head = p < h.n_heads;
   float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f}, gs[2] = {0.f, 0.f}, m1[2] = {0.f, 0.f}, m2[2] = {0.f, 0.f};
@@ -349,8 +357,8 @@ __global__ __launch_bounds__(64 * HB) void heads_bwd2_kernel(const wsis_heads h,
       mean[cb] = saved[(p * 2 + 0) * HC + col];
       rstd[cb] = saved[(p * 2 + 1) * HC + col];
       gs[cb] = h.gamma[p][col] * rstd[cb];
-      m1[cb] = training ? L.m1[p][col] : 0.0f;
-      m2[cb] = training ? L.m2[p][col] : 0.0f;
+      m1[cb] = sums[(p * 2 + 0) * HC + col];
+      m2[cb] = sums[(p * 2 + 1) * HC + col];
     }
   }
   const float* src = live ? (is_head ? dZ + (int64_t)p * S * HC : h.dout[p]) : nullptr;
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(64 * HB) void heads_bwd2_kernel(const wsis_heads h,
           if (is_head) {
             const float hv = ok ? H[g * HC + col] : 0.0f;
             const float xh = (hv - mean[cb]) * rstd[cb];
-            v = ok ? gs[cb] * ((v - m1[cb]) - xh * m2[cb]) : 0.0f;
+            v = ok ? gs[cb] * ((v - m1[cb]) - xh * m2[cb]) : 0.0f;      // (eval mode: m1 = m2 = 0)
           }
           dh[cb][i] = v;
           db[cb] += v;
@@ -506,7 +514,7 @@ extern "C" int64_t wsis_heads_workspace_bytes(int64_t S, int32_t n_heads, int32_
   const int64_t part = n_slices * n_heads * 2 * HC;                  // forward partials / backward partials
   const int64_t dz = (int64_t)n_heads * S * HC;
   const int64_t pw = np * ((int64_t)(n_heads + n_lin) * W1P + (int64_t)n_heads * W2P);
-  return (part + dz + pw) * (int64_t)sizeof(float) + 1024;
+  return (part + dz + pw + (int64_t)n_heads * 2 * HC) * (int64_t)sizeof(float) + 1024;
 }
 
 extern "C" int wsis_heads_fwd(const wsis_heads* h, const float* d_x, int64_t S, float eps, float momentum, int32_t training,
@@ -525,8 +533,10 @@ extern "C" int wsis_heads_fwd(const wsis_heads* h, const float* d_x, int64_t S, 
                      (int)training);
   WSIS_LAUNCH_CHECK();
   if (h->n_heads > 0) {
-    hipLaunchKernelGGL(heads_lin2_kernel, dim3(n_slices, (unsigned)((h->n_heads + 3) / 4)), dim3(256), 0, st, *h, S, part,
-                       d_saved, eps, momentum, (int)training);
+    hipLaunchKernelGGL(heads_fin_fwd_kernel, dim3((unsigned)h->n_heads), dim3(64 * FIN_G), 0, st, *h, S, part, d_saved, eps,
+                       momentum, (int)training);
+    WSIS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(heads_lin2_kernel, dim3(n_slices, (unsigned)((h->n_heads + 3) / 4)), dim3(256), 0, st, *h, S, d_saved);
     WSIS_LAUNCH_CHECK();
   }
   return WSIS_OK;
@@ -545,9 +555,13 @@ extern "C" int wsis_heads_bwd(const wsis_heads* h, const float* d_x, int64_t S, 
   float* dZ = partb + n_slices * h->n_heads * 2 * HC;
   float* partW1 = dZ + (int64_t)h->n_heads * S * HC;
   float* partW2 = partW1 + (int64_t)np * nb * W1P;
+  float* sums = partW2 + (int64_t)np * h->n_heads * W2P;
   if (h->n_heads > 0) {
     hipLaunchKernelGGL(heads_bwd1_kernel, dim3((unsigned)np, (unsigned)((h->n_heads + 3) / 4)), dim3(256), 0, st, *h, S,
                        d_saved, dZ, partb, partW2, np);
+    WSIS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(heads_fin_bwd_kernel, dim3((unsigned)h->n_heads), dim3(64 * FIN_G), 0, st, *h, S, partb, sums,
+                       (int)training);
     WSIS_LAUNCH_CHECK();
   }
   static bool attr_set = false;       // (one process per GPU: include/wsis_hip.h)
@@ -556,8 +570,8 @@ extern "C" int wsis_heads_bwd(const wsis_heads* h, const float* d_x, int64_t S, 
                                        (int)sizeof(Bwd2Lds)));
     attr_set = true;
   }
-  hipLaunchKernelGGL(heads_bwd2_kernel, dim3((unsigned)np), dim3(64 * HB), sizeof(Bwd2Lds), st, *h, d_x, S, d_saved, dZ, partb,
-                     d_dx, partW1, np, (int)training);
+  hipLaunchKernelGGL(heads_bwd2_kernel, dim3((unsigned)np), dim3(64 * HB), sizeof(Bwd2Lds), st, *h, d_x, S, d_saved, dZ, sums,
+                     d_dx, partW1, np);
   WSIS_LAUNCH_CHECK();
   const int total = nb * W1P + h->n_heads * W2P;
   hipLaunchKernelGGL(heads_bwd3_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, *h, partW1, partW2, np);

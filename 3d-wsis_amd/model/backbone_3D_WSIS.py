@@ -174,7 +174,7 @@ class Network(nn.Module):
 
         ecc_outputs = self.ecc(embeddings)
 
-        # the four heads and the q / k / v layers read the same rows: ONE operator (2 launches forward, 3 backward,
+        # the four heads and the q / k / v layers read the same rows: ONE operator (3 launches forward, 4 backward,
         # csrc/heads.hip) where it applies, else module by module
         fused = wsis_ops.sp_heads(ecc_outputs, [self.sp_sem_seg, self.sp_offset_vector_head, self.sp_occupancy_head,
                                                 self.sp_ins_size_head], [self.w_qs, self.w_ks, self.w_vs])

@@ -755,7 +755,7 @@ def tall_sequential(seq, x):
 
 class _SpHeads(Function):
     """All heads Linear(64,64) -> BatchNorm1d -> ReLU -> Linear(64,cout) and bias-free Linear(64,64) layers that read the
-    same [S,64] rows (backbone_3D_WSIS.py:59-64, 195-216, 253) as ONE autograd node: two launches forward, three
+    same [S,64] rows (backbone_3D_WSIS.py:59-64, 195-216, 253) as ONE autograd node: three launches forward, four
     backward (csrc/heads.hip) instead of a module chain per head (4 launches forward and ~12 backward each, plus the
     gradient accumulation of the shared input)."""
 

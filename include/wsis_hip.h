@@ -474,7 +474,7 @@ int wsis_colsum(const float* d_x, int64_t M, int32_t C, float* d_out, void* d_ws
  * :195-204 (sp_sem_seg / sp_offset_vector_head / sp_occupancy_head / sp_ins_size_head on the GNN output), :210-216 (the
  * bias-free w_qs / w_ks / w_vs on the same rows) and :253 (feature_term), cin == 64.  All blocks of one call read the same
  * input x [S,64]: blocks 0 .. n_heads-1 are heads (cout <= 32), blocks n_heads .. n_heads+n_lin-1 plain Linear(64,64)
- * layers without bias.  Forward = 2 launches, backward = 3 (csrc/heads.hip), fixed summation orders, exact fp32.
+ * layers without bias.  Forward = 3 launches, backward = 4 (csrc/heads.hip), fixed summation orders, exact fp32.
  * The tables hold DEVICE pointers in torch's layouts (Linear weight [out,in]); the struct itself is host memory.
  *   forward   reads W1,b1,gamma,beta,W2,b2 (+ running_* in eval mode), writes hidden[p] [S,64] (heads: the pre-BatchNorm
  *             activations, kept for backward; plain layers: their OUTPUT), out[p] [S,cout[p]], d_saved [n_heads,2,64]

@@ -45,3 +45,21 @@ def test_device_ops_refuse_cpu_tensors():
         pointgroup_ops.voxelization(torch.zeros(4, 3), torch.zeros((2, 3), dtype=torch.int32), 4)
     with pytest.raises(wsis_native.WsisError):
         torch_scatter.scatter(torch.zeros(4, 3), torch.zeros(4, dtype=torch.long), dim=0, reduce="mean")
+
+
+def test_heads_struct_matches_header():
+    """wsis_native.Heads (ctypes) against ``typedef struct wsis_heads`` of include/wsis_hip.h: same fields, same order,
+    same array length -- the struct crosses the boundary by pointer"""
+    text = open(os.path.join(ROOT, "include", "wsis_hip.h")).read()
+    body = re.search(r"typedef struct wsis_heads \{(.*?)\} wsis_heads;", text, flags=re.S).group(1)
+    n_max = int(re.search(r"#define WSIS_HEADS_MAX (\d+)", text).group(1))
+    assert n_max == wsis_native.HEADS_MAX
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            names.append(re.sub(r"\[.*", "", part.strip().split()[-1].lstrip("*")))
+    assert names == [f[0] for f in wsis_native.Heads._fields_]
+    assert ctypes.sizeof(wsis_native.Heads) == 4 * 2 + 4 * n_max + 8 * n_max * 17
