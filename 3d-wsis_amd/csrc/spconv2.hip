@@ -241,7 +241,7 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
   // persistent form (spconv_fwd2p_kernel): launches of more than one round of resident work items
   {
     const char* pe = getenv("WSIS_FWD2P");          // (read per call)
-    const int fwd2p = pe ? atoi(pe) : 1;
+    const int fwd2p = pe ? atoi(pe) : 0;
     static int cus = 0;
     if (!cus) {
       int dev = 0;
@@ -252,8 +252,9 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
     // measured (tools/conv2p_bench.py): one scene per step (level 0: 1.56 rounds, level 1: 1.6) the hardware's own
     // dispatch of one-shot workgroups is as good a queue and has no per-item ticket -- 59.8 -> 63.3 us at level 0,
     // 46.0 -> 52.1 at level 1; four scenes per step (6.4 rounds of one-wave items) 202 -> 180 us for the 3x3x3 layers of
-    // level 0, while the short 2x2x2 items (42 -> 51) and the 4-wave items (139 -> 152) stay slower: the default takes the
-    // persistent form for one-wave items of >= 16 offsets from 4 rounds on (WSIS_FWD2P=2: wherever it applies)
+    // level 0, while the short 2x2x2 items (42 -> 51) and the 4-wave items (139 -> 152) stay slower.  Inside the step (the
+    // weight gradients beside the dIn products) even that gain is gone: 21.92 (off) / 21.97 (one-wave items of >= 16 offsets
+    // from 4 rounds on: WSIS_FWD2P=1) / 22.41 ms (wherever it applies: =2) per 4-scene step, in-process A/B -> default OFF
     const bool p_shape = fwd2p >= 2 ? (p.NW == 1 || p.NW == 2 || p.NW == 4) : (p.NW == 1 && K >= 16);
     if (fwd2p && !bn_in && n_targets == 0 && d_sync && p.NB == 1 && p.ZS == 1 && p.DA == 2 && p.BD && p_shape &&
         items < ((int64_t)1 << 30)) {

@@ -482,10 +482,12 @@ int dw2_env(const char* name, int dflt) {
 
 // workgroups per combination (= slabs): ~target waves over the launch, never more than there are slices
 int dw2_P(int64_t M_out, int K, int Cin, int Cout) {
-  const int target = dw2_env("WSIS_DW2_WAVES", 1024);      // (read per call) one 4-wave workgroup per CU: the launches share the GPU with the dIn products of the main stream (2048: +1.5 % per step)
+  // (read per call) the launches share the GPU with the dIn products of the main stream: up to 8,192 slices one 4-wave
+  // workgroup per CU (2,048 waves: +1.5 % per one-scene step), above that two (1,024 waves: +0.7 % per four-scene step)
+  const int64_t n_slices = (M_out + 31) / 32;
+  const int target = dw2_env("WSIS_DW2_WAVES", n_slices >= 8192 ? 2048 : 1024);
   const int NOG = (K + GS - 1) / GS;
   const int64_t combos = (int64_t)NOG * (Cin / 32) * ((Cout + 31) / 32);
-  const int64_t n_slices = (M_out + 31) / 32;
   int64_t P = (target / WGW + combos - 1) / combos;
   const int64_t cap = (n_slices + WGW - 1) / WGW;
   if (P > cap) P = cap;

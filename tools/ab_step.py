@@ -1,6 +1,7 @@
 """A/B of two environment settings inside ONE process: blocks of steps alternate between the settings (every switch is
 read per call or per pass), each block timed by events; removes the box-to-box and clock-ramp spread of separate runs.
-    python tools/ab_step.py WSIS_BRANCH=0 WSIS_BRANCH=1 [blocks] [steps per block]"""
+    python tools/ab_step.py WSIS_BRANCH=0 WSIS_BRANCH=1 [blocks] [steps per block]
+AB_SCENES=4 selects bench.py's C3 batch (scenes 1-4 per step) instead of the C2 scene."""
 import importlib, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 importlib.import_module("3d-wsis_amd")
@@ -19,7 +20,9 @@ blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 per = int(sys.argv[4]) if len(sys.argv) > 4 else 40
 cfg = harness.default_cfg()
 dev = torch.device("cuda", 0)
-batch = harness.to_device(harness.collate([harness.bench_scene(1)]), dev)
+n_scenes = int(os.environ.get("AB_SCENES", "1"))
+cfg.batch_size = n_scenes
+batch = harness.to_device(harness.collate([harness.bench_scene(1 + i) for i in range(n_scenes)]), dev)
 model, crit, opt = harness.build_model(cfg, dev)
 
 
@@ -32,7 +35,7 @@ for spec in (A, B):
     setenv(spec)
     for _ in range(20):
         step()
-for _ in range(260):
+for _ in range(260 if n_scenes == 1 else 60):
     step()
 res = {A: [], B: []}
 for b in range(blocks):
