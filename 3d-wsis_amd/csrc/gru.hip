@@ -66,13 +66,13 @@ struct GruRow {
   float r, z, n, hy;   // lanes 0..31
 };
 
-__device__ __forceinline__ GruRow gru_row_fwd(GruLds& L, int wave, int lane, const float* __restrict__ x,
+__device__ __forceinline__ GruRow gru_row_fwd(GruLds& L, int wave, int lane, float xval,
                                               const float* __restrict__ h, const float* __restrict__ big,
                                               const float* __restrict__ bih, const float* __restrict__ bhh,
                                               int64_t row) {
   GruRow R;
   const int c = lane & 31;
-  R.x = x[row * GC + c];
+  R.x = xval;
   R.h = h[row * GC + c];
   float* hrow = L.row[wave][0];
   float* xrow = L.row[wave][1];
@@ -118,8 +118,38 @@ __device__ __forceinline__ GruRow gru_row_fwd(GruLds& L, int wave, int lane, con
   return R;
 }
 
+// mean over the messages of row `row`'s segment, lane (grp = lane >> 5, c): rows beg + grp, beg + grp + 2, ... in
+// ascending order, then the two groups added, then / count -- the arithmetic and order of segment_reduce_kernel<1>
+// (segment.hip) at C = 32, so the fused launch gives the values of the two it replaces
+__device__ __forceinline__ float gru_seg_mean(const float* __restrict__ m, const int32_t* __restrict__ perm,
+                                              const int32_t* __restrict__ off, int64_t row, int lane) {
+  const int c = lane & 31, grp = lane >> 5;
+  const int beg = off[row], end = off[row + 1];
+  float acc = 0.0f;
+  constexpr int U = 8;
+  int j = beg + grp;
+  for (; j + (U - 1) * 2 < end; j += U * 2) {
+    int32_t p[U];
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) p[u] = perm[j + u * 2];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = m[(int64_t)p[u] * GC + c];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += v[u];
+  }
+  for (; j < end; j += 2) acc += m[(int64_t)perm[j] * GC + c];
+  acc += __shfl_xor(acc, 32, 64);
+  const int cnt = end - beg;
+  return acc / (float)(cnt > 0 ? cnt : 1);
+}
+
+// MEAN: the cell's input is the segmented mean of the edge messages m [E,32] (CSR perm / off over the rows), formed
+// here and written to x_out [S,32] (the backward needs it) -- the scatter-mean launch in front of the cell folded in
+template <bool MEAN>
 __global__ __launch_bounds__(64 * GRU_WF) void gru_fwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ h, const float* __restrict__ Wig,
+    const float* __restrict__ x, const int32_t* __restrict__ perm, const int32_t* __restrict__ off,
+    float* __restrict__ x_out, const float* __restrict__ h, const float* __restrict__ Wig,
     const float* __restrict__ big, const float* __restrict__ Wih, const float* __restrict__ Whh,
     const float* __restrict__ bih, const float* __restrict__ bhh, float* __restrict__ hy, int64_t S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -129,7 +159,14 @@ __global__ __launch_bounds__(64 * GRU_WF) void gru_fwd_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nw = (int64_t)gridDim.x * GRU_WF;
   for (int64_t row = (int64_t)blockIdx.x * GRU_WF + wave; row < S; row += nw) {
-    const GruRow R = gru_row_fwd(L, wave, lane, x, h, big, bih, bhh, row);
+    float xv;
+    if (MEAN) {
+      xv = gru_seg_mean(x, perm, off, row, lane);
+      if (lane < 32) x_out[row * GC + lane] = xv;
+    } else {
+      xv = x[row * GC + (lane & 31)];
+    }
+    const GruRow R = gru_row_fwd(L, wave, lane, xv, h, big, bih, bhh, row);
     if (lane < 32) hy[row * GC + lane] = R.hy;
   }
 }
@@ -140,6 +177,7 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void gru_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ h, const float* __restrict__ Wig,
     const float* __restrict__ big, const float* __restrict__ Wih, const float* __restrict__ Whh,
     const float* __restrict__ bih, const float* __restrict__ bhh, const float* __restrict__ dhy,
+    const float* __restrict__ dhy2, int64_t dhy2_pitch,
     float* __restrict__ dx, float* __restrict__ dh, float* __restrict__ partial, int64_t S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   GruLds& L = *reinterpret_cast<GruLds*>(smem);
@@ -161,8 +199,11 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void gru_bwd_kernel(
   float* dgi = L.row[wave][2];
   float* dgh = L.row[wave][3];
   for (int64_t row = (int64_t)blockIdx.x * GRU_WAVES + wave; row < S; row += nw) {
-    const GruRow R = gru_row_fwd(L, wave, lane, x, h, big, bih, bhh, row);
-    const float g = dhy[row * GC + c];
+    const GruRow R = gru_row_fwd(L, wave, lane, x[row * GC + c], h, big, bih, bhh, row);
+    // upstream gradient = dhy (+ dhy2: the output gradient of this hidden state in a concatenated sequence, added here
+    // instead of by a launch of its own; either may be NULL)
+    float g = dhy ? dhy[row * GC + c] : 0.0f;
+    if (dhy2) g = dhy ? g + dhy2[row * dhy2_pitch + c] : dhy2[row * dhy2_pitch + c];
     // gates (lanes 0..31 meaningful; upper half mirrors the same c)
     const float dn = g * (1.0f - R.z);
     const float dz = g * (R.h - R.n);
@@ -330,24 +371,50 @@ int64_t wsis_gru_cell_workspace_bytes(int64_t S) {
   return (int64_t)gru_blocks(S) * GRU_P * (int64_t)sizeof(float) + 256;
 }
 
+static int gru_fwd_impl(const float* d_x, const int32_t* d_perm, const int32_t* d_off, float* d_x_out, const float* d_h,
+                        const float* d_Wig, const float* d_big, const float* d_Wih, const float* d_Whh, const float* d_bih,
+                        const float* d_bhh, float* d_hy, int64_t S, void* stream) {
+  const size_t lds = sizeof(GruLds);
+  static bool attr_set = false;       // (one process per GPU: include/wsis_hip.h)
+  if (!attr_set) {
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)gru_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)gru_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  if (d_perm)
+    hipLaunchKernelGGL(gru_fwd_kernel<true>, dim3(gru_blocks(S, GRU_WF, 1)), dim3(64 * GRU_WF), lds, as_stream(stream), d_x,
+                       d_perm, d_off, d_x_out, d_h, d_Wig, d_big, d_Wih, d_Whh, d_bih, d_bhh, d_hy, S);
+  else
+    hipLaunchKernelGGL(gru_fwd_kernel<false>, dim3(gru_blocks(S, GRU_WF, 1)), dim3(64 * GRU_WF), lds, as_stream(stream), d_x,
+                       d_perm, d_off, d_x_out, d_h, d_Wig, d_big, d_Wih, d_Whh, d_bih, d_bhh, d_hy, S);
+  WSIS_LAUNCH_CHECK();
+  return WSIS_OK;
+}
+
 int wsis_gru_cell_fwd(const float* d_x, const float* d_h, const float* d_Wig, const float* d_big,
                       const float* d_Wih, const float* d_Whh, const float* d_bih, const float* d_bhh, float* d_hy,
                       int64_t S, int32_t C, void* stream) {
   WSIS_REQUIRE(S >= 0 && C == GC, "GRUCellEx kernel supports C == 32");
   if (S == 0) return WSIS_OK;
   WSIS_REQUIRE(d_x && d_h && d_Wig && d_big && d_Wih && d_Whh && d_bih && d_bhh && d_hy, "null pointer");
-  const size_t lds = sizeof(GruLds);
-  WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)gru_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3(gru_blocks(S, GRU_WF, 1)), dim3(64 * GRU_WF), lds, as_stream(stream), d_x, d_h,
-                     d_Wig, d_big, d_Wih, d_Whh, d_bih, d_bhh, d_hy, S);
-  WSIS_LAUNCH_CHECK();
-  return WSIS_OK;
+  return gru_fwd_impl(d_x, nullptr, nullptr, nullptr, d_h, d_Wig, d_big, d_Wih, d_Whh, d_bih, d_bhh, d_hy, S, stream);
+}
+
+int wsis_gru_cell_fwd_mean(const float* d_m, const int32_t* d_perm, const int32_t* d_off, float* d_x_out, const float* d_h,
+                           const float* d_Wig, const float* d_big, const float* d_Wih, const float* d_Whh, const float* d_bih,
+                           const float* d_bhh, float* d_hy, int64_t S, int32_t C, void* stream) {
+  WSIS_REQUIRE(S >= 0 && C == GC, "GRUCellEx kernel supports C == 32");
+  if (S == 0) return WSIS_OK;
+  WSIS_REQUIRE(d_m && d_perm && d_off && d_x_out && d_h && d_Wig && d_big && d_Wih && d_Whh && d_bih && d_bhh && d_hy,
+               "null pointer");
+  return gru_fwd_impl(d_m, d_perm, d_off, d_x_out, d_h, d_Wig, d_big, d_Wih, d_Whh, d_bih, d_bhh, d_hy, S, stream);
 }
 
 // one backward evaluation; slot >= 0 selects the slab region of a sequence (wsis_gru_cell_bwd_seq), n_reduce > 0
 // runs the fixed-order slab reduce over that many slabs
 static int gru_bwd_impl(const float* d_x, const float* d_h, const float* d_Wig, const float* d_big, const float* d_Wih,
-                        const float* d_Whh, const float* d_bih, const float* d_bhh, const float* d_dhy, float* d_dx,
+                        const float* d_Whh, const float* d_bih, const float* d_bhh, const float* d_dhy, const float* d_dhy2,
+                        int64_t dhy2_pitch, float* d_dx,
                         float* d_dh, float* d_dWig, float* d_dbig, float* d_dWih, float* d_dWhh, float* d_dbih,
                         float* d_dbhh, int64_t S, int slot, int n_reduce, void* d_ws, hipStream_t st) {
   const size_t lds = sizeof(GruLds);
@@ -360,7 +427,7 @@ static int gru_bwd_impl(const float* d_x, const float* d_h, const float* d_Wig, 
   float* base = static_cast<float*>(d_ws);
   float* partial = base + (int64_t)slot * nb * GRU_P;
   hipLaunchKernelGGL(gru_bwd_kernel, dim3(nb), dim3(64 * GRU_WAVES), lds, st, d_x, d_h, d_Wig, d_big, d_Wih, d_Whh,
-                     d_bih, d_bhh, d_dhy, d_dx, d_dh, partial, S);
+                     d_bih, d_bhh, d_dhy, d_dhy2, dhy2_pitch, d_dx, d_dh, partial, S);
   WSIS_LAUNCH_CHECK();
   if (n_reduce > 0) {
     hipLaunchKernelGGL(gru_reduce_kernel, dim3((GRU_P + RED_OUT - 1) / RED_OUT), dim3(RED_OUT * RED_LANES), 0, st, base,
@@ -380,23 +447,24 @@ int wsis_gru_cell_bwd(const float* d_x, const float* d_h, const float* d_Wig, co
                    d_dWig && d_dbig && d_dWih && d_dWhh && d_dbih && d_dbhh && d_ws,
                "null pointer");
   WSIS_REQUIRE(ws_bytes >= wsis_gru_cell_workspace_bytes(S), "workspace too small");
-  return gru_bwd_impl(d_x, d_h, d_Wig, d_big, d_Wih, d_Whh, d_bih, d_bhh, d_dhy, d_dx, d_dh, d_dWig, d_dbig, d_dWih,
+  return gru_bwd_impl(d_x, d_h, d_Wig, d_big, d_Wih, d_Whh, d_bih, d_bhh, d_dhy, nullptr, 0, d_dx, d_dh, d_dWig, d_dbig, d_dWih,
                       d_dWhh, d_dbih, d_dbhh, S, 0, gru_blocks(S), d_ws, as_stream(stream));
 }
 
 int wsis_gru_cell_bwd_seq(const float* d_x, const float* d_h, const float* d_Wig, const float* d_big,
                           const float* d_Wih, const float* d_Whh, const float* d_bih, const float* d_bhh,
-                          const float* d_dhy, float* d_dx, float* d_dh, float* d_dWig, float* d_dbig, float* d_dWih,
-                          float* d_dWhh, float* d_dbih, float* d_dbhh, int64_t S, int32_t C, int32_t slot,
-                          int32_t n_slots, int32_t finish, void* d_ws, int64_t ws_bytes, void* stream) {
+                          const float* d_dhy, const float* d_dhy2, int64_t dhy2_pitch, float* d_dx, float* d_dh, float* d_dWig,
+                          float* d_dbig, float* d_dWih, float* d_dWhh, float* d_dbih, float* d_dbhh, int64_t S, int32_t C,
+                          int32_t slot, int32_t n_slots, int32_t finish, void* d_ws, int64_t ws_bytes, void* stream) {
   WSIS_REQUIRE(S >= 1 && C == GC, "GRUCellEx kernel supports C == 32, S >= 1");
   WSIS_REQUIRE(n_slots >= 1 && slot >= 0 && slot < n_slots, "bad slot");
-  WSIS_REQUIRE(d_x && d_h && d_Wig && d_big && d_Wih && d_Whh && d_bih && d_bhh && d_dhy && d_dx && d_dh && d_ws,
+  WSIS_REQUIRE(d_x && d_h && d_Wig && d_big && d_Wih && d_Whh && d_bih && d_bhh && (d_dhy || d_dhy2) && d_dx && d_dh && d_ws,
                "null pointer");
+  WSIS_REQUIRE(!d_dhy2 || dhy2_pitch >= GC, "pitch of the second gradient");
   WSIS_REQUIRE(!finish || (d_dWig && d_dbig && d_dWih && d_dWhh && d_dbih && d_dbhh), "null pointer");
   WSIS_REQUIRE(ws_bytes >= (wsis_gru_cell_workspace_bytes(S) - 256) * n_slots + 256, "workspace too small");
-  return gru_bwd_impl(d_x, d_h, d_Wig, d_big, d_Wih, d_Whh, d_bih, d_bhh, d_dhy, d_dx, d_dh, d_dWig, d_dbig, d_dWih,
-                      d_dWhh, d_dbih, d_dbhh, S, slot, finish ? gru_blocks(S) * n_slots : 0, d_ws, as_stream(stream));
+  return gru_bwd_impl(d_x, d_h, d_Wig, d_big, d_Wih, d_Whh, d_bih, d_bhh, d_dhy, d_dhy2, dhy2_pitch, d_dx, d_dh, d_dWig, d_dbig,
+                      d_dWih, d_dWhh, d_dbih, d_dbhh, S, slot, finish ? gru_blocks(S) * n_slots : 0, d_ws, as_stream(stream));
 }
 
 }  // extern "C"

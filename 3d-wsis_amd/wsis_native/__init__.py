@@ -133,7 +133,8 @@ _HIP_SIGS = {
     "wsis_heads_workspace_bytes": (I64, [I64, I32, I32]),
     "wsis_heads_fwd": (I32, [P, P, I64, F32, F32, I32, P, P, I64, P]),
     "wsis_heads_bwd": (I32, [P, P, I64, I32, P, P, P, I64, P]),
-    "wsis_gru_cell_bwd_seq": (I32, [P] * 17 + [I64, I32, I32, I32, I32, P, I64, P]),
+    "wsis_gru_cell_bwd_seq": (I32, [P] * 10 + [I64] + [P] * 8 + [I64, I32, I32, I32, I32, P, I64, P]),
+    "wsis_gru_cell_fwd_mean": (I32, [P] * 12 + [I64, I32, P]),
     "wsis_affinity_dense_build": (I32, [P, P, P, I64, P, I64, P]),
     "wsis_affinity_transition": (I32, [P, P, P, P, P, I32, F32, P, I64, P]),
     "wsis_dgemm": (I32, [P, P, P, I64, I64, I64, P]),

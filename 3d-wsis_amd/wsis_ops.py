@@ -602,10 +602,15 @@ class _EccGruLoop(Function):
             _n.check(lib.wsis_ecc_contract_fwd(_n.ptr(h), _n.ptr(U), _n.ptr(csr_dst.perm), _n.ptr(csr_dst.offsets),
                                                _n.ptr(m), S, E, st), "ecc_contract_fwd")
             inp = torch.empty((S, 32), dtype=torch.float32, device=hx.device)
-            _n.check(lib.wsis_segment_reduce_fwd(_n.ptr(m), _n.ptr(csr_src.perm), _n.ptr(csr_src.offsets), _n.ptr(inp),
-                                                 None, E, S, 32, 1, st), "segment_reduce_fwd")
-            _n.check(lib.wsis_gru_cell_fwd(_n.ptr(inp), _n.ptr(hxs[i]), *[_n.ptr(t) for t in gp], _n.ptr(hxs[i + 1]), S,
-                                           32, st), "gru_cell_fwd")
+            if own:      # the mean over the in-edges is formed by the cell's launch (same order of additions)
+                _n.check(lib.wsis_gru_cell_fwd_mean(_n.ptr(m), _n.ptr(csr_src.perm), _n.ptr(csr_src.offsets), _n.ptr(inp),
+                                                    _n.ptr(hxs[i]), *[_n.ptr(t) for t in gp], _n.ptr(hxs[i + 1]), S, 32,
+                                                    st), "gru_cell_fwd_mean")
+            else:
+                _n.check(lib.wsis_segment_reduce_fwd(_n.ptr(m), _n.ptr(csr_src.perm), _n.ptr(csr_src.offsets),
+                                                     _n.ptr(inp), None, E, S, 32, 1, st), "segment_reduce_fwd")
+                _n.check(lib.wsis_gru_cell_fwd(_n.ptr(inp), _n.ptr(hxs[i]), *[_n.ptr(t) for t in gp], _n.ptr(hxs[i + 1]),
+                                               S, 32, st), "gru_cell_fwd")
             Us.append(U)
             inps.append(inp)
         ctx.save_for_backward(h, Waug, *gp, hx_all, *inps, *Us)
@@ -626,7 +631,12 @@ class _EccGruLoop(Function):
         dev = h.device
         dout = dout.contiguous().float()
         d_slices = [dout[:, 32 * i:32 * (i + 1)] for i in range(R + 1)] if cat_all else None
-        d_hx = d_slices[R].contiguous() if cat_all else dout
+        own = os.environ.get("WSIS_ECC_OWN_GEMM", "1") != "0"
+        # the gradient that reaches hx_{i+1}: what the later iterations pass down (d_carry; none for the last state) plus,
+        # with cat_all, its own slice of the output gradient -- summed by the cell's backward as it loads them (own) or by
+        # a launch per iteration
+        pitch = dout.shape[1]
+        d_carry = None if cat_all else dout
         dh = torch.empty_like(h) if R > 0 else torch.zeros_like(h)      # written by the first evaluated iteration
         # the six GRU parameter gradients: every iteration leaves its slabs in its own region, ONE reduce at the end
         dgp = [torch.empty_like(t) for t in gp] if R > 0 else [torch.zeros_like(t) for t in gp]
@@ -636,12 +646,18 @@ class _EccGruLoop(Function):
         # row-split MFMA reduction (the sparse-conv dW kernel, K = 1, dense rows) instead of R one-workgroup GEMMs
         dU_all = torch.empty((R * S, Waug.shape[1]), dtype=torch.float32, device=dev)
         WaugT = Waug.t()
-        own = os.environ.get("WSIS_ECC_OWN_GEMM", "1") != "0"
         for i in reversed(range(R)):
-            d_inp, d_hprev = torch.empty_like(d_hx), torch.empty_like(d_hx)
-            _n.check(lib.wsis_gru_cell_bwd_seq(_n.ptr(inps[i]), _n.ptr(hxs[i]), *[_n.ptr(t) for t in gp], _n.ptr(d_hx),
-                                               _n.ptr(d_inp), _n.ptr(d_hprev), *[_n.ptr(t) for t in dgp], S, 32,
-                                               R - 1 - i, R, 1 if i == 0 else 0, _n.ptr(ws), ws_bytes, st),
+            d_inp, d_hprev = torch.empty((S, 32), dtype=torch.float32, device=dev), torch.empty((S, 32), dtype=torch.float32,
+                                                                                                device=dev)
+            if own:
+                extra = (dout.data_ptr() + 4 * 32 * (i + 1)) if cat_all else None
+            else:
+                extra = None
+                if cat_all:      # materialise carry + slice
+                    d_carry = d_slices[i + 1].contiguous() if d_carry is None else d_carry.add_(d_slices[i + 1])
+            _n.check(lib.wsis_gru_cell_bwd_seq(_n.ptr(inps[i]), _n.ptr(hxs[i]), *[_n.ptr(t) for t in gp], _n.ptr(d_carry),
+                                               extra, pitch, _n.ptr(d_inp), _n.ptr(d_hprev), *[_n.ptr(t) for t in dgp], S,
+                                               32, R - 1 - i, R, 1 if i == 0 else 0, _n.ptr(ws), ws_bytes, st),
                      "gru_cell_bwd_seq")
             dU = dU_all[i * S:(i + 1) * S]
             if own:
@@ -650,19 +666,18 @@ class _EccGruLoop(Function):
                                                         _n.ptr(csr_src.offsets), _n.ptr(csr_dst.perm),
                                                         _n.ptr(csr_dst.offsets), _n.ptr(dU), _n.ptr(dh), S, E,
                                                         0 if i == R - 1 else 1, st), "ecc_contract_bwd_mean")
-                d_hx = d_hprev.addmm_(dU, WaugT)
-                if cat_all:
-                    d_hx += d_slices[i]
-                continue
-            d_m = torch.empty((E, 32), dtype=torch.float32, device=dev)
-            _n.check(lib.wsis_segment_reduce_bwd(_n.ptr(d_inp), _n.ptr(csr_src.index), _n.ptr(csr_src.offsets), None,
-                                                 _n.ptr(d_m), E, S, 32, 1, st), "segment_reduce_bwd")
-            _n.check(lib.wsis_ecc_contract_bwd_acc(_n.ptr(h), _n.ptr(Us[i]), _n.ptr(d_m), _n.ptr(csr_dst.perm),
-                                                   _n.ptr(csr_dst.offsets), _n.ptr(dU), _n.ptr(dh), S, E,
-                                                   0 if i == R - 1 else 1, st), "ecc_contract_bwd")
-            d_hx = d_hprev.addmm_(dU, WaugT)          # in place: no copy of d_hprev into a new output first
-            if cat_all:
-                d_hx += d_slices[i]
+            else:
+                d_m = torch.empty((E, 32), dtype=torch.float32, device=dev)
+                _n.check(lib.wsis_segment_reduce_bwd(_n.ptr(d_inp), _n.ptr(csr_src.index), _n.ptr(csr_src.offsets), None,
+                                                     _n.ptr(d_m), E, S, 32, 1, st), "segment_reduce_bwd")
+                _n.check(lib.wsis_ecc_contract_bwd_acc(_n.ptr(h), _n.ptr(Us[i]), _n.ptr(d_m), _n.ptr(csr_dst.perm),
+                                                       _n.ptr(csr_dst.offsets), _n.ptr(dU), _n.ptr(dh), S, E,
+                                                       0 if i == R - 1 else 1, st), "ecc_contract_bwd")
+            d_carry = d_hprev.addmm_(dU, WaugT)          # in place: no copy of d_hprev into a new output first
+        if R == 0:
+            d_hx = d_slices[0].contiguous() if cat_all else dout
+        else:
+            d_hx = d_carry.add_(d_slices[0]) if cat_all else d_carry
         dWaug = None
         if ctx.needs_input_grad[2] and R == 0:
             dWaug = torch.zeros_like(Waug)

@@ -524,12 +524,20 @@ int wsis_gru_cell_bwd(const float* d_x, const float* d_h, const float* d_Wig, co
 /* The same backward as evaluation `slot` of a sequence of `n_slots` evaluations that share the six parameter
  * tensors (the R repeats of spg_modules.py:152-185): every evaluation leaves its parameter-gradient slabs in its own
  * region of d_ws (n_slots x the single-call workspace); the call with finish != 0 reduces ALL regions in one
- * fixed-order launch into d_dW* / d_db* (= the sum over the sequence; may be NULL on the other calls). */
+ * fixed-order launch into d_dW* / d_db* (= the sum over the sequence; may be NULL on the other calls).
+ * The upstream gradient of the evaluation is d_dhy + d_dhy2 (either may be NULL): d_dhy2 [S, pitch >= 32] is the output
+ * gradient of this hidden state inside the concatenated sequence (cat_all), added on load instead of by a launch. */
 int wsis_gru_cell_bwd_seq(const float* d_x, const float* d_h, const float* d_Wig, const float* d_big,
                           const float* d_Wih, const float* d_Whh, const float* d_bih, const float* d_bhh,
-                          const float* d_dhy, float* d_dx, float* d_dh, float* d_dWig, float* d_dbig, float* d_dWih,
-                          float* d_dWhh, float* d_dbih, float* d_dbhh, int64_t S, int32_t C, int32_t slot,
-                          int32_t n_slots, int32_t finish, void* d_ws, int64_t ws_bytes, void* stream);
+                          const float* d_dhy, const float* d_dhy2, int64_t dhy2_pitch, float* d_dx, float* d_dh, float* d_dWig,
+                          float* d_dbig, float* d_dWih, float* d_dWhh, float* d_dbih, float* d_dbhh, int64_t S, int32_t C,
+                          int32_t slot, int32_t n_slots, int32_t finish, void* d_ws, int64_t ws_bytes, void* stream);
+/* wsis_gru_cell_fwd whose input is the segmented MEAN of the edge messages d_m [E,32] over the CSR (d_perm, d_off) of the
+ * rows (spg_modules.py:97-121 aggr='mean' followed by the cell, :168-183): the mean is formed per row in the order of
+ * wsis_segment_reduce_fwd and written to d_x_out [S,32] (kept for the backward) -- one launch instead of two. */
+int wsis_gru_cell_fwd_mean(const float* d_m, const int32_t* d_perm, const int32_t* d_off, float* d_x_out, const float* d_h,
+                           const float* d_Wig, const float* d_big, const float* d_Wih, const float* d_Whh, const float* d_bih,
+                           const float* d_bhh, float* d_hy, int64_t S, int32_t C, void* stream);
 
 /* ---- a17: dense inter-superpoint affinity + label propagation -------------------------------
  * train_scannetv2.py:562-570, modules/datasets/scannetv2_dataset.py:664-721 (fp64, host numpy).
