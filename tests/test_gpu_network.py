@@ -530,3 +530,33 @@ def test_rulebooks_sized_from_host_counts_equal_the_read_back_build(monkeypatch)
     build(wrong)
     with pytest.raises(_n.WsisError):
         ops.verify_pending_counts()
+
+
+@pytest.mark.gpu
+def test_branch_stream_gives_the_results_of_one_stream(monkeypatch):
+    """the filter net and the point-level head on the rulebook side stream (WSIS_BRANCH=1, the default; their backward
+    follows them there) against everything on the current stream (WSIS_BRANCH=0): the same kernels on the same inputs, so
+    every loss of 8 optimizer steps over scenes of three sizes and every final parameter must be EQUAL -- a missed
+    cross-stream dependency shows up here as a difference (or as a NaN)"""
+    cfg = harness.default_cfg()
+    rooms = [(3.0, 2.5, 2.4), (1.8, 1.4, 1.1), (4.2, 3.1, 2.5)]
+    scenes = [harness.collate([harness.make_scene(500 + i, room=r, n_box=3)]) for i, r in enumerate(rooms)]
+
+    def run(flag):
+        monkeypatch.setenv("WSIS_BRANCH", flag)
+        torch.manual_seed(0)
+        model, crit, opt = harness.build_model(cfg, "cuda")
+        out = []
+        for it in range(8):
+            b = harness.to_device(scenes[it % len(scenes)], "cuda")
+            loss, _ = harness.train_step(model, crit, opt, b, cfg)
+            out.append(float(loss))
+        torch.cuda.synchronize()
+        return out, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    la, pa = run("1")
+    lb, pb = run("0")
+    lc, pc = run("1")
+    assert la == lb == lc and all(x == x for x in la)
+    assert [k for k in pa if not torch.equal(pa[k], pb[k])] == []
+    assert [k for k in pa if not torch.equal(pa[k], pc[k])] == []
