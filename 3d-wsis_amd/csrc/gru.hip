@@ -8,6 +8,8 @@
 //   gi = rownorm(Wih xin), gh = rownorm(Whh h)              rownorm(v) = (v - mean)/sqrt(var + 1e-5) over 3C
 //   r = sigmoid(gi_r + bih_r + gh_r + bhh_r), z = sigmoid(gi_z + bih_z + gh_z + bhh_z)
 //   n = tanh(gi_n + bih_n + r * (gh_n + bhh_n)),  hy = n + z * (h - n)
+#include <cstdlib>
+
 #include "common.h"
 
 using namespace wsis;
@@ -28,29 +30,62 @@ __device__ __forceinline__ float wsum(float v) {
 __device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 struct GruLds {
-  float WigT[GC][GC];    // [j][c]
-  float WihT[GC][G3];    // [j][o]
-  float WhhT[GC][G3];
+  float WigT[GC][GC + 1];    // [j][c]   (rows padded by one float: the transposed stores below hit 32 different banks)
+  float WihT[GC][G3 + 1];    // [j][o]
+  float WhhT[GC][G3 + 1];
   float Wih[G3][GC];     // [o][j]   (backward only)
   float Whh[G3][GC];
   float Wig[GC][GC];     // [c][j]
   float row[GRU_WF][4][G3];      // per-wave scratch rows (GRU_WF >= GRU_WAVES)
 };
 
+// the three weight matrices -> LDS (transposed, and as they are for the backward).  Every global load of the workgroup is
+// issued before the first LDS store: one memory latency for the whole staging (a load -> store loop ran 16 dependent
+// round trips, 13 of the backward kernel's 28 us on 2,289 rows)
+template <int NT>
 __device__ __forceinline__ void gru_load_weights(GruLds& L, const float* Wig, const float* Wih, const float* Whh,
                                                  bool need_plain) {
-  for (int f = threadIdx.x; f < GC * GC; f += blockDim.x) {
-    const int c = f / GC, j = f % GC;
-    L.WigT[j][c] = Wig[f];
-    if (need_plain) L.Wig[c][j] = Wig[f];
+  constexpr int N_IH = (G3 * GC / 4 + NT - 1) / NT;      // float4 pieces per thread of Wih / Whh
+  constexpr int N_IG = (GC * GC / 4 + NT - 1) / NT;
+  float4 a[N_IH], b[N_IH], g[N_IG];
+#pragma unroll
+  for (int u = 0; u < N_IH; ++u) {
+    const int f4 = threadIdx.x + u * NT;
+    const bool ok = f4 < G3 * GC / 4;
+    a[u] = ok ? reinterpret_cast<const float4*>(Wih)[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    b[u] = ok ? reinterpret_cast<const float4*>(Whh)[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int f = threadIdx.x; f < G3 * GC; f += blockDim.x) {
-    const int o = f / GC, j = f % GC;
-    L.WihT[j][o] = Wih[f];
-    L.WhhT[j][o] = Whh[f];
-    if (need_plain) {
-      L.Wih[o][j] = Wih[f];
-      L.Whh[o][j] = Whh[f];
+#pragma unroll
+  for (int u = 0; u < N_IG; ++u) {
+    const int f4 = threadIdx.x + u * NT;
+    g[u] = f4 < GC * GC / 4 ? reinterpret_cast<const float4*>(Wig)[f4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < N_IH; ++u) {
+    const int f4 = threadIdx.x + u * NT;
+    if (f4 < G3 * GC / 4) {
+      const int o = (f4 * 4) / GC, j = (f4 * 4) % GC;
+      const float av[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, bv[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        L.WihT[j + e][o] = av[e];
+        L.WhhT[j + e][o] = bv[e];
+      }
+      if (need_plain) {
+        *reinterpret_cast<float4*>(&L.Wih[o][j]) = a[u];
+        *reinterpret_cast<float4*>(&L.Whh[o][j]) = b[u];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < N_IG; ++u) {
+    const int f4 = threadIdx.x + u * NT;
+    if (f4 < GC * GC / 4) {
+      const int c = (f4 * 4) / GC, j = (f4 * 4) % GC;
+      const float gv[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) L.WigT[j + e][c] = gv[e];
+      if (need_plain) *reinterpret_cast<float4*>(&L.Wig[c][j]) = g[u];
     }
   }
 }
@@ -154,7 +189,7 @@ __global__ __launch_bounds__(64 * GRU_WF) void gru_fwd_kernel(
     const float* __restrict__ bih, const float* __restrict__ bhh, float* __restrict__ hy, int64_t S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   GruLds& L = *reinterpret_cast<GruLds*>(smem);
-  gru_load_weights(L, Wig, Wih, Whh, false);
+  gru_load_weights<64 * GRU_WF>(L, Wig, Wih, Whh, false);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t nw = (int64_t)gridDim.x * GRU_WF;
@@ -181,7 +216,7 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void gru_bwd_kernel(
     float* __restrict__ dx, float* __restrict__ dh, float* __restrict__ partial, int64_t S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   GruLds& L = *reinterpret_cast<GruLds*>(smem);
-  gru_load_weights(L, Wig, Wih, Whh, true);
+  gru_load_weights<64 * GRU_WAVES>(L, Wig, Wih, Whh, true);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = lane & 31, hi = lane >> 5;
@@ -355,7 +390,12 @@ __global__ __launch_bounds__(RED_OUT * RED_LANES) void gru_reduce_kernel(
     dbig[i - (2 * G3 * GC + GC * GC + 2 * G3)] = s;
 }
 
-int gru_blocks(int64_t S, int waves = GRU_WAVES, int rows_per_wave = 2) {
+// workgroups of the backward launch: three rows per wave (191 workgroups on 2,289 rows).  What a workgroup pays once --
+// staging, the wave-ordered slab merge, the 30 KB slab -- is ~11 us, a row ~5: 2 rows per wave / 256 workgroups take the
+// same 25 us but leave a third more slabs to gru_reduce_kernel (19.5 -> 16.4 us); 1 row per wave / 572 workgroups 37 us
+int gru_blocks(int64_t S, int waves = GRU_WAVES, int rows_per_wave = 3) {
+  const char* e = getenv("WSIS_GRU_ROWS");          // (tuning knob, read per call) rows per wave of the backward launch
+  if (e && waves == GRU_WAVES && atoi(e) > 0) rows_per_wave = atoi(e);
   int64_t b = ceil_div(S, waves * rows_per_wave);
   if (b < 1) b = 1;
   if (b > 256) b = 256;
