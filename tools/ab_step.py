@@ -8,6 +8,11 @@ importlib.import_module("3d-wsis_amd")
 import torch
 import harness
 
+if os.environ.get("AB_DIST", "0") == "1":      # a one-rank RCCL process group beside the step (no gradient exchange)
+    os.environ["WSIS_FORCE_DIST"] = "1"
+    import wsis_parallel
+    wsis_parallel.init_distributed()
+
 
 def setenv(spec):
     for kv in spec.split(","):

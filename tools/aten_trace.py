@@ -17,6 +17,11 @@ from torch.utils._python_dispatch import TorchDispatchMode
 
 import harness
 
+if os.environ.get("AB_DIST", "0") == "1":      # a one-rank RCCL process group beside the step (no gradient exchange)
+    os.environ["WSIS_FORCE_DIST"] = "1"
+    import wsis_parallel
+    wsis_parallel.init_distributed()
+
 cfg = harness.default_cfg()
 dev = torch.device("cuda", 0)
 batch = harness.to_device(harness.collate([harness.bench_scene(1)]), dev)
