@@ -153,3 +153,12 @@ for name in order:
         hh = (host_t[name][i] - h0) * 1e6
         lead.append(g - hh)
     print("%-16s %s" % (name, " ".join("%8.0f" % v for v in lead)))
+
+print("== host time between the marks, mean over steps 2..%d (us): what issuing each phase costs the host ==" % (N - 1))
+for a, b in zip(order[:-1], order[1:]):
+    d = [(host_t[b][i] - host_t[a][i]) * 1e6 for i in range(2, N)]
+    print("%-16s -> %-16s %8.1f" % (a, b, sum(d) / len(d)))
+d = [(host_t["step_begin"][i + 1] - host_t["opt_end"][i]) * 1e6 for i in range(2, N)]
+print("%-16s -> %-16s %8.1f" % ("opt_end", "next step_begin", sum(d) / len(d)))
+d = [(host_t["step_begin"][i + 1] - host_t["step_begin"][i]) * 1e6 for i in range(2, N)]
+print("host step %8.1f" % (sum(d) / len(d)))
