@@ -8,6 +8,7 @@
 //   gi = rownorm(Wih xin), gh = rownorm(Whh h)              rownorm(v) = (v - mean)/sqrt(var + 1e-5) over 3C
 //   r = sigmoid(gi_r + bih_r + gh_r + bhh_r), z = sigmoid(gi_z + bih_z + gh_z + bhh_z)
 //   n = tanh(gi_n + bih_n + r * (gh_n + bhh_n)),  hy = n + z * (h - n)
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -312,40 +313,39 @@ __global__ __launch_bounds__(64 * GRU_WAVES) void gru_bwd_kernel(
       dh[row * GC + c] = dhc;
     }
   }
-  // per-workgroup slab [Wih 96x32][Whh 96x32][Wig 32x32][bih 96][bhh 96][big 32]: the waves add their
-  // accumulators into one LDS slab in wave order (fixed order -> deterministic), then the slab goes out coalesced
+  // per-workgroup slab [Wih 96x32][Whh 96x32][Wig 32x32][bih 96][bhh 96][big 32]: every wave leaves its accumulators in a
+  // slab of its own (the weight images are no longer needed: 4 x 29.7 KB of LDS), then all threads add the four copies
+  // of an element in wave order -- the order of the wave-by-wave merge this replaces (three barriers fewer) -- and the
+  // sum goes out coalesced
   __syncthreads();                                   // every wave is done with the weights: reuse their LDS
-  float* slab = reinterpret_cast<float*>(smem);
-  static_assert(sizeof(GruLds) >= GRU_P * sizeof(float), "slab must fit in the weight region");
-  for (int w = 0; w < GRU_WAVES; ++w) {
-    if (wave == w) {
-      const bool first = (w == 0);
+  float* const mine = reinterpret_cast<float*>(smem) + wave * GRU_P;
 #pragma unroll
-      for (int t = 0; t < 48; ++t) {
-        const int o = hi + 2 * t;
-        float* a = slab + o * GC + c;
-        float* b = slab + G3 * GC + o * GC + c;
-        *a = first ? aWih[t] : *a + aWih[t];
-        *b = first ? aWhh[t] : *b + aWhh[t];
-      }
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        float* a = slab + 2 * G3 * GC + (hi + 2 * t) * GC + c;
-        *a = first ? aWig[t] : *a + aWig[t];
-      }
-      float* pb = slab + 2 * G3 * GC + GC * GC;
-      pb[lane] = first ? abih1 : pb[lane] + abih1;
-      pb[G3 + lane] = first ? abhh1 : pb[G3 + lane] + abhh1;
-      if (two) {
-        pb[64 + lane] = first ? abih2 : pb[64 + lane] + abih2;
-        pb[G3 + 64 + lane] = first ? abhh2 : pb[G3 + 64 + lane] + abhh2;
-        pb[2 * G3 + lane] = first ? abig : pb[2 * G3 + lane] + abig;
-      }
-    }
-    __syncthreads();
+  for (int t = 0; t < 48; ++t) {
+    const int o = hi + 2 * t;
+    mine[o * GC + c] = aWih[t];
+    mine[G3 * GC + o * GC + c] = aWhh[t];
   }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) mine[2 * G3 * GC + (hi + 2 * t) * GC + c] = aWig[t];
+  {
+    float* pb = mine + 2 * G3 * GC + GC * GC;
+    pb[lane] = abih1;
+    pb[G3 + lane] = abhh1;
+    if (two) {
+      pb[64 + lane] = abih2;
+      pb[G3 + 64 + lane] = abhh2;
+      pb[2 * G3 + lane] = abig;
+    }
+  }
+  __syncthreads();
+  const float* const s0 = reinterpret_cast<const float*>(smem);
   float* p = partial + (int64_t)blockIdx.x * GRU_P;
-  for (int f = threadIdx.x; f < GRU_P; f += blockDim.x) p[f] = slab[f];
+  for (int f = threadIdx.x; f < GRU_P; f += blockDim.x) {
+    float v = s0[f];
+#pragma unroll
+    for (int w = 1; w < GRU_WAVES; ++w) v += s0[w * GRU_P + f];
+    p[f] = v;
+  }
 }
 
 constexpr int RED_OUT = 32;    // outputs per workgroup of the slab reduce
@@ -457,7 +457,7 @@ static int gru_bwd_impl(const float* d_x, const float* d_h, const float* d_Wig, 
                         int64_t dhy2_pitch, float* d_dx,
                         float* d_dh, float* d_dWig, float* d_dbig, float* d_dWih, float* d_dWhh, float* d_dbih,
                         float* d_dbhh, int64_t S, int slot, int n_reduce, void* d_ws, hipStream_t st) {
-  const size_t lds = sizeof(GruLds);
+  const size_t lds = std::max(sizeof(GruLds), (size_t)GRU_WAVES * GRU_P * sizeof(float));      // (the four slabs of the merge)
   const int nb = gru_blocks(S);
   static bool attr_set = false;
   if (!attr_set) {
