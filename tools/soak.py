@@ -1,4 +1,5 @@
-"""soak: training steps over scenes of varying size, twice with the same seeds: identical loss sequences, no NaN"""
+"""soak: training steps over scenes of varying size, twice with the same seeds: identical loss sequences, no NaN
+(SOAK_STEPS, SOAK_NOSYNC=1: no device read-back inside the loop)"""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); importlib.import_module("3d-wsis_amd")
@@ -14,8 +15,9 @@ def run():
     for it in range(int(os.environ.get("SOAK_STEPS", "90"))):
         b = harness.to_device(scenes[it % len(scenes)], "cuda")
         loss, _ = harness.train_step(model, crit, opt, b, cfg)
-        out.append(float(loss))
-    return out
+        # SOAK_NOSYNC=1: the losses are read at the end -- the host runs steps ahead of the GPU, as in bench.py
+        out.append(loss.detach() if os.environ.get("SOAK_NOSYNC", "0") == "1" else float(loss))
+    return [float(x) for x in out]
 t0 = time.time(); a = run(); b = run()
 import math
 print("steps", len(a), "nan", sum(math.isnan(x) for x in a), "identical", a == b, "first/last", a[0], a[-1], "time %.1fs" % (time.time() - t0))
