@@ -7,6 +7,8 @@
 // Forward: one thread per row keeps the per-class sums in registers (static indices), a workgroup reduces them with
 // wave shuffles + a 4-entry LDS stage, one partial row per workgroup; a single-workgroup final kernel sums the partials
 // in fp64 in a fixed order and evaluates the loss -> deterministic.  Backward: one pass, analytic gradient.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace wsis {
@@ -37,9 +39,13 @@ __global__ __launch_bounds__(SL_THREADS) void sem_loss_fwd_kernel(const float* _
     const float* row = x + r * C;
     float v[SL_CMAX];
     float m = -INFINITY, xl = 0.0f;
+    // (branch-free loads -- clamped column, masked value: behind a conditional load hipcc waits for each one before it
+    // issues the next)
+#pragma unroll
+    for (int c = 0; c < SL_CMAX; ++c) v[c] = row[c < C ? c : C - 1];
 #pragma unroll
     for (int c = 0; c < SL_CMAX; ++c) {
-      v[c] = c < C ? row[c] : -INFINITY;
+      v[c] = c < C ? v[c] : -INFINITY;
       m = fmaxf(m, v[c]);
       if ((int64_t)c == lab && c < C) xl = v[c];
     }
@@ -155,8 +161,10 @@ __global__ __launch_bounds__(SL_THREADS) void sem_loss_bwd_kernel(const float* _
     float v[SL_CMAX];
     float m = -INFINITY;
 #pragma unroll
+    for (int c = 0; c < SL_CMAX; ++c) v[c] = row[c < C ? c : C - 1];      // (branch-free loads, see the forward kernel)
+#pragma unroll
     for (int c = 0; c < SL_CMAX; ++c) {
-      v[c] = c < C ? row[c] : -INFINITY;
+      v[c] = c < C ? v[c] : -INFINITY;
       m = fmaxf(m, v[c]);
     }
     float Z = 0.0f;
@@ -290,15 +298,25 @@ __global__ void sp_reg_bwd_kernel(const float* __restrict__ p_off, const float* 
 // and two launches backward on 2,289 rows, and one launch per `loss = loss + term`; here one workgroup walks the rows
 // (fp32 per row, folded in fp64 in a fixed order) and one thread adds the terms in the reference's order.
 //   out[0] = sum_kept (logsumexp(row) - row[label]) / n_kept     out[1] = sum of all scores     out[2] = n_kept
-__global__ __launch_bounds__(SR_THREADS) void sp_ce_fwd_kernel(const float* __restrict__ scores, const int64_t* __restrict__ labels,
-                                                                int64_t S, int C, int64_t ignore, float* __restrict__ out) {
-  __shared__ double sh[SR_THREADS / 64][3];
+// one row per thread, 256 rows per workgroup; workgroup sums (fp64, fixed order) go to `partial` write-through, the last
+// workgroup to arrive (ticket in the caller's sync slot, self-resetting) adds them in workgroup order.  As ONE workgroup
+// walking all rows the kernel was bound by one compute unit's expf rate: 2,289 x 20 calls = 23 us.
+constexpr int CE_THREADS = 256;
+
+__global__ __launch_bounds__(CE_THREADS) void sp_ce_fwd_kernel(const float* __restrict__ scores, const int64_t* __restrict__ labels,
+                                                                int64_t S, int C, int64_t ignore, double* __restrict__ partial,
+                                                                unsigned* __restrict__ ticket, float* __restrict__ out) {
+  __shared__ double sh[CE_THREADS / 64][3];
+  __shared__ int s_last;
   float a[3] = {0.f, 0.f, 0.f};
-  for (int64_t r = threadIdx.x; r < S; r += SR_THREADS) {
+  const int64_t r = (int64_t)blockIdx.x * CE_THREADS + threadIdx.x;
+  if (r < S) {
     const float* row = scores + r * C;
-    float v[32];                           // the row once, all loads in flight (C <= 32: checked by the host)
+    float v[32];                           // the row once, all loads in flight (branch-free: clamped column, masked value)
 #pragma unroll
-    for (int c = 0; c < 32; ++c) v[c] = c < C ? row[c] : -INFINITY;
+    for (int c = 0; c < 32; ++c) v[c] = row[c < C ? c : C - 1];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v[c] = c < C ? v[c] : -INFINITY;
     float mx = v[0], sum = 0.f;
 #pragma unroll
     for (int c = 1; c < 32; ++c) mx = fmaxf(mx, v[c]);
@@ -308,11 +326,11 @@ __global__ __launch_bounds__(SR_THREADS) void sp_ce_fwd_kernel(const float* __re
       se += c < C ? expf(v[c] - mx) : 0.0f;
       sum += c < C ? v[c] : 0.0f;
     }
-    a[1] += sum;
+    a[1] = sum;
     const int64_t lab = labels[r];
     if (lab != ignore && lab >= 0 && lab < C) {
-      a[0] += (logf(se) + mx) - row[lab];
-      a[2] += 1.0f;
+      a[0] = (logf(se) + mx) - row[lab];
+      a[2] = 1.0f;
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -324,14 +342,26 @@ __global__ __launch_bounds__(SR_THREADS) void sp_ce_fwd_kernel(const float* __re
     if (lane == 0) sh[wave][q] = v;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double t[3] = {0, 0, 0};
-    for (int w = 0; w < SR_THREADS / 64; ++w)
-      for (int q = 0; q < 3; ++q) t[q] += sh[w][q];
-    out[0] = (float)(t[0] / t[2]);        // n_kept == 0 -> nan, as torch
-    out[1] = (float)t[1];
-    out[2] = (float)t[2];
+  if (threadIdx.x < 3) {
+    double t = 0.0;
+    for (int w = 0; w < CE_THREADS / 64; ++w) t += sh[w][threadIdx.x];
+    st_sc1(partial + (int64_t)blockIdx.x * 3 + threadIdx.x, t);
   }
+  wait_stores_left();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(ticket, 1u);
+    s_last = t == gridDim.x - 1;
+    if (s_last) *ticket = 0u;              // self-cleaning: ready for the next launch on this stream
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x != 0) return;
+  double t[3] = {0, 0, 0};
+  for (unsigned g = 0; g < gridDim.x; ++g)
+    for (int q = 0; q < 3; ++q) t[q] += ld_sc1(partial + (int64_t)g * 3 + q);
+  out[0] = (float)(t[0] / t[2]);        // n_kept == 0 -> nan, as torch
+  out[1] = (float)t[1];
+  out[2] = (float)t[2];
 }
 
 // d scores[r, c] = g * (softmax(row)[c] - [c == label]) / n_kept for kept rows, 0 for the others
@@ -346,12 +376,22 @@ __global__ void sp_ce_bwd_kernel(const float* __restrict__ scores, const int64_t
       for (int c = 0; c < C; ++c) d[r * C + c] = 0.f;
       continue;
     }
-    float mx = row[0];
-    for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+    float v[32];                           // the row once (branch-free loads, C <= 32)
+#pragma unroll
+    for (int c = 0; c < 32; ++c) v[c] = row[c < C ? c : C - 1];
+    float mx = v[0];
+#pragma unroll
+    for (int c = 1; c < 32; ++c) mx = fmaxf(mx, c < C ? v[c] : v[0]);
     float se = 0.f;
-    for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      v[c] = c < C ? expf(v[c] - mx) : 0.0f;
+      se += v[c];
+    }
     const float inv = 1.0f / se;
-    for (int c = 0; c < C; ++c) d[r * C + c] = w * (expf(row[c] - mx) * inv - ((int64_t)c == lab ? 1.0f : 0.0f));
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < C) d[r * C + c] = w * (v[c] * inv - ((int64_t)c == lab ? 1.0f : 0.0f));
   }
 }
 
@@ -595,8 +635,11 @@ __global__ __launch_bounds__(DL_THREADS) void disc_loss_bwd_kernel(const float* 
 }
 
 int sl_blocks(int64_t N) {
+  const char* e = getenv("WSIS_SL_BLOCKS");          // (tuning knob, read per call; <= SL_MAX_BLOCKS)
+  int cap = e ? atoi(e) : 256;      // (one workgroup per CU: 22 + 19 us forward + finish at 512 workgroups, 27 + 10.5 at 256, 33.5 + 7 at 128)
+  if (cap < 1 || cap > SL_MAX_BLOCKS) cap = SL_MAX_BLOCKS;
   int64_t b = ceil_div(N > 0 ? N : 1, SL_THREADS);
-  if (b > SL_MAX_BLOCKS) b = SL_MAX_BLOCKS;
+  if (b > cap) b = cap;
   return (int)b;
 }
 
@@ -671,19 +714,26 @@ int wsis_sp_regression_loss_bwd(const float* d_pred_off, const float* d_gt_off, 
   return WSIS_OK;
 }
 
+int64_t wsis_sp_ce_loss_workspace_bytes(int64_t S) {
+  if (S < 0) return -1;
+  return ceil_div(S > 0 ? S : 1, CE_THREADS) * 3 * (int64_t)sizeof(double) + 256;
+}
+
 int wsis_sp_ce_loss_fwd(const float* d_scores, const int64_t* d_labels, int64_t S, int32_t C, int64_t ignore_label,
-                        float* d_out3, void* stream) {
-  WSIS_REQUIRE(S >= 0 && C >= 1 && C <= 32 && d_out3, "bad args (C <= 32)");
-  WSIS_REQUIRE(S == 0 || (d_scores && d_labels), "null pointer");
-  hipLaunchKernelGGL(sp_ce_fwd_kernel, dim3(1), dim3(SR_THREADS), 0, as_stream(stream), d_scores, d_labels, S, (int)C, ignore_label,
-                     d_out3);
+                        float* d_out3, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream) {
+  WSIS_REQUIRE(S >= 1 && C >= 1 && C <= 32 && d_out3, "bad args (S >= 1, C <= 32)");
+  WSIS_REQUIRE(d_scores && d_labels && d_ws && d_sync, "null pointer");
+  WSIS_REQUIRE(ws_bytes >= wsis_sp_ce_loss_workspace_bytes(S), "workspace too small");
+  double* partial = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(d_ws) + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(sp_ce_fwd_kernel, dim3((unsigned)ceil_div(S, CE_THREADS)), dim3(CE_THREADS), 0, as_stream(stream), d_scores,
+                     d_labels, S, (int)C, ignore_label, partial, static_cast<SyncSlot*>(d_sync)->ticket, d_out3);
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }
 
 int wsis_sp_ce_loss_bwd(const float* d_scores, const int64_t* d_labels, int64_t S, int32_t C, int64_t ignore_label,
                         const float* d_out3, const float* d_grad_loss, float* d_dscores, void* stream) {
-  WSIS_REQUIRE(S >= 0 && C >= 1, "bad args");
+  WSIS_REQUIRE(S >= 0 && C >= 1 && C <= 32, "bad args (C <= 32)");
   if (S == 0) return WSIS_OK;
   WSIS_REQUIRE(d_scores && d_labels && d_out3 && d_grad_loss && d_dscores, "null pointer");
   hipLaunchKernelGGL(sp_ce_bwd_kernel, dim3(grid_for(S, 256)), dim3(256), 0, as_stream(stream), d_scores, d_labels, S, (int)C,

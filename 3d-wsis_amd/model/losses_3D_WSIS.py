@@ -103,7 +103,7 @@ class MultiTaskLoss(nn.Module):
 
             sp_semantic_scores = loss_inp["sp_semantic"]
             if (not indexed and sp_semantic_scores.is_cuda and sp_semantic_scores.dim() == 2
-                    and sp_semantic_scores.shape[1] <= 32 and os.environ.get("WSIS_FUSE_SP_CE", "1") != "0"):
+                    and sp_semantic_scores.shape[1] <= 32 and sp_semantic_scores.shape[0] >= 1 and os.environ.get("WSIS_FUSE_SP_CE", "1") != "0"):
                 import wsis_ops      # cross entropy + the logged sum of the scores: one launch each way (csrc/loss.hip)
                 superpoint_semantic_loss, sp_score_sum = wsis_ops.superpoint_cross_entropy(
                     sp_semantic_scores, sp_sem_labels, self.ignore_label)

@@ -149,7 +149,8 @@ _HIP_SIGS = {
     "wsis_semantic_loss_workspace_bytes": (I64, [I64]),
     "wsis_semantic_loss_fwd": (I32, [P, P, I64, I32, I64, P, P, P, I64, P]),
     "wsis_semantic_loss_bwd": (I32, [P, P, I64, I32, I64, P, P, P, P]),
-    "wsis_sp_ce_loss_fwd": (I32, [P, P, I64, I32, I64, P, P]),
+    "wsis_sp_ce_loss_workspace_bytes": (I64, [I64]),
+    "wsis_sp_ce_loss_fwd": (I32, [P, P, I64, I32, I64, P, P, I64, P, P]),
     "wsis_sp_ce_loss_bwd": (I32, [P, P, I64, I32, I64, P, P, P, P]),
     "wsis_loss_sum": (I32, [P, I32, ctypes.c_uint32, P, P]),
     "wsis_sp_regression_loss_fwd": (I32, [P] * 8 + [I64, I64, P, P]),

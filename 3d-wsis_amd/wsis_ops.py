@@ -993,8 +993,11 @@ class _SpCrossEntropy(Function):
         labels = labels.contiguous().long()
         S, C = scores.shape
         out = torch.empty(3, dtype=torch.float32, device=scores.device)
-        _n.check(_n.hip().wsis_sp_ce_loss_fwd(_n.ptr(scores), _n.ptr(labels), S, C, int(ignore_label), _n.ptr(out),
-                                              _n.stream_ptr()), "sp_ce_loss_fwd")
+        lib = _n.hip()
+        ws_bytes = lib.wsis_sp_ce_loss_workspace_bytes(S)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=scores.device)
+        _n.check(lib.wsis_sp_ce_loss_fwd(_n.ptr(scores), _n.ptr(labels), S, C, int(ignore_label), _n.ptr(out), _n.ptr(ws),
+                                         ws_bytes, _n.ptr(_n.sync_block(scores.device)), _n.stream_ptr()), "sp_ce_loss_fwd")
         ctx.save_for_backward(scores, labels, out)
         ctx.ignore_label = int(ignore_label)
         loss, total = out[0], out[1]

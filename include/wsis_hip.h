@@ -611,12 +611,14 @@ int wsis_semantic_loss_bwd(const float* d_scores, const int64_t* d_labels, int64
                            const float* d_saved, const float* d_grad_loss, float* d_dscores, void* stream);
 
 /* Superpoint semantic term (losses_3D_WSIS.py:72-74: CrossEntropyLoss(ignore_index) on the [S,C] superpoint scores, mean
- * over the kept rows) with the logged scores.sum(): d_out3 = {loss, sum of all scores, n_kept}; one launch each way.
+ * over the kept rows) with the logged scores.sum(): d_out3 = {loss, sum of all scores, n_kept}; one launch each way (the
+ * forward finishes its workgroup sums by a ticket in the caller's sync slot, d_sync: see wsis_sync_bytes; S >= 1, C <= 32).
  * wsis_loss_sum: out = t_0 + t_1 + ... in order (the weighted sum of losses_3D_WSIS.py:130-151, all weights 1); bit i of
  * `paired` adds term i to term i+1 first (the reference's `offset_norm_loss + offset_dir_loss`).  d_terms is a HOST array
  * of n <= 8 device scalars. */
+int64_t wsis_sp_ce_loss_workspace_bytes(int64_t S);
 int wsis_sp_ce_loss_fwd(const float* d_scores, const int64_t* d_labels, int64_t S, int32_t C, int64_t ignore_label,
-                        float* d_out3, void* stream);
+                        float* d_out3, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream);
 int wsis_sp_ce_loss_bwd(const float* d_scores, const int64_t* d_labels, int64_t S, int32_t C, int64_t ignore_label,
                         const float* d_out3, const float* d_grad_loss, float* d_dscores, void* stream);
 int wsis_loss_sum(const float* const* d_terms, int32_t n, uint32_t paired, float* d_out, void* stream);
