@@ -574,7 +574,7 @@ int waves_grid(int64_t segments) {
 // with fc_position = Linear(3,16) -> ReLU -> Linear(16,1).  The reference runs two gathers, a subtraction and three
 // module launches forward and a dozen small launches backward (two of them [E,16] x [16,3] weight gradients) over
 // E ~ 20 k rows; here one thread per edge does the whole chain, and the backward leaves the 81 parameter-gradient sums
-// of a workgroup (butterfly inside the wave, waves added in order) as one partial row, summed by a second tiny launch.
+// of a workgroup (thread order, through an LDS tile) as one partial row, summed by a second tiny launch.
 constexpr int PE_H = 16;                           // hidden width
 constexpr int PE_G = PE_H * 3 + PE_H + PE_H + 1;   // dW1 [16,3], db1 [16], dW2 [16], db2
 
@@ -605,14 +605,18 @@ __global__ __launch_bounds__(256) void pos_enc_fwd_kernel(const float* __restric
   pos[e] = p;
 }
 
+constexpr int PE_TP = 256 + 4;          // row pitch of the workgroup's transposition tile (floats)
+
 __global__ __launch_bounds__(256) void pos_enc_bwd_kernel(const float* __restrict__ centre, const int64_t* __restrict__ eu,
                                                           const int64_t* __restrict__ ev, const float* __restrict__ W1,
                                                           const float* __restrict__ b1, const float* __restrict__ W2,
                                                           const float* __restrict__ dpos, float* __restrict__ partial,
                                                           int64_t E) {
-  __shared__ float red[4][PE_G];
+  // the 81 sums of a workgroup through an LDS tile [81][256]: every thread stores its 81 terms in its column, thread i
+  // adds row i in thread order (16-byte reads).  As 81 wave butterflies of six cross-lane exchanges each the reduction
+  // was 486 ds_bpermute per wave: 13 of the kernel's 20 us.
+  extern __shared__ __attribute__((aligned(16))) float pe_tile[];
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float g[PE_G];
 #pragma unroll
   for (int i = 0; i < PE_G; ++i) g[i] = 0.0f;
@@ -631,16 +635,21 @@ __global__ __launch_bounds__(256) void pos_enc_bwd_kernel(const float* __restric
     g[PE_G - 1] = gp;
   }
 #pragma unroll
-  for (int i = 0; i < PE_G; ++i) {
-    float v = g[i];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == 0) red[wave][i] = v;
-  }
+  for (int i = 0; i < PE_G; ++i) pe_tile[i * PE_TP + threadIdx.x] = g[i];
   __syncthreads();
-  if (threadIdx.x < PE_G)
-    partial[(int64_t)blockIdx.x * PE_G + threadIdx.x] =
-        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  if (threadIdx.x < PE_G) {
+    const float4* row = reinterpret_cast<const float4*>(pe_tile + threadIdx.x * PE_TP);
+    float sum = 0.0f;
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) {
+      const float4 v = row[q];
+      sum += v.x;
+      sum += v.y;
+      sum += v.z;
+      sum += v.w;
+    }
+    partial[(int64_t)blockIdx.x * PE_G + threadIdx.x] = sum;
+  }
 }
 
 // workgroup partials added in workgroup order: eight lanes per sum split the rows, added in lane order
@@ -831,8 +840,14 @@ int wsis_pos_enc_bwd(const float* d_centre, const int64_t* d_eu, const int64_t* 
   WSIS_REQUIRE(ws_bytes >= wsis_pos_enc_workspace_bytes(E), "workspace too small");
   const int n = (int)ceil_div(E, 256);
   float* partial = static_cast<float*>(d_ws);
-  hipLaunchKernelGGL(pos_enc_bwd_kernel, dim3((unsigned)n), dim3(256), 0, as_stream(stream), d_centre, d_eu, d_ev, d_W1, d_b1, d_W2,
-                     d_dpos, partial, E);
+  const size_t ldsb = (size_t)PE_G * PE_TP * sizeof(float);       // 84 KB
+  static bool attr_set = false;       // (one process per GPU: include/wsis_hip.h)
+  if (!attr_set) {
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)pos_enc_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(pos_enc_bwd_kernel, dim3((unsigned)n), dim3(256), ldsb, as_stream(stream), d_centre, d_eu, d_ev, d_W1, d_b1,
+                     d_W2, d_dpos, partial, E);
   WSIS_LAUNCH_CHECK();
   hipLaunchKernelGGL(pos_enc_bwd_final_kernel, dim3(1), dim3(PE_G * 8), 0, as_stream(stream), partial, n, d_dW1, d_db1, d_dW2,
                      d_db2);

@@ -17,6 +17,7 @@ namespace {
 constexpr int SL_CMAX = 32;                  // classes held in registers
 constexpr int SL_THREADS = 256;
 constexpr int SL_VALS = 3 * SL_CMAX + 2;     // A[32] B[32] K[32] ce n
+constexpr int SL_TP = SL_THREADS + 4;        // row pitch of the reduction tile (floats)
 constexpr int SL_MAX_BLOCKS = 512;
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -28,7 +29,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(SL_THREADS) void sem_loss_fwd_kernel(const float* __restrict__ x,
                                                                   const int64_t* __restrict__ y, int64_t N, int C,
                                                                   int64_t ignore, float* __restrict__ partial) {
-  __shared__ float sh[SL_THREADS / 64][SL_VALS];
+  extern __shared__ __attribute__((aligned(16))) float sl_tile[];
   float A[SL_CMAX], B[SL_CMAX], K[SL_CMAX];
 #pragma unroll
   for (int c = 0; c < SL_CMAX; ++c) A[c] = B[c] = K[c] = 0.0f;
@@ -67,28 +68,29 @@ __global__ __launch_bounds__(SL_THREADS) void sem_loss_fwd_kernel(const float* _
     ce += (m + logZ) - xl;      // -log_softmax(x)[y]
     n += 1.0f;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the 98 sums of the workgroup through an LDS tile [98][256]: every thread stores its terms in its column, thread v
+  // adds row v in thread order (16-byte reads).  (98 wave butterflies were 588 ds_bpermute per wave: ~15 us of LDS
+  // crossbar time per workgroup.)
 #pragma unroll
   for (int c = 0; c < SL_CMAX; ++c) {
-    const float a = wave_sum(A[c]), b = wave_sum(B[c]), k = wave_sum(K[c]);
-    if (lane == 0) {
-      sh[wave][c] = a;
-      sh[wave][SL_CMAX + c] = b;
-      sh[wave][2 * SL_CMAX + c] = k;
-    }
+    sl_tile[c * SL_TP + threadIdx.x] = A[c];
+    sl_tile[(SL_CMAX + c) * SL_TP + threadIdx.x] = B[c];
+    sl_tile[(2 * SL_CMAX + c) * SL_TP + threadIdx.x] = K[c];
   }
-  {
-    const float a = wave_sum(ce), b = wave_sum(n);
-    if (lane == 0) {
-      sh[wave][3 * SL_CMAX] = a;
-      sh[wave][3 * SL_CMAX + 1] = b;
-    }
-  }
+  sl_tile[(3 * SL_CMAX) * SL_TP + threadIdx.x] = ce;
+  sl_tile[(3 * SL_CMAX + 1) * SL_TP + threadIdx.x] = n;
   __syncthreads();
   if (threadIdx.x < SL_VALS) {
+    const float4* row = reinterpret_cast<const float4*>(sl_tile + threadIdx.x * SL_TP);
     float s = 0.0f;
-#pragma unroll
-    for (int w = 0; w < SL_THREADS / 64; ++w) s += sh[w][threadIdx.x];
+#pragma unroll 8
+    for (int q = 0; q < SL_THREADS / 4; ++q) {
+      const float4 v = row[q];
+      s += v.x;
+      s += v.y;
+      s += v.z;
+      s += v.w;
+    }
     partial[(int64_t)blockIdx.x * SL_VALS + threadIdx.x] = s;
   }
 }
@@ -150,44 +152,58 @@ __global__ __launch_bounds__(SL_THREADS) void sem_loss_bwd_kernel(const float* _
   const float g = gout[0];
   const float inv_n = 1.0f / saved[2 * C];
   const float inv_c = 1.0f / (float)C;
-  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t lab = y[r];
-    float* out = dx + r * C;
+  // a trip of the workgroup covers SL_THREADS consecutive rows; their gradient rows are written to an LDS tile of odd pitch
+  // and leave as consecutive floats (with every thread storing its own row -- 80-byte stride -- a store instruction
+  // touched 40 cache lines with 4 bytes each)
+  __shared__ float tile[SL_THREADS * (SL_CMAX + 1)];
+  const int pitch = C | 1;
+  for (int64_t r0 = blockIdx.x * (int64_t)blockDim.x; r0 < N; r0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = r0 + threadIdx.x;
+    float* const mine = tile + threadIdx.x * pitch;
+    const int64_t lab = r < N ? y[r] : ignore;
     if (lab == ignore) {
-      for (int c = 0; c < C; ++c) out[c] = 0.0f;
-      continue;
+      for (int c = 0; c < C; ++c) mine[c] = 0.0f;
+    } else {
+      const float* row = x + r * C;
+      float v[SL_CMAX];
+      float m = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < SL_CMAX; ++c) v[c] = row[c < C ? c : C - 1];      // (branch-free loads, see the forward kernel)
+#pragma unroll
+      for (int c = 0; c < SL_CMAX; ++c) {
+        v[c] = c < C ? v[c] : -INFINITY;
+        m = fmaxf(m, v[c]);
+      }
+      float Z = 0.0f;
+#pragma unroll
+      for (int c = 0; c < SL_CMAX; ++c) {
+        v[c] = c < C ? expf(v[c] - m) : 0.0f;
+        Z += v[c];
+      }
+      const float inv = 1.0f / Z;
+      // dL/dp_c = (1/C) (2 p_c Num_c / Den_c^2 - 2 [y = c] / Den_c);  dx_j = p_j (gp_j - sum_c gp_c p_c) + (p_j - [y=j]) / n
+      float gp[SL_CMAX];
+      float dot = 0.0f;
+#pragma unroll
+      for (int c = 0; c < SL_CMAX; ++c) {
+        const float p = v[c] * inv;
+        v[c] = p;
+        const float den = s_den[c];
+        gp[c] = c < C ? inv_c * (2.0f * p * s_num[c] / (den * den) - (((int64_t)c == lab) ? 2.0f / den : 0.0f)) : 0.0f;
+        dot += gp[c] * p;
+      }
+#pragma unroll
+      for (int c = 0; c < SL_CMAX; ++c)
+        if (c < C) mine[c] = g * (v[c] * (gp[c] - dot) + (v[c] - (((int64_t)c == lab) ? 1.0f : 0.0f)) * inv_n);
     }
-    const float* row = x + r * C;
-    float v[SL_CMAX];
-    float m = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < SL_CMAX; ++c) v[c] = row[c < C ? c : C - 1];      // (branch-free loads, see the forward kernel)
-#pragma unroll
-    for (int c = 0; c < SL_CMAX; ++c) {
-      v[c] = c < C ? v[c] : -INFINITY;
-      m = fmaxf(m, v[c]);
+    __syncthreads();
+    const int64_t rows = N - r0 < (int64_t)blockDim.x ? N - r0 : (int64_t)blockDim.x;
+    float* const dst = dx + r0 * C;
+    for (int64_t f = threadIdx.x; f < rows * C; f += blockDim.x) {
+      const int rr = (int)(f / C), cc = (int)(f - (int64_t)rr * C);
+      dst[f] = tile[rr * pitch + cc];
     }
-    float Z = 0.0f;
-#pragma unroll
-    for (int c = 0; c < SL_CMAX; ++c) {
-      v[c] = c < C ? expf(v[c] - m) : 0.0f;
-      Z += v[c];
-    }
-    const float inv = 1.0f / Z;
-    // dL/dp_c = (1/C) (2 p_c Num_c / Den_c^2 - 2 [y = c] / Den_c);  dx_j = p_j (gp_j - sum_c gp_c p_c) + (p_j - [y=j]) / n
-    float gp[SL_CMAX];
-    float dot = 0.0f;
-#pragma unroll
-    for (int c = 0; c < SL_CMAX; ++c) {
-      const float p = v[c] * inv;
-      v[c] = p;
-      const float den = s_den[c];
-      gp[c] = c < C ? inv_c * (2.0f * p * s_num[c] / (den * den) - (((int64_t)c == lab) ? 2.0f / den : 0.0f)) : 0.0f;
-      dot += gp[c] * p;
-    }
-#pragma unroll
-    for (int c = 0; c < SL_CMAX; ++c)
-      if (c < C) out[c] = g * (v[c] * (gp[c] - dot) + (v[c] - (((int64_t)c == lab) ? 1.0f : 0.0f)) * inv_n);
+    __syncthreads();
   }
 }
 
@@ -664,7 +680,13 @@ int wsis_semantic_loss_fwd(const float* d_scores, const int64_t* d_labels, int64
   hipStream_t st = as_stream(stream);
   const int nblk = sl_blocks(N);
   float* partial = static_cast<float*>(d_ws);
-  hipLaunchKernelGGL(sem_loss_fwd_kernel, dim3(nblk), dim3(SL_THREADS), 0, st, d_scores, d_labels, N, (int)C,
+  const size_t ldsb = (size_t)SL_VALS * SL_TP * sizeof(float);      // 102 KB
+  static bool attr_set = false;       // (one process per GPU: include/wsis_hip.h)
+  if (!attr_set) {
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)sem_loss_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sem_loss_fwd_kernel, dim3(nblk), dim3(SL_THREADS), ldsb, st, d_scores, d_labels, N, (int)C,
                      ignore_label, partial);
   WSIS_LAUNCH_CHECK();
   hipLaunchKernelGGL(sem_loss_final_kernel, dim3(1), dim3(1024), 0, st, partial, nblk, (int)C, d_out2, d_saved);
