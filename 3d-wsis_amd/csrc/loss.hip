@@ -459,10 +459,32 @@ struct DlParams {
 __device__ __forceinline__ void dl_stage(const float* __restrict__ x, const int64_t* __restrict__ ins,
                                          const int64_t* __restrict__ sem, int S, int I, int64_t ignore, float* xs,
                                          short* slot) {
-  for (int t = threadIdx.x; t < S * DL_D; t += DL_THREADS) xs[t] = x[t];
-  for (int r = threadIdx.x; r < S; r += DL_THREADS) {
-    const int64_t a = ins[r];
-    slot[r] = (a != ignore && sem[r] != ignore && a >= 0 && a < I) ? (short)a : (short)-1;
+  // every load of the thread in flight before its first LDS store (a load -> store loop runs one memory round trip per
+  // iteration: 16 of them for 2,289 rows, most of the kernel's 30 us); branch-free: clamped index, masked store
+  constexpr int NX = DL_ROWS * DL_D / DL_THREADS, NR = DL_ROWS / DL_THREADS;
+  const int n = S * DL_D;
+  float v[NX];
+#pragma unroll
+  for (int u = 0; u < NX; ++u) {
+    const int t = threadIdx.x + u * DL_THREADS;
+    v[u] = x[t < n ? t : 0];
+  }
+  int64_t a[NR], b[NR];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int r = threadIdx.x + u * DL_THREADS;
+    a[u] = ins[r < S ? r : 0];
+    b[u] = sem[r < S ? r : 0];
+  }
+#pragma unroll
+  for (int u = 0; u < NX; ++u) {
+    const int t = threadIdx.x + u * DL_THREADS;
+    if (t < n) xs[t] = v[u];
+  }
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int r = threadIdx.x + u * DL_THREADS;
+    if (r < S) slot[r] = (a[u] != ignore && b[u] != ignore && a[u] >= 0 && a[u] < I) ? (short)a[u] : (short)-1;
   }
 }
 
@@ -590,7 +612,19 @@ __global__ __launch_bounds__(DL_THREADS) void disc_loss_bwd_kernel(const float* 
   __shared__ float kk[DL_ROWS];
   dl_stage(x, ins, sem, S, I, ignore, xs, slot);
   for (int t = threadIdx.x; t < DL_SLOTS * 8; t += DL_THREADS) mu[t >> 3][t & 7] = saved[t];
-  for (int r = threadIdx.x; r < S; r += DL_THREADS) kk[r] = saved[DL_SLOTS * 8 + r];
+  {
+    float kv[DL_ROWS / DL_THREADS];      // (loads first, then the LDS stores: see dl_stage)
+#pragma unroll
+    for (int u = 0; u < DL_ROWS / DL_THREADS; ++u) {
+      const int r = threadIdx.x + u * DL_THREADS;
+      kv[u] = saved[DL_SLOTS * 8 + (r < S ? r : 0)];
+    }
+#pragma unroll
+    for (int u = 0; u < DL_ROWS / DL_THREADS; ++u) {
+      const int r = threadIdx.x + u * DL_THREADS;
+      if (r < S) kk[r] = kv[u];
+    }
+  }
   __syncthreads();
   const float n = saved[DL_SLOTS * 8 + DL_ROWS];
   const float den = n * (n - 1.0f) > 1.0f ? n * (n - 1.0f) : 1.0f;
@@ -603,8 +637,22 @@ __global__ __launch_bounds__(DL_THREADS) void disc_loss_bwd_kernel(const float* 
     float via = 0.f;
     if (d < DL_D && mu[a][7] > 0.f) {
       const float m = mu[a][d];
-      for (int r = r0; r < r1; ++r)
-        if (slot[r] == a) via += kk[r] * (xs[r * DL_D + d] - m);
+      // eight rows per trip, their LDS reads issued together (as the forward sums: a read, a compare and two dependent
+      // reads per row left the loop latency-bound); same additions in the same order
+      for (int r = r0; r < r1; r += 8) {
+        short sl[8];
+        float kv[8], xv[8];
+#pragma unroll
+        for (int u8 = 0; u8 < 8; ++u8) {
+          const int rr = r + u8 < r1 ? r + u8 : r1 - 1;
+          sl[u8] = slot[rr];
+          kv[u8] = kk[rr];
+          xv[u8] = xs[rr * DL_D + d];
+        }
+#pragma unroll
+        for (int u8 = 0; u8 < 8; ++u8)
+          if (r + u8 < r1 && sl[u8] == a) via += kv[u8] * (xv[u8] - m);
+      }
     }
     psum[threadIdx.x] = via;
   }
