@@ -181,6 +181,32 @@ int dw2_launch_swapped(const float* d_X, const float* d_mean, const float* d_var
                        float eps, int relu, const int32_t* d_nbr_b, const int32_t* d_order_b, int flip, const float* d_dY,
                        float* d_dW, int64_t M_in, int64_t M_out, int K, int Cin, int Cout, void* d_ws, hipStream_t st);
 
+// row / column of element t of a row-major [rows, C] tensor without a 64-bit division per element: a runtime int64
+// division is ~100 instructions on this ISA -- in segment_bwd_kernel it, not HBM, set the time (21 us for 25 MB).
+// Powers of two shift, everything below 2^32 elements divides in 32 bits.
+#ifdef __HIPCC__
+struct RowCol {
+  int64_t row;
+  int col;
+};
+__device__ __forceinline__ RowCol row_col(int64_t t, int C, int64_t total) {
+  RowCol rc;
+  if ((C & (C - 1)) == 0) {
+    const int sh = __ffs(C) - 1;
+    rc.row = t >> sh;
+    rc.col = (int)(t & (C - 1));
+  } else if (total < ((int64_t)1 << 32)) {
+    const uint32_t q = (uint32_t)t / (uint32_t)C;
+    rc.row = q;
+    rc.col = (int)((uint32_t)t - q * (uint32_t)C);
+  } else {
+    rc.row = t / C;
+    rc.col = (int)(t - rc.row * C);
+  }
+  return rc;
+}
+#endif
+
 // ---- device-side hash (linear-index keys) --------------------------------------------------
 constexpr int64_t kEmptyKey = -1;
 

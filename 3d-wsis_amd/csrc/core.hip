@@ -30,8 +30,9 @@ __global__ void voxelize_fwd_kernel(const float* __restrict__ feats, const int32
   const int64_t total = M * C;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = t / C;
-    const int c = (int)(t - m * C);
+    const RowCol rc = row_col(t, C, total);
+    const int64_t m = rc.row;
+    const int c = rc.col;
     const int32_t* row = v2p + m * stride;
     const int n = row[0];
     const float w = (mode == 4 && n > 0) ? 1.0f / (float)n : 1.0f;
@@ -46,8 +47,9 @@ __global__ void voxelize_bwd_kernel(const float* __restrict__ dout, const int32_
   const int64_t total = M * C;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t m = t / C;
-    const int c = (int)(t - m * C);
+    const RowCol rc = row_col(t, C, total);
+    const int64_t m = rc.row;
+    const int c = rc.col;
     const int32_t* row = v2p + m * stride;
     const int n = row[0];
     const float w = (mode == 4 && n > 0) ? 1.0f / (float)n : 1.0f;
@@ -68,16 +70,18 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const IdxT* __
     float4* o4 = reinterpret_cast<float4*>(out);
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * blockDim.x) {
-      const int64_t p = t / C4;
-      const int c = (int)(t - p * C4);
+      const RowCol rc = row_col(t, C4, total);
+      const int64_t p = rc.row;
+      const int c = rc.col;
       o4[t] = s4[(int64_t)idx[p] * C4 + c];
     }
   } else {
     const int64_t total = N * C;
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * blockDim.x) {
-      const int64_t p = t / C;
-      const int c = (int)(t - p * C);
+      const RowCol rc = row_col(t, C, total);
+      const int64_t p = rc.row;
+      const int c = rc.col;
       out[t] = src[(int64_t)idx[p] * C + c];
     }
   }

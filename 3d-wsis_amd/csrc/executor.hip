@@ -37,8 +37,9 @@ __global__ void cat_rows_kernel(const float* __restrict__ a, const float* __rest
   const int Ca_w = Ca / W, C_w = (Ca + Cb) / W;
   const int64_t total = M * C_w;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = t / C_w;
-    const int c = (int)(t - r * C_w);
+    const RowCol rc = row_col(t, C_w, total);
+    const int64_t r = rc.row;
+    const int c = rc.col;
     const float* src = c < Ca_w ? a + (r * Ca_w + c) * W : b + (r * (C_w - Ca_w) + (c - Ca_w)) * W;
     if (W == 4)
       reinterpret_cast<float4*>(out)[t] = *reinterpret_cast<const float4*>(src);
@@ -53,8 +54,9 @@ __global__ void split_rows_kernel(const float* __restrict__ in, float* __restric
   const int Ca_w = Ca / W, C_w = (Ca + Cb) / W;
   const int64_t total = M * C_w;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = t / C_w;
-    const int c = (int)(t - r * C_w);
+    const RowCol rc = row_col(t, C_w, total);
+    const int64_t r = rc.row;
+    const int c = rc.col;
     float* dst = c < Ca_w ? a + (r * Ca_w + c) * W : b + (r * (C_w - Ca_w) + (c - Ca_w)) * W;
     if (W == 4)
       *reinterpret_cast<float4*>(dst) = reinterpret_cast<const float4*>(in)[t];

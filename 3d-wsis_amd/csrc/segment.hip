@@ -169,21 +169,36 @@ __global__ __launch_bounds__(256) void segment_reduce_narrow_kernel(
   }
 }
 
+// W = 4: four channels per thread (C % 4 == 0, 16-byte aligned rows): a quarter of the index / offset loads and of the
+// store instructions -- same values (the division is per element either way)
+template <int W>
 __global__ void segment_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ index,
                                    const int32_t* __restrict__ offsets, float* __restrict__ dsrc, int64_t N,
                                    int C, int reduce) {
-  const int64_t total = N * C;
+  const int Cw = C / W;
+  const int64_t total = N * Cw;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t p = t / C;
-    const int c = (int)(t - p * C);
+    const RowCol rc = row_col(t, Cw, total);
+    const int64_t p = rc.row;
+    const int c = rc.col * W;
     const int64_t s = index[p];
-    float g = dout[s * C + c];
+    float div = 1.0f;
     if (reduce == 1) {
       const int cnt = offsets[s + 1] - offsets[s];
-      g = g / (float)(cnt > 0 ? cnt : 1);
+      div = (float)(cnt > 0 ? cnt : 1);
     }
-    dsrc[t] = g;
+    if (W == 4) {
+      float4 g = *reinterpret_cast<const float4*>(dout + s * C + c);
+      if (reduce == 1) {
+        g.x = g.x / div; g.y = g.y / div; g.z = g.z / div; g.w = g.w / div;
+      }
+      *reinterpret_cast<float4*>(dsrc + p * C + c) = g;
+    } else {
+      float g = dout[s * C + c];
+      if (reduce == 1) g = g / div;
+      dsrc[p * C + c] = g;
+    }
   }
 }
 
@@ -399,8 +414,13 @@ int wsis_segment_reduce_bwd(const float* d_dout, const int64_t* d_index, const i
                        d_dsrc, S, C);
   } else {
     WSIS_REQUIRE(d_index && d_offsets, "null pointer");
-    hipLaunchKernelGGL(segment_bwd_kernel, dim3(grid_for(N * C, 256)), dim3(256), 0, st, d_dout, d_index,
-                       d_offsets, d_dsrc, N, C, reduce);
+    const bool vec = C % 4 == 0 && ((reinterpret_cast<uintptr_t>(d_dout) | reinterpret_cast<uintptr_t>(d_dsrc)) & 15) == 0;
+    if (vec)
+      hipLaunchKernelGGL(segment_bwd_kernel<4>, dim3(grid_for(N * (C / 4), 256)), dim3(256), 0, st, d_dout, d_index,
+                         d_offsets, d_dsrc, N, C, reduce);
+    else
+      hipLaunchKernelGGL(segment_bwd_kernel<1>, dim3(grid_for(N * C, 256)), dim3(256), 0, st, d_dout, d_index,
+                         d_offsets, d_dsrc, N, C, reduce);
   }
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
