@@ -250,7 +250,12 @@ __global__ __launch_bounds__(256) void ecc_contract_bwd_kernel(const float* __re
       int32_t eid[EBATCH];
 #pragma unroll
       for (int i = 0; i < EBATCH; ++i) eid[i] = perm_dst[i < n ? j0 + i : j0];
-      float hv[EBATCH], dv[EBATCH];
+      float hv[EBATCH], dv[EBATCH], ov[EBATCH];
+      // (the edge rows of dh that this trip accumulates into are read here, with the other loads of the trip: as
+      // `*o + p` inside the per-edge loop each was a global round trip of its own behind the previous edge's store --
+      // ~9 dependent round trips per node; an edge row belongs to exactly one wave of the launch)
+#pragma unroll
+      for (int i = 0; i < EBATCH; ++i) ov[i] = accumulate ? dh[(int64_t)eid[i] * EH + lane] : 0.0f;
 #pragma unroll
       for (int i = 0; i < EBATCH; ++i) {
         hv[i] = h[(int64_t)eid[i] * EH + lane];
@@ -290,8 +295,7 @@ __global__ __launch_bounds__(256) void ecc_contract_bwd_kernel(const float* __re
             p += v.z * ur[q * 4 + 2];
             p += v.w * ur[q * 4 + 3];
           }
-          float* o = dh + (int64_t)eid[i] * EH + lane;     // every edge row is written by exactly one wave
-          *o = accumulate ? *o + p : p;
+          dh[(int64_t)eid[i] * EH + lane] = accumulate ? ov[i] + p : p;     // every edge row is written by exactly one wave
         }
       }
     }
