@@ -171,6 +171,14 @@ int64_t spconv_in_dw_workspace_bytes(int64_t M_out);
 int spconv_in_dw_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY, float* d_dW,
                         int64_t M_out, void* d_ws, hipEvent_t ka, hipEvent_t kb, hipStream_t st);
 
+// role-split ring convolution (csrc/spconv3.hip), dispatched from wsis_spconv_fwd_t*: plan = 0 (not taken) or the team
+// size; epi = the BnEpi of the launch
+int spconv_ring_plan(int64_t M_out, int K, int Cin, int Cout);
+int spconv_ring_launch(int nt, const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT, int flip,
+                       const float* d_bias, const float* d_residual, float* d_out, float* d_stats, const void* epi,
+                       unsigned* d_err, int64_t M_in, int64_t M_out, int K, int Cin, int Cout, hipEvent_t ka, hipEvent_t kb, hipStream_t st,
+                       unsigned long long* d_dbg = nullptr);
+
 // wave-autonomous weight-gradient kernel (csrc/spconv_dw2.hip), dispatched from wsis_spconv_dw
 bool dw2_supported(int K, int Cin, int Cout);
 bool dw2_fits(int64_t M_in, int64_t M_out, int K, int Cin, int Cout);   // 32-bit buffer offsets

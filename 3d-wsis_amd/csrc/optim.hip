@@ -33,6 +33,10 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   p = p - step_size * (m / denom);
 }
 
+// p.grad.data.clamp_(-gc, gc) of train_scannetv2.py:246-248: torch's clamp propagates NaN (fminf / fmaxf would
+// return the bound and hide a diverged branch)
+__device__ __forceinline__ float clamp_keep_nan(float g, float gc) { return g != g ? g : fminf(fmaxf(g, -gc), gc); }
+
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamSeg* __restrict__ segs,
                                                     const int32_t* __restrict__ blocks, float lr, float b1, float b2,
                                                     float eps, float wd) {   // lr = decay, b1 = 1-beta1, wd = 1-beta2
@@ -49,10 +53,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamSeg* __restrict__ 
     float4 p = *reinterpret_cast<float4*>(sg.p + i0);
     float4 g = *reinterpret_cast<const float4*>(sg.g + i0);
     if (gc > 0.0f) {
-      g.x = fminf(fmaxf(g.x, -gc), gc);
-      g.y = fminf(fmaxf(g.y, -gc), gc);
-      g.z = fminf(fmaxf(g.z, -gc), gc);
-      g.w = fminf(fmaxf(g.w, -gc), gc);
+      g.x = clamp_keep_nan(g.x, gc);
+      g.y = clamp_keep_nan(g.y, gc);
+      g.z = clamp_keep_nan(g.z, gc);
+      g.w = clamp_keep_nan(g.w, gc);
       *reinterpret_cast<float4*>(gw + i0) = g;
     }
     float4 m = *reinterpret_cast<float4*>(sg.m + i0);
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamSeg* __restrict__ 
       float p = sg.p[i], m = sg.m[i], v = sg.v[i];
       float g = sg.g[i];
       if (gc > 0.0f) {
-        g = fminf(fmaxf(g, -gc), gc);
+        g = clamp_keep_nan(g, gc);
         gw[i] = g;
       }
       adam_one(p, g, m, v, lr, b1, b2, eps, wd, step_size, inv_sqrt_bc2);

@@ -238,6 +238,18 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
   // wave -- measured neutral on every level: not kept)
   const int flip_deal = (flip ? 1 : 0) | (((deal_env ? atoi(deal_env) : 0) != 0 && p.ZS == 1) ? 2 : 0);
   ProfScope prof(0, st, /*exact_events=*/true);
+  // role-split ring form (spconv3.hip): the levels with many work items
+  if (!bn_in && n_targets == 0 && !fused) {
+    const int nt = spconv_ring_plan(M_out, K, Cin, Cout);
+    if (nt) {
+      const int rc = spconv_ring_launch(nt, d_X, d_nbr, d_order, d_WT, flip ? 1 : 0, d_bias, d_residual, d_out, d_stats, &epi,
+                                        d_sync ? &static_cast<SyncSlot*>(d_sync)->err : nullptr, M_in, M_out, K, Cin, Cout, prof.ka(), prof.kb(), st);
+      if (rc != WSIS_OK) return rc;
+      prof.stop();
+      WSIS_LAUNCH_CHECK();
+      return WSIS_OK;
+    }
+  }
   // persistent form (spconv_fwd2p_kernel): launches of more than one round of resident work items
   {
     const char* pe = getenv("WSIS_FWD2P");          // (read per call)

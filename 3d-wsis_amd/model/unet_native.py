@@ -414,8 +414,11 @@ class UNetProgram(object):
 
     # ---- compile (once per mode) / bind (per scene) ------------------------------------------------------------
     def _mode_key(self, need_dx):
-        return (need_dx, _fuse_stats_enabled(), _fuse_fin_enabled(), _fuse_apply_level(), os.environ.get("WSIS_FWD2", "1"),
-                tuple(bn.training for bn in self.bns), tuple(p.data_ptr() for p in self.params),
+        # bn_sync: the synced pass intercepts training-mode BatchNorm ops only -- the forms that finish the statistics
+        # inside the producing convolution or apply them inside the consuming one leave no such op, so a program
+        # compiled with them must never serve a synced pass (and the other way round)
+        return (need_dx, self.bn_sync is not None, _fuse_stats_enabled(), _fuse_fin_enabled(), _fuse_apply_level(),
+                os.environ.get("WSIS_FWD2", "1"), tuple(bn.training for bn in self.bns), tuple(p.data_ptr() for p in self.params),
                 tuple(bn.running_mean.data_ptr() if bn.running_mean is not None else 0 for bn in self.bns))
 
     def compiled(self, need_dx):
@@ -433,6 +436,8 @@ class UNetProgram(object):
         self._stats_src, self._fuse_stats = {}, _fuse_stats_enabled()
         self._virt, self._fuse_apply_lvl = {}, _fuse_apply_level()
         self._fuse_fin = _fuse_fin_enabled() and self._fuse_stats
+        if self.bn_sync is not None:      # every BatchNorm layer stays an op of its own: _run_synced runs it between parts
+            self._fuse_fin, self._fuse_apply_lvl = False, 99
         y, b_in = self._conv(rec, _EXT | 0, net.input_conv[0], _subm(0), 0, 0)
         y, b_u = self._ublock(rec, y, net.unet, 0)
         out, b_out = self._bn_relu(rec, y, net.output_layer[0], 0)
@@ -548,9 +553,9 @@ class UNetFunction(Function):
         none = fwd_lut[:0]
         luts = {_FWD: fwd_lut, _TBL: table_lut, _EXT: np.array([x.data_ptr(), 0], dtype=np.uint64), _BWD: none,
                 _PAR: none}
-        sy = prog.bn_sync
+        sy = prog.bn_sync.new_pass() if prog.bn_sync is not None else None      # row counts / arenas belong to THIS pass
         if sy is not None:
-            sy.arenas, sy.counts = [arena], {}
+            sy.arenas = [arena]
             _run_synced(_n.hip(), c.fwd.instantiate(Mvec, luts), x.device, sy)
         else:
             _run(_n.hip(), c.fwd.instantiate(Mvec, luts), x.device)
@@ -634,6 +639,13 @@ class _BnSync(object):
                     self.by_ptr[t.data_ptr()] = t
         self.counts = {}          # mean pointer of a layer -> global row count (fp64 device scalar), forward -> backward
         self.arenas = []
+
+    def new_pass(self):
+        """the state of one forward + backward pass: two forward passes before a backward (gradient accumulation, an
+        extra training-mode forward) must not wipe each other's global row counts"""
+        p = _BnSync.__new__(_BnSync)
+        p.group, p.by_ptr, p.counts, p.arenas = self.group, self.by_ptr, {}, []
+        return p
 
     def view(self, ptr, numel):
         ptr = int(ptr)
@@ -725,27 +737,31 @@ def _run_synced(lib, ops, device, sy):
     sync = _n.ptr(_n.sync_block(device))
     st = _n.stream_ptr()
     keep = []                     # every part's workspace stays alive until the weight-gradient side stream is joined
-    i = 0
-    while i < n:
-        j = i
-        while j < n and not is_bn[j]:
-            j += 1
-        if j > i:
-            p = base + i * item
-            wsb = lib.wsis_run_ops_workspace_bytes(p, j - i)
-            if wsb < 0:
-                raise _n.WsisError("run_ops workspace query failed")
-            ws = torch.empty(wsb, dtype=torch.uint8, device=device)
-            keep.append(ws)
-            _n.check(lib.wsis_run_ops_part(p, j - i, _n.ptr(ws), wsb, sync, st, 0), "run_ops_part")
-        if j < n:
-            if int(kinds[j]) == OP_BN_RELU:
-                _bn_fwd_synced(lib, ops[j], sy, device, st, sync)
-            else:
-                _bn_bwd_synced(lib, ops[j], sy, device, st)
-            j += 1
-        i = j
-    _n.check(lib.wsis_run_ops_part(None, 0, None, 0, sync, st, 1), "run_ops_part")
+    # whatever happens between the parts (a collective that times out, a failed check), the joining call must be issued:
+    # it clears the side stream's pending join and orders the queued weight-gradient launches before `keep` is freed
+    try:
+        i = 0
+        while i < n:
+            j = i
+            while j < n and not is_bn[j]:
+                j += 1
+            if j > i:
+                p = base + i * item
+                wsb = lib.wsis_run_ops_workspace_bytes(p, j - i)
+                if wsb < 0:
+                    raise _n.WsisError("run_ops workspace query failed")
+                ws = torch.empty(wsb, dtype=torch.uint8, device=device)
+                keep.append(ws)
+                _n.check(lib.wsis_run_ops_part(p, j - i, _n.ptr(ws), wsb, sync, st, 0), "run_ops_part")
+            if j < n:
+                if int(kinds[j]) == OP_BN_RELU:
+                    _bn_fwd_synced(lib, ops[j], sy, device, st, sync)
+                else:
+                    _bn_bwd_synced(lib, ops[j], sy, device, st)
+                j += 1
+            i = j
+    finally:
+        _n.check(lib.wsis_run_ops_part(None, 0, None, 0, sync, st, 1), "run_ops_part")
     return keep
 
 

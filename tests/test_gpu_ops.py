@@ -917,6 +917,28 @@ def test_flat_adamw_gradient_clamp_inside_the_step():
 
 
 @pytest.mark.gpu
+def test_flat_adamw_gradient_clamp_keeps_nan():
+    """``p.grad.data.clamp_(-1, 1)`` (train_scannetv2.py:247-249) propagates NaN: a diverged ECC gradient must surface
+    in .grad and in the parameter, not turn into the bound (fminf / fmaxf drop it); vector path and scalar tail"""
+    import wsis_optim as optim
+    a = [torch.ones(64, 4).cuda().requires_grad_(True), torch.ones(7).cuda().requires_grad_(True)]
+    mine = optim.FlatAdamW(a, lr=1e-3, weight_decay=0.0)
+    assert mine.set_grad_clamp(a, 1.0) == 2
+    for p in a:
+        gr = torch.full(p.shape, 5.0).cuda()
+        gr.view(-1)[1] = float("nan")
+        gr.view(-1)[-1] = float("nan")
+        p.grad = gr
+    mine.step()
+    for p in a:
+        gv, pv = p.grad.view(-1), p.detach().view(-1)
+        assert torch.isnan(gv[1]) and torch.isnan(gv[-1]) and torch.isnan(pv[1]) and torch.isnan(pv[-1])
+        keep = torch.ones_like(gv, dtype=torch.bool)
+        keep[1] = keep[-1] = False
+        assert torch.equal(gv[keep], torch.ones_like(gv[keep])) and bool(torch.isfinite(pv[keep]).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("S", [1190, 5, 3000])
 def test_fused_superpoint_regression_losses_match_torch_formulation(S):
     """wsis_sp_regression_loss_fwd/bwd against the torch evaluation of losses_3D_WSIS.py:79-96,113-127 in fp64
