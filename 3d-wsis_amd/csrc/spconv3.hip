@@ -358,30 +358,37 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, lptr lds, LDS_A
 
   // ---- weight-fragment generator: runs R_LB steps ahead of the MFMAs, across work items
   struct BGen {
-    int i, k, ch;
+    int i, ch;
     uint32_t rem;
     bool valid, null;
     ItemPos pos;
     const char* wb;          // WT + by * w_bstride
+    const char* wk;          // ... + kk * w_kstride: chunk ch of the step is at wk + 128 ch
   } gb;
+  auto bgen_k = [&](BGen& g, int k) {
+    const int kk = (a.flip & 1) ? a.K - 1 - k : k;
+    g.wk = g.wb + kk * w_kstride;
+  };
   auto bgen_item = [&](BGen& g) {
     if (g.pos.e >= a.total) {
       g.valid = false;
+      g.wk = reinterpret_cast<const char*>(a.WT);      // past the end: any readable tile (never used)
+      g.ch = 0;
       return;
     }
     const uint32_t m = get_mask(g.i);
     g.null = m == 0u;
-    g.k = m ? __builtin_ctz(m) : 0;
     g.rem = m & (m - 1u);
     g.ch = 0;
     g.wb = reinterpret_cast<const char*>(a.WT) + g.pos.by * w_bstride;
+    bgen_k(g, m ? __builtin_ctz(m) : 0);
   };
   auto bgen_next = [&](BGen& g) {
     if (!g.valid) return;
     if (!g.null && ++g.ch < nchunk) return;
     g.ch = 0;
     if (!g.null && g.rem) {
-      g.k = __builtin_ctz(g.rem);
+      bgen_k(g, __builtin_ctz(g.rem));
       g.rem &= g.rem - 1u;
       return;
     }
@@ -390,9 +397,7 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, lptr lds, LDS_A
     bgen_item(g);
   };
   auto addrB = [&](const BGen& g) -> const char* {
-    const int kk = (a.flip & 1) ? a.K - 1 - g.k : g.k;
-    const uint64_t bp = g.valid ? reinterpret_cast<uint64_t>(g.wb) + (uint64_t)(kk * w_kstride + g.ch * 128)
-                                : reinterpret_cast<uint64_t>(a.WT);      // past the end: any readable tile (never used)
+    const uint64_t bp = reinterpret_cast<uint64_t>(g.wk) + (uint64_t)(g.ch * 128);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bp);
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32));
     return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
@@ -480,7 +485,6 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, lptr lds, LDS_A
             fin_c[xx] = __builtin_amdgcn_readfirstlane(ctl->finp[q][xx]);
             return fin_c[xx] >= need;
           });
-          if (DIAG) st.v[3] += now<DIAG>() - w0;
         }
       }
     }
@@ -550,8 +554,13 @@ __device__ __forceinline__ void ring_consumer(const RingArgs& a, lptr lds, LDS_A
     RING_SB();
     bgen_next(gb);
     RING_SB();
+    const unsigned long long w_m = now<DIAG>();
     mfma(af[S & 1], bq[S], 9, 16);
     RING_SB();
+    if (DIAG) {      // (s_memtime returns once the wave's earlier instructions have ISSUED: + the last MFMA's issue slot)
+      asm volatile("s_nop 0" ::: "memory");
+      st.v[3] += now<DIAG>() - w_m;
+    }
     ++n;
     if (++t == T) item_end();
   };
@@ -618,8 +627,10 @@ __device__ __forceinline__ void ring_helper(const RingArgs& a, lptr lds, LDS_AS 
   float* const stats = a.stats;
   const int Cout = a.Cout;
   unsigned idle = 0;
+  bool fetched = false;             // the table pieces of header th are in flight / landed
+  int passes_since_fetch = 0;
 
-  auto make_header = [&]() {
+  auto fetch_table = [&]() {
     const lptr tb = tab + (th & 1) * R_TAB_BYTES;
     const int64_t t0 = (int64_t)hpos.bx * 32;
     const bool full = t0 + 32 <= a.M_out;
@@ -648,8 +659,13 @@ __device__ __forceinline__ void ring_helper(const RingArgs& a, lptr lds, LDS_AS 
                                              0, 0);
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+  };
+  auto make_header = [&]() {
+    const lptr tb = tab + (th & 1) * R_TAB_BYTES;
+    const int64_t t0 = (int64_t)hpos.bx * 32;
+    const bool full = t0 + 32 <= a.M_out;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the table pieces (fetched a finish_item ago: landed long since)
     // -- header
     const bool row_ok = t0 + r31 < a.M_out;
     int32_t my_row = a.order ? (int32_t)lds_ld_lane(tb + nk * 128 + r31 * 4) : (int32_t)(t0 + r31);
@@ -713,10 +729,17 @@ __device__ __forceinline__ void ring_helper(const RingArgs& a, lptr lds, LDS_AS 
     const int i = fi;
     const int bx = fpos.bx, by = fpos.by;
     const int cch = by * 32 + r31;               // output channel of this lane
-    int32_t rows[16];
+    int32_t rows[16];      // rows (reg & 3) + 8 (reg >> 2) + 4 half: four consecutive entries per group
+    {
+      const lptr rp = CTL_PTR(rowid) + (c0 * R_HR + i % R_HR) * 128 + half * 16;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg)
-      rows[reg] = (int32_t)lds_ld_lane(CTL_PTR(rowid) + ((c0 * R_HR + i % R_HR) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half) * 4);
+      for (int g = 0; g < 4; ++g) {
+        uint32_t v[4];
+        lds_ld4<4>(rp + g * 32, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rows[4 * g + e] = (int32_t)v[e];
+      }
+    }
     const float bv = bias ? bias[cch] : 0.0f;
     float rv[16], xv[16];
     if (residual) {
@@ -805,15 +828,22 @@ __device__ __forceinline__ void ring_helper(const RingArgs& a, lptr lds, LDS_AS 
         pre_c = pre;
       }
       if ((unsigned)th > iss_c + 1u) iss_c = lds_ld(CTL_PTR(iss) + c * 4);
-      if ((unsigned)th < pre_c + R_HR && (unsigned)th <= iss_c + 1u) {
+      if (!fetched && (unsigned)th < pre_c + R_HR && (unsigned)th <= iss_c + 1u) {
+        fetch_table();               // the pieces fly while this wave finishes a work item (below)
+        fetched = true;
+        progress = true;
+      } else if (fetched && (passes_since_fetch > 0 || !f_live)) {
         const unsigned long long w0 = now<DIAG>();
         make_header();
         if (DIAG) st.v[1] += now<DIAG>() - w0;
+        fetched = false;
+        passes_since_fetch = 0;
         ++th;
         hpos.next(stride);
         h_live = hpos.e < a.total;
         progress = true;
       }
+      if (fetched) ++passes_since_fetch;
     }
     // (2) the next work item to finish: its header is there (always, before its steps) and every consumer of the team
     // has written its partial accumulator

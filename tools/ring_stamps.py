@@ -52,7 +52,7 @@ def row(name, a, cols):
         v = a[..., j].reshape(-1)[live]
         s += f" {lab} p50 {np.median(v):7.0f} max {v.max():7.0f} |"
     print(s)
-row("consumer", d[:, 0:4], [(1, "wait_prod"), (6, "prod stalls"), (2, "wait_mask"), (3, "wait_fin"), (7, "wait_B"), (4, "steps"), (5, "items")])
+row("consumer", d[:, 0:4], [(1, "wait_prod"), (6, "prod stalls"), (2, "wait_mask"), (3, "7-MFMA block"), (7, "wait_B"), (4, "steps"), (5, "items")])
 row("loader", d[:, 4:8], [(1, "step passes"), (7, "ring-full passes"), (6, "max vm out"), (5, "steps")])
 row("helper", d[:, 8:12], [(1, "header cyc"), (2, "finish cyc"), (3, "items finished")])
 c = d[:, 0:4]; live = c[..., 0] > 0
