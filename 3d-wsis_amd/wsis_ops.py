@@ -1030,12 +1030,12 @@ class _LossSum(Function):
         out = torch.empty((), dtype=torch.float32, device=ts[0].device)
         arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
         _n.check(_n.hip().wsis_loss_sum(arr, len(ts), int(paired), _n.ptr(out), _n.stream_ptr()), "loss_sum")
-        ctx.n = len(ts)
+        ctx.meta = [(t.shape, t.dtype) for t in terms]      # a term may be [1] or another float type: its gradient too
         return out
 
     @staticmethod
     def backward(ctx, g):
-        return (None,) + (g,) * ctx.n
+        return (None,) + tuple(g.reshape(shape).to(dtype) for shape, dtype in ctx.meta)
 
 
 def loss_sum(terms, paired=0):

@@ -7,6 +7,14 @@ reverse parameter order (gradients become ready in roughly that order), so a few
 361 small ones -- sized for xGMI's per-link bandwidth rather than for launch count."""
 import os
 
+# RCCL's helper threads wait on HSA signals by interrupt unless told otherwise, which costs the launch-bound issuing
+# thread of this path ~6 % with a process group up (DESIGN.md section 6).  The HSA runtime reads the variable when it
+# starts -- with the first GPU call of the process, torch.cuda.is_available() included -- so it is set here, at import,
+# for a process that will join a group (torch.distributed.run exports WORLD_SIZE), unless the caller has chosen a value.
+# Single-process runs are left alone.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("WSIS_FORCE_DIST", "0") == "1":
+    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+
 import torch
 import torch.distributed as dist
 
@@ -18,18 +26,10 @@ def init_distributed(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force = os.environ.get("WSIS_FORCE_DIST", "0") == "1"    # exercise the collective path with one rank (tests)
     if (world > 1 or force) and not dist.is_initialized():
-        # RCCL's helper threads wait on HSA signals by interrupt unless told otherwise, which costs the launch-bound
-        # issuing thread of this path ~6 %.  The switch only works before the HSA runtime starts,
-        # i.e. before anything in the process touches the GPU: set it here when that is still possible, refuse to go on
-        # silently slow when it is not (WSIS_ALLOW_INTERRUPT_WAITS=1 accepts the slower mode)
-        if os.environ.get("HSA_ENABLE_INTERRUPT") != "0":
-            if torch.cuda.is_available() and torch.cuda.is_initialized():
-                if os.environ.get("WSIS_ALLOW_INTERRUPT_WAITS", "0") != "1":
-                    raise RuntimeError("wsis_parallel.init_distributed: the GPU runtime is already up without "
-                                       "HSA_ENABLE_INTERRUPT=0; call init_distributed() before the first GPU call, export "
-                                       "HSA_ENABLE_INTERRUPT=0, or set WSIS_ALLOW_INTERRUPT_WAITS=1")
-            else:
-                os.environ["HSA_ENABLE_INTERRUPT"] = "0"
+        if os.environ.get("HSA_ENABLE_INTERRUPT") != "0" and os.environ.get("WSIS_ALLOW_INTERRUPT_WAITS", "0") != "1":
+            import warnings
+            warnings.warn("wsis_parallel.init_distributed: HSA_ENABLE_INTERRUPT is not 0 (set before this module was "
+                          "imported): RCCL's interrupt-driven signal waits cost the issuing thread ~6 % per step")
         if backend is None:   # WSIS_DIST_BACKEND=gloo: control-flow tests of N ranks on one GPU (RCCL refuses that)
             backend = os.environ.get("WSIS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -52,9 +52,10 @@ def shard_scenes(scene_ids, rank, world):
 def convert_sync_batchnorm(model, group=None):
     """torch.nn.SyncBatchNorm.convert_sync_batchnorm for this build (train_scannetv2.py:734-736 converts when
     num_gpus > 1): every BatchNorm1d keeps its class, parameters and state-dict names and is marked to take its batch
-    statistics over all ranks of ``group`` (wsis_ops._SyncBatchNormReLU: two small all-reduces per layer and pass).
-    The UNet then runs as the per-module walk -- the one-call executor has no collective inside.  Default of this
-    build without the call: per-rank statistics.  Returns the model."""
+    statistics over all ranks of ``group``.  Heads and GNN layers go through wsis_ops._SyncBatchNormReLU (one all-gather
+    forward, one all-reduce backward per layer); the UNet KEEPS the native executor: unet_native._BnSync issues its op
+    list in parts (wsis_run_ops_part) that stop in front of every training-mode BatchNorm op and runs the layer's
+    exchange between two parts.  Default of this build without the call: per-rank statistics.  Returns the model."""
     n = 0
     for m in model.modules():
         if isinstance(m, torch.nn.BatchNorm1d):

@@ -566,14 +566,15 @@ def main():
         harness.start_rulebooks(pipe, batch)
         batch["rulebooks"] = pipe.finish()
 
-    def step():
+    def step(exchange=True):
         if not args.hoist_graphs:          # a new batch needs its segment CSRs / edge graph: part of the step
             harness.build_batch_graphs(batch)
         if pre is not None:
             harness.prefetch_rulebooks(pre, batch)
         if pipe is not None:
             harness.start_rulebooks(pipe, batch)
-        out = harness.train_step(model, criterion, optimizer, batch, cfg, grad_sync=grad_sync, pipeline=pipe)
+        out = harness.train_step(model, criterion, optimizer, batch, cfg, grad_sync=grad_sync if exchange else None,
+                                 pipeline=pipe)
         if pre is not None:
             batch["rulebooks"] = pre.result()
         if pipe is not None:
@@ -593,6 +594,32 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # The N = 1 point of the 1 -> 8 series is NOT the default line (one scene per step): every --gpus N > 1 line steps
+    # `spg` scenes per GPU, and a step of 4 scenes runs ~1.5x the scenes/s of a step of one on the same GPU.  So every
+    # line carries `scaling_baseline`: what ONE GPU does with this line's per-GPU batch and no gradient exchange --
+    # measured here, in this process, on this rank's own batch (N > 1), or taken from the 4-scene side measurement of
+    # the default run (N = 1).  Efficiency of a line = value / (n_gpus x scaling_baseline.scenes_per_s).
+    local_base = None
+    if use_dist and grad_sync is not None:
+        nb = max(5, min(20, args.steps))
+        for _ in range(3):
+            step(exchange=False)
+        fence()
+        tb0 = time.perf_counter()
+        for _ in range(nb):
+            step(exchange=False)
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - tb0
+        if use_dist:
+            tt = torch.tensor([tb], dtype=torch.float64, device=device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tb = float(tt.item())
+        local_base = {"scenes_per_gpu": spg, "scenes_per_s": round(spg * nb / tb, 3), "ms_per_step": round(tb / nb * 1e3, 3),
+                      "how": f"{nb} steps of this line's per-GPU batch in this process with the gradient exchange off "
+                             "(slowest rank); BatchNorm mode as in the line"}
+        for _ in range(2):      # back to the timed configuration
+            step()
 
     fence()
     t0 = time.perf_counter()
@@ -722,6 +749,19 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         out.update(extra)
+        if local_base is None and world == 1 and spg == 1 and "c3_batch4_train" in extra:
+            c3 = extra["c3_batch4_train"]
+            local_base = {"scenes_per_gpu": 4, "scenes_per_s": c3["scenes_per_s"], "ms_per_step": c3["ms_per_step"],
+                          "how": "c3_batch4_train of this run: 4 scenes per step on this GPU, no process group -- the "
+                                 "N = 1 point of the 1 -> 8 series (python bench.py --gpus 1 --scenes-per-gpu 4 prints it "
+                                 "as a line of its own); NOT this line's one-scene value"}
+        elif local_base is None and world == 1:
+            local_base = {"scenes_per_gpu": spg, "scenes_per_s": round(scenes_per_s, 3), "ms_per_step": round(ms_per_step, 3),
+                          "how": "this line (one GPU, no process group)"}
+        out["scaling_baseline"] = local_base
+        out["per_gpu_scenes_per_s"] = round(scenes_per_s / world, 3)
+        if local_base and world > 1:
+            out["efficiency_vs_scaling_baseline"] = round(scenes_per_s / (world * local_base["scenes_per_s"]), 4)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -1013,6 +1013,11 @@ def test_loss_sum_adds_in_the_reference_order():
     want = ((((t[0] + t[1]) + (t[2] + t[3])) + t[4]) + t[5]) + t[6]
     assert float(got) == float(want)
     assert all(float(x.grad) == 2.0 for x in terms)
+    # a term of shape [1] (e.g. a loss built with keepdim) or of another float type gets its gradient in its own shape / type
+    a = torch.tensor([0.5], dtype=torch.float32, device="cuda", requires_grad=True)
+    b = torch.tensor(0.25, dtype=torch.float64, device="cuda", requires_grad=True)
+    (3.0 * wsis_ops.loss_sum([a, b])).backward()
+    assert a.grad.shape == (1,) and float(a.grad) == 3.0 and b.grad.dtype == torch.float64 and float(b.grad) == 3.0
 
 
 @pytest.mark.gpu
