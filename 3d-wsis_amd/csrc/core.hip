@@ -172,7 +172,15 @@ extern "C" int wsis_debug_gap_probe(int variant, int n, float* d_buf, void* stre
   for (int i = 0; i < n; ++i) {
     size_t lds = (variant & 1) ? 32768 : 0;
     if ((variant & 4) && (i & 1)) lds = 0;
-    if (variant & 8) {
+    if (variant & 16) {      // the launch form of the conv / BatchNorm entry points (event pair, null outside profiling)
+      if (variant & 8) {
+        GapArgs a{};
+        a.p = d_buf;
+        hipExtLaunchKernelGGL(gap_probe_big_kernel, grid, block, lds, st, nullptr, nullptr, 0u, a);
+      } else {
+        hipExtLaunchKernelGGL(gap_probe_kernel, grid, block, lds, st, nullptr, nullptr, 0u, d_buf);
+      }
+    } else if (variant & 8) {
       GapArgs a{};
       a.p = d_buf;
       hipLaunchKernelGGL(gap_probe_big_kernel, grid, block, lds, st, a);

@@ -208,6 +208,7 @@ class UNetProgram(object):
         self.flat_tail = None        # spare floats behind the gradients (parallel.GradSync packs the other
         self.tail_floats = 0         # parameters' gradients there: ONE collective per step)
         self.overlap = None          # wsis_parallel.GradSync: early all-reduce of the finished first part (see backward)
+        self._garena = None          # _GradArena of the last backward program
         self.bn_sync = None          # _BnSync while the model's BatchNorm layers share their statistics across ranks
         self._cache = {}
 
@@ -534,12 +535,41 @@ def _view(arena, base, offset, shape):
     return arena[off:off + numel * 4].view(torch.float32).view(shape)
 
 
-class UNetFunction(Function):
-    """features [M0, Cin] -> [M0, m]; ``prog`` is a bound UNetProgram, ``params`` its parameters (so that autograd
-    routes their gradients)."""
+class _GradArena(object):
+    """the flat parameter-gradient buffer of a compiled backward program, with the per-parameter views of it.  Kept by
+    the program from one backward pass to the next (the executor overwrites every gradient in it; the alignment gaps and
+    the tail were zeroed once): a pass costs the host no allocation, no 230 slice / view calls."""
 
     @staticmethod
-    def forward(ctx, x, prog, *params):
+    def key_of(prog, c, ptotal, tail, dev):
+        return (id(c), int(ptotal), int(tail), dev, tuple(p.requires_grad for p in prog.params))
+
+    def __init__(self, prog, c, poffs, ptotal, tail, dev):
+        self.key = self.key_of(prog, c, ptotal, tail, dev)
+        self.c = c                                   # (keeps id(c) from being reused while this buffer lives)
+        self.arena, self.base = _arena_tensor(ptotal + tail, dev, zero=True)   # alignment gaps are all-reduced too
+        self.flat = self.arena.view(torch.float32)
+        self.first = (self.base - self.arena.data_ptr()) // 4
+        self.lut = poffs.astype(np.uint64) + np.uint64(self.base)
+        self.params, self.views = [], []
+        for i, p in enumerate(prog.params):
+            gid = c.grad_ids[i]
+            if gid >= 0 and p.requires_grad:
+                off = self.first + int(poffs[gid]) // 4
+                self.params.append(p)
+                self.views.append(self.flat[off:off + p.numel()].view(p.shape))
+        t0 = self.first + (ptotal + 3) // 4
+        self.tail = self.flat[t0:t0 + prog.tail_floats] if prog.tail_floats else None
+
+
+class UNetFunction(Function):
+    """features [M0, Cin] -> [M0, m]; ``prog`` is a bound UNetProgram.  Its parameters are NOT inputs of the node:
+    ``backward`` stores their gradients (views of the program's flat buffer) in ``.grad`` itself -- what 230
+    AccumulateGrad nodes did, ~1 ms of host time per step.  ``anchor`` (any parameter that requires a gradient) only
+    makes autograd run the node when the input features need no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, prog, anchor=None):
         _n.require_cuda(x)
         x = x if (x.dtype == torch.float32 and x.is_contiguous()) else x.contiguous().float()
         need_dx = bool(x.requires_grad)
@@ -564,7 +594,7 @@ class UNetFunction(Function):
         # pass -- an inference pass right here (its result is used next; the read waits for the rulebook chain on the
         # side stream only), a training pass at the end of its backward pass, i.e. before the optimizer can use a
         # gradient (reading here would park the issuing thread for the length of the rulebook chain, ~1 ms per step)
-        if not (torch.is_grad_enabled() and (need_dx or any(p.requires_grad for p in params))):
+        if not (torch.is_grad_enabled() and (need_dx or anchor is not None)):
             sp_ops.verify_pending_counts()
         prog.account(c.acc_f, Mvec, tensors)
         out = _view(arena, base, offs[c.out_id], (int(Mvec[0]), c.out_channels))
@@ -581,12 +611,16 @@ class UNetFunction(Function):
         poffs, ptotal = c.par_arena.layout(Mvec)
         garena, gbase = _arena_tensor(btotal, dev)
         tail = int(prog.tail_floats) * 4
-        parena, pbase = _arena_tensor(ptotal + tail, dev, zero=True)   # alignment gaps are all-reduced too
-        luts = {_FWD: ctx.fwd_lut, _BWD: boffs.astype(np.uint64) + np.uint64(gbase),
-                _PAR: poffs.astype(np.uint64) + np.uint64(pbase), _TBL: ctx.table_lut,
+        # the program's own gradient buffer while no parameter still holds a gradient (zero_grad(set_to_none=True), the
+        # reference's loop); otherwise (gradient accumulation, a second backward pass) a buffer of this pass's own
+        ga = prog._garena
+        if ga is None or ga.key != _GradArena.key_of(prog, c, ptotal, tail, dev):
+            ga = prog._garena = _GradArena(prog, c, poffs, ptotal, tail, dev)
+        if any(p.grad is not None for p in ga.params):
+            ga = _GradArena(prog, c, poffs, ptotal, tail, dev)
+        parena, pflat, first = ga.arena, ga.flat, ga.first
+        luts = {_FWD: ctx.fwd_lut, _BWD: boffs.astype(np.uint64) + np.uint64(gbase), _PAR: ga.lut, _TBL: ctx.table_lut,
                 _EXT: np.array([ctx.x.data_ptr(), d_out.data_ptr()], dtype=np.uint64)}
-        pflat = parena.view(torch.float32)
-        first = (pbase - parena.data_ptr()) // 4
         hook = prog.overlap
         if ctx.sy is not None:
             ctx.sy.arenas = [ctx.arena, garena, parena]
@@ -603,22 +637,13 @@ class UNetFunction(Function):
         else:
             _run(_n.hip(), c.bwd.instantiate(Mvec, luts), dev)
         prog.account(c.acc_b, Mvec, ctx.tensors)
-        grads, covered = [], []
-        for i, p in enumerate(prog.params):
-            gid = c.grad_ids[i]
-            if gid < 0 or not ctx.needs_input_grad[2 + i]:
-                grads.append(None)
-            else:
-                off = first + int(poffs[gid]) // 4
-                grads.append(pflat[off:off + p.numel()].view(p.shape))
-                covered.append(p)
+        for p, v in zip(ga.params, ga.views):
+            p.grad = v if p.grad is None else p.grad + v
         # data-parallel hook: the gradients of ``flat_params`` are views of ``flat_grad`` (parallel.GradSync)
-        prog.flat_grad, prog.flat_params = pflat, covered
-        t0 = first + (ptotal + 3) // 4
-        prog.flat_tail = pflat[t0:t0 + prog.tail_floats] if prog.tail_floats else None
+        prog.flat_grad, prog.flat_params, prog.flat_tail = pflat, ga.params, ga.tail
         dx = _view(garena, gbase, boffs[c.dx_id], tuple(ctx.x.shape)) if c.dx_id >= 0 else None
         sp_ops.verify_pending_counts()       # (see forward: the counts of this pass's rulebooks, long written by now)
-        return (dx, None) + tuple(grads)
+        return dx, None, None
 
 
 
@@ -792,4 +817,5 @@ def run_unet(net, input_tensor, sync_group=None):
     elif prog.bn_sync is None or prog.bn_sync.group is not sync_group:
         prog.bn_sync = _BnSync(prog, sync_group)
     prog.bind(input_tensor)
-    return UNetFunction.apply(input_tensor.features, prog, *prog.params)
+    anchor = next((p for p in prog.params if p.requires_grad), None) if torch.is_grad_enabled() else None
+    return UNetFunction.apply(input_tensor.features, prog, anchor)
