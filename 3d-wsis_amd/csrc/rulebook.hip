@@ -273,13 +273,17 @@ __global__ void tile_key_kernel(const int32_t* __restrict__ indices, const uint3
   }
 }
 
-// ---- tile scheduling.  The convolution kernels launch one workgroup per 128-row tile, all of them resident at once,
-// and the dispatcher hands workgroup i to CU i % n_cu: a launch lasts as long as its most loaded CU.  Whole tiles of the
-// locality order are therefore re-arranged by weight (number of offsets any of their rows uses = steps of the tile):
-// sorted heaviest first and dealt in a snake over bands of n_cu tiles (band 0 ascending, band 1 descending, ...), so
-// every CU receives one tile of each weight band and the light end of one band meets the heavy end of the next.
-// C2 level 0: 72.4 -> 62.1 us per launch; unsorted, the most loaded CU carries ~1.6x the mean number of steps.
-constexpr int SCHED_TM = 128;
+// ---- slice scheduling.  A launch lasts as long as its most loaded CU, and the dispatcher hands workgroup i of a launch
+// to CU i % n_cu while workgroups fit (measured, tools/conv2_stamps.py: exact for every workgroup that is resident from
+// the start; later ones go wherever a slot frees).  The 32-row slices of the locality order -- the work items of the
+// convolution kernels -- are therefore re-arranged by weight (number of kernel offsets any of their rows uses = steps of
+// the slice), heaviest first, stable (equal weights keep the locality order).  The DEAL is the launch's: the forward /
+// dIn kernel maps its workgroup index through a snake over bands of n_cu work items (spconv2.hip), the weight-gradient
+// kernel deals its waves the same way (spconv_dw2.hip).  Round 5: the unit went from 128-row tiles (the round-1 kernel's
+// work item) to slices, the snake from the order itself into the launches (an item is a slice x an output block: the
+// bands of a launch depend on its channel count), and every level is scheduled (levels 2-4 were not: their most
+// loaded CU carried 51 steps against a mean of 26).  WSIS_TILE_BAND = n > 0 puts the round-1 snake back into the order.
+constexpr int SCHED_TM = 32;
 
 __global__ __launch_bounds__(64) void tile_weight_kernel(const int32_t* __restrict__ order,
                                                          const uint32_t* __restrict__ mask, int64_t n_tiles,
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(64) void tile_weight_kernel(const int32_t* __restri
   const int64_t t = blockIdx.x;
   if (t >= n_tiles) return;
   const int lane = threadIdx.x;
-  uint32_t m = mask[order[t * SCHED_TM + lane]] | mask[order[t * SCHED_TM + 64 + lane]];
+  uint32_t m = lane < SCHED_TM ? mask[order[t * SCHED_TM + lane]] : 0u;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m |= __shfl_xor(m, off, 64);
   if (lane == 0) {
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(64) void tile_weight_batch_kernel(TileBatch b, cons
   const int32_t* ord = order + b.base[t];
   const uint32_t* mask = b.mask[t];
   const int lane = threadIdx.x;
-  uint32_t m = mask[ord[tile * SCHED_TM + lane]] | mask[ord[tile * SCHED_TM + 64 + lane]];
+  uint32_t m = lane < SCHED_TM ? mask[ord[tile * SCHED_TM + lane]] : 0u;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) m |= __shfl_xor(m, off, 64);
   if (lane == 0) {
@@ -392,20 +396,13 @@ __global__ void tile_permute_batch_kernel(TileBatch b, const int32_t* __restrict
   }
 }
 
-int sched_band() {
-  static int cus = 0;
-  if (cus == 0) {
-    const char* e = getenv("WSIS_TILE_BAND");     // tuning knob: snake period (a huge value = plain heaviest-first)
-    if (e && atoi(e) > 0) cus = atoi(e);
+int sched_band() {      // snake period of the ORDER: none by default (the launches deal, see above)
+  static int band = -1;
+  if (band < 0) {
+    const char* e = getenv("WSIS_TILE_BAND");
+    band = (e && atoi(e) > 0) ? atoi(e) : 0;
   }
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
+  return band;
 }
 
 __global__ void iota_kernel(int32_t* __restrict__ p, int64_t n) {
@@ -669,7 +666,7 @@ int wsis_tile_order(const int32_t* d_indices, const uint32_t* d_mask, int64_t M,
 
   // ---- tile scheduling (WSIS_TILE_SCHED=0 switches it off; levels below WSIS_TILE_SCHED_MIN full tiles keep the
   //      plain locality order: their offsets are split over blockIdx.z and the dispatch pattern differs)
-  static int sched = -1, sched_min = 150;
+  static int sched = -1, sched_min = 4;
   if (sched < 0) {
     const char* e = getenv("WSIS_TILE_SCHED");
     sched = e ? atoi(e) : 1;
@@ -698,7 +695,7 @@ int wsis_tile_order(const int32_t* d_indices, const uint32_t* d_mask, int64_t M,
     // with workgroup id = tile + n_tiles * z, so CU c holds tiles c, c + n_cu mod n_tiles, ... of successive slices.
     const int n_cu = sched_band();
     const int64_t grid_tiles = (M + SCHED_TM - 1) / SCHED_TM;
-    int band = grid_tiles >= n_cu ? n_cu : (int)(n_cu % grid_tiles);
+    int band = n_cu <= 0 ? 0x7fffffff : grid_tiles >= n_cu ? n_cu : (int)(n_cu % grid_tiles);
     if (band == 0) band = (int)grid_tiles;
     hipLaunchKernelGGL(tile_permute_kernel, dim3(grid_for(M, 256)), dim3(256), 0, st, ord0, tsorted, M, n_tiles,
                        band, d_order);
@@ -749,7 +746,7 @@ int wsis_tile_order_batch(int32_t n, const void* const* h_indices, const void* c
   int32_t* iota = reinterpret_cast<int32_t*>(ws + 2 * a8);
   void* temp = ws + 2 * a8 + a4;
   size_t temp_bytes = (size_t)ws_bytes - (2 * a8 + a4);
-  static int sched = -1, sched_min = 150;
+  static int sched = -1, sched_min = 4;
   if (sched < 0) {
     const char* e = getenv("WSIS_TILE_SCHED");
     sched = e ? atoi(e) : 1;
@@ -763,7 +760,7 @@ int wsis_tile_order_batch(int32_t n, const void* const* h_indices, const void* c
     const bool on = sched && b.mask[t] && n_tiles >= sched_min;
     b.tile_base[t + 1] = b.tile_base[t] + (on ? n_tiles : 0);
     const int64_t grid_tiles = (h_M[t] + SCHED_TM - 1) / SCHED_TM;
-    int band = grid_tiles >= n_cu ? n_cu : (grid_tiles > 0 ? (int)(n_cu % grid_tiles) : 1);
+    int band = n_cu <= 0 ? 0x7fffffff : grid_tiles >= n_cu ? n_cu : (grid_tiles > 0 ? (int)(n_cu % grid_tiles) : 1);
     if (band == 0) band = (int)grid_tiles;
     b.band[t] = band > 0 ? band : 1;
   }

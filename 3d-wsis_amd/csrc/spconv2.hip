@@ -21,19 +21,48 @@
 
 namespace {
 
+// Workgroup index -> work item.  The grid is ONE-dimensional: the dispatcher hands workgroup i to CU i % n_cu while
+// workgroups fit (tools/conv2_stamps.py), and the launch lasts as long as its most loaded CU.  The slices of the tile
+// order come heaviest first (rulebook.hip: slice scheduling), the output blocks and offset slabs of a slice weigh the
+// same: item j of the weight order = (slice j / (gy gz), block, slab), and the workgroups take the items in a snake over
+// bands of `band` (= n_cu) items -- band 0 ascending, band 1 descending, ... -- so every CU gets one item of each weight
+// band and the light end of one band meets the heavy end of the next (C2 level 2, 96 -> 96: the most loaded CU carried
+// 51 steps against a mean of 26 with the old (slice, block) grid; 33 with this deal).  Which workgroup computes an item
+// has no influence on its result.
+struct ItemMap {
+  int bx, by, bz;
+};
+__device__ __forceinline__ ItemMap item_of(int i, int gx, int gy, int gz, int band) {
+  const int total = gx * gy * gz;
+  const int b = i / band, c = i - b * band;
+  int j = i;
+  if (b & 1) {
+    const int left = total - b * band;
+    j = b * band + ((left < band ? left : band) - 1 - c);
+  }
+  ItemMap m;
+  const int per = gy * gz;
+  m.bx = j / per;
+  const int r = j - m.bx * per;
+  m.by = r / gz;
+  m.bz = r - m.by * gz;
+  return m;
+}
+
 template <int NB, int NW, int DA, bool BD, bool DIAG = false, bool FB = false>
 __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ WT, const float* __restrict__ bias, const float* __restrict__ residual,
     float* __restrict__ out, float* __restrict__ partial, int64_t M_out, int K, int Cin, int Cout, int flip_deal,
-    uint32_t x_bytes, float* __restrict__ stats, BnEpi epi, BnIn bin, StatFin fin,
+    uint32_t x_bytes, float* __restrict__ stats, BnEpi epi, BnIn bin, StatFin fin, int gz, int band,
     unsigned long long* __restrict__ dbg = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   WgSync sync;
   const LateVals late{bias, residual, out, partial, stats, epi};
+  const int gx = (int)((M_out + SL - 1) / SL), gy = Cout / (32 * NB);
+  const ItemMap it = item_of((int)blockIdx.x, gx, gy, gz, band);
   fwd2_body<NB, NW, DA, BD, DIAG, FB, false>(X, nbrS, order, WT, late, M_out, K, Cin, Cout, flip_deal, x_bytes, bin, &fin, dbg,
-                                            (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.y,
-                                            (int)gridDim.z, lds, (int)threadIdx.x, sync);
+                                            it.bx, it.by, it.bz, gy, gz, lds, (int)threadIdx.x, sync);
 }
 
 
@@ -228,7 +257,16 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
     }
   }
   hipStream_t st = as_stream(stream);
-  const dim3 grid((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32 / p.NB), (unsigned)p.ZS);
+  WSIS_REQUIRE(ceil_div(M_out, SL) * (Cout / 32 / p.NB) * p.ZS < ((int64_t)1 << 31), "too many work items");
+  const dim3 grid((unsigned)(ceil_div(M_out, SL) * (Cout / 32 / p.NB) * p.ZS), 1u, 1u);
+  static int n_cu = 0;                 // snake period of the item deal (item_of): the CUs of the device
+  if (!n_cu) {
+    int dev = 0, v = 0;
+    WSIS_HIP_CHECK(hipGetDevice(&dev));
+    WSIS_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = v > 0 ? v : 256;
+  }
+  const int deal_band = env_int("WSIS_FWD2_SNAKE", 1) ? n_cu : 0x7fffffff;      // (read per call; 0: items in weight order)
   // WSIS_FWD2_DEAL=1 (read per call; default 0): active offsets dealt round-robin to the waves of a work item instead
   // of ownership by offset index.  Measured neutral on the C2 step (level 1: 1046 -> 1035-1050 us per step, level 2:
   // 855 -> 835) -- the waves of a work item are not what its lifetime waits for -- and it gives up the tile-order
@@ -316,7 +354,7 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
     }                                                                                                            \
     hipExtLaunchKernelGGL((spconv_fwd2_kernel<nb, nw, da, bd, false, fb>), grid, dim3(64 * nw), (uint32_t)ldsb, st, \
                           prof.ka(), prof.kb(), 0u, d_X, d_nbr, d_order, d_WT, d_bias, d_residual, d_out, partial,   \
-                          M_out, K, Cin, Cout, flip_deal, x_bytes, d_stats, epi, bin, fin,                          \
+                          M_out, K, Cin, Cout, flip_deal, x_bytes, d_stats, epi, bin, fin, (int)p.ZS, deal_band,    \
                           (unsigned long long*)nullptr);                                                            \
   } while (0)
 #define WSIS_F2(nb, nw, da)             \
@@ -347,6 +385,8 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
     case 123: WSIS_F2(1, 2, 3); break;
     case 122: WSIS_F2(1, 2, 2); break;
     case 142: WSIS_F2(1, 4, 2); break;
+    case 143: WSIS_F2(1, 4, 3); break;
+    case 144: WSIS_F2(1, 4, 4); break;
     case 182: WSIS_F2(1, 8, 2); break;
     case 213: WSIS_F2(2, 1, 3); break;
     case 212: WSIS_F2(2, 1, 2); break;
@@ -387,26 +427,27 @@ int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_
                             float* d_out, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, int32_t variant,
                             unsigned long long* d_dbg, void* d_sync, void* stream) {
   WSIS_REQUIRE(wsis_spconv_fwd_t_supported(K, Cin, Cout) && d_dbg, "bad args");
-  const dim3 grid((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32), 1);
+  const dim3 grid((unsigned)(ceil_div(M_out, SL) * (Cout / 32)), 1, 1);
   hipStream_t st = as_stream(stream);
+  const int diag_band = env_int("WSIS_FWD2_SNAKE", 1) ? 256 : 0x7fffffff;
   const int dflags = (variant >> 8) << 4;      // experiment bits (see the kernel)
   variant &= 0xff;
   if (variant == 0) {
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 2, true, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, dflags,
-                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, d_dbg);
+                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, 1, diag_band, d_dbg);
   } else if (variant >= 2) {      // the production small-level form: 4 waves per work item, `variant - 1` offset slabs
-    const dim3 g4((unsigned)ceil_div(M_out, SL), (unsigned)(Cout / 32), (unsigned)(variant - 1));
+    const dim3 g4((unsigned)(ceil_div(M_out, SL) * (Cout / 32) * (variant - 1)), 1, 1);
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES * 4;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 4, 2, true, true>), g4, dim3(256), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, d_out, M_out, K, Cin, Cout, dflags,
-                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, d_dbg);
+                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, variant - 1, diag_band, d_dbg);
   } else {
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 3, false>::WAVE_BYTES;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 3, false, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, 0,
-                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, d_dbg);
+                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, 1, diag_band, d_dbg);
   }
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;

@@ -530,9 +530,12 @@ __device__ __forceinline__ void fwd2_body(
     gen_next(gB);
     if (T > 1) issueA_all();                        // A1
     if (DA >= 3 && T > 2) issueA_all();             // A2
-    {   // A0, B0 landed; A1 [A2] may fly
+    if (DA >= 4 && T > 3) issueA_all();             // A3
+    {   // A0, B0 landed; A1 [A2 [A3]] may fly
       const int young = (T > DA ? DA : T) - 1;
-      if (young >= 2)
+      if (young >= 3)
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (young == 2)
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (young == 1)
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -550,8 +553,9 @@ __device__ __forceinline__ void fwd2_body(
     arS = 1 == DA ? 0 : 1;
     int t = 0;
     auto iter = [&](const f32x4 (&ac)[4], f32x4 (&bc)[NB][4], f32x4 (&an)[4], f32x4 (&bn)[NB][4]) {
-      // top: A(t+1) and B(t) landed, the fragment reads of step t are back; A(t+2) (DA = 3) may still fly
-      if (DA >= 3 && t + 2 < T)
+      // top: A(t+1) and B(t) landed, the fragment reads of step t are back; A(t+DA-1) (DA >= 3: the pieces issued
+      // behind B(t) in the previous iteration) may still fly
+      if (DA >= 3 && t + DA - 1 < T)
         asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -919,7 +923,7 @@ __device__ __forceinline__ void fwd2_body(
     d[4] = t3 - d_t2;
     d[5] = (unsigned long long)T;
     d[6] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID, 32 bits
-    d[7] = 0;
+    d[7] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
   }
 }
 
@@ -1147,6 +1151,13 @@ Plan2 plan2(int64_t M_out, int K, int Cin, int Cout, bool fused = false) {
   p.NW = nw;
   p.ZS = zs;
   p.DA = (da_pref == 2 || nw >= 4) ? 2 : 3;     // 4+ waves per workgroup: two workgroups per CU need the short ring
+  if (nw == 4 && p.NB == 1 && p.BD) {
+    // 4-wave items (levels 1-2 of a scene): ring depth 3 = 52 KB of LDS per workgroup, three per CU.  The launch lasts
+    // as long as its heaviest waves, and with depth 2 a wave makes a step per gather latency (~3,400 cycles) even once
+    // it has its SIMD to itself; with depth 3 the gather of step t + 2 has two steps to land (read per call)
+    const int d = env_int("WSIS_FWD2_DA_NW4", 2);
+    if (d >= 2 && d <= 4) p.DA = d;
+  }
   p.BD = bd_pref ? 1 : 0;
   return p;
 }

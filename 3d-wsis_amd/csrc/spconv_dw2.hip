@@ -127,14 +127,22 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
   const int xcd = XCD ? (int)(blockIdx.x & 7) : 0;
   const int64_t stride = XCD ? (int64_t)(gridDim.x >> 3) * WGW : (int64_t)gridDim.x * WGW;      // waves per XCD
   const int64_t first_m = XCD ? (int64_t)(blockIdx.x >> 3) * WGW + wave : (int64_t)blockIdx.x * WGW + wave;
-  auto slice_of = [&](int64_t m) -> int64_t {
-    if (!XCD) return m;
-    const int sh = XSH & 255;
-    return ((((m >> sh) << 3) + xcd) << sh) | (m & ((1 << sh) - 1));
-  };
   // number of enumerated positions: every position whose slice index is in range is a slice; positions past the
   // last full chunk round may map beyond n_slices and are skipped as empty
   const int64_t n_pos = XCD ? ((((n_slices + (1 << (XSH & 255)) - 1) >> (XSH & 255)) + 7) >> 3) << (XSH & 255) : n_slices;
+  // The tile order comes heaviest slice first (rulebook.hip: slice scheduling): both deals run as a snake -- the waves
+  // take the positions of every second FULL round of `stride` in reverse, the XCDs every second round of 8 chunks --
+  // so that no wave (and no XCD) always gets the heavy end of a round.
+  auto slice_of = [&](int64_t pos) -> int64_t {
+    const int64_t n = pos / stride;
+    int64_t m = pos;
+    if ((n & 1) && (n + 1) * stride <= n_pos) m = n * stride + (stride - 1 - (pos - n * stride));
+    if (!XCD) return m;
+    const int sh = XSH & 255;
+    const int64_t q = m >> sh;
+    const int xq = (q & 1) ? 7 - xcd : xcd;
+    return (((q << 3) + xq) << sh) | (m & ((1 << sh) - 1));
+  };
   const int64_t first = first_m;
 
   f32x16 acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7;

@@ -55,3 +55,46 @@ for lo, hi in ((0, 1), (1, 15), (15, 22), (22, 1e9)):
               f"epilogue p50 {np.median(epi[m]) / 2100:.1f} p90 {np.percentile(epi[m], 90) / 2100:.1f}, lifetime p50 {np.median((end_us - start_us)[m]):.1f}")
 late = np.argsort(-end_us)[:8]
 print("last finishers: " + ", ".join(f"(wg {i} steps {int(T[i])} start {start_us[i]:.1f} end {end_us[i]:.1f} cyc/step {per[i]:.0f} pro {pro[i] / 2100:.1f} epi {epi[i] / 2100:.1f} us)" for i in late))
+
+# ---- per compute unit: how the dispatcher spread the work items (HW_ID: cu_id 11:8, sh_id 12, se_id 15:13; XCC_ID 3:0)
+hw, xcc = d[:, 6].astype(np.int64), d[:, 7].astype(np.int64) & 15
+cu_key = (xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
+keys, inv = np.unique(cu_key, return_inverse=True)
+n_cu = len(keys)
+wg_per = np.bincount(inv, minlength=n_cu)
+steps_per = np.bincount(inv, weights=T, minlength=n_cu)
+end_per = np.zeros(n_cu); np.maximum.at(end_per, inv, end_us)
+first_wave_steps = np.zeros(n_cu)
+print(f"compute units seen: {n_cu}; workgroups per CU min {wg_per.min()} p50 {int(np.median(wg_per))} max {wg_per.max()}")
+print(f"steps (wave 0) per CU: min {steps_per.min():.0f} p10 {np.percentile(steps_per, 10):.0f} p50 {np.median(steps_per):.0f} "
+      f"p90 {np.percentile(steps_per, 90):.0f} max {steps_per.max():.0f}  (mean {steps_per.mean():.1f})")
+print(f"last end per CU us: min {end_per.min():.1f} p10 {np.percentile(end_per, 10):.1f} p50 {np.median(end_per):.1f} p90 {np.percentile(end_per, 90):.1f} max {end_per.max():.1f}")
+cc = np.corrcoef(steps_per, end_per)[0, 1]
+print(f"correlation(steps per CU, last end per CU) = {cc:.2f}")
+order = np.argsort(-end_per)[:6]
+for j in order:
+    m = inv == j
+    print(f"  CU {keys[j]:#06x}: {m.sum()} wgs, steps {T[m].astype(int).tolist()[:16]}, starts {np.round(start_us[m], 1).tolist()[:16]}, last end {end_per[j]:.1f}")
+# the first 3 workgroups by index: which CU
+print("CU of workgroups 0..15:", [hex(int(k)) for k in cu_key[:16]])
+
+# ---- does workgroup i go to the CU of workgroup i - 256?  and what would a balanced deal of these items give
+idx_all = np.arange(len(cu_key))
+same = np.mean(cu_key[256:] == cu_key[:-256]) if len(cu_key) > 256 else float('nan')
+print(f"fraction of workgroups i >= 256 on the CU of workgroup i - 256: {same:.2f}")
+for j in order[:3]:
+    print(f"  CU {keys[j]:#06x}: workgroup ids {idx_all[inv == j].tolist()[:24]}")
+Ts = np.sort(T)[::-1]
+def deal(seq, n=256, snake=True):
+    load = np.zeros(n)
+    for i, w in enumerate(seq):
+        b, c = divmod(i, n)
+        load[(n - 1 - c) if (snake and b & 1) else c] += w
+    return load
+def lpt(seq, n=256):
+    load = np.zeros(n)
+    for w in seq:
+        load[np.argmin(load)] += w
+    return load
+print(f"max steps per CU: measured {steps_per.max():.0f} | dealt i % 256 in launch order {deal(T, snake=False).max():.0f} | "
+      f"sorted + snake {deal(Ts).max():.0f} | sorted + least-loaded (LPT) {lpt(Ts).max():.0f} | mean {T.sum() / 256:.1f}")
