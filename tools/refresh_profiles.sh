@@ -4,7 +4,7 @@ export GRAFT_REPO_ROOT
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh'
 # then copy gpurun_out/${R}_* into profiles/ (see profiles/README.md).
 set -x
-R=${R:-r04}
+R=${R:-r05}
 cd $GRAFT_REPO_ROOT
 timeout 900 python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err
 tail -c 400 gpurun_out/${R}_bench_default.json
