@@ -1182,7 +1182,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 static unsigned* bn_tickets(void* d_sync) {
   static int on = -1;
   if (on < 0) {
-    const char* e = getenv("WSIS_BN_TICKET");
+    const char* e = tune_env("WSIS_BN_TICKET");
     on = e ? atoi(e) : 1;
   }
   if (!on || !d_sync) return nullptr;
@@ -1220,6 +1220,9 @@ int wsis_bn_stats_finalize(const float* d_partials, int64_t n_part, int64_t M, i
 // grid of a producer-consumer launch over M x C elements: every workgroup resident (<= 2 per CU of this device),
 // a multiple of the channel groups; 0 when the one-launch form does not apply
 static int bn_fused_grid(int64_t M, int C, int need_chunk_wgs, int which = 0) {
+#if !WSIS_EXPERIMENTAL
+  return 0;      // the polled producer / consumer form (WSIS_BN_FUSED_APPLY) is in the EXPERIMENTAL build only
+#endif
   // read per call (a test switches the form on): WSIS_BN_FUSED_APPLY for both directions, WSIS_BN_FUSED_FWD / _BWD per
   // direction.  Default OFF since round 3: with the flag / ticket words in caller slots (one more arrival counter per
   // workgroup) and the convolutions on one-launch plans the two-launch form measures faster -- 10.37 / 10.38 ms per C2
@@ -1229,7 +1232,7 @@ static int bn_fused_grid(int64_t M, int C, int need_chunk_wgs, int which = 0) {
   const int on = e ? atoi(e) : 0;
   const char* ed = getenv(which ? "WSIS_BN_FUSED_BWD" : "WSIS_BN_FUSED_FWD");
   const int on_dir = ed ? atoi(ed) : on;
-  const char* g = getenv("WSIS_BN_FUSED_GRID");
+  const char* g = tune_env("WSIS_BN_FUSED_GRID");
   int gmax = g ? atoi(g) : 256;
   if (gmax < 64 || gmax > 512) gmax = 256;
   int n_cu = 0;

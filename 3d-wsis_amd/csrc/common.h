@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <cstdlib>
 
 #include <cstdint>
 #include <cstdio>
@@ -11,6 +12,21 @@
 #include "../../include/wsis_hip.h"
 
 namespace wsis {
+// Tuning knobs (launch plans, scheduling periods, grid sizes ...) are LIVE in the EXPERIMENTAL build only -- the in-process
+// A/B tools sweep them there -- and compile to their measured defaults in the default library: what bench.py runs reads
+// a dozen switches (selectors the tests need), not ninety.
+inline const char* tune_env(const char* name) {
+#if WSIS_EXPERIMENTAL
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+inline int tune_int(const char* name, int dflt) {
+  const char* e = tune_env(name);
+  return e ? atoi(e) : dflt;
+}
 
 std::string& err_slot();
 int fail(int code, const char* fmt, ...);

@@ -159,6 +159,8 @@ __global__ void gap_probe_big_kernel(GapArgs a) {
 }
 }  // namespace
 
+extern "C" int32_t wsis_experimental(void) { return WSIS_EXPERIMENTAL ? 1 : 0; }
+
 extern "C" int wsis_debug_gap_probe(int variant, int n, float* d_buf, void* stream) {
   hipStream_t st = wsis::as_stream(stream);
   const bool small = (variant & 2) != 0;

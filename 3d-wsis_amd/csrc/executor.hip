@@ -21,7 +21,9 @@
 #include <algorithm>
 
 #include "common.h"
+#if WSIS_EXPERIMENTAL
 #include "deep.h"
+#endif
 
 using namespace wsis;
 
@@ -268,7 +270,7 @@ DwWorker& dw_worker() {
   return *w;
 }
 bool dw_thread_enabled() {
-  const char* e = getenv("WSIS_DW_THREAD");
+  const char* e = tune_env("WSIS_DW_THREAD");
   return e ? atoi(e) != 0 : true;
 }
 
@@ -308,9 +310,13 @@ inline int64_t dw_ws_of(const wsis_op& op) {
 int64_t op_ws_bytes(const wsis_op& op, bool on) {
   switch (op.kind) {
     case WSIS_OP_CONV:
+#if WSIS_EXPERIMENTAL
       if (op.flags & (WSIS_OPF_BN_IN | WSIS_OPF_STAT_FIN))
         return up(std::max(wsis_spconv_fwd_f_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout),
                            wsis_spconv_fwd_t_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout)));
+#else
+      if (op.flags & (WSIS_OPF_BN_IN | WSIS_OPF_STAT_FIN)) return -1;      // EXPERIMENTAL build only
+#endif
       if (use_fwd2(op, on)) return up(wsis_spconv_fwd_t_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout));
       return up(wsis_spconv_fwd_workspace_bytes(op.M_out, op.K, op.Cin, op.Cout));
     case WSIS_OP_BN_RELU:
@@ -330,6 +336,7 @@ int64_t op_ws_bytes(const wsis_op& op, bool on) {
 }
 
 
+#if WSIS_EXPERIMENTAL      // (make EXPERIMENTAL=1: the retired designs of DESIGN.md section 8)
 // ---- resident deep-level kernel (deep.hip): which ops of a pass can run as phases of ONE launch ------------------------
 // rows of the tensor an op WRITES (a dIn product writes M_in rows); 0: the op writes nothing on the caller's stream
 inline int64_t deep_rows(const wsis_op& op) {
@@ -613,6 +620,10 @@ int deep_build(const wsis_op* ops, int n, int i0, int i1, const char* wt_base, c
   return WSIS_OK;
 }
 
+#else
+inline int64_t deep_ws_bytes(const wsis_op*, int, bool) { return 0; }
+#endif
+
 }  // namespace
 
 extern "C" {
@@ -649,7 +660,7 @@ int wsis_run_ops_part(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_byte
   return run_ops_impl(ops, n, d_ws, ws_bytes, d_sync, stream, -1, nullptr, last == 0);
 }
 
-// WSIS_GRAPH=N (opt-in experiment, default 0): the launches of a pass are recorded into HIP graphs of ~N ops each
+// WSIS_GRAPH=N (EXPERIMENTAL build, default 0): the launches of a pass are recorded into HIP graphs of ~N ops each
 // (N < 4: one graph per pass; the weight-gradient side stream joins the capture through its fork / join events) and
 // replayed with one hipGraphLaunch per chunk; the executable graph of a chunk is kept and patched
 // (hipGraphExecUpdate) when the next scene's pass has the same kernel sequence.  Measured on the C2 step: results
@@ -658,6 +669,9 @@ int wsis_run_ops_part(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_byte
 // per step.  The way to make it pay is to patch node parameters without re-recording.
 int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream,
                         int32_t mark_op, void* waiter_stream) {
+#if !WSIS_EXPERIMENTAL
+  return run_ops_impl(ops, n, d_ws, ws_bytes, d_sync, stream, mark_op, waiter_stream);
+#else
   const char* ge = getenv("WSIS_GRAPH");        // read per pass (a test switches it)
   const int graph_mode = ge ? atoi(ge) : 0;
   if (!graph_mode || mark_op >= 0 || g_prof_on || n == 0)
@@ -718,6 +732,7 @@ int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
     i0 = i1;
   }
   return WSIS_OK;
+#endif
 }
 
 static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream,
@@ -782,6 +797,7 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   // resident deep-level launches (deep.hip): phase table + private slab regions of the largest run
   const int64_t deep_bytes = deep_ws_bytes(ops, n, on);
   char* const deep_ws = ws;
+  (void)deep_ws;
   ws += deep_bytes;
   ws_bytes -= deep_bytes;
   SideStream* side = (dw_bytes > 0 && dw_stream_enabled()) ? side_stream_for(st) : nullptr;
@@ -834,14 +850,17 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
     }
     return issue_dw(op, dw_ws, dw_bytes, dw_stream);
   };
+#if WSIS_EXPERIMENTAL
   const bool deep_on = deep_bytes > 0 && d_sync != nullptr && !capturing;
   std::vector<DeepOp> deep_tab;
   std::vector<std::pair<int, std::pair<int, int>>> deep_convs;
+#endif
   const char* slab_bn_env = getenv("WSIS_SLAB_BN_PARTIALS");      // one-shot path: slab-split dIn products write the
   const bool slab_bn_partials = slab_bn_env && atoi(slab_bn_env) != 0;   // BatchNorm partials too (the resident kernel's form)
   std::vector<char> bn_unfused(n, 0);     // BatchNorm backward ops whose dIn pass did not write partials this run
   for (int i = 0; i < n; ++i) {
     int rc = WSIS_OK;
+#if WSIS_EXPERIMENTAL
     if (deep_on && deep_op_ok(ops, n, i, on)) {
       const int i1 = deep_run_end(ops, n, i, mark_op >= i ? mark_op : -1, on);
       if (i1 - i >= kDeepMinOps) {
@@ -880,11 +899,16 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
         goto op_done;
       }
     }
+#endif
     {
     const wsis_op& op = ops[i];
     switch (op.kind) {
       case WSIS_OP_CONV:
         if (op.flags & (WSIS_OPF_BN_IN | WSIS_OPF_STAT_FIN)) {
+#if !WSIS_EXPERIMENTAL
+          rc = fail(WSIS_ERR_ARG, "op %d: the fused BatchNorm forms of the convolution are in the EXPERIMENTAL build only", i);
+          break;
+#else
           if (wt_off[i] < 0) {
             rc = fail(WSIS_ERR_ARG, "op %d: fused BatchNorm requested from a convolution that is not on wsis_spconv_fwd_t", i);
             break;
@@ -922,6 +946,7 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
                                  (op.flags & WSIS_OPF_STATS) ? (float*)op.out[1] : nullptr, tg, nt, op.M_in, op.M_out, op.K,
                                  op.Cin, op.Cout, ws, ws_bytes, sync_slot(d_sync, i), stream);
           break;
+#endif
         }
         if (wt_off[i] >= 0)
           rc = wsis_spconv_fwd_t((const float*)op.in[0], (const int32_t*)op.in[1], (const int32_t*)op.in[2],
@@ -1090,7 +1115,9 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
       first_err = rc;
       break;
     }
+#if WSIS_EXPERIMENTAL
   op_done:
+#endif
     if (i == mark_op) {
       // milestone: waiter_stream continues once everything issued so far -- on the caller's stream AND on the
       // weight-gradient side stream -- has run (gradient exchange of the finished part of the flat buffer while the
@@ -1144,6 +1171,7 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   return first_err;
 }
 
+#if WSIS_EXPERIMENTAL
 // diagnostic (not part of the ABI header): phases of profiled resident launch `which` (0 = first since profiling was
 // switched on): kind, NW, ZS, rows, Cin, Cout, K and the time from the end of the previous phase to the end of this one
 // (grid barrier included) in microseconds; returns the number of phases (or -1)
@@ -1169,5 +1197,7 @@ int wsis_debug_deep_phases(int32_t which, int32_t* info, double* us, int32_t cap
   }
   return n;
 }
+
+#endif
 
 }  // extern "C"

@@ -699,7 +699,7 @@ __global__ __launch_bounds__(DL_THREADS) void disc_loss_bwd_kernel(const float* 
 }
 
 int sl_blocks(int64_t N) {
-  const char* e = getenv("WSIS_SL_BLOCKS");          // (tuning knob, read per call; <= SL_MAX_BLOCKS)
+  const char* e = tune_env("WSIS_SL_BLOCKS");          // (tuning knob, read per call; <= SL_MAX_BLOCKS)
   int cap = e ? atoi(e) : 256;      // (one workgroup per CU: 22 + 19 us forward + finish at 512 workgroups, 27 + 10.5 at 256, 33.5 + 7 at 128)
   if (cap < 1 || cap > SL_MAX_BLOCKS) cap = SL_MAX_BLOCKS;
   int64_t b = ceil_div(N > 0 ? N : 1, SL_THREADS);

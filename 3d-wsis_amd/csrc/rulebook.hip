@@ -399,7 +399,7 @@ __global__ void tile_permute_batch_kernel(TileBatch b, const int32_t* __restrict
 int sched_band() {      // snake period of the ORDER: none by default (the launches deal, see above)
   static int band = -1;
   if (band < 0) {
-    const char* e = getenv("WSIS_TILE_BAND");
+    const char* e = tune_env("WSIS_TILE_BAND");
     band = (e && atoi(e) > 0) ? atoi(e) : 0;
   }
   return band;
@@ -668,9 +668,9 @@ int wsis_tile_order(const int32_t* d_indices, const uint32_t* d_mask, int64_t M,
   //      plain locality order: their offsets are split over blockIdx.z and the dispatch pattern differs)
   static int sched = -1, sched_min = 4;
   if (sched < 0) {
-    const char* e = getenv("WSIS_TILE_SCHED");
+    const char* e = tune_env("WSIS_TILE_SCHED");
     sched = e ? atoi(e) : 1;
-    e = getenv("WSIS_TILE_SCHED_MIN");
+    e = tune_env("WSIS_TILE_SCHED_MIN");
     if (e) sched_min = atoi(e);
   }
   const int64_t n_tiles = M / SCHED_TM;
@@ -748,9 +748,9 @@ int wsis_tile_order_batch(int32_t n, const void* const* h_indices, const void* c
   size_t temp_bytes = (size_t)ws_bytes - (2 * a8 + a4);
   static int sched = -1, sched_min = 4;
   if (sched < 0) {
-    const char* e = getenv("WSIS_TILE_SCHED");
+    const char* e = tune_env("WSIS_TILE_SCHED");
     sched = e ? atoi(e) : 1;
-    e = getenv("WSIS_TILE_SCHED_MIN");
+    e = tune_env("WSIS_TILE_SCHED_MIN");
     if (e) sched_min = atoi(e);
   }
   const int n_cu = sched_band();

@@ -512,9 +512,9 @@ __global__ void spconv_reduce4_kernel(const float4* __restrict__ partial, const 
 int fwd_nb(int64_t M_out, int Cout) {
   static int nb_small = -1, small_tiles = -1;
   if (nb_small < 0) {
-    const char* e = getenv("WSIS_FWD_NB_SMALL");
+    const char* e = tune_env("WSIS_FWD_NB_SMALL");
     nb_small = e ? atoi(e) : 1;
-    e = getenv("WSIS_FWD_SMALL_TILES");
+    e = tune_env("WSIS_FWD_SMALL_TILES");
     small_tiles = e ? atoi(e) : 100;
   }
   const int nblk = (Cout + 31) / 32;
@@ -530,7 +530,7 @@ int fwd_nb(int64_t M_out, int Cout) {
 int fwd_ksplit(int64_t M_out, int K, int Cout) {
   static int target = -1;   // WSIS_KSPLIT_TARGET: workgroups aimed for when splitting the offsets (tuning knob)
   if (target < 0) {
-    const char* e = getenv("WSIS_KSPLIT_TARGET");
+    const char* e = tune_env("WSIS_KSPLIT_TARGET");
     target = e ? atoi(e) : 1024;
   }
   const int NB = fwd_nb(M_out, Cout);
@@ -823,7 +823,7 @@ __global__ void dw_reduce4_kernel(const float4* __restrict__ partial, float4* __
 int dw_base_chunks(int64_t M_out) {
   static int div = -1;   // WSIS_DW_DIV: rows per unit-weight chunk below which a level gets fewer chunks (tuning knob)
   if (div < 0) {
-    const char* e = getenv("WSIS_DW_DIV");
+    const char* e = tune_env("WSIS_DW_DIV");
     div = e ? atoi(e) : 256;
     if (div < 64) div = 64;
   }
@@ -928,7 +928,7 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
   const dim3 grid((unsigned)ceil_div(M_out, TM), (unsigned)ceil_div(Cout, NB * 32), (unsigned)kz);
   static int xcd_aware = -1;
   if (xcd_aware < 0) {
-    const char* e = getenv("WSIS_XCD_AWARE");
+    const char* e = tune_env("WSIS_XCD_AWARE");
     xcd_aware = e ? atoi(e) : 0;
   }
   // WSIS_CONV_MATH (read per call, so a process can switch): 0 = exact fp32 MFMA (default), 1 = split-bf16 products

@@ -36,7 +36,20 @@ __device__ __forceinline__ ItemMap item_of(int i, int gx, int gy, int gz, int ba
   const int total = gx * gy * gz;
   const int b = i / band, c = i - b * band;
   int j = i;
-  if (b & 1) {
+  const int F = total / band, R = total - F * band;      // full rounds of the CUs, workgroups of the partial last one
+  if (F >= 1 && F <= 3 && R > 0 && band < 0x7fffffff) {
+    // a few items per CU, all resident at once (levels 2-4 of a scene): the R CUs that hold one item more get the
+    // LIGHTEST (F + 1) R items, the other band - R CUs the heaviest F (band - R), a snake inside each group.  C2 level 2
+    // (618 items, weights 81 .. 27 steps): most loaded CU 180 steps with the plain snake -- its partial third band lands
+    // on the CUs that already hold the heaviest items -- 135 with this deal, 120 = the greedy bound, mean 106
+    const int nB = band - R;
+    if (c >= R) {
+      const int bb = c - R;
+      j = b * nB + ((b & 1) ? nB - 1 - bb : bb);
+    } else {
+      j = F * nB + b * R + ((b & 1) ? R - 1 - c : c);
+    }
+  } else if (b & 1) {
     const int left = total - b * band;
     j = b * band + ((left < band ? left : band) - 1 - c);
   }
@@ -66,6 +79,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
 }
 
 
+#if WSIS_EXPERIMENTAL
 // ---- persistent form for launches of more than one round of work items (levels 0-1 of a scene: 4,803 one-wave items
 // over 3,072 resident waves are 1.56 rounds whose second round runs on 7 of the 12 wave slots of a CU).  gridDim.x
 // workgroups -- as many as are resident at once -- stay on the machine: each starts with work item blockIdx.x and then
@@ -115,6 +129,8 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2p_kernel(
   }
 }
 
+#endif      // WSIS_EXPERIMENTAL
+
 // out = sum_z partial[z] (+ bias, + residual)
 __global__ void spconv2_reduce_kernel(const float4* __restrict__ partial, const float4* __restrict__ bias,
                                       const float4* __restrict__ residual, float4* __restrict__ out, int64_t total4,
@@ -159,6 +175,7 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
                              void* d_ws, int64_t ws_bytes, void* d_sync, void* stream, const wsis_bn_in* bn_in = nullptr,
                              const wsis_stat_target* targets = nullptr, int32_t n_targets = 0, bool fused = false);
 
+#if WSIS_EXPERIMENTAL
 int64_t wsis_spconv_fwd_f_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout) {
   if (M_out < 0 || !wsis_spconv_fwd_t_supported(K, Cin, Cout)) return -1;
   const int64_t n_part = (M_out + 31) / 32;
@@ -175,6 +192,8 @@ int wsis_spconv_fwd_f(const float* d_X, const wsis_bn_in* bn_in, const int32_t* 
   return spconv_fwd_t_impl(d_X, d_nbr, d_order, d_WT, flip, d_bias, d_residual, d_out, d_stats, BnEpi{}, M_in, M_out, K,
                            Cin, Cout, d_ws, ws_bytes, d_sync, stream, bn_in, targets, n_targets, true);
 }
+
+#endif
 
 int wsis_spconv_fwd_t(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_WT, int32_t flip,
                       const float* d_bias, const float* d_residual, float* d_out, float* d_stats, int64_t M_in,
@@ -239,7 +258,11 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
   if (n_targets > 0) {
     const int64_t n_part = ceil_div(M_out, SL);
     WSIS_REQUIRE(p.NB == 1 && p.ZS == 1, "in-launch statistics finish: plan without slabs expected");
+#if WSIS_EXPERIMENTAL
     WSIS_REQUIRE(d_ws && ws_bytes >= wsis_spconv_fwd_f_workspace_bytes(M_out, K, Cin, Cout), "workspace too small");
+#else
+    return fail(WSIS_ERR_ARG, "in-launch statistics finish: EXPERIMENTAL build only");
+#endif
     fin.G = bn_fin_chunks(n_part);
     fin.per = (int)ceil_div(n_part, fin.G);
     WSIS_REQUIRE((int64_t)(fin.G + 1) * (Cout / 32) <= (int64_t)(sizeof(SyncSlot::fin) / sizeof(unsigned)), "too many tickets");
@@ -266,16 +289,17 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
     WSIS_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
     n_cu = v > 0 ? v : 256;
   }
-  const int deal_band = env_int("WSIS_FWD2_SNAKE", 1) ? n_cu : 0x7fffffff;      // (read per call; 0: items in weight order)
+  const int deal_band = tune_int("WSIS_FWD2_SNAKE", 1) ? n_cu : 0x7fffffff;      // (read per call; 0: items in weight order)
   // WSIS_FWD2_DEAL=1 (read per call; default 0): active offsets dealt round-robin to the waves of a work item instead
   // of ownership by offset index.  Measured neutral on the C2 step (level 1: 1046 -> 1035-1050 us per step, level 2:
   // 855 -> 835) -- the waves of a work item are not what its lifetime waits for -- and it gives up the tile-order
   // independence of the results, so it stays off.
-  const char* deal_env = getenv("WSIS_FWD2_DEAL");
+  const char* deal_env = tune_env("WSIS_FWD2_DEAL");
   // (wave priorities by step count -- s_setprio 1..3 for waves with many steps, the launch lasts as long as its longest
   // wave -- measured neutral on every level: not kept)
   const int flip_deal = (flip ? 1 : 0) | (((deal_env ? atoi(deal_env) : 0) != 0 && p.ZS == 1) ? 2 : 0);
   ProfScope prof(0, st, /*exact_events=*/true);
+#if WSIS_EXPERIMENTAL
   // role-split ring form (spconv3.hip): the levels with many work items
   if (!bn_in && n_targets == 0 && !fused) {
     const int nt = spconv_ring_plan(M_out, K, Cin, Cout);
@@ -313,7 +337,7 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
       const int wave_cap = 12 / p.NW > 0 ? 12 / p.NW : 1;      // 3 waves per SIMD: the occupancy the one-shot kernel runs at
       if (per_cu > wave_cap) per_cu = wave_cap;
       const int64_t resident = (int64_t)cus * per_cu;
-      const char* me = getenv("WSIS_FWD2P_MIN");      // rounds (x 100) from which the persistent form is taken
+      const char* me = tune_env("WSIS_FWD2P_MIN");      // rounds (x 100) from which the persistent form is taken
       const int64_t min_pct = me ? atoi(me) : (fwd2p >= 2 ? 110 : 400);
       if (items * 100 >= resident * min_pct) {
         unsigned* q = static_cast<SyncSlot*>(d_sync)->fin;
@@ -343,6 +367,7 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
       }
     }
   }
+#endif      // WSIS_EXPERIMENTAL
 #define WSIS_F2X(nb, nw, da, bd, fb)                                                                             \
   do {                                                                                                           \
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<nb, da, bd>::WAVE_BYTES * nw + (fb ? (size_t)Cin * 12 : 0); \
@@ -362,11 +387,16 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
     WSIS_F2X(nb, nw, da, true, false);  \
   else                                  \
     WSIS_F2X(nb, nw, da, false, false)
+#if WSIS_EXPERIMENTAL
 #define WSIS_F2B(nw) /* NB = 1, DA = 2, weights to registers: with or without the fused input BatchNorm */ \
   if (bn_in)                                                                                               \
     WSIS_F2X(1, nw, 2, true, true);                                                                        \
   else                                                                                                     \
     WSIS_F2X(1, nw, 2, true, false)
+#else
+#define WSIS_F2B(nw) WSIS_F2X(1, nw, 2, true, false)
+  WSIS_REQUIRE(!bn_in, "fused input BatchNorm: EXPERIMENTAL build only");
+#endif
   if (p.NB == 1 && p.DA == 2 && p.BD && (bn_in || p.NW == 16)) {
     switch (p.NW) {
       case 1: WSIS_F2B(1); break;
@@ -429,7 +459,7 @@ int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_
   WSIS_REQUIRE(wsis_spconv_fwd_t_supported(K, Cin, Cout) && d_dbg, "bad args");
   const dim3 grid((unsigned)(ceil_div(M_out, SL) * (Cout / 32)), 1, 1);
   hipStream_t st = as_stream(stream);
-  const int diag_band = env_int("WSIS_FWD2_SNAKE", 1) ? 256 : 0x7fffffff;
+  const int diag_band = tune_int("WSIS_FWD2_SNAKE", 1) ? 256 : 0x7fffffff;
   const int dflags = (variant >> 8) << 4;      // experiment bits (see the kernel)
   variant &= 0xff;
   if (variant == 0) {

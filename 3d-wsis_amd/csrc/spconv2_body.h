@@ -1100,8 +1100,8 @@ Plan2 plan2(int64_t M_out, int K, int Cin, int Cout, bool fused = false) {
   static int nb_pref = -1, target = -1, nw_force = -1, zs_force = -1, da_pref = -1, nw_max = -1, bd_pref = -1;
   static int noslab_all = -1, nw_max_noslab = 16;
   if (noslab_all < 0) {
-    noslab_all = env_int("WSIS_FWD2_NOSLAB", 1);
-    nw_max_noslab = env_int("WSIS_FWD2_NW_MAX_NOSLAB", 16);
+    noslab_all = tune_int("WSIS_FWD2_NOSLAB", 1);
+    nw_max_noslab = tune_int("WSIS_FWD2_NW_MAX_NOSLAB", 16);
   }
   noslab = noslab || noslab_all != 0;
   // ... except where a launch has so few work items that ONE item per CU is its whole schedule: the 344-row level of
@@ -1112,13 +1112,13 @@ Plan2 plan2(int64_t M_out, int K, int Cin, int Cout, bool fused = false) {
   const int slab_items = slab_env ? atoi(slab_env) : 96;
   if (!fused && noslab && K >= 16 && ceil_div(M_out, SL) * (Cout / 32) <= slab_items) noslab = false;
   if (nb_pref < 0) {
-    bd_pref = env_int("WSIS_FWD2_BD", 1);
+    bd_pref = tune_int("WSIS_FWD2_BD", 1);
     nb_pref = env_int("WSIS_FWD2_NB", 1);
-    target = env_int("WSIS_FWD2_WAVES", 8192);
-    nw_force = env_int("WSIS_FWD2_NW", 0);
-    zs_force = env_int("WSIS_FWD2_ZS", 0);
+    target = tune_int("WSIS_FWD2_WAVES", 8192);
+    nw_force = tune_int("WSIS_FWD2_NW", 0);
+    zs_force = tune_int("WSIS_FWD2_ZS", 0);
     da_pref = env_int("WSIS_FWD2_DA", 2);
-    nw_max = env_int("WSIS_FWD2_NW_MAX", 4);
+    nw_max = tune_int("WSIS_FWD2_NW_MAX", 4);
   }
   Plan2 p;
   const int nblk = Cout / 32;
@@ -1155,7 +1155,7 @@ Plan2 plan2(int64_t M_out, int K, int Cin, int Cout, bool fused = false) {
     // 4-wave items (levels 1-2 of a scene): ring depth 3 = 52 KB of LDS per workgroup, three per CU.  The launch lasts
     // as long as its heaviest waves, and with depth 2 a wave makes a step per gather latency (~3,400 cycles) even once
     // it has its SIMD to itself; with depth 3 the gather of step t + 2 has two steps to land (read per call)
-    const int d = env_int("WSIS_FWD2_DA_NW4", 2);
+    const int d = tune_int("WSIS_FWD2_DA_NW4", 2);
     if (d >= 2 && d <= 4) p.DA = d;
   }
   p.BD = bd_pref ? 1 : 0;

@@ -483,8 +483,8 @@ __global__ __launch_bounds__(256) void dw2_reduce_kernel(const float4* __restric
   }
 }
 
-int dw2_env(const char* name, int dflt) {
-  const char* e = getenv(name);
+int dw2_env(const char* name, int dflt) {      // (launch-plan knobs: live in the EXPERIMENTAL build)
+  const char* e = tune_env(name);
   return e ? atoi(e) : dflt;
 }
 

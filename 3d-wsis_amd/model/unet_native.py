@@ -61,7 +61,10 @@ def _fuse_fin_enabled():
     40 launches fewer, but every workgroup of the convolution then waits for its partial stores and a ticket before it
     retires -- the level-0 layers run 59 -> 71 us, which is what the shorter apply pass (25 -> 10 us) gives back:
     10.56 / 10.77 against 10.52 / 10.70 ms per step in alternating runs."""
-    return os.environ.get("WSIS_FUSE_BN_FIN", "0") != "0"
+    on = os.environ.get("WSIS_FUSE_BN_FIN", "0") != "0"
+    if on:
+        _n.require_experimental("WSIS_FUSE_BN_FIN (statistics finished inside the convolution)")
+    return on
 
 
 def _fuse_apply_level():
@@ -71,7 +74,10 @@ def _fuse_apply_level():
     launch against a 10 us apply pass, level 3: +4 us against 3 us) and the own-rows weight gradient 30 % longer, so the
     apply pass stays a launch of its own; the fused form remains for memory-tight runs (no activation copy)."""
     v = os.environ.get("WSIS_FUSE_BN_APPLY", "")
-    return int(v) if v.lstrip("-").isdigit() else 99
+    lvl = int(v) if v.lstrip("-").isdigit() else 99
+    if lvl < 99:
+        _n.require_experimental("WSIS_FUSE_BN_APPLY (BatchNorm applied by the consuming convolution)")
+    return lvl
 
 
 def _fuse_stats_enabled():
@@ -805,9 +811,21 @@ def _run(lib, ops, device, mark_op=-1, waiter=None):
         _n.check(lib.wsis_run_ops(p, n, _n.ptr(ws), ws_bytes, sync, _n.stream_ptr()), "run_ops")
 
 
+_EXPERIMENTAL_SWITCHES = ("WSIS_DEEP", "WSIS_FWD2P", "WSIS_RING", "WSIS_GRAPH", "WSIS_BN_FUSED_APPLY", "WSIS_BN_FUSED_FWD", "WSIS_BN_FUSED_BWD")
+
+
+def _check_experimental_switches():
+    """the switches of the retired designs exist in the EXPERIMENTAL build only: asking for one on
+    the default library is an error, not a silent no-op"""
+    for k in _EXPERIMENTAL_SWITCHES:
+        if os.environ.get(k, "0") not in ("", "0"):
+            _n.require_experimental(k + "=" + os.environ[k])
+
+
 def run_unet(net, input_tensor, sync_group=None):
     """input_conv + unet + output_layer of ``net`` on ``input_tensor`` (SparseConvTensor) -> features [M0, m].
     ``sync_group``: the process group the BatchNorm layers take their batch statistics over (None: per rank)"""
+    _check_experimental_switches()
     prog = getattr(net, "_native_prog", None)
     if prog is None:
         prog = UNetProgram(net)

@@ -77,13 +77,9 @@ _HIP_SIGS = {
     "wsis_spconv_fwd_t_workspace_bytes": (I64, [I64, I32, I32, I32]),
     "wsis_spconv_fwd_t": (I32, [P, P, P, P, I32, P, P, P, P, I64, I64, I32, I32, I32, P, I64, P, P]),
     "wsis_spconv_fwd_t_slabs": (I32, [I64, I32, I32, I32]),
-    "wsis_spconv_fwd_f_workspace_bytes": (I64, [I64, I32, I32, I32]),
-    "wsis_spconv_fwd_f": (I32, [P, P, P, P, P, I32, P, P, P, P, P, I32, I64, I64, I32, I32, I32, P, I64, P, P]),
     "wsis_bn_bwd_from_partials": (I32, [P, I64, P, P, P, P, P, P, F32, I32, P, P, P, P, I64, I32, P, I64, P, P]),
     "wsis_sync_bytes": (I64, []),
     "wsis_run_ops_part": (I32, [P, I32, P, I64, P, P, I32]),
-    "wsis_deep_launches": (I64, []),
-    "wsis_deep_phases": (I64, []),
     "wsis_bn_bwd_apply": (I32, [P, P, P, P, P, P, P, P, F32, I32, P, P, I64, I32, P]),
     "wsis_spconv_fwd_t_bn": (I32, [P, P, P, P, I32, P, P, P, P, P, P, P, F32, I32, I64, I64, I32, I32, I32, P, I64, P, P]),
     "wsis_bn_stats_finalize_workspace_bytes": (I64, [I64, I32]),
@@ -164,6 +160,16 @@ _HIP_SIGS = {
     "wsis_run_ops_workspace_bytes": (I64, [P, I32]),
     "wsis_run_ops": (I32, [P, I32, P, I64, P, P]),
     "wsis_run_ops_marked": (I32, [P, I32, P, I64, P, P, I32, P]),
+    "wsis_experimental": (I32, []),
+}
+
+# entry points of the EXPERIMENTAL build only (make -C 3d-wsis_amd/csrc EXPERIMENTAL=1; include/wsis_hip.h guards them):
+# the retired designs of DESIGN.md section 8.  Bound when the loaded library reports wsis_experimental() == 1.
+_HIP_SIGS_EXPERIMENTAL = {
+    "wsis_spconv_fwd_f_workspace_bytes": (I64, [I64, I32, I32, I32]),
+    "wsis_spconv_fwd_f": (I32, [P, P, P, P, P, I32, P, P, P, P, P, I32, I64, I64, I32, I32, I32, P, I64, P, P]),
+    "wsis_deep_launches": (I64, []),
+    "wsis_deep_phases": (I64, []),
 }
 
 
@@ -191,11 +197,25 @@ def hip():
         # The other order leaves two HIP runtimes in the process (this library then sees zero devices).
         import torch  # noqa: F401
         _hip = _bind(_load("libwsis_hip.so"), _HIP_SIGS)
+        if _hip.wsis_experimental():
+            _bind(_hip, _HIP_SIGS_EXPERIMENTAL)
     return _hip
 
 
-def declared_symbols():
-    return sorted(_HOST_SIGS), sorted(_HIP_SIGS)
+def experimental():
+    """True when the loaded libwsis_hip.so is the EXPERIMENTAL build (the retired designs of DESIGN.md section 8)"""
+    return bool(hip().wsis_experimental())
+
+
+def require_experimental(what):
+    if not experimental():
+        raise WsisError(f"{what} is part of the EXPERIMENTAL build only: make -C 3d-wsis_amd/csrc EXPERIMENTAL=1 "
+                        f"(or WSIS_EXPERIMENTAL=1 python -c 'import __graft_entry__ as g; g.build()')")
+
+
+def declared_symbols(experimental=False):
+    hip_names = sorted(list(_HIP_SIGS) + (list(_HIP_SIGS_EXPERIMENTAL) if experimental else []))
+    return sorted(_HOST_SIGS), hip_names
 
 
 def check_host(status, what):

@@ -243,6 +243,9 @@ int wsis_spconv_fwd_t_bn(const float* d_X, const int32_t* d_nbr, const int32_t* 
                          const float* d_bn_var, const float* d_bn_gamma, const float* d_bn_beta, float eps, int32_t relu,
                          int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes,
                          void* d_sync, void* stream);
+/* ---- EXPERIMENTAL build only (make -C 3d-wsis_amd/csrc EXPERIMENTAL=1; wsis_experimental() says which build a library
+ * is): the retired designs of DESIGN.md section 8 -- measured slower than the default path, kept buildable and tested.
+ * The default library does not export the entry points inside these guards. */
 /* The fused form of wsis_spconv_fwd_t for one layer of `BatchNorm1d -> ReLU -> conv` chains (sparse_unet3d.py:127-143):
  *   bn_in   (optional) BatchNorm(+ReLU) of the INPUT applied while the gathered rows are read: the activation
  *           relu(bn(x)) is never written; mean / var are the batch statistics (training) or the running statistics;
@@ -268,11 +271,13 @@ typedef struct wsis_stat_target {
   float momentum;
   int32_t reserved;
 } wsis_stat_target;
+#if defined(WSIS_EXPERIMENTAL) && WSIS_EXPERIMENTAL
 int64_t wsis_spconv_fwd_f_workspace_bytes(int64_t M_out, int32_t K, int32_t Cin, int32_t Cout);
 int wsis_spconv_fwd_f(const float* d_X, const wsis_bn_in* bn_in, const int32_t* d_nbr, const int32_t* d_order,
                       const float* d_WT, int32_t flip, const float* d_bias, const float* d_residual, float* d_out,
                       float* d_stats, const wsis_stat_target* targets, int32_t n_targets, int64_t M_in, int64_t M_out,
                       int32_t K, int32_t Cin, int32_t Cout, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream);
+#endif /* WSIS_EXPERIMENTAL */
 /* WT[k'] = W[k]^T with k' = (flip ? K-1-k : k); W [K,Cin,Cout] -> WT [K,Cout,Cin]. */
 int wsis_weight_transpose(const float* d_W, float* d_WT, int32_t K, int32_t Cin, int32_t Cout,
                           int32_t flip, void* stream);
@@ -720,12 +725,16 @@ int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
 int wsis_run_ops_part(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream,
                       int32_t last);
 
+#if defined(WSIS_EXPERIMENTAL) && WSIS_EXPERIMENTAL
 /* A run of consecutive ops whose output tensors have at most WSIS_DEEP_ROWS (8192) rows -- the deep UNet levels of a
  * scene, sparse_unet3d.py:321-350 -- is issued as ONE resident launch (csrc/deep.hip: 256 workgroups walk the ops as
  * phases with grid barriers between them; same kernels' code, same order of additions, results identical to the
  * launch-by-launch form).  WSIS_DEEP=0 switches it off.  Counters of this process, for tests: */
 int64_t wsis_deep_launches(void);
 int64_t wsis_deep_phases(void);
+#endif /* WSIS_EXPERIMENTAL */
+/* 1: this library was built with EXPERIMENTAL=1 (the guarded entry points above exist), 0: the default build */
+int32_t wsis_experimental(void);
 #ifdef __cplusplus
 }
 #endif

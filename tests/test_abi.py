@@ -8,10 +8,21 @@ import wsis_native
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
+def _declared(experimental=None):
+    """entry points include/wsis_hip.h declares for the build ``experimental`` says (None: the loaded library's own
+    flavour, wsis_experimental()): the declarations inside `#if defined(WSIS_EXPERIMENTAL) && WSIS_EXPERIMENTAL` guards
+    belong to the EXPERIMENTAL build only"""
+    if experimental is None:
+        experimental = wsis_native.experimental()
     text = open(os.path.join(ROOT, "include", "wsis_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(wsis_\w+)\s*\(", text)))
+    guard = r"#if defined\(WSIS_EXPERIMENTAL\) && WSIS_EXPERIMENTAL\n(.*?)#endif"
+    guarded = "".join(re.findall(guard, text, flags=re.S))
+    base = re.sub(guard, "", text, flags=re.S)
+    names = set(re.findall(r"\b(wsis_\w+)\s*\(", base))
+    extra = set(re.findall(r"\b(wsis_\w+)\s*\(", guarded))
+    assert extra and not (extra & names)
+    return sorted(names | extra) if experimental else sorted(names)
 
 
 def test_header_symbols_exported():
@@ -25,8 +36,25 @@ def test_header_symbols_exported():
 
 
 def test_binding_table_matches_header():
-    host_names, hip_names = wsis_native.declared_symbols()
-    assert sorted(host_names + hip_names) == _declared()
+    for flavour in (False, True):
+        host_names, hip_names = wsis_native.declared_symbols(experimental=flavour)
+        assert sorted(host_names + hip_names) == _declared(flavour)
+
+
+def test_default_build_does_not_export_the_retired_designs():
+    """the default library is what bench.py runs: the entry points of the retired designs exist
+    in the EXPERIMENTAL build only, and asking for one of their switches on the default build is an error"""
+    import pytest
+    hip = ctypes.CDLL(os.path.join(ROOT, "3d-wsis_amd", "libwsis_hip.so"))
+    extra = sorted(set(_declared(True)) - set(_declared(False)))
+    if wsis_native.experimental():
+        assert all(hasattr(hip, n) for n in extra)
+        return
+    assert not any(hasattr(hip, n) for n in extra)
+    for sym in ("wsis_debug_ring_diag", "wsis_debug_deep_phases"):
+        assert not hasattr(hip, sym)
+    with pytest.raises(wsis_native.WsisError):
+        wsis_native.require_experimental("WSIS_DEEP=1")
 
 
 def test_libraries_load_and_report_version():

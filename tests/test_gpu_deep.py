@@ -16,7 +16,7 @@ import torch
 import harness
 import wsis_native
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.experimental]
 
 
 def _one_pass(monkeypatch, deep, batch_host, cfg, train=True, rows=None, fence=None):

@@ -103,6 +103,7 @@ def pyramid():
 
 
 @pytest.mark.parametrize("level,kind,cin,cout,res", CASES)
+@pytest.mark.experimental
 def test_fused_conv_equals_the_unfused_sequence_bit_for_bit(pyramid, level, kind, cin, cout, res, monkeypatch):
     # the fused forms finish every product in one launch; compared with the unfused sequence on the same plan (the default
     # plan gives launches of <= 96 work items offset slabs: another, equally fixed, order of additions)
@@ -233,6 +234,7 @@ print("OK")
 """
 
 
+@pytest.mark.experimental
 def test_network_with_and_without_the_batchnorm_fusion(tmp_path):
     """every BatchNorm applied by its consuming convolution (WSIS_FUSE_BN_APPLY=0: from level 0 on) and the statistics
     finished inside the producers' launches (WSIS_FUSE_BN_FIN=1) against the BatchNorm as launches of its own (the

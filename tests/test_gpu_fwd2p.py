@@ -9,7 +9,7 @@ import harness
 import wsis_native as _n
 from spconv import ops
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.experimental]
 DEV = "cuda"
 
 

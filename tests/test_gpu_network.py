@@ -253,6 +253,7 @@ def test_training_over_scenes_of_varying_size_is_reproducible():
     assert a == b
 
 
+@pytest.mark.experimental
 def test_graph_replay_of_the_op_list_equals_eager_launches(monkeypatch):
     """WSIS_GRAPH=16: the executor records its launches (dW side stream included) into HIP graphs of ~16 ops and
     replays them; loss and every gradient must be EQUAL to the eagerly launched pass, also for a second scene of a

@@ -1340,6 +1340,7 @@ def test_batch_graphs_built_on_the_side_stream_equal_the_in_stream_build(monkeyp
 
 # ---------------------------------------------------------------- BatchNorm: statistics finish + apply in one launch
 @pytest.mark.gpu
+@pytest.mark.experimental
 @pytest.mark.parametrize("M,C", [(153685, 32), (40003, 64), (12011, 96), (3300, 128), (1100, 160), (70, 32), (200000, 256)])
 def test_bn_finalize_apply_in_one_launch_equals_the_two_calls(M, C, monkeypatch):
     monkeypatch.setenv("WSIS_BN_FUSED_APPLY", "1")      # (the one-launch form is opt-in since round 3)
@@ -1393,6 +1394,7 @@ def test_bn_finalize_apply_in_one_launch_equals_the_two_calls(M, C, monkeypatch)
 
 
 @pytest.mark.gpu
+@pytest.mark.experimental
 def test_fused_batchnorm_launches_on_two_streams_concurrently_do_not_interfere(monkeypatch):
     monkeypatch.setenv("WSIS_BN_FUSED_APPLY", "1")
     """the sync words of the one-launch BatchNorm forms live in the caller's slots (no device globals): 1,000 launches on

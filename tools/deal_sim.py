@@ -85,3 +85,20 @@ for name, sl in (("plain (slice, block) grid", plain), ("snake over the weight o
             tot, busiest, w0 = loads(sl, pw)
         print(f"{name:28s} {rule:12s}: steps per CU  whole items max {tot.max():.0f} mean {tot.mean():.1f} | busiest waves max "
               f"{busiest.max():.0f} mean {busiest.mean():.1f} | wave 0 max {w0.max():.0f} mean {w0.mean():.1f}")
+
+# ---- two-group snake: the R CUs that hold one item more (the partial last round) get the LIGHTEST (F + 1) R items, the
+# other 256 - R CUs the heaviest F (256 - R); a snake inside each group
+F, R = n_items // 256, n_items % 256
+nB = 256 - R
+ii = np.arange(n_items); cu = ii % 256; r = ii // 256
+inB = cu >= R
+b = cu - R
+itemB = np.where(r % 2 == 0, r * nB + b, r * nB + (nB - 1 - b))
+a = cu
+itemA = F * nB + np.where(r % 2 == 0, r * R + a, r * R + (R - 1 - a))
+item = np.where(inB, itemB, itemA)
+assert sorted(item.tolist()) == list(range(n_items)), "not a permutation"
+for rule, pw in (("k % NW", own), ("active dealt", deal)):
+    tot = np.bincount(cu, weights=w_slice[item // gy] * nchunk, minlength=256)
+    busiest = np.bincount(cu, weights=pw[item // gy].max(1) * nchunk, minlength=256)
+    print(f"{'two-group snake':28s} {rule:12s}: steps per CU  whole items max {tot.max():.0f} mean {tot.mean():.1f} | busiest waves max {busiest.max():.0f} mean {busiest.mean():.1f}")
