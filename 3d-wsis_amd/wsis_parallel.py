@@ -19,6 +19,29 @@ import torch
 import torch.distributed as dist
 
 
+def warm_streams(device=None):
+    """gives every stream of a training step -- the current one, the rulebook / branch stream, the count-check stream and
+    the library's weight-gradient stream -- its first command, i.e. its hardware queue.  HIP maps streams onto
+    GPU_MAX_HW_QUEUES (4) hardware queues in the order of their first use; a process group created first puts RCCL's
+    streams in between, and two streams of a step then share a queue (the one-rank RCCL line read 9.5 ms per step against
+    7.9 without a group: tools/rccl_ab.sh).  ``init_distributed`` calls it before it creates the group."""
+    if not torch.cuda.is_available():
+        return
+    import wsis_native as _n
+    from spconv import ops as sp_ops
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (dev.type, dev.index)
+    chk = sp_ops._CHECK_STREAMS.get(key)
+    if chk is None:
+        chk = sp_ops._CHECK_STREAMS[key] = torch.cuda.Stream(device=dev)
+    with torch.cuda.device(dev):
+        _n.check(_n.hip().wsis_warm_streams(_n.stream_ptr()), "warm_streams")      # main + weight-gradient stream
+        for st in (sp_ops._side_stream(dev), chk):
+            with torch.cuda.stream(st):
+                torch.zeros(1, device=dev).add_(1.0)
+        torch.cuda.synchronize(dev)
+
+
 def init_distributed(backend=None):
     """reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -36,6 +59,7 @@ def init_distributed(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+            warm_streams()              # this process's streams take their hardware queues before RCCL's do
         import datetime
         # WSIS_DIST_TIMEOUT (seconds): a rank that dies or raises must not leave its peers blocked in a collective for
         # the backend's default of 10-30 minutes

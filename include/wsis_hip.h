@@ -718,6 +718,10 @@ int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, vo
  * pass still runs (the reference's DDP buckets, train_scannetv2.py:738).  mark_op < 0: no milestone. */
 int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream,
                         int32_t mark_op, void* waiter_stream);
+/* Creates the library's weight-gradient side stream of `stream` and binds both to their hardware queues (first command).
+ * Call before creating an RCCL communicator in the same process (wsis_parallel.warm_streams does): streams take their
+ * hardware queue in the order of their first use, and two streams of a step must not end up sharing one. */
+int wsis_warm_streams(void* stream);
 /* A pass issued in PARTS -- the host does something between two parts (the statistics exchange of a SyncBatchNorm layer:
  * train_scannetv2.py:734-736 converts every BatchNorm when num_gpus > 1; model/unet_native.py).  Parts with last == 0
  * leave the weight-gradient side stream un-joined; the part with last != 0 (n may be 0) joins everything forked since.

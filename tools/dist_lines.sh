@@ -6,11 +6,11 @@ set -x
 R=${R:-r05}
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
-WSIS_FORCE_DIST=1 timeout -k 10 240 python bench.py --gpus 1 --steps 20 --warmup 5 --setup-steps 100 --no-cpu-baseline --no-stages > $O/${R}_bench_rccl1.json 2> $O/${R}_bench_rccl1.err
+WSIS_FORCE_DIST=1 timeout -k 10 240 python bench.py --gpus 1 --steps 40 --warmup 5 --no-cpu-baseline --no-stages > $O/${R}_bench_rccl1.json 2> $O/${R}_bench_rccl1.err
 tail -c 300 $O/${R}_bench_rccl1.json
-WSIS_FORCE_DIST=1 timeout -k 10 240 python bench.py --gpus 1 --scenes-per-gpu 4 --steps 20 --warmup 5 --setup-steps 60 --no-cpu-baseline --no-stages > $O/${R}_bench_rccl1_spg4.json 2> $O/${R}_bench_rccl1_spg4.err
+WSIS_FORCE_DIST=1 timeout -k 10 240 python bench.py --gpus 1 --scenes-per-gpu 4 --steps 20 --warmup 5 --setup-steps 150 --no-cpu-baseline --no-stages > $O/${R}_bench_rccl1_spg4.json 2> $O/${R}_bench_rccl1_spg4.err
 tail -c 300 $O/${R}_bench_rccl1_spg4.json
-WSIS_FORCE_DIST=1 timeout -k 10 240 python bench.py --gpus 1 --scenes-per-gpu 4 --sync-bn --steps 20 --warmup 5 --setup-steps 60 --no-cpu-baseline --no-stages > $O/${R}_bench_rccl1_syncbn.json 2> $O/${R}_bench_rccl1_syncbn.err
+WSIS_FORCE_DIST=1 timeout -k 10 240 python bench.py --gpus 1 --scenes-per-gpu 4 --sync-bn --steps 20 --warmup 5 --setup-steps 150 --no-cpu-baseline --no-stages > $O/${R}_bench_rccl1_syncbn.json 2> $O/${R}_bench_rccl1_syncbn.err
 tail -c 300 $O/${R}_bench_rccl1_syncbn.json
 WSIS_DIST_BACKEND=gloo timeout -k 10 240 python bench.py --gpus 2 --small --steps 5 --warmup 2 --setup-steps 5 --no-cpu-baseline --no-stages > $O/${R}_bench_gloo2_small.json 2> $O/${R}_bench_gloo2_small.err
 tail -c 300 $O/${R}_bench_gloo2_small.json
