@@ -32,7 +32,7 @@ namespace {
 struct ItemMap {
   int bx, by, bz;
 };
-__device__ __forceinline__ ItemMap item_of(int i, int gx, int gy, int gz, int band) {
+__host__ __device__ __forceinline__ ItemMap item_of(int i, int gx, int gy, int gz, int band) {
   const int total = gx * gy * gz;
   const int b = i / band, c = i - b * band;
   int j = i;
@@ -449,6 +449,17 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
     WSIS_LAUNCH_CHECK();
   }
   return WSIS_OK;
+}
+
+// diagnostic (not part of the ABI header; host only, no GPU call): the work item of workgroup i of a launch of
+// gx slices x gy blocks x gz slabs dealt over bands of `band` -- the map of item_of, for tests/test_item_deal.py
+int wsis_debug_item_of(int32_t i, int32_t gx, int32_t gy, int32_t gz, int32_t band, int32_t* out3) {
+  if (!out3 || gx < 1 || gy < 1 || gz < 1 || band < 1 || i < 0 || (int64_t)i >= (int64_t)gx * gy * gz) return -1;
+  const ItemMap m = item_of(i, gx, gy, gz, band);
+  out3[0] = m.bx;
+  out3[1] = m.by;
+  out3[2] = m.bz;
+  return 0;
 }
 
 // diagnostic (not part of the ABI header): the NW = 1 kernel with per-workgroup stamps, dbg[ceil(M/32) * Cout/32 * 8];

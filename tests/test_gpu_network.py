@@ -561,3 +561,63 @@ def test_branch_stream_gives_the_results_of_one_stream(monkeypatch):
     assert la == lb == lc and all(x == x for x in la)
     assert [k for k in pa if not torch.equal(pa[k], pb[k])] == []
     assert [k for k in pa if not torch.equal(pa[k], pc[k])] == []
+
+
+def test_unet_gradients_accumulate_and_follow_requires_grad():
+    """the UNet's parameters are not inputs of its autograd node (model/unet_native.py): its backward pass stores the
+    gradients in ``.grad`` itself.  The semantics of autograd must hold all the same: a second backward pass without
+    ``zero_grad`` ADDS to what is there (exactly: the two passes are identical, so every gradient doubles), a parameter
+    with ``requires_grad=False`` gets none while its neighbours keep theirs, and the fast path (gradients as views of the
+    program's persistent buffer) comes back once the gradients are cleared."""
+    cfg, batch_host, model, crit, opt, _ = _setup(1, 31, (1.5, 1.2, 1.0))
+    batch = harness.to_device(batch_host, "cuda")
+    model.train()
+
+    def grads():
+        loss, _ = harness.forward_loss(model, crit, batch, cfg)
+        loss.backward()
+        return {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+
+    model.zero_grad(set_to_none=True)
+    g1 = {n: g.clone() for n, g in grads().items()}
+    unet_names = [n for n in g1 if n.startswith(("unet.", "input_conv.", "output_layer."))]
+    assert len(unet_names) > 100
+    prog = model._native_prog
+    lo, hi = prog.flat_grad.data_ptr(), prog.flat_grad.data_ptr() + prog.flat_grad.numel() * 4
+    params = dict(model.named_parameters())
+    assert all(lo <= params[n].grad.data_ptr() < hi for n in unet_names)             # views of the flat buffer
+    g2 = grads()                                                                       # no zero_grad: accumulate
+    for n in g1:
+        assert torch.equal(g2[n], g1[n] + g1[n]), n
+    assert not any(lo <= params[n].grad.data_ptr() < hi for n in unet_names)           # (a buffer of their own now)
+    # frozen parameter
+    model.zero_grad(set_to_none=True)
+    frozen = unet_names[len(unet_names) // 2]
+    params[frozen].requires_grad_(False)
+    g3 = grads()
+    assert frozen not in g3
+    for n in g1:
+        if n != frozen:
+            assert torch.equal(g3[n], g1[n]), n
+    params[frozen].requires_grad_(True)
+    model.zero_grad(set_to_none=True)
+    g4 = grads()
+    for n in g1:
+        assert torch.equal(g4[n], g1[n]), n
+    lo, hi = prog.flat_grad.data_ptr(), prog.flat_grad.data_ptr() + prog.flat_grad.numel() * 4
+    assert all(lo <= params[n].grad.data_ptr() < hi for n in unet_names)
+
+
+def test_warm_streams_is_idempotent_and_leaves_results_alone():
+    """wsis_parallel.warm_streams() (what init_distributed runs before it creates a process group: every stream of a
+    step takes its hardware queue first) can be called at any time, any number of times"""
+    import wsis_parallel
+    cfg, batch_host, model, crit, opt, _ = _setup(1, 33, (1.2, 1.0, 0.8))
+    batch = harness.to_device(batch_host, "cuda")
+    model.train()
+    wsis_parallel.warm_streams()
+    l0, _ = harness.forward_loss(model, crit, batch, cfg)
+    wsis_parallel.warm_streams()
+    wsis_parallel.warm_streams("cuda:0")
+    l1, _ = harness.forward_loss(model, crit, batch, cfg)
+    assert torch.equal(l0, l1)
