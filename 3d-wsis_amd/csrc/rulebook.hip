@@ -173,6 +173,97 @@ __global__ void down_cand_kernel(const int32_t* __restrict__ indices, int64_t M,
   }
 }
 
+// ---- output coordinates of a strided convolution WITHOUT a sort (round 5): the distinct output cells of a level are the
+// set bits of a bitmap over the output grid (batch x shape_out, linear index = bit index), so "sorted unique keys" is a
+// prefix popcount: mark (atomicOr), count per 1,024-word chunk, scan the chunk sums, emit.  5 launches instead of the 13
+// of candidate keys + merge sort + unique (each a few microseconds of pure latency on ~10^5 keys); identical output --
+// ascending linear index, SURVEY App. A.1.  Used when k == s, p == 0 (every input voxel has ONE output cell: the UNet's
+// SparseConv3d k2 s2) and the bitmap fits the level's sort workspace; otherwise the sort path below.
+constexpr int BM_WORDS_PER_WG = 1024;      // 256 threads x 4 words
+
+__global__ void down_mark_kernel(const int32_t* __restrict__ indices, int64_t M, Geo g, int64_t n_cells,
+                                 uint32_t* __restrict__ bitmap) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < M; r += (int64_t)gridDim.x * blockDim.x) {
+    const int4 c = reinterpret_cast<const int4*>(indices)[r];
+    const int o0 = c.y / g.s[0], o1 = c.z / g.s[1], o2 = c.w / g.s[2];
+    if (o0 >= g.shape_out[0] || o1 >= g.shape_out[1] || o2 >= g.shape_out[2]) continue;
+    const int64_t key = lin_key(c.x, o0, o1, o2, g.shape_out);
+    if (key < 0 || key >= n_cells) continue;      // (a batch index past batch_size: not an output of this build)
+    atomicOr(bitmap + (key >> 5), 1u << (key & 31));
+  }
+}
+
+__device__ __forceinline__ int bm_block_scan(int v, int* lds, int& total) {      // exclusive scan over 256 threads
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) lds[wave] = x;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += lds[w];
+  total = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  return base + x - v;
+}
+
+__global__ __launch_bounds__(256) void bitmap_count_kernel(const uint32_t* __restrict__ bitmap, int64_t n_words,
+                                                           int32_t* __restrict__ chunk_sum) {
+  __shared__ int lds[4];
+  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  int pc = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (w0 + j < n_words) pc += __popc(bitmap[w0 + j]);
+  int total;
+  (void)bm_block_scan(pc, lds, total);
+  if (threadIdx.x == 0) chunk_sum[blockIdx.x] = total;
+}
+
+// one workgroup: chunk sums -> exclusive prefix in place, total -> *count
+__global__ __launch_bounds__(256) void bitmap_scan_kernel(int32_t* __restrict__ chunk_sum, int n_chunks,
+                                                          int32_t* __restrict__ count) {
+  __shared__ int lds[4];
+  int carry = 0;
+  for (int c0 = 0; c0 < n_chunks; c0 += 256) {
+    const int i = c0 + (int)threadIdx.x;
+    const int v = i < n_chunks ? chunk_sum[i] : 0;
+    int total;
+    const int ex = bm_block_scan(v, lds, total);
+    if (i < n_chunks) chunk_sum[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) *count = carry;
+}
+
+__global__ __launch_bounds__(256) void bitmap_emit_kernel(const uint32_t* __restrict__ bitmap, int64_t n_words,
+                                                          const int32_t* __restrict__ chunk_base,
+                                                          int64_t* __restrict__ out_keys) {
+  __shared__ int lds[4];
+  const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  uint32_t w[4];
+  int pc = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    w[j] = w0 + j < n_words ? bitmap[w0 + j] : 0u;
+    pc += __popc(w[j]);
+  }
+  int total;
+  int64_t at = chunk_base[blockIdx.x] + bm_block_scan(pc, lds, total);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t m = w[j];
+    while (m) {
+      const int b = __builtin_ctz(m);
+      m &= m - 1u;
+      out_keys[at++] = ((w0 + j) << 5) | b;
+    }
+  }
+}
+
 __global__ void down_fix_count_kernel(const int64_t* __restrict__ out_keys, int64_t invalid,
                                       int32_t* __restrict__ count) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -583,6 +674,41 @@ int wsis_rulebook_down_keys(const int32_t* d_indices_in, int64_t M_in, const int
   return WSIS_OK;
 }
 
+namespace {
+// bitmap form of wsis_rulebook_down_keys (see down_mark_kernel); false: does not apply, nothing was issued
+bool down_keys_bitmap(const int32_t* d_indices_in, int64_t M_in, const int32_t* h_in_shape3, const int32_t* h_out_shape3,
+                      const int32_t* k, const int32_t* s3, const int32_t* p, int32_t batch_size, int64_t* d_out_keys,
+                      int32_t* d_count, void* d_ws, int64_t ws_bytes, hipStream_t st, int* rc_out) {
+  *rc_out = WSIS_OK;
+  for (int j = 0; j < 3; ++j)
+    if (k[j] != s3[j] || p[j] != 0) return false;
+  if (batch_size < 1 || M_in < 1 || !d_ws) return false;
+  const int64_t n_cells = (int64_t)batch_size * h_out_shape3[0] * h_out_shape3[1] * h_out_shape3[2];
+  if (n_cells < 1 || n_cells > ((int64_t)1 << 31)) return false;
+  const int64_t n_words = (n_cells + 31) >> 5;
+  const int64_t n_chunks = (n_words + BM_WORDS_PER_WG - 1) / BM_WORDS_PER_WG;
+  const int64_t need = (int64_t)align256((size_t)n_words * 4) + (int64_t)align256((size_t)n_chunks * 4);
+  if (need > ws_bytes || n_chunks > (1 << 22)) return false;
+  Geo g;
+  if (fill_geo(g, h_in_shape3, h_out_shape3, k, s3, p) != 0) return false;
+  uint32_t* bitmap = static_cast<uint32_t*>(d_ws);
+  int32_t* chunk = reinterpret_cast<int32_t*>(static_cast<char*>(d_ws) + align256((size_t)n_words * 4));
+  auto fail_hip = [&](hipError_t e) {
+    *rc_out = fail(WSIS_ERR_HIP, "down_keys_bitmap: %s", hipGetErrorString(e));
+    return true;
+  };
+  hipError_t e = hipMemsetAsync(bitmap, 0, (size_t)n_words * 4, st);
+  if (e != hipSuccess) return fail_hip(e);
+  hipLaunchKernelGGL(down_mark_kernel, dim3(grid_for(M_in, 256)), dim3(256), 0, st, d_indices_in, M_in, g, n_cells, bitmap);
+  hipLaunchKernelGGL(bitmap_count_kernel, dim3((unsigned)n_chunks), dim3(256), 0, st, bitmap, n_words, chunk);
+  hipLaunchKernelGGL(bitmap_scan_kernel, dim3(1), dim3(256), 0, st, chunk, (int)n_chunks, d_count);
+  hipLaunchKernelGGL(bitmap_emit_kernel, dim3((unsigned)n_chunks), dim3(256), 0, st, bitmap, n_words, chunk, d_out_keys);
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e);
+  return true;
+}
+}  // namespace
+
 int wsis_rulebook_down_fill(const int32_t* d_indices_in, int64_t M_in, const int32_t* h_in_shape3,
                             const int32_t* h_out_shape3, const int32_t* h_ksize3,
                             const int32_t* h_stride3, const int32_t* h_pad3,
@@ -967,9 +1093,13 @@ int wsis_rulebook_pyramid(const int32_t* d_indices0, int64_t M0, const int32_t* 
     const int64_t M_out = L.off[l + 1][WSIS_PYR_ROWS];
     int32_t out_shape[3];
     for (int j = 0; j < 3; ++j) out_shape[j] = (shape[j] - 2) / 2 + 1;
-    rc = wsis_rulebook_down_keys(indices, M, shape, out_shape, k2, s2, p0, static_cast<int64_t*>(at(l, WSIS_PYR_CAND)),
-                                 static_cast<int64_t*>(at(l, WSIS_PYR_OUT_KEYS)), static_cast<int32_t*>(at(l, WSIS_PYR_COUNT)),
-                                 at(l, WSIS_PYR_DOWN_WS), wsis_rulebook_down_workspace_bytes(M), stream);
+    // output cells: bitmap + prefix popcount where it applies (5 launches), candidate keys + sort + unique otherwise (13)
+    if (!down_keys_bitmap(indices, M, shape, out_shape, k2, s2, p0, batch_size, static_cast<int64_t*>(at(l, WSIS_PYR_OUT_KEYS)),
+                          static_cast<int32_t*>(at(l, WSIS_PYR_COUNT)), at(l, WSIS_PYR_DOWN_WS),
+                          wsis_rulebook_down_workspace_bytes(M), as_stream(stream), &rc))
+      rc = wsis_rulebook_down_keys(indices, M, shape, out_shape, k2, s2, p0, static_cast<int64_t*>(at(l, WSIS_PYR_CAND)),
+                                   static_cast<int64_t*>(at(l, WSIS_PYR_OUT_KEYS)), static_cast<int32_t*>(at(l, WSIS_PYR_COUNT)),
+                                   at(l, WSIS_PYR_DOWN_WS), wsis_rulebook_down_workspace_bytes(M), stream);
     if (rc != WSIS_OK) return rc;
     int32_t* idx_out = static_cast<int32_t*>(at(l + 1, WSIS_PYR_INDICES));
     rc = wsis_rulebook_down_fill(indices, M, shape, out_shape, k2, s2, p0, static_cast<const int64_t*>(at(l, WSIS_PYR_OUT_KEYS)),

@@ -9,6 +9,8 @@ idx, shape = b["voxel_coords_int"], b["spatial_shape"]
 feat = torch.zeros(idx.shape[0], 1, device="cuda")
 def build():
     t = spconv.SparseConvTensor(feat, idx, shape, 1)
+    if os.environ.get("RB_COUNTS", "1") != "0" and b.get("level_counts") is not None:
+        t._level_counts = b["level_counts"]      # the loader's host-side counts: the whole pyramid from ONE native call
     ops.prebuild_unet_rulebooks(t, 5, side_stream=False)
     return t
 for flag in ("1", "0", "1", "0"):
