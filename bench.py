@@ -12,8 +12,7 @@ rank, no data-path collective, weak scaling.  `python bench.py --gpus N` without
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      -- dominant kernel family (the forward / dIn launches of the 49 sparse convs: spconv_fwd2_kernel,
-                   spconv_in_kernel for the 6-channel input conv; the persistent form spconv_fwd2p_kernel only with
-                   WSIS_FWD2P=1): algorithmic gather/scatter bytes (P*(Cin+Cout)*4 + P*8 per launch,
+                   spconv_in_kernel for the 6-channel input conv): algorithmic gather/scatter bytes (P*(Cin+Cout)*4 + P*8 per launch,
                    SURVEY 8d) / HIP-event time of those launches, against the 8 TB/s HBM peak.
   cpu_baseline  -- the oracle (torch-CPU restatement mirroring upstream's gather -> mm -> scatter-add) timed on
                    this box's host cores on the same scene (rank 0, N = 1 only).
@@ -669,8 +668,7 @@ def main():
         k = summ.get("spconv_fwd_kernel")
         if k and k["ms"] > 0:
             gbs = k["bytes"] / (k["ms"] * 1e-3) / 1e9
-            roof = {"kernel": "spconv_fwd2_kernel (spconv_in_kernel for the 6-channel input conv; the persistent form "
-                              "spconv_fwd2p_kernel only with WSIS_FWD2P=1) INCLUDING the fixed-order slab sums that "
+            roof = {"kernel": "spconv_fwd2_kernel (spconv_in_kernel for the 6-channel input conv) INCLUDING the fixed-order slab sums that "
                               "finish a product (spconv2_reduce_kernel / spconv2_reduce_stats_kernel)",
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
