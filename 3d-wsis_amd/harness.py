@@ -511,7 +511,11 @@ def forward_loss(model, criterion, batch, cfg, epoch=5):
     if cfg.model.use_coords:
         feats = torch.cat((feats, coords_float), 1)
     voxel_feats = pointgroup_ops.voxelization(feats, batch["v2p_map"], cfg.mode)
-    input_ = spconv.SparseConvTensor(voxel_feats, batch["voxel_coords_int"], batch["spatial_shape"], cfg.batch_size)
+    # batch_size as the reference passes it (the configured one) -- but never below the scenes this batch really holds:
+    # the rulebook build sizes its output-cell bitmap by it (upstream sizes its dense grid the same way)
+    n_scenes = int(batch["sp_batch_offsets"].shape[0]) - 1 if "sp_batch_offsets" in batch else 0
+    input_ = spconv.SparseConvTensor(voxel_feats, batch["voxel_coords_int"], batch["spatial_shape"],
+                                     max(int(cfg.batch_size), n_scenes))
     input_._ready_event = batch.get("coords_ready_event")
     counts = batch.get("level_counts")
     if counts is not None and len(counts) == model.blocks - 1:

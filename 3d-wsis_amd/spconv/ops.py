@@ -281,7 +281,9 @@ def verify_pending_counts():
                            % (_n.sync_errors(),))
     for g, (_, want, _) in zip(got, pend):
         if int(g) != int(want):
-            raise _n.WsisError("strided rulebook: the device found %d output voxels, the batch's level_counts said %d"
+            raise _n.WsisError("strided rulebook: the device found %d output voxels, the batch's level_counts said %d "
+                               "(a hint that does not belong to these coordinates, or a SparseConvTensor batch_size below "
+                               "the number of scenes in the batch: batch indices >= batch_size are not part of the build)"
                                % (int(g), int(want)))
 
 
