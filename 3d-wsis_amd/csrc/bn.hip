@@ -1293,6 +1293,31 @@ int wsis_bn_stats_finalize_apply(const float* d_partials, int64_t n_part, int64_
   return WSIS_OK;
 }
 
+// grid of an apply pass over `work` vector items in `cw` channel groups: eight items per thread (four trips of two) where
+// that still leaves 512 workgroups, else one workgroup per 256 items up to 512 -- rounded down to a multiple of the
+// channel groups (a thread then keeps its channel group for its whole walk).  The round-4 grid (one item per thread up
+// to 2,048 workgroups) left a level-0 thread 2.3 items -- a third trip that a third of the threads take -- and a level-1
+// thread ONE: nothing in flight behind it.  tools/bn_bench.py, apply / backward apply in us: 153,685 x 32: 9.0 / 14.7 ->
+// 7.4 / 12.0; 26,819 x 64: 9.5 / 16.4 -> 4.7 / 9.1; 26,819 x 128: 11.3 / 18.4 -> 6.5 / 10.2; small levels unchanged.
+static int bn_apply_grid(int64_t work, int cw, int pt_unused) {
+  (void)pt_unused;
+  const int pt = tune_int("WSIS_BN_APPLY_PT", 8);
+  int64_t g;
+  if (pt < 0) {      // the round-4 grid
+    g = grid_for(work, 256);
+  } else {
+    g = ceil_div(work, (int64_t)256 * pt);
+    if (g < 512) {
+      g = ceil_div(work, 256);
+      if (g > 512) g = 512;
+    }
+    if (g > 16384) g = 16384;
+  }
+  if (g < 1) g = 1;
+  if (g > cw) g -= g % cw;
+  return (int)g;
+}
+
 int wsis_bn_apply(const float* d_x, const float* d_mean, const float* d_var, const float* d_gamma,
                   const float* d_beta, float eps, int32_t relu, float* d_y, int64_t M, int32_t C, void* stream) {
   WSIS_REQUIRE(M >= 0 && C >= 1, "bad sizes");
@@ -1301,8 +1326,7 @@ int wsis_bn_apply(const float* d_x, const float* d_mean, const float* d_var, con
   const int64_t work = (C & 3) == 0 ? (M * C) >> 2 : M * C;
   // grid rounded to a multiple of the channel groups: a thread then keeps one channel group for its whole walk
   const int cw = (C & 3) == 0 ? C >> 2 : C;
-  int grid = grid_for(work, 256);
-  if (grid > cw) grid -= grid % cw;
+  const int grid = bn_apply_grid(work, cw, 2);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, as_stream(stream), d_x, d_mean, d_var,
                      d_gamma, d_beta, eps, relu, d_y, M, C);
   WSIS_LAUNCH_CHECK();
@@ -1352,8 +1376,7 @@ int wsis_bn_bwd_from_partials(const float* d_partials, int64_t n_part, const flo
   if (d_dx) {
     const int64_t work = (C & 3) == 0 ? (M * C) >> 2 : M * C;
     const int cw = (C & 3) == 0 ? C >> 2 : C;
-    int grid = grid_for(work, 256);
-    if (grid > cw) grid -= grid % cw;
+    const int grid = bn_apply_grid(work, cw, 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, d_x, d_dy, d_mean, d_var, d_gamma, d_beta,
                        d_dgamma, d_dbeta, d_addend, eps, relu, 1, d_dx, M, C);
     WSIS_LAUNCH_CHECK();
@@ -1367,8 +1390,7 @@ int wsis_bn_bwd_apply(const float* d_x, const float* d_dy, const float* d_mean, 
   WSIS_REQUIRE(M >= 1 && C >= 1 && d_x && d_dy && d_mean && d_var && d_sum_dz_xhat && d_sum_dz && d_dx, "bad args");
   const int64_t work = (C & 3) == 0 ? (M * C) >> 2 : M * C;
   const int cw = (C & 3) == 0 ? C >> 2 : C;
-  int grid = grid_for(work, 256);
-  if (grid > cw) grid -= grid % cw;
+  const int grid = bn_apply_grid(work, cw, 2);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, as_stream(stream), d_x, d_dy, d_mean, d_var, d_gamma,
                      d_beta, d_sum_dz_xhat, d_sum_dz, d_addend, eps, relu, 1, d_dx, M, C);
   WSIS_LAUNCH_CHECK();
@@ -1401,8 +1423,7 @@ int wsis_bn_bwd(const float* d_x, const float* d_dy, const float* d_mean, const 
     // grid rounded to a multiple of the channel groups: a thread then keeps one channel group for its whole walk
     const int64_t work = (C & 3) == 0 ? (M * C) >> 2 : M * C;
     const int cw = (C & 3) == 0 ? C >> 2 : C;
-    int grid = grid_for(work, 256);
-    if (grid > cw) grid -= grid % cw;
+    const int grid = bn_apply_grid(work, cw, 2);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, st, d_x, d_dy, d_mean, d_var, d_gamma, d_beta,
                        d_dgamma, d_dbeta, d_addend, eps, relu, training, d_dx, M, C);
     WSIS_LAUNCH_CHECK();

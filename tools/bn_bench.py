@@ -19,4 +19,6 @@ for M,C in [(153685,32),(153685,64),(26819,64),(26819,128),(6500,96),(1600,128),
     t_bwd_red=timeit(lambda: lib.wsis_bn_bwd(x.data_ptr(),dy.data_ptr(),mean.data_ptr(),var.data_ptr(),g.data_ptr(),b.data_ptr(),1e-4,1,1,None,dg.data_ptr(),db.data_ptr(),None,M,C,ws.data_ptr(),wsb,st))
     t_bwd=timeit(lambda: lib.wsis_bn_bwd(x.data_ptr(),dy.data_ptr(),mean.data_ptr(),var.data_ptr(),g.data_ptr(),b.data_ptr(),1e-4,1,1,dx.data_ptr(),dg.data_ptr(),db.data_ptr(),None,M,C,ws.data_ptr(),wsb,st))
     mb=M*C*4/1e6
+    if os.environ.get("BN_COMPACT"):
+        print(f"M={M:7d} C={C:4d}: apply {t_apply:5.1f}us  bwd apply {t_bwd-t_bwd_red:5.1f}us"); continue
     print(f"M={M:7d} C={C:4d} ({mb:6.1f} MB/tensor): stats {t_stats:6.1f}us ({mb/t_stats*1e-3*1e3:6.0f} GB/s)  apply {t_apply:6.1f}us ({2*mb/t_apply:6.0f} GB/s)  bwd reduce {t_bwd_red:6.1f}us ({2*mb/t_bwd_red:6.0f} GB/s)  bwd total {t_bwd:6.1f}us (apply part {t_bwd-t_bwd_red:6.1f}us, {3*mb/max(t_bwd-t_bwd_red,1e-3):6.0f} GB/s)")
