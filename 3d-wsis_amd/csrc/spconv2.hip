@@ -34,6 +34,26 @@ struct ItemMap {
 };
 __host__ __device__ __forceinline__ ItemMap item_of(int i, int gx, int gy, int gz, int band) {
   const int total = gx * gy * gz;
+  ItemMap m;
+  const int per = gy * gz;
+  if (band < 0) {
+    // XCD-chunked deal: workgroup i runs on XCD i % 8 (static round-robin), each XCD with its own 4 MB L2.  XCD x takes
+    // runs of C = -band consecutive items of the weight order -- runs x, x + 8, x + 16, ... -- so slices that are
+    // neighbours in space (the order is Morton inside a weight class) gather through the same L2; inside a run the
+    // direction alternates (the CUs of an XCD take its items round-robin)
+    const int C = -band, x = i & 7, q = i >> 3;
+    const int nb = total / (8 * C);
+    int j = i;
+    if (q < nb * C) {
+      const int sb = q / C, w = q - sb * C;
+      j = (sb * 8 + x) * C + ((sb & 1) ? C - 1 - w : w);
+    }
+    m.bx = j / per;
+    const int r = j - m.bx * per;
+    m.by = r / gz;
+    m.bz = r - m.by * gz;
+    return m;
+  }
   const int b = i / band, c = i - b * band;
   int j = i;
   const int F = total / band, R = total - F * band;      // full rounds of the CUs, workgroups of the partial last one
@@ -53,8 +73,6 @@ __host__ __device__ __forceinline__ ItemMap item_of(int i, int gx, int gy, int g
     const int left = total - b * band;
     j = b * band + ((left < band ? left : band) - 1 - c);
   }
-  ItemMap m;
-  const int per = gy * gz;
   m.bx = j / per;
   const int r = j - m.bx * per;
   m.by = r / gz;
@@ -62,7 +80,7 @@ __host__ __device__ __forceinline__ ItemMap item_of(int i, int gx, int gy, int g
   return m;
 }
 
-template <int NB, int NW, int DA, bool BD, bool DIAG = false, bool FB = false>
+template <int NB, int NW, int DA, bool BD, bool DIAG = false, bool FB = false, bool TR = false>
 __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ WT, const float* __restrict__ bias, const float* __restrict__ residual,
@@ -74,12 +92,33 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
   const LateVals late{bias, residual, out, partial, stats, epi};
   const int gx = (int)((M_out + SL - 1) / SL), gy = Cout / (32 * NB);
   const ItemMap it = item_of((int)blockIdx.x, gx, gy, gz, band);
-  fwd2_body<NB, NW, DA, BD, DIAG, FB, false>(X, nbrS, order, WT, late, M_out, K, Cin, Cout, flip_deal, x_bytes, bin, &fin, dbg,
-                                            it.bx, it.by, it.bz, gy, gz, lds, (int)threadIdx.x, sync);
+  fwd2_body<NB, NW, DA, BD, DIAG, FB, false, TR>(X, nbrS, order, WT, late, M_out, K, Cin, Cout, flip_deal, x_bytes, bin, &fin,
+                                                dbg, it.bx, it.by, it.bz, gy, gz, lds, (int)threadIdx.x, sync);
 }
 
 
 #if WSIS_EXPERIMENTAL
+// ---- one-wave work items with both operands straight to registers (spconv2_body.h: RG).  Four waves per SIMD: the
+// register file is what bounds the waves per CU here (5.4 KB of LDS per item), so the kernel is held to 128 registers.
+// Bit-identical, measured SLOWER on level 0 (61.4 against 55.2 us): the long items and the last round run a step per
+// 1,700-2,500 cycles instead of 2,700-3,600, but a row-per-lane load touches 4x the cache lines per instruction of the
+// coalesced LDS-DMA piece and the full rounds go from 5,300 to 7,800 cycles per step.  Kept as WSIS_FWD2_RG=1.
+template <bool DIAG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void spconv_fwd2rg_kernel(
+    const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
+    const float* __restrict__ WT, const float* __restrict__ bias, const float* __restrict__ residual,
+    float* __restrict__ out, float* __restrict__ partial, int64_t M_out, int K, int Cin, int Cout, int flip_deal,
+    uint32_t x_bytes, float* __restrict__ stats, BnEpi epi, BnIn bin, StatFin fin, int gz, int band,
+    unsigned long long* __restrict__ dbg = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  WgSync sync;
+  const LateVals late{bias, residual, out, partial, stats, epi};
+  const int gx = (int)((M_out + SL - 1) / SL), gy = Cout / 32;
+  const ItemMap it = item_of((int)blockIdx.x, gx, gy, gz, band);
+  fwd2_body<1, 1, 2, true, DIAG, false, false, false, true>(X, nbrS, order, WT, late, M_out, K, Cin, Cout, flip_deal, x_bytes, bin,
+                                                            &fin, dbg, it.bx, it.by, it.bz, gy, gz, lds, (int)threadIdx.x, sync);
+}
+
 // ---- persistent form for launches of more than one round of work items (levels 0-1 of a scene: 4,803 one-wave items
 // over 3,072 resident waves are 1.56 rounds whose second round runs on 7 of the 12 wave slots of a CU).  gridDim.x
 // workgroups -- as many as are resident at once -- stay on the machine: each starts with work item blockIdx.x and then
@@ -289,7 +328,12 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
     WSIS_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
     n_cu = v > 0 ? v : 256;
   }
-  const int deal_band = tune_int("WSIS_FWD2_SNAKE", 1) ? n_cu : 0x7fffffff;      // (read per call; 0: items in weight order)
+  // launches of many one-wave items (level 0 of a scene: several rounds of the CUs): runs of 64 items per XCD, so the
+  // gathers of neighbouring slices share an L2 (level 0, 32 -> 32: 56.3 -> 52.7 us, 64 -> 32: 96.0 -> 86.3; with fewer
+  // items per CU the balance of the snake matters more: levels 1-2 measured 0 ... +15 % slower, they keep the snake)
+  const int64_t n_items = ceil_div(M_out, SL) * (Cout / (32 * p.NB)) * p.ZS;
+  const int xcd_run = tune_int("WSIS_FWD2_XCD", (p.NW == 1 && n_items >= 8 * 64 * 8) ? 64 : 0);
+  const int deal_band = xcd_run > 0 ? -xcd_run : tune_int("WSIS_FWD2_SNAKE", 1) ? n_cu : 0x7fffffff;      // (read per call; 0: items in weight order)
   // WSIS_FWD2_DEAL=1 (read per call; default 0): active offsets dealt round-robin to the waves of a work item instead
   // of ownership by offset index.  Measured neutral on the C2 step (level 1: 1046 -> 1035-1050 us per step, level 2:
   // 855 -> 835) -- the waves of a work item are not what its lifetime waits for -- and it gives up the tile-order
@@ -368,20 +412,32 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
     }
   }
 #endif      // WSIS_EXPERIMENTAL
-#define WSIS_F2X(nb, nw, da, bd, fb)                                                                             \
+#define WSIS_F2Y(nb, nw, da, bd, fb, tr)                                                                         \
   do {                                                                                                           \
-    const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<nb, da, bd>::WAVE_BYTES * nw + (fb ? (size_t)Cin * 12 : 0); \
+    const size_t ldsb = (size_t)((tr) ? HDR_TR_BYTES : HDR_BYTES) + (size_t)Layout<nb, da, bd>::WAVE_BYTES * nw + \
+                        (fb ? (size_t)Cin * 12 : 0);                                                             \
     static size_t attr_set = 0;                                                                                  \
     if (attr_set < ldsb) {                                                                                       \
-      WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_fwd2_kernel<nb, nw, da, bd, false, fb>,             \
+      WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_fwd2_kernel<nb, nw, da, bd, false, fb, tr>,         \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));               \
       attr_set = ldsb;                                                                                           \
     }                                                                                                            \
-    hipExtLaunchKernelGGL((spconv_fwd2_kernel<nb, nw, da, bd, false, fb>), grid, dim3(64 * nw), (uint32_t)ldsb, st, \
+    hipExtLaunchKernelGGL((spconv_fwd2_kernel<nb, nw, da, bd, false, fb, tr>), grid, dim3(64 * nw), (uint32_t)ldsb, st, \
                           prof.ka(), prof.kb(), 0u, d_X, d_nbr, d_order, d_WT, d_bias, d_residual, d_out, partial,   \
                           M_out, K, Cin, Cout, flip_deal, x_bytes, d_stats, epi, bin, fin, (int)p.ZS, deal_band,    \
                           (unsigned long long*)nullptr);                                                            \
   } while (0)
+#define WSIS_F2X(nb, nw, da, bd, fb) WSIS_F2Y(nb, nw, da, bd, fb, false)
+#if WSIS_EXPERIMENTAL
+#define WSIS_F2RG() /* one-wave items, both operands to registers: LDS = gather table + epilogue scratch */           \
+  do {                                                                                                           \
+    const size_t ldsb = (size_t)HDR_BYTES + (fin.chunk ? (size_t)Layout<1, 2, true>::WAVE_BYTES : (size_t)RG_SCRATCH_BYTES); \
+    hipExtLaunchKernelGGL((spconv_fwd2rg_kernel<false>), grid, dim3(64), (uint32_t)ldsb, st, \
+                          prof.ka(), prof.kb(), 0u, d_X, d_nbr, d_order, d_WT, d_bias, d_residual, d_out, partial,   \
+                          M_out, K, Cin, Cout, flip_deal, x_bytes, d_stats, epi, bin, fin, (int)p.ZS, deal_band,    \
+                          (unsigned long long*)nullptr);                                                            \
+  } while (0)
+#endif
 #define WSIS_F2(nb, nw, da)             \
   if (p.BD)                             \
     WSIS_F2X(nb, nw, da, true, false);  \
@@ -397,6 +453,9 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
 #define WSIS_F2B(nw) WSIS_F2X(1, nw, 2, true, false)
   WSIS_REQUIRE(!bn_in, "fused input BatchNorm: EXPERIMENTAL build only");
 #endif
+  // one-wave items with the table entries in registers (8.25 instead of 12.3 KB of LDS per item): needs a gather table
+  // (the 1x1x1 convolutions have none) and row indices the 24-bit multiply holds
+  const bool tr_ok = d_nbr != nullptr && !bn_in && M_in < ((int64_t)1 << 24) && tune_int("WSIS_FWD2_TR", 1) != 0;
   if (p.NB == 1 && p.DA == 2 && p.BD && (bn_in || p.NW == 16)) {
     switch (p.NW) {
       case 1: WSIS_F2B(1); break;
@@ -411,7 +470,19 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
   const int key = p.NB * 100 + p.NW * 10 + p.DA;
   switch (key) {
     case 113: WSIS_F2(1, 1, 3); break;
-    case 112: WSIS_F2(1, 1, 2); break;
+    case 112:
+#if WSIS_EXPERIMENTAL
+      if (p.BD && !bn_in && tune_int("WSIS_FWD2_RG", 0) != 0)
+        WSIS_F2RG();
+      else if (p.BD && tr_ok && tune_int("WSIS_FWD2_TR_DA", 2) == 3)
+        WSIS_F2Y(1, 1, 3, true, false, true);      // the table's 4 KB as a third ring slot: 12 waves per CU, as before
+      else
+#endif
+      if (p.BD && tr_ok)
+        WSIS_F2Y(1, 1, 2, true, false, true);
+      else
+        WSIS_F2(1, 1, 2);
+      break;
     case 123: WSIS_F2(1, 2, 3); break;
     case 122: WSIS_F2(1, 2, 2); break;
     case 142: WSIS_F2(1, 4, 2); break;
@@ -430,6 +501,8 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
 #undef WSIS_F2B
 #undef WSIS_F2
 #undef WSIS_F2X
+#undef WSIS_F2Y
+#undef WSIS_F2RG
   prof.stop();
   WSIS_LAUNCH_CHECK();
   if (p.ZS > 1 && d_stats) {
@@ -454,7 +527,7 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
 // diagnostic (not part of the ABI header; host only, no GPU call): the work item of workgroup i of a launch of
 // gx slices x gy blocks x gz slabs dealt over bands of `band` -- the map of item_of, for tests/test_item_deal.py
 int wsis_debug_item_of(int32_t i, int32_t gx, int32_t gy, int32_t gz, int32_t band, int32_t* out3) {
-  if (!out3 || gx < 1 || gy < 1 || gz < 1 || band < 1 || i < 0 || (int64_t)i >= (int64_t)gx * gy * gz) return -1;
+  if (!out3 || gx < 1 || gy < 1 || gz < 1 || band == 0 || i < 0 || (int64_t)i >= (int64_t)gx * gy * gz) return -1;
   const ItemMap m = item_of(i, gx, gy, gz, band);
   out3[0] = m.bx;
   out3[1] = m.by;
@@ -470,10 +543,29 @@ int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_
   WSIS_REQUIRE(wsis_spconv_fwd_t_supported(K, Cin, Cout) && d_dbg, "bad args");
   const dim3 grid((unsigned)(ceil_div(M_out, SL) * (Cout / 32)), 1, 1);
   hipStream_t st = as_stream(stream);
-  const int diag_band = tune_int("WSIS_FWD2_SNAKE", 1) ? 256 : 0x7fffffff;
+  const int diag_xcd = tune_int("WSIS_FWD2_XCD", (variant & 0xff) < 2 && grid.x >= 8 * 64 * 8 ? 64 : 0);
+  const int diag_band = diag_xcd > 0 ? -diag_xcd : tune_int("WSIS_FWD2_SNAKE", 1) ? 256 : 0x7fffffff;
   const int dflags = (variant >> 8) << 4;      // experiment bits (see the kernel)
   variant &= 0xff;
-  if (variant == 0) {
+#if WSIS_EXPERIMENTAL
+  if (variant == 0 && tune_int("WSIS_FWD2_RG", 0) != 0) {
+    const size_t ldsb = (size_t)HDR_BYTES + (size_t)RG_SCRATCH_BYTES;
+    hipLaunchKernelGGL((spconv_fwd2rg_kernel<true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order,
+                       d_WT, (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, dflags,
+                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, 1, diag_band, d_dbg);
+  } else if (variant == 0 && d_nbr && tune_int("WSIS_FWD2_TR", 1) != 0 && tune_int("WSIS_FWD2_TR_DA", 2) == 3) {
+    const size_t ldsb = (size_t)HDR_TR_BYTES + (size_t)Layout<1, 3, true>::WAVE_BYTES;
+    hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 3, true, true, false, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order,
+                       d_WT, (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, dflags,
+                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, 1, diag_band, d_dbg);
+  } else
+#endif
+  if (variant == 0 && d_nbr && tune_int("WSIS_FWD2_TR", 1) != 0) {      // the production one-wave form
+    const size_t ldsb = (size_t)HDR_TR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES;
+    hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 2, true, true, false, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order,
+                       d_WT, (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, dflags,
+                       (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, 1, diag_band, d_dbg);
+  } else if (variant == 0) {
     const size_t ldsb = (size_t)HDR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES;
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 2, true, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order, d_WT,
                        (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, dflags,

@@ -21,6 +21,8 @@ constexpr int DB = 2;             // ring depth of the weight rows (steps); the 
 constexpr int A_BYTES = SL * 128;
 constexpr int HDR_BYTES = (KMAX + 2) * 128;   // nbT [32][32] + rowId [32] + klist [32]: ONE per workgroup (the waves of a
                                               // work item share the slice; each writes the identical header itself)
+constexpr int HDR_TR_BYTES = 256;             // TR (one-wave items, table entries in registers): rowId [32] only
+constexpr int RG_SCRATCH_BYTES = 1024;        // RG (gathered rows straight to registers): no ring, epilogue scratch only
 
 __device__ __attribute__((aligned(256))) float g_zero_row[64];   // source of masked rows (never written)
 
@@ -250,7 +252,8 @@ struct LateVals {
   __device__ __forceinline__ BnEpi epi() const { return epi_; }
 };
 
-template <int NB, int NW, int DA, bool BD, bool DIAG, bool FB, bool WT, typename Sync, typename Late>
+template <int NB, int NW, int DA, bool BD, bool DIAG, bool FB, bool WT, bool TR = false, bool RG = false, typename Sync,
+          typename Late>
 __device__ __forceinline__ void fwd2_body(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ WTp, const Late late, int64_t M_out, int K, int Cin, int Cout, int flip_deal,
@@ -258,6 +261,9 @@ __device__ __forceinline__ void fwd2_body(
     unsigned long long* __restrict__ dbg, const int bx, const int by, const int bz, const int gy, const int gz,
     unsigned char* const lds, const int tid, Sync& sync) {
   static_assert(!FB || (BD && NB == 1), "the fused input BatchNorm is built for the weights-to-registers form");
+  static_assert(!TR || (BD && NB == 1 && NW == 1 && (DA == 2 || DA == 3) && !FB),
+                "table entries in registers: the one-wave form only");
+  static_assert(!RG || (BD && NB == 1 && NW == 1 && DA == 2 && !FB && !TR), "gathered rows to registers: the one-wave form only");
   // flip_deal: bit 0 = offset k uses weight slice K - 1 - k; bit 1 = the waves of a work item are dealt the slice's
   // ACTIVE offsets round-robin (see the ownership block below)
   const int flip = flip_deal & 1;
@@ -277,14 +283,16 @@ __device__ __forceinline__ void fwd2_body(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r31 = lane & 31, half = lane >> 5;
-  int32_t* const nbT = reinterpret_cast<int32_t*>(lds);
-  int32_t* const rowId = nbT + KMAX * 32;
-  int32_t* const klist = rowId + 32;
-  unsigned char* const Aring = lds + HDR_BYTES + wave * L::WAVE_BYTES;
+  // TR: the header is the slice's row ids alone; the gather table is staged in the (still empty) ring for the first
+  // three steps and read from the packed table in memory, one iteration ahead, for the rest (see the TR walk)
+  constexpr int HDR = TR ? HDR_TR_BYTES : HDR_BYTES;
+  int32_t* const nbT = reinterpret_cast<int32_t*>(TR ? lds + HDR_TR_BYTES : lds);
+  int32_t* const rowId = TR ? reinterpret_cast<int32_t*>(lds) : nbT + KMAX * 32;
+  unsigned char* const Aring = lds + HDR + wave * L::WAVE_BYTES;
   unsigned char* const Bring = Aring + DA * A_BYTES;
   // FB: per-channel (mean, scale, shift) of the input BatchNorm behind the rings, 3 x Cin floats; every wave writes
   // the identical values itself (like the header: no workgroup barrier in the prologue)
-  float* const coef = reinterpret_cast<float*>(lds + HDR_BYTES + NW * L::WAVE_BYTES);
+  float* const coef = reinterpret_cast<float*>(lds + HDR + NW * L::WAVE_BYTES);
   if (FB) {
     for (int c = lane; c < Cin; c += 64) {
       coef[c] = bin.mean[c];
@@ -319,7 +327,7 @@ __device__ __forceinline__ void fwd2_body(
       const int k = 2 * j + half;
       const bool ok = k < K && t < M_out;
       const int32_t g = ok ? (nbrS ? v[j] : my_row) : -1;
-      nbT[k * 32 + r31] = g >= 0 ? (int32_t)((uint32_t)g * a_pitch32) : (int32_t)NO_ROW;
+      nbT[k * 32 + r31] = TR ? g : g >= 0 ? (int32_t)((uint32_t)g * a_pitch32) : (int32_t)NO_ROW;
       const unsigned long long b = __ballot(g >= 0);
       if ((uint32_t)b) mask |= 1u << (2 * j);
       if ((uint32_t)(b >> 32)) mask |= 1u << (2 * j + 1);
@@ -462,7 +470,257 @@ __device__ __forceinline__ void fwd2_body(
   };
 
   if (DIAG) d_t1 = __builtin_amdgcn_s_memtime();
-  if (BD && T > 0) {
+  if constexpr (RG) {
+    // ---- one-wave work items, BOTH operands straight to registers.  Lane (row r31, half) loads the 64 bytes of its own
+    // gathered row that it multiplies -- exactly the fragment the LDS ring hands it -- and its 64 bytes of the weight
+    // column, each as four 16-byte buffer loads (a missing pair / a finished stream: offset past the end of the buffer,
+    // the load returns zero and touches no memory).  No LDS-DMA (an LDS-DMA instruction costs its wave 100-185 cycles to
+    // issue, four per step: a wave alone on its SIMD -- the long items and the last round of a launch -- made a step per
+    // ~2,200 cycles against 1,024 of MFMAs), no ring in LDS (the gather table is all a work item keeps there: 5.4 KB, so
+    // the register file alone bounds the waves per CU), no fragment reads.
+    // Pipeline: two register sets per operand, refilled a QUARTER at a time.  The four MFMAs of quarter q of step t
+    // read a[t&1][q], b[t&1][q]; right behind them the same registers are loaded for step t + 2 -- every load has two
+    // full steps to land.  Loads are issued in a fixed pattern (B then A per quarter, dummies past the end), so before
+    // any quarter exactly 14 younger loads may be in flight: one constant counted wait.
+    // Same operands, same chain: bit-identical to the ring form.
+    if (T > 0) {
+      Gen g;
+      gen_init(g);
+      typedef int v4i __attribute__((ext_vector_type(4)));
+      auto make_rs = [&](const void* p, uint32_t bytes) {
+        const uint64_t pa = reinterpret_cast<uint64_t>(p);
+        v4i r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)pa);
+        r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(pa >> 32) & 0xffffu));
+        r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+        r[3] = __builtin_amdgcn_readfirstlane(0x00020000);
+        return r;
+      };
+      const v4i rsA = make_rs(X, x_bytes);
+      const v4i rsW = make_rs(WTp, (uint32_t)((int64_t)K * Cout * Cin * 4));
+      const uint32_t a_lane = (uint32_t)half * 64u;
+      const uint32_t b_lane = (uint32_t)(r31 * Cin + half * 16) * 4u;
+      // per step: lane offsets of the two streams and their scalar parts (chunk of the row / block of the weights)
+      struct Step {
+        uint32_t offa, offb, soa, sow;
+      };
+      bool t_dbg = false;                             // (DIAG: the weights are loaded for the first step only)
+      auto entry_of = [&](const Gen& gg) { return dbg_row0 ? (uint32_t)r31 * a_pitch32 : (uint32_t)nbT[gg.k * 32 + r31]; };
+      auto step_of = [&](const Gen& gg, uint32_t e) {
+        Step st;
+        st.offa = gg.valid ? e + a_lane : NO_ROW;
+        st.offb = (gg.valid && !(dbg_noB && t_dbg)) ? b_lane : NO_ROW;
+        const int kk = flip ? K - 1 - gg.k : gg.k;
+        st.soa = __builtin_amdgcn_readfirstlane((uint32_t)gg.c * 128u);
+        st.sow = __builtin_amdgcn_readfirstlane((uint32_t)((((int64_t)kk * Cout + col0) * Cin + gg.c * 32) * 4));
+        return st;
+      };
+#define WSIS_RG_LOAD(nop, dst, off, rs, so, imm) \
+  asm volatile(nop "buffer_load_dwordx4 %0, %1, %2, %3 offen offset:" #imm : "=v"(dst) : "v"(off), "s"(rs), "s"(so) : "memory")
+      auto fill = [&](const Step& st, f32x4 (&a)[4], f32x4 (&b)[NB][4], int q) {
+        if (q == 0) {
+          WSIS_RG_LOAD("s_nop 4\n\t", b[0][0], st.offb, rsW, st.sow, 0);
+          WSIS_RG_LOAD("", a[0], st.offa, rsA, st.soa, 0);
+        } else if (q == 1) {
+          WSIS_RG_LOAD("s_nop 4\n\t", b[0][1], st.offb, rsW, st.sow, 16);
+          WSIS_RG_LOAD("", a[1], st.offa, rsA, st.soa, 16);
+        } else if (q == 2) {
+          WSIS_RG_LOAD("s_nop 4\n\t", b[0][2], st.offb, rsW, st.sow, 32);
+          WSIS_RG_LOAD("", a[2], st.offa, rsA, st.soa, 32);
+        } else {
+          WSIS_RG_LOAD("s_nop 4\n\t", b[0][3], st.offb, rsW, st.sow, 48);
+          WSIS_RG_LOAD("", a[3], st.offa, rsA, st.soa, 48);
+        }
+      };
+      f32x4 a0[4], a1[4], b0[NB][4], b1[NB][4];
+      uint32_t e_next;                                // table entry of the step the next iteration loads
+      {
+        const Step s0 = step_of(g, entry_of(g));
+        gen_next(g);
+        t_dbg = true;
+        const Step s1 = step_of(g, entry_of(g));
+        gen_next(g);
+        e_next = entry_of(g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fill(s0, a0, b0, q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fill(s1, a1, b1, q);
+      }
+      int t = 0;
+      auto iter = [&](f32x4 (&a)[4], f32x4 (&b)[NB][4]) {
+        const Step st = step_of(g, e_next);           // step t + 2 (a finished stream: dummies)
+        gen_next(g);
+        e_next = entry_of(g);                         // (an LDS read: back long before the next iteration)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+          asm volatile("" : "+v"(a[q]), "+v"(b[0][q])::"memory");
+          __builtin_amdgcn_sched_barrier(0);
+          mfma(a, b, 4 * q, 4 * q + 4);
+          __builtin_amdgcn_sched_barrier(0);
+          fill(st, a, b, q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        ++t;
+      };
+      while (t < T) {
+        iter(a0, b0);
+        if (t < T) iter(a1, b1);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummies of the last two steps
+#undef WSIS_RG_LOAD
+    }
+  } else if constexpr (TR) {
+    // ---- one-wave work items with the gather-table entries in REGISTERS: the 4 KB table image is what kept a work
+    // item at 12.3 KB of LDS (12 waves per CU); without it 8.25 KB -> 16 waves per CU, the register file's own limit.
+    // The lane that issues piece (i, lane) of a step needs the entry of row i*8 + (lane >> 3) under the step's offset:
+    // 4 registers per step.  Steps 0 .. 2 take them from the table image the prologue staged in the still empty ring
+    // (no second trip to memory before the first gather); step s >= 3 loads them from the packed table itself during
+    // iteration s - 3 (the lines were read by the prologue: L2 hits) -- they ride the vmcnt(0) the next iteration
+    // starts with.  Issue order of iteration t: B(t+1), T(t+3), A(t+2).  Same MFMA chain, same operands: results
+    // bit-identical to the table-in-LDS form.
+    if (T > 0) {
+      Gen gA, gB, gT;
+      gen_init(gA);
+      gen_init(gB);
+      int aS = 0, arS = 0;
+      const int rows = (int)(M_out - t0 < (int64_t)SL ? M_out - t0 : (int64_t)SL);      // rows of a ragged last slice
+      const uint32_t b_voff = (uint32_t)(r31 * Cin + half * 16) * 4u;
+      auto loadBr = [&](const Gen& g, f32x4 (&b)[NB][4]) {
+        const int kk = flip ? K - 1 - g.k : g.k;
+        const uint64_t bp = reinterpret_cast<uint64_t>(Wb) + (uint64_t)((((int64_t)kk * Cout + col0) * Cin + g.c * 32) * 4);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bp);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(bp >> 32));
+        const char* base = reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(b[0][0]) : "v"(b_voff), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(b[0][1]) : "v"(b_voff), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(b[0][2]) : "v"(b_voff), "s"(base) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:48" : "=v"(b[0][3]) : "v"(b_voff), "s"(base) : "memory");
+      };
+      auto tieB = [&](f32x4 (&b)[NB][4]) {
+        asm volatile("" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3])::"memory");
+      };
+      // the 4 entries of a step: rows i*8 + d_row, clamped to the slice's last row (a ragged last slice must not read
+      // past the table; the entries of rows that do not exist are masked at the issue)
+      auto loadT = [&](const Gen& g, int32_t (&n)[4]) {
+        const uint64_t tp = reinterpret_cast<uint64_t>(nbrS) + (uint64_t)(((int64_t)g.k * M_out + t0) * 4);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)tp);
+        const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(tp >> 32));
+        const char* base = reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+        uint32_t vo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = i * 8 + d_row;
+          vo[i] = (uint32_t)(r < rows ? r : rows - 1) * 4u;
+        }
+        asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(n[0]) : "v"(vo[0]), "s"(base) : "memory");
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(n[1]) : "v"(vo[1]), "s"(base) : "memory");
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(n[2]) : "v"(vo[2]), "s"(base) : "memory");
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(n[3]) : "v"(vo[3]), "s"(base) : "memory");
+      };
+      auto tieT = [&](int32_t (&n)[4]) { asm volatile("" : "+v"(n[0]), "+v"(n[1]), "+v"(n[2]), "+v"(n[3])::"memory"); };
+      auto stagedT = [&](const Gen& g, int32_t (&n)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) n[i] = nbT[g.k * 32 + i * 8 + d_row];
+      };
+      auto issueAr = [&](const Gen& g, const int32_t (&n)[4], int slot, int i) {
+        const int32_t e = dbg_row0 ? i * 8 + d_row : n[i];
+        const bool ok = g.valid && e >= 0 && i * 8 + d_row < rows;
+        const uint32_t off = ok ? __umul24((uint32_t)e, a_pitch32) + a_po[i] : NO_ROW;
+        bdma16(rsX, off, (uint32_t)g.c * 128u, Aring + slot * A_BYTES + i * 1024);
+      };
+      f32x4 a0[4], a1[4], b0[NB][4], b1[NB][4];
+      int32_t nA[4], nB[4];
+      {
+        // steps 0 .. DA from the staged image; the ring may be written only once these reads are back
+        int32_t n0[4], n1[4], n2[4];
+        gT = gA;
+        stagedT(gT, n0);
+        gen_next(gT);
+        stagedT(gT, n1);
+        gen_next(gT);
+        if (DA == 3) {
+          stagedT(gT, n2);
+          gen_next(gT);
+        }
+        stagedT(gT, nA);
+        gen_next(gT);                                 // gT: step DA + 1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issueAr(gA, n0, 0, i);      // A0
+        gen_next(gA);
+        loadBr(gB, b0);                                         // B0
+        gen_next(gB);
+        if (T > 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) issueAr(gA, n1, 1, i);    // A1
+          gen_next(gA);
+        }
+        if (DA == 3 && T > 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) issueAr(gA, n2, 2, i);    // A2
+          gen_next(gA);
+        }
+      }
+      {   // A0, B0 landed; A1 [A2] may fly
+        const int young = (T > DA ? DA : T) - 1;
+        if (young >= 2)
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (young == 1)
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      tieB(b0);
+      readfrag(0, 0, a0, b0);
+      arS = 1;
+      int t = 0;
+      auto iter = [&](const f32x4 (&ac)[4], f32x4 (&bc)[NB][4], f32x4 (&an)[4], f32x4 (&bn)[NB][4], int32_t (&nc)[4],
+                      int32_t (&nn)[4]) {
+        // top: A(t+1), B(t), T(t+DA) landed, the fragment reads of step t are back; DA = 3: A(t+2), the pieces issued
+        // last in the previous iteration, may still fly
+        if (DA == 3 && t + 2 < T)
+          asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        tieB(bc);
+        tieT(nc);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(ac, bc, 0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < T) {
+          readfrag(arS, 0, an, bn);
+          arS = arS + 1 == DA ? 0 : arS + 1;
+          if (!dbg_noB) loadBr(gB, bn);
+          gen_next(gB);
+        }
+        if (t + DA + 1 < T) loadT(gT, nn);
+        gen_next(gT);
+        const bool more = t + DA < T;
+        __builtin_amdgcn_sched_barrier(0);
+        mfma(ac, bc, 4, 8);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (more) issueAr(gA, nc, aS, i);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma(ac, bc, 8 + i, 9 + i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) {
+          gen_next(gA);
+          aS = aS + 1 == DA ? 0 : aS + 1;
+        }
+        mfma(ac, bc, 12, 16);
+        ++t;
+      };
+      while (t < T) {
+        iter(a0, b0, a1, b1, nA, nB);
+        if (t < T) iter(a1, b1, a0, b0, nB, nA);
+      }
+    }
+  } else if (BD && T > 0) {
     // ---- weights straight to registers, gathered rows through the DA-deep LDS ring.  Every vector-memory operation
     // of the walk is counted by hand: the weight loads are inline asm (beside LDS-DMA pieces in flight hipcc waits
     // vmcnt(0) for any load it can see, which would drain the ring every step), nothing is issued for steps that do
@@ -840,7 +1098,7 @@ __device__ __forceinline__ void fwd2_body(
       float v = 0.0f;
 #pragma unroll
       for (int w = 0; w < NW; ++w)
-        v += reinterpret_cast<const float*>(lds + HDR_BYTES + w * L::WAVE_BYTES)[e];
+        v += reinterpret_cast<const float*>(lds + HDR + w * L::WAVE_BYTES)[e];
       if (bias) v += bv;
       if (residual) v += rv[it];
       keep[it] = live[it] ? v : 0.0f;
@@ -861,7 +1119,7 @@ __device__ __forceinline__ void fwd2_body(
     }
     if (bn_mode) {                  // both sums are plain: one exchange
       sync();
-      float* sred = reinterpret_cast<float*>(lds + HDR_BYTES);
+      float* sred = reinterpret_cast<float*>(lds + HDR);
       const int colw = NB * 32;
       sred[tid] = sa;
       sred[64 * NW + tid] = sq;
@@ -883,7 +1141,7 @@ __device__ __forceinline__ void fwd2_body(
       }
     } else if (stats && final_pass) {      // threads of one column: t, t + NB*32, ...; added in that order
       sync();              // the accumulator copies in the rings are no longer needed
-      float* sred = reinterpret_cast<float*>(lds + HDR_BYTES);
+      float* sred = reinterpret_cast<float*>(lds + HDR);
       const int colw = NB * 32, me = tid % colw;
       sred[tid] = sa;
       sync();
@@ -909,7 +1167,7 @@ __device__ __forceinline__ void fwd2_body(
       }
       if (NB == 1 && finp && finp->chunk && wave == 0)      // (the partials of a 32-channel block are stored by lanes 0-31 of wave 0)
         stat_finish(*finp, stats, M_out, Cout, (int64_t)bx, col0, gy, by,
-                    reinterpret_cast<double*>(lds + HDR_BYTES));
+                    reinterpret_cast<double*>(lds + HDR));
     }
   }
   if (DIAG && dbg && tid == 0) {

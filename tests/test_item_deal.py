@@ -29,7 +29,7 @@ def _items(fn, gx, gy, gz, band):
 
 @pytest.mark.parametrize("gx,gy,gz", [(1, 1, 1), (7, 1, 1), (206, 3, 1), (48, 4, 1), (11, 5, 8), (839, 2, 1), (300, 1, 1),
                                       (256, 1, 1), (257, 1, 1), (512, 2, 1), (341, 3, 1), (1025, 1, 1), (4803, 1, 1)])
-@pytest.mark.parametrize("band", [256, 8, 0x7fffffff])
+@pytest.mark.parametrize("band", [256, 8, 0x7fffffff, -64, -5])      # < 0: runs of -band items per XCD
 def test_item_of_is_a_bijection(gx, gy, gz, band):
     it = _items(_lib(), gx, gy, gz, band)
     assert (it[:, 0] >= 0).all() and (it[:, 0] < gx).all()
@@ -41,12 +41,30 @@ def test_item_of_is_a_bijection(gx, gy, gz, band):
         assert lin.tolist() == list(range(gx * gy * gz))
 
 
+def test_xcd_runs_keep_neighbouring_items_on_one_xcd():
+    """band = -C: workgroup i runs on XCD i % 8; the items an XCD computes form runs of C consecutive items of the weight
+    order (full super-blocks of 8 C; the remainder is dealt plainly), and every XCD gets the same number of full runs"""
+    fn = _lib()
+    gx, C = 4803, 64
+    it = _items(fn, gx, 1, 1, -C)[:, 0]
+    nb = gx // (8 * C)
+    for x in range(8):
+        mine = it[x::8]
+        full = np.sort(mine[mine < nb * 8 * C])
+        assert len(full) == nb * C
+        runs = full.reshape(nb, C)
+        assert (np.diff(runs, axis=1) == 1).all()                  # each run: C consecutive items
+        assert (runs[:, 0] // C % 8 == x).all()                    # runs x, x + 8, x + 16, ...
+    assert (it[nb * 8 * C:] == np.arange(nb * 8 * C, gx)).all()    # remainder in launch order
+
+
 def test_item_of_rejects_bad_arguments():
     fn = _lib()
     out = np.zeros(3, dtype=np.int32)
     assert fn(5, 1, 1, 1, 256, out.ctypes.data) == -1
     assert fn(0, 0, 1, 1, 256, out.ctypes.data) == -1
     assert fn(0, 1, 1, 1, 256, None) == -1
+    assert fn(0, 1, 1, 1, 0, out.ctypes.data) == -1
 
 
 @pytest.mark.parametrize("gx,gy", [(206, 3), (48, 4), (300, 2), (120, 5)])

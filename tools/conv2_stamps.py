@@ -29,6 +29,8 @@ for _ in range(3):
                 variant, dbg.data_ptr(), _n.sync_block().data_ptr(), _n.stream_ptr()), "diag")
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().reshape(-1, 8).astype(np.float64)
+if os.environ.get('STAMPS_DUMP'):
+    np.save(os.environ['STAMPS_DUMP'], dbg.cpu().numpy().reshape(-1, 8))      # raw stamps for offline models
 r0, r1 = d[:, 0], d[:, 1]
 t_first = r0.min()
 start_us, end_us = (r0 - t_first) / 100.0, (r1 - t_first) / 100.0          # 100 MHz
