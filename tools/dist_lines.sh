@@ -15,6 +15,10 @@ tail -c 300 $O/${R}_bench_rccl1_syncbn.json
 WSIS_DIST_BACKEND=gloo timeout -k 10 240 python bench.py --gpus 2 --small --steps 5 --warmup 2 --setup-steps 5 --no-cpu-baseline --no-stages > $O/${R}_bench_gloo2_small.json 2> $O/${R}_bench_gloo2_small.err
 tail -c 300 $O/${R}_bench_gloo2_small.json
 WSIS_DIST_BACKEND=gloo timeout -k 10 240 python bench.py --gpus 2 --small --sync-bn --steps 5 --warmup 2 --setup-steps 5 --no-cpu-baseline --no-stages > $O/${R}_bench_gloo2_syncbn_small.json 2> $O/${R}_bench_gloo2_syncbn_small.err
+# (the gloo library prints its own connection lines on stdout: keep the JSON line alone in the .json, the rest in the .err)
+for f in $O/${R}_bench_gloo2_small $O/${R}_bench_gloo2_syncbn_small; do
+  [ -f $f.json ] && { grep -v '^{' $f.json >> $f.err; grep '^{' $f.json | tail -1 > $f.json.tmp; mv $f.json.tmp $f.json; }
+done
 tail -c 300 $O/${R}_bench_gloo2_syncbn_small.json
 timeout -k 10 200 python tools/aten_trace.py > $O/${R}_aten_trace.txt 2>&1
 AB_DIST=1 timeout -k 10 200 python tools/aten_trace.py > $O/${R}_aten_trace_dist.txt 2>&1
