@@ -98,6 +98,30 @@ __global__ __launch_bounds__(64 * NW) void spconv_fwd2_kernel(
 
 
 #if WSIS_EXPERIMENTAL
+// ---- table entries in registers (TR) and, per ITEM, the walk: the LDS-DMA ring for the items of the full rounds, the
+// register-gather walk (spconv2_body.h: rg_walk) for the waves that end up alone on their SIMD -- items of at least
+// `rg_steps` active offsets (flip_deal bits 8..15) and every workgroup dispatched after the first `late_from` (= the
+// launch's resident capacity; packed above gz, which is 1 here).  Bit-identical.  Measured (WSIS_FWD2_RGH=12): the long
+// items end at 31-38 instead of 43-50 us and a level-0 launch alone takes 50.5-52 instead of 52.6-54.5 us -- and the step,
+// where the weight gradients share the texture path, gets SLOWER: 7.763 against 7.732 ms, four scenes 21.40 against 20.86.
+template <bool DIAG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void spconv_fwd2h_kernel(
+    const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
+    const float* __restrict__ WT, const float* __restrict__ bias, const float* __restrict__ residual,
+    float* __restrict__ out, float* __restrict__ partial, int64_t M_out, int K, int Cin, int Cout, int flip_deal,
+    uint32_t x_bytes, float* __restrict__ stats, BnEpi epi, BnIn bin, StatFin fin, int gz_late, int band,
+    unsigned long long* __restrict__ dbg = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  WgSync sync;
+  const LateVals late{bias, residual, out, partial, stats, epi};
+  const int gx = (int)((M_out + SL - 1) / SL), gy = Cout / 32;
+  const int late_from = gz_late >> 8;
+  const ItemMap it = item_of((int)blockIdx.x, gx, gy, 1, band);
+  const int fd = flip_deal | ((late_from > 0 && (int)blockIdx.x >= late_from) ? 8 : 0);
+  fwd2_body<1, 1, 2, true, DIAG, false, false, true, false, true>(X, nbrS, order, WT, late, M_out, K, Cin, Cout, fd, x_bytes, bin,
+                                                                   &fin, dbg, it.bx, it.by, it.bz, gy, 1, lds, (int)threadIdx.x, sync);
+}
+
 // ---- one-wave work items with both operands straight to registers (spconv2_body.h: RG).  Four waves per SIMD: the
 // register file is what bounds the waves per CU here (5.4 KB of LDS per item), so the kernel is held to 128 registers.
 // Bit-identical, measured SLOWER on level 0 (61.4 against 55.2 us): the long items and the last round run a step per
@@ -455,6 +479,12 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
 #endif
   // one-wave items with the table entries in registers (8.25 instead of 12.3 KB of LDS per item): needs a gather table
   // (the 1x1x1 convolutions have none) and row indices the 24-bit multiply holds
+  // per-item walk (spconv_fwd2h_kernel): items of >= rgh_steps steps and the workgroups behind the first full round of
+  // 16 per CU; only where a launch HAS a second round or long items to speak of (many one-wave items)
+  const int rgh_steps = n_items >= 8 * 64 * 8 ? tune_int("WSIS_FWD2_RGH", 0) & 255 : 0;      // (EXPERIMENTAL build only)
+  // (the late rule only where the launch's last round is a partial SECOND round: with many rounds the workgroups behind
+  // the first are the bulk, and a bulk that walks by register gather saturates the texture path)
+  const int rgh_late = (tune_int("WSIS_FWD2_RGH_LATE", 1) && n_items > 16 * n_cu && n_items <= 2 * 16 * n_cu) ? 16 * n_cu : 0;
   const bool tr_ok = d_nbr != nullptr && !bn_in && M_in < ((int64_t)1 << 24) && tune_int("WSIS_FWD2_TR", 1) != 0;
   if (p.NB == 1 && p.DA == 2 && p.BD && (bn_in || p.NW == 16)) {
     switch (p.NW) {
@@ -477,6 +507,15 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
       else if (p.BD && tr_ok && tune_int("WSIS_FWD2_TR_DA", 2) == 3)
         WSIS_F2Y(1, 1, 3, true, false, true);      // the table's 4 KB as a third ring slot: 12 waves per CU, as before
       else
+#endif
+#if WSIS_EXPERIMENTAL
+      if (p.BD && tr_ok && p.ZS == 1 && rgh_steps > 0) {
+        const size_t ldsb = (size_t)HDR_TR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES;
+        hipExtLaunchKernelGGL((spconv_fwd2h_kernel<false>), grid, dim3(64), (uint32_t)ldsb, st, prof.ka(), prof.kb(), 0u, d_X,
+                              d_nbr, d_order, d_WT, d_bias, d_residual, d_out, partial, M_out, K, Cin, Cout,
+                              flip_deal | (rgh_steps << 8), x_bytes, d_stats, epi, bin, fin, 1 | (rgh_late << 8), deal_band,
+                              (unsigned long long*)nullptr);
+      } else
 #endif
       if (p.BD && tr_ok)
         WSIS_F2Y(1, 1, 2, true, false, true);
@@ -558,6 +597,15 @@ int wsis_debug_spconv2_diag(const float* d_X, const int32_t* d_nbr, const int32_
     hipLaunchKernelGGL((spconv_fwd2_kernel<1, 1, 3, true, true, false, true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order,
                        d_WT, (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout, dflags,
                        (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{}, BnIn{}, StatFin{}, 1, diag_band, d_dbg);
+  } else
+#endif
+#if WSIS_EXPERIMENTAL
+  if (variant == 0 && d_nbr && tune_int("WSIS_FWD2_TR", 1) != 0 && grid.x >= 8 * 64 * 8 && (tune_int("WSIS_FWD2_RGH", 0) & 255) > 0) {
+    const size_t ldsb = (size_t)HDR_TR_BYTES + (size_t)Layout<1, 2, true>::WAVE_BYTES;      // the production form of big launches
+    hipLaunchKernelGGL((spconv_fwd2h_kernel<true>), grid, dim3(64), ldsb, st, d_X, d_nbr, d_order,
+                       d_WT, (const float*)nullptr, (const float*)nullptr, d_out, (float*)nullptr, M_out, K, Cin, Cout,
+                       dflags | ((tune_int("WSIS_FWD2_RGH", 0) & 255) << 8), (uint32_t)(M_out * Cin * 4), (float*)nullptr, BnEpi{},
+                       BnIn{}, StatFin{}, 1 | ((tune_int("WSIS_FWD2_RGH_LATE", 1) ? 16 * 256 : 0) << 8), diag_band, d_dbg);
   } else
 #endif
   if (variant == 0 && d_nbr && tune_int("WSIS_FWD2_TR", 1) != 0) {      // the production one-wave form

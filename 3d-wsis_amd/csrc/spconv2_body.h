@@ -252,8 +252,15 @@ struct LateVals {
   __device__ __forceinline__ BnEpi epi() const { return epi_; }
 };
 
-template <int NB, int NW, int DA, bool BD, bool DIAG, bool FB, bool WT, bool TR = false, bool RG = false, typename Sync,
-          typename Late>
+// flip_deal bits 8..15 (TR kernels built with RGH): items of at least that many ACTIVE OFFSETS take the register-gather
+// walk (0: none); bit 3 (set by the kernel for workgroups dispatched after the first full round): this item does
+__device__ __forceinline__ int rg_min_steps(int flip_deal) {
+  const int m = (flip_deal >> 8) & 255;
+  return m ? m : 0x00ffffff;
+}
+
+template <int NB, int NW, int DA, bool BD, bool DIAG, bool FB, bool WT, bool TR = false, bool RG = false, bool RGH = false,
+          typename Sync, typename Late>
 __device__ __forceinline__ void fwd2_body(
     const float* __restrict__ X, const int32_t* __restrict__ nbrS, const int32_t* __restrict__ order,
     const float* __restrict__ WTp, const Late late, int64_t M_out, int K, int Cin, int Cout, int flip_deal,
@@ -264,6 +271,7 @@ __device__ __forceinline__ void fwd2_body(
   static_assert(!TR || (BD && NB == 1 && NW == 1 && (DA == 2 || DA == 3) && !FB),
                 "table entries in registers: the one-wave form only");
   static_assert(!RG || (BD && NB == 1 && NW == 1 && DA == 2 && !FB && !TR), "gathered rows to registers: the one-wave form only");
+  static_assert(!RGH || TR, "the per-item choice of the walk lives in the table-in-registers kernel");
   // flip_deal: bit 0 = offset k uses weight slice K - 1 - k; bit 1 = the waves of a work item are dealt the slice's
   // ACTIVE offsets round-robin (see the ownership block below)
   const int flip = flip_deal & 1;
@@ -470,20 +478,21 @@ __device__ __forceinline__ void fwd2_body(
   };
 
   if (DIAG) d_t1 = __builtin_amdgcn_s_memtime();
-  if constexpr (RG) {
-    // ---- one-wave work items, BOTH operands straight to registers.  Lane (row r31, half) loads the 64 bytes of its own
-    // gathered row that it multiplies -- exactly the fragment the LDS ring hands it -- and its 64 bytes of the weight
-    // column, each as four 16-byte buffer loads (a missing pair / a finished stream: offset past the end of the buffer,
-    // the load returns zero and touches no memory).  No LDS-DMA (an LDS-DMA instruction costs its wave 100-185 cycles to
-    // issue, four per step: a wave alone on its SIMD -- the long items and the last round of a launch -- made a step per
-    // ~2,200 cycles against 1,024 of MFMAs), no ring in LDS (the gather table is all a work item keeps there: 5.4 KB, so
-    // the register file alone bounds the waves per CU), no fragment reads.
-    // Pipeline: two register sets per operand, refilled a QUARTER at a time.  The four MFMAs of quarter q of step t
-    // read a[t&1][q], b[t&1][q]; right behind them the same registers are loaded for step t + 2 -- every load has two
-    // full steps to land.  Loads are issued in a fixed pattern (B then A per quarter, dummies past the end), so before
-    // any quarter exactly 14 younger loads may be in flight: one constant counted wait.
-    // Same operands, same chain: bit-identical to the ring form.
-    if (T > 0) {
+  // ---- register-gather walk (RG): the whole walk of a one-wave work item with BOTH operands straight to registers.
+  // Lane (row r31, half) loads the 64 bytes of its own gathered row that it multiplies -- exactly the fragment the LDS
+  // ring hands it -- and its 64 bytes of the weight column, each as four 16-byte buffer loads (a missing pair / a
+  // finished stream: offset past the end of the buffer, the load returns zero and touches no memory).  No LDS-DMA (an
+  // LDS-DMA instruction costs its wave 100-185 cycles to issue, four per step: a wave alone on its SIMD -- the long items
+  // and the last round of a launch -- makes a step per 2,200-2,700 cycles against 1,024 of MFMAs), no ring, no fragment
+  // reads.  Two register sets per operand, refilled a QUARTER at a time: the four MFMAs of quarter q of step t read
+  // a[t&1][q], b[t&1][q]; right behind them the same registers are loaded for step t + 2 -- every load has two full
+  // steps to land.  Loads go out in a fixed pattern (B then A per quarter, dummies past the end), so before any quarter
+  // exactly 14 younger loads may be in flight: one constant counted wait.  Same operands, same chain: bit-identical to
+  // the ring form.  The price: a row-per-lane load touches four cache lines per quad of lanes where the coalesced
+  // LDS-DMA piece touches one -- with every wave of a full round walking this way the texture path saturates (7,760
+  // cycles per step against 5,300), so it is the walk of the waves that run ALONE (see the TR block).
+  // `entry_at(i)`: byte offset of the row under table image entry i (0x80000000 for a missing pair).
+  auto rg_walk = [&](auto entry_at) {
       Gen g;
       gen_init(g);
       typedef int v4i __attribute__((ext_vector_type(4)));
@@ -505,7 +514,7 @@ __device__ __forceinline__ void fwd2_body(
         uint32_t offa, offb, soa, sow;
       };
       bool t_dbg = false;                             // (DIAG: the weights are loaded for the first step only)
-      auto entry_of = [&](const Gen& gg) { return dbg_row0 ? (uint32_t)r31 * a_pitch32 : (uint32_t)nbT[gg.k * 32 + r31]; };
+      auto entry_of = [&](const Gen& gg) { return dbg_row0 ? (uint32_t)r31 * a_pitch32 : entry_at(gg.k * 32 + r31); };
       auto step_of = [&](const Gen& gg, uint32_t e) {
         Step st;
         st.offa = gg.valid ? e + a_lane : NO_ROW;
@@ -569,7 +578,9 @@ __device__ __forceinline__ void fwd2_body(
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dummies of the last two steps
 #undef WSIS_RG_LOAD
-    }
+  };
+  if constexpr (RG) {
+    if (T > 0) rg_walk([&](int i) { return (uint32_t)nbT[i]; });
   } else if constexpr (TR) {
     // ---- one-wave work items with the gather-table entries in REGISTERS: the 4 KB table image is what kept a work
     // item at 12.3 KB of LDS (12 waves per CU); without it 8.25 KB -> 16 waves per CU, the register file's own limit.
@@ -579,7 +590,16 @@ __device__ __forceinline__ void fwd2_body(
     // iteration s - 3 (the lines were read by the prologue: L2 hits) -- they ride the vmcnt(0) the next iteration
     // starts with.  Issue order of iteration t: B(t+1), T(t+3), A(t+2).  Same MFMA chain, same operands: results
     // bit-identical to the table-in-LDS form.
-    if (T > 0) {
+    // Per ITEM (flip_deal bit 3: this workgroup was dispatched after the launch's first full round; or a long item):
+    // the waves that end up alone on their SIMD take the register-gather walk above -- it reads the same staged image
+    // (row indices; nothing overwrites it without a ring in use).
+    const bool rg_item = RGH && T > 0 && (T >= rg_min_steps(flip_deal) * nchunk || (flip_deal & 8));
+    if (rg_item) {
+      rg_walk([&](int i) {
+        const int32_t g = nbT[i];
+        return g >= 0 ? __umul24((uint32_t)g, a_pitch32) : NO_ROW;
+      });
+    } else if (T > 0) {
       Gen gA, gB, gT;
       gen_init(gA);
       gen_init(gB);

@@ -206,16 +206,35 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
     for (int j = 0; j < GS; ++j) m |= (uint32_t)((b >> (8 * j)) & 1ull) << j;
     return m;
   };
+  // (the four row ids of a tile are read together, then the four pieces go out: left as one expression per piece hipcc
+  // builds read -> wait -> multiply -> DMA four times over, behind a branch on the lane's piece mask)
+  const uint32_t y_ok_mask = y_piece_ok ? 0xffffffffu : 0u;
   auto issueB = [&](const int32_t* hb, unsigned char* dst) {
     const int32_t* p = hb + GS * 32 + d_row;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)      // pieces past the row's last column (partial last block) read as zero too
-      bdma16(rsY, y_piece_ok ? (uint32_t)p[i * 8] * y_pitch + d_po : 0xffffff00u, dst + i * 1024);
+    const int32_t r0 = p[0], r1 = p[8], r2 = p[16], r3 = p[24];
+    __builtin_amdgcn_sched_barrier(0);
+    // pieces past the row's last column (partial last block) read as zero too
+    const uint32_t o0 = (((uint32_t)r0 * y_pitch + d_po) & y_ok_mask) | (0xffffff00u & ~y_ok_mask);
+    const uint32_t o1 = (((uint32_t)r1 * y_pitch + d_po) & y_ok_mask) | (0xffffff00u & ~y_ok_mask);
+    const uint32_t o2 = (((uint32_t)r2 * y_pitch + d_po) & y_ok_mask) | (0xffffff00u & ~y_ok_mask);
+    const uint32_t o3 = (((uint32_t)r3 * y_pitch + d_po) & y_ok_mask) | (0xffffff00u & ~y_ok_mask);
+    __builtin_amdgcn_sched_barrier(0);
+    bdma16(rsY, o0, dst);
+    bdma16(rsY, o1, dst + 1024);
+    bdma16(rsY, o2, dst + 2048);
+    bdma16(rsY, o3, dst + 3072);
   };
   auto issueA = [&](const int32_t* hb, int j, unsigned char* dst) {
     const int32_t* p = hb + j * 32 + d_row;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bdma16(rsX, (uint32_t)p[i * 8] * x_pitch + d_po, dst + i * 1024);
+    const int32_t r0 = p[0], r1 = p[8], r2 = p[16], r3 = p[24];
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t o0 = (uint32_t)r0 * x_pitch + d_po, o1 = (uint32_t)r1 * x_pitch + d_po;
+    const uint32_t o2 = (uint32_t)r2 * x_pitch + d_po, o3 = (uint32_t)r3 * x_pitch + d_po;
+    __builtin_amdgcn_sched_barrier(0);
+    bdma16(rsX, o0, dst);
+    bdma16(rsX, o1, dst + 1024);
+    bdma16(rsX, o2, dst + 2048);
+    bdma16(rsX, o3, dst + 3072);
   };
   // MFMA operands: lane (channel r31, half) takes rows 2s + half of a 32-row image, s = 0 .. 15
   auto readfrag = [&](const unsigned char* img, float (&f)[16]) {
