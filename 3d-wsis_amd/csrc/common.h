@@ -199,6 +199,7 @@ int spconv_ring_launch(int nt, const float* d_X, const int32_t* d_nbr, const int
 bool dw2_supported(int K, int Cin, int Cout);
 bool dw2_fits(int64_t M_in, int64_t M_out, int K, int Cin, int Cout);   // 32-bit buffer offsets
 int64_t dw2_workspace_bytes(int64_t M_out, int K, int Cin, int Cout);
+void dw2_set_batch_rows(int64_t rows);      // launch-plan hint of the weight-gradient launches (wsis_hint_batch_rows)
 int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY, float* d_dW,
                int64_t M_in, int64_t M_out, int K, int Cin, int Cout, void* d_ws, hipStream_t st);
 int dw2_launch_swapped(const float* d_X, const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta,

@@ -1154,6 +1154,12 @@ int wsis_spconv_dw_bn(const float* d_X, const float* d_mean, const float* d_var,
                             M_in, M_out, K, Cin, Cout, d_ws, st);
 }
 
+int wsis_hint_batch_rows(int64_t rows) {
+  WSIS_REQUIRE(rows >= 0, "bad row count");
+  dw2_set_batch_rows(rows);
+  return WSIS_OK;
+}
+
 int wsis_spconv_dw(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY,
                    float* d_dW, int64_t M_in, int64_t M_out, int32_t K, int32_t Cin, int32_t Cout, void* d_ws,
                    int64_t ws_bytes, void* stream) {

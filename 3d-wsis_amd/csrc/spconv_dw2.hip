@@ -17,6 +17,8 @@
 // workgroup share a combination and add their accumulators through LDS in wave order; workgroup slabs are added in
 // workgroup order by dw2_reduce_kernel: no atomics, bit-reproducible.  Dense 1x1 layers (no table) and a partial last
 // output block (Cout % 4 == 0) are covered too.  Measurements and what bounds it: DESIGN.md 4.1.
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "common.h"
@@ -508,11 +510,19 @@ int dw2_env(const char* name, int dflt) {      // (launch-plan knobs: live in th
 }
 
 // workgroups per combination (= slabs): ~target waves over the launch, never more than there are slices
-int dw2_P(int64_t M_out, int K, int Cin, int Cout) {
-  // (read per call) the launches share the GPU with the dIn products of the main stream: up to 8,192 slices one 4-wave
-  // workgroup per CU (2,048 waves: +1.5 % per one-scene step), above that two (1,024 waves: +0.7 % per four-scene step)
+// Launch-plan hint (wsis_hint_batch_rows): rows of the finest level of the batch being trained.  One scene per step the
+// main stream's chain of dIn products is the step's critical path and the weight gradients beside it should stay small
+// (1,024 waves: one 4-wave workgroup per CU; 2,048 cost the step +0.6 ... +1.5 %); from two scenes per step on the GPU is
+// busy throughout and what counts is how fast the gradients get done (2,048 waves at every level: -0.4 / -0.6 / -1.9 %
+// at 2 / 3 / 4 scenes per step; tools/ab_step.py).  Never a matter of correctness: the workspace covers both plans.
+std::atomic<int64_t> g_batch_rows{0};
+constexpr int64_t WIDE_ROWS = 250000;
+
+int dw2_P_plan(int64_t M_out, int K, int Cin, int Cout, bool wide) {
+  // (read per call) up to 8,192 slices one 4-wave workgroup per CU, above that -- or with the batch hint -- two
   const int64_t n_slices = (M_out + 31) / 32;
-  const int target = dw2_env("WSIS_DW2_WAVES", n_slices >= 8192 ? 2048 : 1024);
+  const int64_t lo = dw2_env("WSIS_DW2_LO", 0), hi = dw2_env("WSIS_DW2_HI", 8192);
+  const int target = dw2_env("WSIS_DW2_WAVES", (wide || n_slices >= hi || n_slices < lo) ? 2048 : 1024);
   const int NOG = (K + GS - 1) / GS;
   const int64_t combos = (int64_t)NOG * (Cin / 32) * ((Cout + 31) / 32);
   int64_t P = (target / WGW + combos - 1) / combos;
@@ -521,6 +531,9 @@ int dw2_P(int64_t M_out, int K, int Cin, int Cout) {
   if (P >= 8) P &= ~(int64_t)7;     // multiple of 8: blockIdx.x % 8 is the XCD for every blockIdx.y
   if (P < 1) P = 1;
   return (int)P;
+}
+int dw2_P(int64_t M_out, int K, int Cin, int Cout) {
+  return dw2_P_plan(M_out, K, Cin, Cout, g_batch_rows.load(std::memory_order_relaxed) >= WIDE_ROWS);
 }
 
 }  // namespace
@@ -538,9 +551,12 @@ bool dw2_fits(int64_t M_in, int64_t M_out, int K, int Cin, int Cout) {
   return M_in * Cin * 4 < lim && M_out * Cout * 4 < lim && (int64_t)K * M_out * 4 < lim && M_in >= 1 && M_out >= 1;
 }
 
-int64_t dw2_workspace_bytes(int64_t M_out, int K, int Cin, int Cout) {
-  return (int64_t)dw2_P(M_out, K, Cin, Cout) * K * Cin * Cout * (int64_t)sizeof(float) + 256;
+int64_t dw2_workspace_bytes(int64_t M_out, int K, int Cin, int Cout) {      // (either plan: the hint may change between sizing and launch)
+  const int P = std::max(dw2_P_plan(M_out, K, Cin, Cout, false), dw2_P_plan(M_out, K, Cin, Cout, true));
+  return (int64_t)P * K * Cin * Cout * (int64_t)sizeof(float) + 256;
 }
+
+void dw2_set_batch_rows(int64_t rows) { g_batch_rows.store(rows, std::memory_order_relaxed); }
 
 // the own-rows form (kernel SWAP): conv input x [M_in, Cin] normalised on the fly, gathered conv dY [M_out, Cout] through
 // the dIn table (rows = conv inputs); writes dW [K, Cin, Cout] exactly like dw2_launch

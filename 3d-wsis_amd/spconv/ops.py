@@ -820,6 +820,10 @@ def prebuild_unet_rulebooks(tensor, n_levels, subm_key="subm{}", down_key="spcon
     (``tensor._ready_event``, if set, is waited for on the side stream)."""
     keys = [subm_key.format(first_id + l) for l in range(n_levels)] + \
            [down_key.format(first_id + l) for l in range(n_levels - 1)]
+    if tensor.indices.is_cuda:
+        # launch-plan hint for this batch's weight-gradient products (wsis_hip.h: wsis_hint_batch_rows): every path that
+        # trains on the tensor -- the native executor and the module walk -- passes here with the same row count
+        _n.check(_n.hip().wsis_hint_batch_rows(int(tensor.indices.shape[0])), "hint_batch_rows")
     if all(k in tensor.indice_dict for k in keys):
         return                   # e.g. attached from a RulebookPrefetcher
     if side_stream is None:

@@ -162,6 +162,7 @@ _HIP_SIGS = {
     "wsis_run_ops_marked": (I32, [P, I32, P, I64, P, P, I32, P]),
     "wsis_experimental": (I32, []),
     "wsis_warm_streams": (I32, [P]),
+    "wsis_hint_batch_rows": (I32, [I64]),
 }
 
 # entry points of the EXPERIMENTAL build only (make -C 3d-wsis_amd/csrc EXPERIMENTAL=1; include/wsis_hip.h guards them):

@@ -751,8 +751,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("C2: 1 synthetic ScanNet-shaped scene on 1 GPU" if (world == 1 and spg == 1) else
                                     f"C5-shaped: {spg} synthetic ScanNet-shaped scene(s) per GPU x {world} GPU(s) = "
-                                    f"batch {spg * world}, scenes sharded by rank, gradient all-reduce per step over "
-                                    f"{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend() + ' (control-flow run, ranks may share a GPU)'}") + ", 2 cm voxels, fwd+bwd+AdamW step (SubMConv3d UNet 32..160 + ECC GNN "
+                                    f"batch {spg * world}, scenes sharded by rank, " +
+                                    ("no process group (one rank: nothing to exchange)" if not use_dist else
+                                     "gradient all-reduce per step over " +
+                                     ("RCCL" if dist.get_backend() == "nccl" else
+                                      dist.get_backend() + " (control-flow run, ranks may share a GPU)"))) + ", 2 cm voxels, fwd+bwd+AdamW step (SubMConv3d UNet 32..160 + ECC GNN "
                                     "+ edge affinity + MultiTaskLoss); per-batch segment CSRs / edge graph and all "
                                     "rulebooks are rebuilt inside every step" +
                                     (" EXCEPT the segment CSRs / edge graph (--hoist-graphs)" if args.hoist_graphs

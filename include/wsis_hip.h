@@ -722,6 +722,14 @@ int wsis_run_ops_marked(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
  * Call before creating an RCCL communicator in the same process (wsis_parallel.warm_streams does): streams take their
  * hardware queue in the order of their first use, and two streams of a step must not end up sharing one. */
 int wsis_warm_streams(void* stream);
+/* Launch-plan hint for the weight-gradient products (wsis_spconv_dw, wsis_spconv_dw_bn, the backward ops of wsis_run_ops):
+ * `rows` = active voxels of the finest level of the batch being trained (train_scannetv2.py:191: the rows of the
+ * SparseConvTensor the UNet receives).  From 250,000 rows (two ScanNet scenes per step) the launches take twice the
+ * waves at every level: with several scenes per step the GPU is busy throughout and the gradients should get done
+ * fast; with one scene they should stay out of the way of the dIn products.  0 (initial) = no hint.
+ * Performance only -- results stay within the same tolerance, but the slab partition and with it the order of additions
+ * of a weight gradient follow the plan: give the same hint to runs whose bits are compared. */
+int wsis_hint_batch_rows(int64_t rows);
 /* A pass issued in PARTS -- the host does something between two parts (the statistics exchange of a SyncBatchNorm layer:
  * train_scannetv2.py:734-736 converts every BatchNorm when num_gpus > 1; model/unet_native.py).  Parts with last == 0
  * leave the weight-gradient side stream un-joined; the part with last != 0 (n may be 0) joins everything forked since.
