@@ -479,12 +479,14 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
 #endif
   // one-wave items with the table entries in registers (8.25 instead of 12.3 KB of LDS per item): needs a gather table
   // (the 1x1x1 convolutions have none) and row indices the 24-bit multiply holds
-  // per-item walk (spconv_fwd2h_kernel): items of >= rgh_steps steps and the workgroups behind the first full round of
-  // 16 per CU; only where a launch HAS a second round or long items to speak of (many one-wave items)
-  const int rgh_steps = n_items >= 8 * 64 * 8 ? tune_int("WSIS_FWD2_RGH", 0) & 255 : 0;      // (EXPERIMENTAL build only)
-  // (the late rule only where the launch's last round is a partial SECOND round: with many rounds the workgroups behind
-  // the first are the bulk, and a bulk that walks by register gather saturates the texture path)
+#if WSIS_EXPERIMENTAL
+  // per-item walk (spconv_fwd2h_kernel): items of >= rgh_steps active offsets and the workgroups behind the first full
+  // round of 16 per CU; only where a launch HAS a second round or long items to speak of (many one-wave items); the late
+  // rule only where the launch's last round is a partial SECOND round: with many rounds the workgroups behind the first
+  // are the bulk, and a bulk that walks by register gather saturates the texture path
+  const int rgh_steps = n_items >= 8 * 64 * 8 ? tune_int("WSIS_FWD2_RGH", 0) & 255 : 0;
   const int rgh_late = (tune_int("WSIS_FWD2_RGH_LATE", 1) && n_items > 16 * n_cu && n_items <= 2 * 16 * n_cu) ? 16 * n_cu : 0;
+#endif
   const bool tr_ok = d_nbr != nullptr && !bn_in && M_in < ((int64_t)1 << 24) && tune_int("WSIS_FWD2_TR", 1) != 0;
   if (p.NB == 1 && p.DA == 2 && p.BD && (bn_in || p.NW == 16)) {
     switch (p.NW) {

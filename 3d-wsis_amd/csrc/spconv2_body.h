@@ -391,10 +391,8 @@ __device__ __forceinline__ void fwd2_body(
 
   // per-lane constants of the DMA pieces: instruction i of a 32-row image covers rows i*8 + (lane >> 3)
   const int d_row = lane >> 3, d_piece = lane & 7;
-  const char* const Xb = reinterpret_cast<const char*>(X);
   const char* const Wb = reinterpret_cast<const char*>(WTp);
   const char* const zrow = reinterpret_cast<const char*>(g_zero_row) + d_piece * 16;
-  const int64_t a_pitch = (int64_t)Cin * 4;
 
   // step generators (wave-uniform scalars): next (offset, chunk) of the gathered-row stream / of the weight stream
   struct Gen {
