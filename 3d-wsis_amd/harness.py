@@ -637,8 +637,11 @@ def save_checkpoint(model, filename, optimizer=None, meta=None):
 def load_checkpoint(model, filename, map_location="cpu", strict=True, optimizer=None):
     """``utils/checkpoint.py:105-135``: the state dict sits under "model" (or "state_dict", or is the file itself),
     a leading "module." is stripped; the published checkpoints of the reference load this way (the layout is pinned
-    by tests/test_state_dict_layout.py).  Returns the whole checkpoint dict."""
-    ck = torch.load(filename, map_location=map_location, weights_only=False)
+    by tests/test_state_dict_layout.py).  Read with ``wsis_datasets.safe_torch_load`` (``weights_only=True`` + the numpy
+    reconstructors): a checkpoint is somebody else's file and nothing of it is executed -- one that carries anything
+    but tensors, arrays, containers, strings and numbers is refused.  Returns the whole checkpoint dict."""
+    from wsis_datasets import safe_torch_load
+    ck = safe_torch_load(filename, map_location=map_location)
     if not isinstance(ck, dict):
         raise RuntimeError(f"No state_dict found in checkpoint file {filename}")
     sd = ck.get("model", ck.get("state_dict", ck))

@@ -133,15 +133,49 @@ def read_spg_pickle(path):
     return PlainGraph(vs, edges, f, one)
 
 
+def _numpy_safe_globals():
+    """The globals a ``torch.save`` of plain numpy arrays references, as (callable, path-in-the-file) pairs for
+    ``torch.serialization.safe_globals``: the array reconstructor under both of its module names (files written with
+    numpy 1.x say ``numpy.core.multiarray``, numpy 2 says ``numpy._core.multiarray``), ``ndarray``, ``dtype`` and the
+    per-type dtype classes newer numpy pickles.  Nothing here can run code: ``_reconstruct`` / ``scalar`` build an
+    array / a scalar from bytes (object dtypes are refused below)."""
+    try:
+        from numpy._core.multiarray import _reconstruct, scalar
+    except ImportError:                                            # numpy 1.x
+        from numpy.core.multiarray import _reconstruct, scalar
+    out = [np.ndarray, np.dtype]
+    for mod in ("numpy.core.multiarray", "numpy._core.multiarray"):
+        out += [(_reconstruct, mod + "._reconstruct"), (scalar, mod + ".scalar")]
+    for code in ("f2", "f4", "f8", "i1", "i2", "i4", "i8", "u1", "u2", "u4", "u8", "b1"):
+        cls = type(np.dtype(code))
+        if cls is not np.dtype:
+            out.append(cls)
+    return out
+
+
+def safe_torch_load(path, map_location="cpu"):
+    """``torch.load(..., weights_only=True)`` with the numpy reconstructors allow-listed: tensors, numpy arrays of
+    numeric dtype, containers, strings and numbers load; every other global in the stream (a ``REDUCE`` of
+    ``os.system``, a pickled class) raises ``pickle.UnpicklingError`` before anything of the file runs.  The loader of
+    the reference's own files: per-scene ``.pth`` (``scannetv2_dataset.py:62-73``) and checkpoints
+    (``utils/checkpoint.py:105-135``) are files of somebody else's making."""
+    with torch.serialization.safe_globals(_numpy_safe_globals()):
+        return torch.load(path, map_location=map_location, weights_only=True)
+
+
 def load_scene_file(path):
     """The reference's per-scene ``.pth``: ``(coords, colors, sem, inst, superpoint, scene_name)``
-    (``prepare_data_inst_ScanNetV2.py:166``, read at ``scannetv2_dataset.py:62,72``)."""
-    t = torch.load(path, weights_only=False)
+    (``prepare_data_inst_ScanNetV2.py:166``, read at ``scannetv2_dataset.py:62,72``).  Read with ``safe_torch_load``:
+    nothing of the file is executed."""
+    t = safe_torch_load(path)
     if not (isinstance(t, (tuple, list)) and len(t) == 6):
         raise ValueError(f"{path}: expected the 6-tuple (coords, colors, sem, inst, superpoint, scene)")
     coords, colors, sem, inst, superpoint, scene = t
-    return (np.asarray(coords), np.asarray(colors), np.asarray(sem), np.asarray(inst), np.asarray(superpoint),
-            str(scene))
+    arrays = [np.asarray(a) for a in (coords, colors, sem, inst, superpoint)]
+    for a in arrays:
+        if a.dtype.hasobject:
+            raise ValueError(f"{path}: object arrays are not scene data")
+    return (*arrays, str(scene))
 
 
 class ScenePrep(object):

@@ -101,3 +101,74 @@ def test_spg_pickle_refuses_callables_of_allowed_modules(tmp_path, payload):
         pickle.dump(payload, fh)
     with pytest.raises(pickle.UnpicklingError):
         ds.read_spg_pickle(path)
+
+
+# ---- the reference's torch files: per-scene .pth and checkpoints (round 6: no loader of this package unpickles) ----------
+class _Payload(object):
+    def __init__(self, marker):
+        self.marker = str(marker)
+
+    def __reduce__(self):
+        import os
+        return (os.system, ("echo pwned > " + self.marker,))
+
+
+def _rename_numpy_module(src, dst):
+    """rewrite a torch.save archive so that its pickle names the array reconstructor the way numpy 1.x did
+    (``numpy.core.multiarray``): what the reference's own files, written in 2021, contain."""
+    import zipfile
+    with zipfile.ZipFile(src) as zi, zipfile.ZipFile(dst, "w") as zo:
+        for it in zi.infolist():
+            data = zi.read(it.filename)
+            if it.filename.endswith("data.pkl"):
+                assert b"numpy._core.multiarray" in data
+                data = data.replace(b"cnumpy._core.multiarray\n", b"cnumpy.core.multiarray\n")
+            zo.writestr(it, data)
+
+
+def test_scene_file_loader_executes_nothing(tmp_path):
+    """``load_scene_file`` (scannetv2_dataset.py:62-73) reads numpy tuples through ``weights_only=True`` + an allow-list;
+    a file whose pickle carries a REDUCE of ``os.system`` is refused and the command never runs."""
+    import pickle
+    import torch
+    rng = np.random.default_rng(0)
+    tup = (rng.random((7, 3), dtype=np.float32), rng.random((7, 3)).astype(np.float32), np.arange(7.0),
+           np.arange(7, dtype=np.int32), np.arange(7, dtype=np.int64), "scene0000_00")
+    torch.save(tup, tmp_path / "ok.pth")
+    back = ds.load_scene_file(tmp_path / "ok.pth")
+    assert back[5] == "scene0000_00" and all(np.array_equal(a, b) for a, b in zip(back[:5], tup[:5]))
+    if np.lib.NumpyVersion(np.__version__) >= "2.0.0":
+        _rename_numpy_module(tmp_path / "ok.pth", tmp_path / "ok_numpy1.pth")
+        back = ds.load_scene_file(tmp_path / "ok_numpy1.pth")
+        assert all(np.array_equal(a, b) for a, b in zip(back[:5], tup[:5]))
+    marker = tmp_path / "pwned_scene"
+    torch.save(tup[:4] + (_Payload(marker), "x"), tmp_path / "evil.pth")
+    with pytest.raises(pickle.UnpicklingError):
+        ds.load_scene_file(tmp_path / "evil.pth")
+    assert not marker.exists()
+    torch.save(tup[:4] + (np.array([_Payload(marker)], dtype=object), "x"), tmp_path / "evil_obj.pth")
+    with pytest.raises((pickle.UnpicklingError, ValueError)):
+        ds.load_scene_file(tmp_path / "evil_obj.pth")
+    assert not marker.exists()
+
+
+def test_checkpoint_loader_executes_nothing(tmp_path):
+    """``harness.load_checkpoint`` (utils/checkpoint.py:105-135): same loader; a checkpoint with a code-carrying entry
+    next to a valid state dict is refused before anything is applied to the model."""
+    import pickle
+    import torch
+    import harness
+    model = torch.nn.Linear(3, 2)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    other = torch.nn.Linear(3, 2)
+    marker = tmp_path / "pwned_ck"
+    torch.save({"meta": {"epoch": 3, "hook": _Payload(marker)}, "model": other.state_dict()}, tmp_path / "evil_ck.pth")
+    with pytest.raises(pickle.UnpicklingError):
+        harness.load_checkpoint(model, tmp_path / "evil_ck.pth")
+    assert not marker.exists()
+    assert all(torch.equal(before[k], v) for k, v in model.state_dict().items())
+    torch.save({"meta": {"epoch": 3, "time": "now", "lr": np.float64(1e-3)}, "model": other.state_dict()},
+               tmp_path / "ok_ck.pth")
+    ck = harness.load_checkpoint(model, tmp_path / "ok_ck.pth")
+    assert ck["meta"]["epoch"] == 3 and float(ck["meta"]["lr"]) == 1e-3
+    assert all(torch.equal(a, b) for a, b in zip(other.state_dict().values(), model.state_dict().values()))
