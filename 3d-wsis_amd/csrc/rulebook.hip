@@ -138,16 +138,18 @@ __global__ void subm3_kernel(const int32_t* __restrict__ indices, int64_t M, Geo
 }
 
 // candidate output keys of every active input; invalid candidates get key == invalid
+// (batch_limit > 0: rows whose batch index is not in [0, batch_limit) have no candidate -- what the bitmap form does)
 __global__ void down_cand_kernel(const int32_t* __restrict__ indices, int64_t M, Geo g, int fast,
-                                 int64_t invalid, int64_t* __restrict__ cand) {
+                                 int64_t invalid, int64_t* __restrict__ cand, int32_t batch_limit) {
   const int K = g.k[0] * g.k[1] * g.k[2];
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < M;
        r += (int64_t)gridDim.x * blockDim.x) {
     const int4 c = reinterpret_cast<const int4*>(indices)[r];
     const int p[3] = {c.y, c.z, c.w};
+    const bool in_batch = batch_limit <= 0 || (c.x >= 0 && c.x < batch_limit);
     if (fast) {
       int o[3];
-      bool ok = true;
+      bool ok = in_batch;
       for (int j = 0; j < 3; ++j) {
         o[j] = p[j] / g.s[j];
         ok = ok && o[j] < g.shape_out[j];
@@ -160,7 +162,7 @@ __global__ void down_cand_kernel(const int32_t* __restrict__ indices, int64_t M,
           for (int d = 0; d < g.k[2]; ++d, ++kf) {
             const int kk[3] = {a, b, d};
             int o[3];
-            bool ok = true;
+            bool ok = in_batch;
             for (int j = 0; j < 3; ++j) {
               const int t = p[j] + g.p[j] - kk[j];
               ok = ok && t >= 0 && (t % g.s[j]) == 0;
@@ -188,7 +190,7 @@ __global__ void down_mark_kernel(const int32_t* __restrict__ indices, int64_t M,
     const int o0 = c.y / g.s[0], o1 = c.z / g.s[1], o2 = c.w / g.s[2];
     if (o0 >= g.shape_out[0] || o1 >= g.shape_out[1] || o2 >= g.shape_out[2]) continue;
     const int64_t key = lin_key(c.x, o0, o1, o2, g.shape_out);
-    if (key < 0 || key >= n_cells) continue;      // (a batch index past batch_size: not an output of this build)
+    if (c.x < 0 || key < 0 || key >= n_cells) continue;      // (a batch index outside [0, batch_size): not an output of this build; down_keys_sorted with a batch limit drops the same rows)
     atomicOr(bitmap + (key >> 5), 1u << (key & 31));
   }
 }
@@ -629,11 +631,28 @@ int64_t wsis_rulebook_down_workspace_bytes(int64_t n_cand) {
                    256);
 }
 
+namespace {
+int down_keys_sorted(const int32_t* d_indices_in, int64_t M_in, const int32_t* h_in_shape3,
+                     const int32_t* h_out_shape3, const int32_t* h_ksize3,
+                     const int32_t* h_stride3, const int32_t* h_pad3, int64_t* d_cand,
+                     int64_t* d_out_keys, int32_t* d_count, void* d_ws, int64_t ws_bytes,
+                     void* stream, int32_t batch_limit);
+}
 int wsis_rulebook_down_keys(const int32_t* d_indices_in, int64_t M_in, const int32_t* h_in_shape3,
                             const int32_t* h_out_shape3, const int32_t* h_ksize3,
                             const int32_t* h_stride3, const int32_t* h_pad3, int64_t* d_cand,
                             int64_t* d_out_keys, int32_t* d_count, void* d_ws, int64_t ws_bytes,
                             void* stream) {
+  // (no batch size in this entry point's signature: every row is a candidate; callers validate the batch column)
+  return down_keys_sorted(d_indices_in, M_in, h_in_shape3, h_out_shape3, h_ksize3, h_stride3, h_pad3, d_cand, d_out_keys,
+                          d_count, d_ws, ws_bytes, stream, 0);
+}
+namespace {
+int down_keys_sorted(const int32_t* d_indices_in, int64_t M_in, const int32_t* h_in_shape3,
+                     const int32_t* h_out_shape3, const int32_t* h_ksize3,
+                     const int32_t* h_stride3, const int32_t* h_pad3, int64_t* d_cand,
+                     int64_t* d_out_keys, int32_t* d_count, void* d_ws, int64_t ws_bytes,
+                     void* stream, int32_t batch_limit) {
   WSIS_REQUIRE(M_in >= 0 && h_in_shape3 && h_out_shape3 && h_ksize3 && h_stride3 && h_pad3 && d_count,
                "bad args");
   hipStream_t st = as_stream(stream);
@@ -649,7 +668,7 @@ int wsis_rulebook_down_keys(const int32_t* d_indices_in, int64_t M_in, const int
   // invalid candidates carry the largest int64 so they sort behind every real linear index
   const int64_t invalid = INT64_MAX;
   hipLaunchKernelGGL(down_cand_kernel, dim3(grid_for(M_in, 256)), dim3(256), 0, st, d_indices_in, M_in, g,
-                     fast, invalid, d_cand);
+                     fast, invalid, d_cand, batch_limit);
   WSIS_LAUNCH_CHECK();
   char* ws = static_cast<char*>(d_ws);
   int64_t* d_sorted = reinterpret_cast<int64_t*>(ws);
@@ -673,6 +692,7 @@ int wsis_rulebook_down_keys(const int32_t* d_indices_in, int64_t M_in, const int
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
 }
+}  // namespace
 
 namespace {
 // bitmap form of wsis_rulebook_down_keys (see down_mark_kernel); false: does not apply, nothing was issued
@@ -1097,9 +1117,11 @@ int wsis_rulebook_pyramid(const int32_t* d_indices0, int64_t M0, const int32_t* 
     if (!down_keys_bitmap(indices, M, shape, out_shape, k2, s2, p0, batch_size, static_cast<int64_t*>(at(l, WSIS_PYR_OUT_KEYS)),
                           static_cast<int32_t*>(at(l, WSIS_PYR_COUNT)), at(l, WSIS_PYR_DOWN_WS),
                           wsis_rulebook_down_workspace_bytes(M), as_stream(stream), &rc))
-      rc = wsis_rulebook_down_keys(indices, M, shape, out_shape, k2, s2, p0, static_cast<int64_t*>(at(l, WSIS_PYR_CAND)),
-                                   static_cast<int64_t*>(at(l, WSIS_PYR_OUT_KEYS)), static_cast<int32_t*>(at(l, WSIS_PYR_COUNT)),
-                                   at(l, WSIS_PYR_DOWN_WS), wsis_rulebook_down_workspace_bytes(M), stream);
+      // (same rows as the bitmap form: batch indices outside [0, batch_size) are not part of the build -- the device
+      // count then differs from the caller's hint, which is what the caller checks)
+      rc = down_keys_sorted(indices, M, shape, out_shape, k2, s2, p0, static_cast<int64_t*>(at(l, WSIS_PYR_CAND)),
+                            static_cast<int64_t*>(at(l, WSIS_PYR_OUT_KEYS)), static_cast<int32_t*>(at(l, WSIS_PYR_COUNT)),
+                            at(l, WSIS_PYR_DOWN_WS), wsis_rulebook_down_workspace_bytes(M), stream, batch_size);
     if (rc != WSIS_OK) return rc;
     int32_t* idx_out = static_cast<int32_t*>(at(l + 1, WSIS_PYR_INDICES));
     rc = wsis_rulebook_down_fill(indices, M, shape, out_shape, k2, s2, p0, static_cast<const int64_t*>(at(l, WSIS_PYR_OUT_KEYS)),

@@ -215,6 +215,11 @@ class UNetProgram(object):
         self.tail_floats = 0         # parameters' gradients there: ONE collective per step)
         self.overlap = None          # wsis_parallel.GradSync: early all-reduce of the finished first part (see backward)
         self._garena = None          # _GradArena of the last backward program
+        # True (default): ``.grad`` of the UNet's parameters are views of ONE buffer that the next backward pass
+        # overwrites once the gradients were cleared -- a tensor the caller kept from the previous step changes under
+        # it.  False (or WSIS_PERSISTENT_GRADS=0): every backward pass writes a buffer of its own (the aliasing is
+        # gone; a 44 MB allocation + the cached views rebuilt per step, data-parallel exchange still in place).
+        self.persistent_grads = os.environ.get("WSIS_PERSISTENT_GRADS", "1") != "0"
         self.bn_sync = None          # _BnSync while the model's BatchNorm layers share their statistics across ranks
         self._cache = {}
 
@@ -622,7 +627,7 @@ class UNetFunction(Function):
         ga = prog._garena
         if ga is None or ga.key != _GradArena.key_of(prog, c, ptotal, tail, dev):
             ga = prog._garena = _GradArena(prog, c, poffs, ptotal, tail, dev)
-        if any(p.grad is not None for p in ga.params):
+        if not prog.persistent_grads or any(p.grad is not None for p in ga.params):
             ga = _GradArena(prog, c, poffs, ptotal, tail, dev)
         parena, pflat, first = ga.arena, ga.flat, ga.first
         luts = {_FWD: ctx.fwd_lut, _BWD: boffs.astype(np.uint64) + np.uint64(gbase), _PAR: ga.lut, _TBL: ctx.table_lut,

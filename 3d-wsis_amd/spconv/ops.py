@@ -281,6 +281,9 @@ def verify_pending_counts():
                            % (_n.sync_errors(),))
     for g, (_, want, _) in zip(got, pend):
         if int(g) != int(want):
+            if int(want) == 0:
+                raise _n.WsisError("%d voxel(s) of the batch carry a batch index outside [0, SparseConvTensor.batch_size): "
+                                   "the tables built from them are invalid" % int(g))
             raise _n.WsisError("strided rulebook: the device found %d output voxels, the batch's level_counts said %d "
                                "(a hint that does not belong to these coordinates, or a SparseConvTensor batch_size below "
                                "the number of scenes in the batch: batch indices >= batch_size are not part of the build)"
@@ -646,6 +649,21 @@ def _build_pyramid_gen(tensor, n_levels, subm_key, down_key, first_id):
     hints = getattr(tensor, "_level_counts", None)
     if hints is not None and (len(hints) != n_levels - 1 or os.environ.get("WSIS_LEVEL_COUNTS", "1") == "0"):
         hints = None
+    if batch_size > 0 and indices.is_cuda and indices.shape[0] > 0:
+        # batch indices outside [0, batch_size) are a caller error upstream (they index past its dense grid).  The
+        # native pyramid drops such rows and its count check raises; this walk must not build tables over them either:
+        # with host counts the check rides the pending-count read of this pass, without them the chain stops the
+        # host per level anyway and the check is one more small read.
+        b = indices[:, 0]
+        bad = ((b < 0) | (b >= batch_size)).sum(dtype=torch.int32).reshape(1)
+        if hints is None:
+            if int(bad) != 0:
+                raise _n.WsisError("SparseConvTensor.batch_size = %d but %d voxel(s) carry a batch index outside "
+                                   "[0, batch_size)" % (batch_size, int(bad)))
+        else:
+            ev = torch.cuda.Event()
+            ev.record()
+            _PENDING_COUNTS.append((bad, 0, ev))
     for lvl in range(n_levels):
         kid = first_id + lvl
         key = subm_key.format(kid)

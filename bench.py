@@ -625,6 +625,22 @@ def main():
     local_base = None
     if use_dist and grad_sync is not None:
         nb = max(5, min(20, args.steps))
+        # Exchange REALLY off for these steps: besides grad_sync=None, the hook the native UNet backward calls for the
+        # early half-exchange is unhooked (left armed it would start an all-reduce of half the flat buffer on the
+        # communication stream every step, with nobody waiting for it), and a pending early handle is drained first.
+        # The ranks step on their own batches without averaging, so parameters, buffers and optimizer state are
+        # snapshotted before and put back after: the timed region trains the same replicas as without this block.
+        prog = getattr(model, "_native_prog", None)
+        saved_hook = getattr(prog, "overlap", None) if prog is not None else None
+        if prog is not None:
+            prog.overlap = None
+        if grad_sync._early is not None:
+            grad_sync._early[0].wait()
+            grad_sync._early = None
+        torch.cuda.synchronize()
+        snap_p = [p.detach().clone() for p in model.parameters()]
+        snap_b = [b.detach().clone() for b in model.buffers()]
+        snap_o = optimizer.state_dict() if hasattr(optimizer, "exp_avg") else __import__("copy").deepcopy(optimizer.state_dict())
         for _ in range(3):
             step(exchange=False)
         fence()
@@ -639,7 +655,19 @@ def main():
             tb = float(tt.item())
         local_base = {"scenes_per_gpu": spg, "scenes_per_s": round(spg * nb / tb, 3), "ms_per_step": round(tb / nb * 1e3, 3),
                       "how": f"{nb} steps of this line's per-GPU batch in this process with the gradient exchange off "
-                             "(slowest rank); BatchNorm mode as in the line"}
+                             "(no collective at all: the early half-exchange hook unhooked; slowest rank); BatchNorm mode "
+                             "as in the line; parameters / optimizer state restored afterwards"}
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for p, q in zip(model.parameters(), snap_p):
+                p.copy_(q)
+            for b, q in zip(model.buffers(), snap_b):
+                b.copy_(q)
+        optimizer.load_state_dict(snap_o)
+        del snap_p, snap_b, snap_o
+        if prog is not None:
+            prog.overlap = saved_hook
+        assert grad_sync._early is None, "an early exchange was issued during the exchange-off baseline"
         for _ in range(2):      # back to the timed configuration
             step()
 

@@ -608,6 +608,44 @@ def test_unet_gradients_accumulate_and_follow_requires_grad():
     assert all(lo <= params[n].grad.data_ptr() < hi for n in unet_names)
 
 
+def test_unet_gradient_buffer_aliasing_contract_and_opt_out():
+    """INTEGRATION "Differences": with the default ``prog.persistent_grads = True`` the UNet's ``.grad`` tensors are
+    views of one buffer that the NEXT backward pass overwrites after ``zero_grad(set_to_none=True)`` -- a gradient the
+    caller kept from the previous step (logging, clipping snapshots, manual accumulation) changes under it unless it
+    was cloned.  ``prog.persistent_grads = False`` (``WSIS_PERSISTENT_GRADS=0``) gives every pass a buffer of its own:
+    the kept tensor keeps its values, the new gradients are the same bits."""
+    cfg, batch_host, model, crit, opt, _ = _setup(1, 37, (1.4, 1.1, 0.9))
+    batch_a = harness.to_device(batch_host, "cuda")
+    sc_b = harness.make_scene(38, room=(1.3, 1.2, 0.9), n_box=2)
+    batch_b = harness.to_device(harness.collate([sc_b]), "cuda")
+    model.train()
+    prog_name = next(n for n, _ in model.named_parameters() if n.startswith("unet."))
+    par = dict(model.named_parameters())[prog_name]
+
+    def backward(batch):
+        model.zero_grad(set_to_none=True)
+        loss, _ = harness.forward_loss(model, crit, batch, cfg)
+        loss.backward()
+        return par.grad
+
+    kept = backward(batch_a)                   # NOT cloned
+    copy_a = kept.clone()
+    new = backward(batch_b)
+    assert not torch.equal(new, copy_a)        # a different batch: a different gradient
+    assert kept.data_ptr() == new.data_ptr() and torch.equal(kept, new)       # the kept tensor was overwritten
+    prog = model._native_prog
+    prog.persistent_grads = False
+    try:
+        kept = backward(batch_a)
+        assert torch.equal(kept, copy_a)
+        new2 = backward(batch_b)
+        assert kept.data_ptr() != new2.data_ptr()
+        assert torch.equal(kept, copy_a)       # survives the next pass
+        assert torch.equal(new2, new)          # and the pass computes the same bits
+    finally:
+        prog.persistent_grads = True
+
+
 def test_warm_streams_is_idempotent_and_leaves_results_alone():
     """wsis_parallel.warm_streams() (what init_distributed runs before it creates a process group: every stream of a
     step takes its hardware queue first) can be called at any time, any number of times"""

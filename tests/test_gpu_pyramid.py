@@ -71,3 +71,29 @@ def test_training_step_is_the_same_with_either_build(monkeypatch):
         out = [float(harness.train_step(model, crit, opt, batch, cfg)[0]) for _ in range(2)]
         losses.append(out)
     assert losses[0] == losses[1]
+
+
+@pytest.mark.parametrize("native", ["1", "0"])
+@pytest.mark.parametrize("with_counts", [True, False])
+def test_batch_size_below_the_number_of_scenes_fails_loudly_on_every_build(monkeypatch, native, with_counts):
+    """A ``SparseConvTensor`` whose ``batch_size`` is below the number of scenes in ``indices`` is a caller error
+    (upstream indexes past its dense grid).  Both builds refuse it instead of building different tables: the native
+    pyramid leaves the out-of-range rows out (bitmap AND sort form) and its count check raises; the per-table walk
+    counts the offending rows -- with host counts in the same deferred read, without them right away."""
+    import wsis_native as _n
+    monkeypatch.setenv("WSIS_PYRAMID_NATIVE", native)
+    scenes = [harness.bench_scene(s, room=(1.4, 1.2, 1.0), n_box=1) for s in (21, 22)]
+    batch = harness.to_device(harness.collate(scenes), DEV)
+    t = spconv.SparseConvTensor(torch.zeros(batch["voxel_coords_int"].shape[0], 1, device=DEV), batch["voxel_coords_int"],
+                                batch["spatial_shape"], 1)                      # two scenes, batch_size 1
+    if with_counts:
+        t._level_counts = batch["level_counts"]
+    with pytest.raises(_n.WsisError):
+        ops.prebuild_unet_rulebooks(t, 5)
+        torch.cuda.synchronize()
+        ops.verify_pending_counts()
+    # a valid tensor right behind it builds normally (nothing of the refused build is left pending)
+    ok = _tensor(batch)
+    ops.prebuild_unet_rulebooks(ok, 5)
+    torch.cuda.synchronize()
+    ops.verify_pending_counts()
