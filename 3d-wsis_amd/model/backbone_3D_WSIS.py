@@ -144,6 +144,10 @@ class Network(nn.Module):
             if input.features.is_cuda and os.environ.get("WSIS_PREBUILD", "1") != "0":
                 # all 5 + 4 rulebooks up front: their host syncs happen before the first conv is queued
                 spconv.ops.prebuild_unet_rulebooks(input, self.blocks)
+            elif input.features.is_cuda:
+                # rulebooks built lazily by the modules: the weight-gradient launch-plan hint (process-global, sticky)
+                # still has to be THIS batch's, not whatever batch ran last
+                spconv.ops.hint_batch_rows(int(input.indices.shape[0]))
             output = self.input_conv(input)
             output = self.unet(output)
             output = self.output_layer(output)

@@ -819,12 +819,38 @@ def _run(lib, ops, device, mark_op=-1, waiter=None):
 _EXPERIMENTAL_SWITCHES = ("WSIS_DEEP", "WSIS_FWD2P", "WSIS_RING", "WSIS_GRAPH", "WSIS_BN_FUSED_APPLY", "WSIS_BN_FUSED_FWD", "WSIS_BN_FUSED_BWD")
 
 
+# launch-plan / tuning knobs the C layer reads through tune_env() (csrc/common.h): live in the EXPERIMENTAL build, compiled
+# to their measured defaults in the default library (tests/test_abi.py keeps this list equal to the sources)
+TUNE_KNOBS = (
+    "WSIS_BN_APPLY_PT", "WSIS_BN_FUSED_GRID", "WSIS_BN_TICKET", "WSIS_DW2", "WSIS_DW2_HI", "WSIS_DW2_LO",
+    "WSIS_DW2_WAVES", "WSIS_DW2_XCD", "WSIS_DW2_XSH", "WSIS_DW_DIV", "WSIS_DW_THREAD", "WSIS_FWD2P_MIN",
+    "WSIS_FWD2_BD", "WSIS_FWD2_DA_NW4", "WSIS_FWD2_DEAL", "WSIS_FWD2_NOSLAB", "WSIS_FWD2_NW", "WSIS_FWD2_NW_MAX",
+    "WSIS_FWD2_NW_MAX_NOSLAB", "WSIS_FWD2_RG", "WSIS_FWD2_RGH", "WSIS_FWD2_RGH_LATE", "WSIS_FWD2_SNAKE",
+    "WSIS_FWD2_TR", "WSIS_FWD2_TR_DA", "WSIS_FWD2_WAVES", "WSIS_FWD2_XCD", "WSIS_FWD2_ZS", "WSIS_FWD_NB_SMALL",
+    "WSIS_FWD_SMALL_TILES", "WSIS_KSPLIT_TARGET", "WSIS_SL_BLOCKS", "WSIS_TILE_BAND", "WSIS_TILE_SCHED",
+    "WSIS_TILE_SCHED_MIN", "WSIS_XCD_AWARE")
+_WARNED_KNOBS = set()
+_KNOB_SCAN = [0]
+
+
 def _check_experimental_switches():
     """the switches of the retired designs exist in the EXPERIMENTAL build only: asking for one on
-    the default library is an error, not a silent no-op"""
+    the default library is an error, not a silent no-op; a tuning knob that is set while the default library is loaded
+    (where it compiles to its default) gets ONE warning -- an A/B tool run on the wrong flavour must not report A == B
+    silently"""
     for k in _EXPERIMENTAL_SWITCHES:
         if os.environ.get(k, "0") not in ("", "0"):
             _n.require_experimental(k + "=" + os.environ[k])
+    _KNOB_SCAN[0] += 1
+    if _KNOB_SCAN[0] > 4 and _KNOB_SCAN[0] % 64:       # (the scan is ~10 us of host time: the first passes, then 1 in 64)
+        return
+    ignored = [k for k in TUNE_KNOBS if k in os.environ and k not in _WARNED_KNOBS]
+    if ignored and not _n.experimental():
+        import warnings
+        _WARNED_KNOBS.update(ignored)
+        warnings.warn("tuning knob(s) %s are set but the DEFAULT libwsis_hip.so is loaded: they are live in the "
+                      "EXPERIMENTAL build only (make -C 3d-wsis_amd/csrc EXPERIMENTAL=1) and have no effect here"
+                      % ", ".join(ignored), RuntimeWarning, stacklevel=2)
 
 
 def run_unet(net, input_tensor, sync_group=None):

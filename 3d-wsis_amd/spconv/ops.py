@@ -827,6 +827,15 @@ def _build_pyramid_native(tensor, n_levels, subm_key, down_key, first_id):
     return pyr
 
 
+def hint_batch_rows(rows):
+    """``wsis_hint_batch_rows``: the weight-gradient launch plan follows the rows of the batch being trained.  The hint
+    is ONE word per process (all devices, streams and the weight-gradient worker thread read it) and stays until the
+    next call: every forward pass of the model sets it (``prebuild_unet_rulebooks`` or, with ``WSIS_PREBUILD=0``,
+    ``Network.forward``); a caller that drives ``wsis_spconv_dw`` itself sets it itself (0 = no hint) before runs whose
+    bits it compares."""
+    _n.check(_n.hip().wsis_hint_batch_rows(int(rows)), "hint_batch_rows")
+
+
 def prebuild_unet_rulebooks(tensor, n_levels, subm_key="subm{}", down_key="spconv{}", first_id=1, side_stream=None):
     """Builds every rulebook of a UBlock pyramid (SubM k3 p1 per level, k2 s2 between levels) up front and
     stores them in ``tensor.indice_dict`` under the keys the modules will look up.
@@ -841,7 +850,7 @@ def prebuild_unet_rulebooks(tensor, n_levels, subm_key="subm{}", down_key="spcon
     if tensor.indices.is_cuda:
         # launch-plan hint for this batch's weight-gradient products (wsis_hip.h: wsis_hint_batch_rows): every path that
         # trains on the tensor -- the native executor and the module walk -- passes here with the same row count
-        _n.check(_n.hip().wsis_hint_batch_rows(int(tensor.indices.shape[0])), "hint_batch_rows")
+        hint_batch_rows(int(tensor.indices.shape[0]))
     if all(k in tensor.indice_dict for k in keys):
         return                   # e.g. attached from a RulebookPrefetcher
     if side_stream is None:

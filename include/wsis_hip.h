@@ -728,7 +728,10 @@ int wsis_warm_streams(void* stream);
  * waves at every level: with several scenes per step the GPU is busy throughout and the gradients should get done
  * fast; with one scene they should stay out of the way of the dIn products.  0 (initial) = no hint.
  * Performance only -- results stay within the same tolerance, but the slab partition and with it the order of additions
- * of a weight gradient follow the plan: give the same hint to runs whose bits are compared. */
+ * of a weight gradient follow the plan: give the same hint to runs whose bits are compared.
+ * PROCESS-GLOBAL and sticky: one word shared by every device, stream and the library's weight-gradient worker thread;
+ * it keeps its value until the next call (the Python layer sets it at the top of every forward pass).  A caller of
+ * wsis_spconv_dw / wsis_spconv_dw_bn that never calls this runs with the hint of whatever batch the process saw last. */
 int wsis_hint_batch_rows(int64_t rows);
 /* A pass issued in PARTS -- the host does something between two parts (the statistics exchange of a SyncBatchNorm layer:
  * train_scannetv2.py:734-736 converts every BatchNorm when num_gpus > 1; model/unet_native.py).  Parts with last == 0

@@ -91,3 +91,26 @@ def test_heads_struct_matches_header():
             names.append(re.sub(r"\[.*", "", part.strip().split()[-1].lstrip("*")))
     assert names == [f[0] for f in wsis_native.Heads._fields_]
     assert ctypes.sizeof(wsis_native.Heads) == 4 * 2 + 4 * n_max + 8 * n_max * 17
+
+
+def test_tuning_knob_list_matches_the_sources_and_warns_on_the_default_build(monkeypatch):
+    """every name the C layer reads through tune_env / tune_int / dw2_env (csrc/common.h: live in the EXPERIMENTAL build,
+    a compiled-in default otherwise) is in ``unet_native.TUNE_KNOBS``; setting one while the default library is loaded
+    warns once instead of being a silent no-op (tools/conv_ab.py, ab_step.py on the wrong flavour would read A == B)"""
+    import glob
+    import warnings
+    from model import unet_native
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "3d-wsis_amd", "csrc", "*.h*")):
+        names |= set(re.findall(r"(?:tune_env|tune_int|dw2_env|dw3_env)\(\"(WSIS_\w+)\"", open(f).read()))
+    assert names and names == set(unet_native.TUNE_KNOBS), sorted(names ^ set(unet_native.TUNE_KNOBS))
+    knob = "WSIS_FWD2_WAVES"
+    monkeypatch.setenv(knob, "512")
+    unet_native._WARNED_KNOBS.discard(knob)
+    unet_native._KNOB_SCAN[0] = 0
+    with warnings.catch_warnings(record=True) as got:
+        warnings.simplefilter("always")
+        unet_native._check_experimental_switches()
+        unet_native._check_experimental_switches()
+    hits = [w for w in got if knob in str(w.message)]
+    assert len(hits) == (0 if wsis_native.experimental() else 1)
