@@ -69,7 +69,7 @@ struct ProfRec {
   int s0 = 0, sm = 0, s1 = 0;
 };
 inline bool g_prof_on = false;
-inline std::vector<ProfRec> g_prof[2];   // 0 = spconv_fwd_kernel, 1 = spconv_dw_kernel
+inline std::vector<ProfRec> g_prof[3];   // 0 = spconv_fwd_kernel, 1 = spconv_dw_kernel, 2 = BatchNorm ops of wsis_run_ops (all launches of an op)
 inline std::vector<void*> g_prof_bufs;    // stamp buffers of profiled resident launches (freed when profiling restarts)
 
 struct ProfScope {

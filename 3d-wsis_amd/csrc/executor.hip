@@ -6,6 +6,7 @@
 // Every op maps 1:1 onto the single-op entry points of this library (same kernels, same summation orders, so the
 // results are bit-identical to calling them one by one); CAT / SPLIT / ADD are the elementwise glue of the UNet
 // (torch.cat of the skip connection, its backward, gradient accumulation at the residual fan-out).
+#include <optional>
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
@@ -922,6 +923,10 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
 #endif
     {
     const wsis_op& op = ops[i];
+    // bench.py's BatchNorm line (wsis_prof_records(2, ...)): one event pair around ALL launches of a BatchNorm op
+    const bool is_bn = op.kind == WSIS_OP_BN_RELU || op.kind == WSIS_OP_BN_RELU_BWD;
+    std::optional<ProfScope> bn_prof;
+    if (is_bn && g_prof_on) bn_prof.emplace(2, st);
     switch (op.kind) {
       case WSIS_OP_CONV:
         if (op.flags & (WSIS_OPF_BN_IN | WSIS_OPF_STAT_FIN)) {
@@ -1130,6 +1135,7 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
       default:
         rc = fail(WSIS_ERR_ARG, "wsis_run_ops: unknown op kind");
     }
+    if (bn_prof) bn_prof->stop();
     }
     if (rc != WSIS_OK) {
       first_err = rc;

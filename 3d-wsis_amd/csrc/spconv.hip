@@ -982,7 +982,7 @@ int wsis_spconv_fwd(const float* d_X, const int32_t* d_nbr, const int32_t* d_ord
 }
 
 int wsis_prof_enable(int32_t on) {
-  if (on && !g_prof_on && g_prof[0].empty() && g_prof[1].empty()) {      // a new session: the stamp buffers of the last one
+  if (on && !g_prof_on && g_prof[0].empty() && g_prof[1].empty() && g_prof[2].empty()) {      // a new session: the stamp buffers of the last one
     for (void* b : g_prof_bufs) (void)hipFree(b);
     g_prof_bufs.clear();
   }
@@ -991,7 +991,7 @@ int wsis_prof_enable(int32_t on) {
 }
 
 int wsis_prof_summary(int32_t which, double* total_ms, int64_t* launches) {
-  WSIS_REQUIRE(which >= 0 && which < 2 && total_ms && launches, "bad args");
+  WSIS_REQUIRE(which >= 0 && which < 3 && total_ms && launches, "bad args");
   double ms = 0.0;
   for (ProfRec& r : g_prof[which]) {
     if (r.d_stamps) {
@@ -1018,7 +1018,7 @@ int wsis_prof_summary(int32_t which, double* total_ms, int64_t* launches) {
 }
 
 int wsis_prof_records(int32_t which, double* h_main_ms, double* h_total_ms, int64_t cap, int64_t* n) {
-  WSIS_REQUIRE(which >= 0 && which < 2 && h_main_ms && h_total_ms && n && cap >= 0, "bad args");
+  WSIS_REQUIRE(which >= 0 && which < 3 && h_main_ms && h_total_ms && n && cap >= 0, "bad args");
   WSIS_REQUIRE((int64_t)g_prof[which].size() <= cap, "record buffer too small");
   int64_t i = 0;
   for (ProfRec& r : g_prof[which]) {

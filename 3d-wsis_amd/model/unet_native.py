@@ -311,10 +311,14 @@ class UNetProgram(object):
             rec.op(OP_BN_RELU, sflags, _lvl(lvl), _lvl(lvl), K0, C, C, bn.eps, momentum,
                    inp=(x, _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var), parts[0], parts[1]),
                    out=(0 if fuse else y, mean, var))
+            # algorithmic bytes of the op (bench.py's BatchNorm line): x read + y written; a statistics pass over x
+            # (no epilogue partials) reads x once more
+            self._acc_f.append(("bn_op", 0, lvl, C, (0 if fuse else 2) + (0 if have_parts else 1)))
         elif not fuse:
             # statistics known (finished by the producers, or evaluation mode): apply pass only
             rec.op(OP_BN_RELU, flags & ~(F_TRAINING | F_UPDATE), _lvl(lvl), _lvl(lvl), 0, C, C, bn.eps, momentum,
                    inp=(x, _ptr(bn.weight), _ptr(bn.bias), mean, var), out=(y,))
+            self._acc_f.append(("bn_op", 0, lvl, C, 2))
 
         def bwd(recb, dy, addend=0):
             # ``addend``: gradient arriving at x over a second path (residual skip / UNet skip connection), added
@@ -324,6 +328,9 @@ class UNetProgram(object):
             db = self._grad_handle(bn.bias) if bn.bias is not None else recb.alloc(-1, C)
             recb.op(OP_BN_RELU_BWD, flags & ~F_STATS, _lvl(lvl), _lvl(lvl), 0, C, C, bn.eps, 0.0,      # (F_STATS: _fuse_bn_bwd)
                     inp=(x, dy, mean, var, _ptr(bn.weight), _ptr(bn.bias), addend), out=(dx, dg, db))
+            # x and dy read, dx written, the addend read where there is one (a separate reduction pass over x and dy,
+            # taken when the producing dIn pass left no partials, is not counted: algorithmic = the fused form)
+            self._acc_b.append(("bn_op", 0, lvl, C, 3 + (1 if addend else 0)))
             return dx
         return y, bwd
 
@@ -514,6 +521,10 @@ class UNetProgram(object):
         if prof is None:
             return
         for name, nbr, lvl, Cin, Cout in entries:
+            if name == "bn_op":      # (Cin = channels, Cout = tensors of [rows, channels] the op reads + writes)
+                M = int(Mvec[lvl])
+                prof.end(name, None, M * Cin * Cout * 4, 0, (M, Cin, Cout, M))
+                continue
             t = tensors[nbr & _ID_MASK] if nbr else None
             P = prof.pairs(t, int(Mvec[lvl]))
             prof.end(name, None, P * (Cin + Cout) * 4 + P * 8, 2 * P * Cin * Cout, (int(Mvec[lvl]), Cin, Cout, P))

@@ -401,7 +401,9 @@ def other_configs(harness, device, args):
     sp_ops.PROFILER = sp_ops.KernelProfiler()
     for _ in range(2):
         harness.train_step(model, crit, opt, b, cfg)
-    k = sp_ops.PROFILER.summary().get("spconv_fwd_kernel")
+    summ3 = sp_ops.PROFILER.summary()
+    k = summ3.get("spconv_fwd_kernel")
+    kdw, kbn = summ3.get("spconv_dw_kernel"), summ3.get("bn_op")
     sp_ops.PROFILER = None
     if prev is None:
         del os.environ["WSIS_DW_STREAM"]
@@ -412,6 +414,23 @@ def other_configs(harness, device, args):
         out["c3_batch4_train"]["conv_roofline"] = {"achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                                                    "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 2),
                                                    "launches_per_step": k["launches"] // 2}
+    if kdw and kdw["ms"] > 0:      # the weight-gradient products of the same steps (main kernel + fixed-order slab sum)
+        gbs = kdw["bytes"] / (kdw["ms"] * 1e-3) / 1e9
+        out["c3_batch4_train"]["dw_roofline"] = {"achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                                 "avg_launch_us": round(kdw["ms"] * 1e3 / kdw["launches"], 2),
+                                                 "ms_per_step": round(kdw["ms"] / 2, 3),
+                                                 "ms_per_step_main_kernel_only": round(kdw["ms_main"] / 2, 3),
+                                                 "launches_per_step": kdw["launches"] // 2,
+                                                 "tflops": round(kdw["flops"] / (kdw["ms"] * 1e-3) / 1e12, 2),
+                                                 "mfma_frac_fp32": round(kdw["flops"] / (kdw["ms"] * 1e-3) / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4)}
+    if kbn and kbn["ms"] > 0:      # BatchNorm(+ReLU) ops of the UNet: x read + y written (backward: x, dy read, dx written, + addend)
+        gbs = kbn["bytes"] / (kbn["ms"] * 1e-3) / 1e9
+        out["c3_batch4_train"]["bn_roofline"] = {"achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                                 "ms_per_step": round(kbn["ms"] / 2, 3), "ops_per_step": kbn["launches"] // 2,
+                                                 "alg_bytes_per_step": kbn["bytes"] // 2,
+                                                 "how": "event pair around all launches of each BatchNorm op of the native "
+                                                        "executor (statistics finish + apply; backward finish + apply); "
+                                                        "bytes = (tensors of [rows, C] read + written) x 4"}
     del b
     cfg.batch_size = 1
     big = harness.to_device(harness.collate([harness.bench_scene(5, room=(13.0, 10.0, 3.0), n_box=36)]), device)
@@ -725,6 +744,8 @@ def main():
                               "finish a product (spconv2_reduce_kernel / spconv2_reduce_stats_kernel)",
                     "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": measured_traffic(),
+                    "traffic_source": "profiles/conv_traffic.json: the builder's rocprofv3 PMC passes of this command "
+                                      "(profiles/collect_traffic.py), committed -- NOT measured in this run",
                     "alg_bytes_per_launch": k["bytes"] // k["launches"],
                     "launches_per_step": k["launches"] // args.profile_steps,
                     "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 2),
@@ -753,6 +774,12 @@ def main():
                                   "tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2)}
         if k and d:
             extra["conv_ms_per_step"] = round((k["ms"] + d["ms"]) / args.profile_steps, 3)
+        bno = summ.get("bn_op")
+        if bno and bno["ms"] > 0:      # the UNet's BatchNorm(+ReLU) ops: tensors read + written x 4 bytes / event time
+            extra["bn_ops"] = {"achieved_GBs": round(bno["bytes"] / (bno["ms"] * 1e-3) / 1e9, 1),
+                               "frac": round(bno["bytes"] / (bno["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "ms_per_step": round(bno["ms"] / args.profile_steps, 3),
+                               "ops_per_step": bno["launches"] // args.profile_steps}
 
     if rank == 0 and world == 1 and not args.no_stages:
         extra.update(side_measurements(harness, optimizer, device, args))

@@ -307,7 +307,9 @@ int wsis_spconv_dw_bn(const float* d_X, const float* d_mean, const float* d_var,
  * front of the main kernel, one behind it, and -- where the product is finished by a second launch (the fixed-order sum
  * of offset slabs / workgroup slabs) -- one behind that launch.  wsis_prof_summary synchronises them, returns the
  * summed duration INCLUDING the finishing launches and the count, and clears the list; wsis_prof_records returns the
- * per-product durations in issue order instead (h_main_ms: main kernel only, h_total_ms: with the finishing launch). */
+ * per-product durations in issue order instead (h_main_ms: main kernel only, h_total_ms: with the finishing launch).
+ * which = 2: the BatchNorm ops of wsis_run_ops (forward and backward), one event pair around ALL launches of an op
+ * (statistics finish + apply): h_main_ms == h_total_ms. */
 int wsis_prof_enable(int32_t on);
 int wsis_prof_summary(int32_t which, double* total_ms, int64_t* launches);
 int wsis_prof_records(int32_t which, double* h_main_ms, double* h_total_ms, int64_t cap, int64_t* n);
