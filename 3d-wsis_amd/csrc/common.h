@@ -200,6 +200,19 @@ bool dw2_supported(int K, int Cin, int Cout);
 bool dw2_fits(int64_t M_in, int64_t M_out, int K, int Cin, int Cout);   // 32-bit buffer offsets
 int64_t dw2_workspace_bytes(int64_t M_out, int K, int Cin, int Cout);
 void dw2_set_batch_rows(int64_t rows);      // launch-plan hint of the weight-gradient launches (wsis_hint_batch_rows)
+// Deferred slab sums (the op-list executor, round 6): with a record slot set for the calling thread, dw2_launch /
+// dw2_launch_swapped issue the main kernel only and describe the fixed-order slab sum that finishes the product in the
+// slot; the executor finishes all products of (a part of) a backward pass with ONE dw2_reduce_batch launch -- same
+// arithmetic and order per product as the per-launch sum (bit-identical), without 55 launches of a few microseconds
+// each.  The slabs of every deferred product need their own workspace until that launch has run.
+struct DwRedRec {
+  const float* partial = nullptr;      // nullptr: the product finished itself (shape outside the dw2 kernel, empty level)
+  float* dW = nullptr;
+  int64_t total4 = 0;
+  int32_t P = 0;
+};
+void dw2_set_defer(DwRedRec* slot);    // thread-local; nullptr switches deferral off
+int dw2_reduce_batch(const DwRedRec* recs, int n, hipStream_t st);
 int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY, float* d_dW,
                int64_t M_in, int64_t M_out, int K, int Cin, int Cout, void* d_ws, hipStream_t st);
 int dw2_launch_swapped(const float* d_X, const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta,

@@ -181,8 +181,11 @@ struct DwTask {
   hipStream_t side;
   char* ws;
   int64_t ws_bytes;
+  DwRedRec* rec = nullptr;          // deferred slab sum: the product's record slot (nullptr: the product finishes itself)
+  const DwRedRec* flush = nullptr;  // != nullptr: no product -- ONE launch finishes the deferred products flush[0 .. flush_n)
+  int flush_n = 0;
 };
-int issue_dw(const wsis_op& op, char* dw_ws, int64_t dw_bytes, void* dw_stream) {
+static int issue_dw_raw(const wsis_op& op, char* dw_ws, int64_t dw_bytes, void* dw_stream) {
   if (op.flags & WSIS_OPF_BN_IN)     // the forward input was relu(bn(in[0])) applied on the fly: own-rows form
     return wsis_spconv_dw_bn((const float*)op.in[0], (const float*)op.in[7], (const float*)op.in[8], (const float*)op.in[9],
                              (const float*)op.in[10], op.eps, (op.flags & WSIS_OPF_RELU) ? 1 : 0, (const int32_t*)op.in[5],
@@ -190,6 +193,15 @@ int issue_dw(const wsis_op& op, char* dw_ws, int64_t dw_bytes, void* dw_stream) 
                              (float*)op.out[1], op.M_in, op.M_out, op.K, op.Cin, op.Cout, dw_ws, dw_bytes, dw_stream);
   return wsis_spconv_dw((const float*)op.in[0], (const int32_t*)op.in[3], (const int32_t*)op.in[4], (const float*)op.in[2],
                         (float*)op.out[1], op.M_in, op.M_out, op.K, op.Cin, op.Cout, dw_ws, dw_bytes, dw_stream);
+}
+// rec != nullptr: the product's slab sum is deferred (the dw2 kernel fills the slot; any other path finishes by itself
+// and leaves rec->partial == nullptr)
+int issue_dw(const wsis_op& op, char* dw_ws, int64_t dw_bytes, void* dw_stream, DwRedRec* rec = nullptr) {
+  if (rec) *rec = DwRedRec{};
+  dw2_set_defer(rec);
+  const int rc = issue_dw_raw(op, dw_ws, dw_bytes, dw_stream);
+  dw2_set_defer(nullptr);
+  return rc;
 }
 class DwWorker {
  public:
@@ -242,12 +254,12 @@ class DwWorker {
       int rc = WSIS_OK;
       std::string msg;
       hipError_t he = hipSetDevice(t.dev);
-      if (he == hipSuccess) he = hipStreamWaitEvent(t.side, t.ev, 0);
+      if (he == hipSuccess && t.ev) he = hipStreamWaitEvent(t.side, t.ev, 0);
       if (he != hipSuccess) {
         rc = WSIS_ERR_HIP;
         msg = std::string("dW worker: ") + hipGetErrorString(he);
       } else {
-        rc = issue_dw(t.op, t.ws, t.ws_bytes, t.side);
+        rc = t.flush ? dw2_reduce_batch(t.flush, t.flush_n, t.side) : issue_dw(t.op, t.ws, t.ws_bytes, t.side, t.rec);
         if (rc != WSIS_OK) msg = wsis_last_error();
       }
       std::lock_guard<std::mutex> lock(mu_);
@@ -273,6 +285,16 @@ DwWorker& dw_worker() {
 bool dw_thread_enabled() {
   const char* e = tune_env("WSIS_DW_THREAD");
   return e ? atoi(e) != 0 : true;
+}
+
+// deferred slab sums (one dw2_reduce_batch launch per part of a pass instead of one small launch per product); read per
+// pass.  Off while the profiler brackets every product with events: a product's duration then includes its own sum.
+// Measured (tools/r06_ab_reduce.sh, profiles/r06_ab_reduce_c*.txt): bit-identical and SLOWER in the step -- 7.75 -> 7.90 ms
+// at one scene, 20.36 -> 20.42 at four: the per-product sums hide under the dIn products as they go, the batched launch
+// reads every slab of the pass from HBM (0.44 GB at one scene) at the end of the pass, in front of the join.  Opt-in.
+bool dw_batch_reduce_enabled() {
+  const char* e = getenv("WSIS_DW_BATCH_REDUCE");
+  return (e ? atoi(e) != 0 : false) && !g_prof_on;
 }
 
 bool dw_stream_enabled() {   // read per pass: bench.py switches it off for its event-instrumented roofline steps
@@ -651,7 +673,7 @@ int wsis_warm_streams(void* stream) {
 
 int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n) {
   if (!ops || n < 0) return -1;
-  int64_t need = ALIGN, wt = 0, dw = 0;
+  int64_t need = ALIGN, wt = 0, dw = 0, dw_sum = 0;
   const bool on = fwd2_enabled();
   for (int i = 0; i < n; ++i) {
     const int64_t b = op_ws_bytes(ops[i], on);
@@ -662,9 +684,14 @@ int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n) {
       const int64_t d = dw_ws_of(ops[i]);
       if (d < 0) return -1;
       if (d > dw) dw = d;
+      dw_sum += d;
     }
   }
-  return wt + dw + need + deep_ws_bytes(ops, n, on) + ALIGN;
+  // (deferred slab sums: every product keeps its slabs until the batched launch; the switch is read per pass -- a pass
+  // whose workspace was sized with it off and that runs with it on fails its own size check)
+  const char* be = getenv("WSIS_DW_BATCH_REDUCE");
+  const bool batch = be && atoi(be) != 0;
+  return wt + (batch ? std::max(dw, dw_sum) : dw) + need + deep_ws_bytes(ops, n, on) + ALIGN;
 }
 
 int wsis_run_ops(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_bytes, void* d_sync, void* stream) {
@@ -806,15 +833,26 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   ws_bytes -= wt_total;
   char* const wt_base = static_cast<char*>(d_ws);
   // dW region (shared by the dW launches, which are ordered among themselves on one stream)
-  int64_t dw_bytes = 0;
+  // ... or, with deferred slab sums, one region per product: its slabs live until the batched launch that sums them
+  const bool dw_defer = dw_batch_reduce_enabled();
+  int64_t dw_bytes = 0, dw_sum = 0;
+  int n_dw = 0;
   for (int i = 0; i < n; ++i)
     if (ops[i].kind == WSIS_OP_CONV_BWD && ops[i].out[1]) {
       const int64_t d = dw_ws_of(ops[i]);
       if (d > dw_bytes) dw_bytes = d;
+      dw_sum += d;
+      ++n_dw;
     }
   char* const dw_ws = ws;
-  ws += dw_bytes;
-  ws_bytes -= dw_bytes;
+  ws += dw_defer ? dw_sum : dw_bytes;
+  ws_bytes -= dw_defer ? dw_sum : dw_bytes;
+  if (ws_bytes < 0) return fail(WSIS_ERR_ARG, "wsis_run_ops: workspace too small for the weight-gradient slabs");
+  // record slots of the pass's deferred products (stable addresses: the worker thread fills them) and what has been
+  // flushed so far; the vector outlives every task that points into it (drained before this function returns)
+  std::vector<DwRedRec> dw_recs((size_t)(dw_defer ? n_dw : 0));
+  int dw_next = 0, dw_flushed = 0;
+  int64_t dw_off = 0;
   // resident deep-level launches (deep.hip): phase table + private slab regions of the largest run
   const int64_t deep_bytes = deep_ws_bytes(ops, n, on);
   char* const deep_ws = ws;
@@ -849,6 +887,15 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   // weight gradient of a CONV_BWD op: forked to the side stream behind everything enqueued so far on the caller's stream
   auto dw_issue = [&](const wsis_op& op) -> int {
     void* dw_stream = stream;
+    char* my_ws = dw_ws;
+    int64_t my_bytes = dw_bytes;
+    DwRedRec* rec = nullptr;
+    if (dw_defer && dw_next < n_dw) {
+      my_bytes = dw_ws_of(op);
+      my_ws = dw_ws + dw_off;
+      dw_off += my_bytes;
+      rec = &dw_recs[(size_t)dw_next++];
+    }
     if (side) {   // dY is complete once everything enqueued so far on the caller's stream has run
       hipEvent_t e = next_fork_event(side);
       hipError_t he = e ? hipEventRecord(e, st) : hipErrorOutOfMemory;
@@ -862,14 +909,36 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
         t.ev = e;
         t.dev = cur_dev;
         t.side = side->stream;
-        t.ws = dw_ws;
-        t.ws_bytes = dw_bytes;
+        t.ws = my_ws;
+        t.ws_bytes = my_bytes;
+        t.rec = rec;
         dw_worker().push(t);
         worker_busy = true;
         return WSIS_OK;
       }
     }
-    return issue_dw(op, dw_ws, dw_bytes, dw_stream);
+    return issue_dw(op, my_ws, my_bytes, dw_stream, rec);
+  };
+  // ONE launch finishes the deferred products issued since the last flush (behind them on their stream)
+  auto dw_flush = [&]() -> int {
+    if (!dw_defer || dw_flushed == dw_next) return WSIS_OK;
+    const DwRedRec* recs = dw_recs.data() + dw_flushed;
+    const int cnt = dw_next - dw_flushed;
+    dw_flushed = dw_next;
+    if (side && use_worker) {
+      DwTask t;
+      t.ev = nullptr;
+      t.dev = cur_dev;
+      t.side = side->stream;
+      t.ws = nullptr;
+      t.ws_bytes = 0;
+      t.flush = recs;
+      t.flush_n = cnt;
+      dw_worker().push(t);
+      worker_busy = true;
+      return WSIS_OK;
+    }
+    return dw2_reduce_batch(recs, cnt, side ? side->stream : st);
   };
 #if WSIS_EXPERIMENTAL
   const bool deep_on = deep_bytes > 0 && d_sync != nullptr && !capturing;
@@ -1150,7 +1219,8 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
       // rest of the pass still executes)
       SideStream* ms = side ? side : side_stream_for(st);
       {
-        const int wrc = drain_worker();     // the dW launches up to here are on the side stream before its event
+        int wrc = dw_flush();               // the weight gradients up to here are FINAL behind their stream's event
+        if (wrc == WSIS_OK) wrc = drain_worker();     // the dW launches up to here are on the side stream before its event
         if (wrc != WSIS_OK) {
           first_err = wrc;
           break;
@@ -1170,7 +1240,9 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   }
 #undef RUN_LAUNCH_CHECK
   {
-    const int wrc = drain_worker();
+    int wrc = first_err == WSIS_OK ? dw_flush() : WSIS_OK;      // (every part of a pass finishes its own products)
+    if (wrc != WSIS_OK && first_err == WSIS_OK) first_err = wrc;
+    wrc = drain_worker();
     if (wrc != WSIS_OK && first_err == WSIS_OK) first_err = wrc;
   }
   if (defer_join && first_err == WSIS_OK) {

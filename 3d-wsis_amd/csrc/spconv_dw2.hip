@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -58,7 +59,9 @@ __device__ __forceinline__ void wait_after(int after) {
   switch (after) {
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;      // (8 + a two-instruction header)
     case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
     case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
     case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
   // instructions of 4 bytes per lane (no alignment requirement on M_out); rows past M_out read row M_out - 1 and are
   // overwritten with -1 by fix_tail before the header is used, slots past K re-read slot 0 and are masked
   const bool dense = nbrS == nullptr;          // 1x1 layer without a table: row t pairs with itself (K = 1)
-  const int NH = dense ? 0 : 5;                // DMA instructions of a header
+  const int NH = dense ? 0 : (XSH & 256) ? 2 : 5;      // DMA instructions of a header
   auto issueH = [&](int64_t s, int32_t* hb) {
     if (dense) {                               // written, not loaded: slot 0 and the row list are the identity
       const int64_t tt = s * 32 + r31;
@@ -177,11 +180,20 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
     }
     uint32_t t = (uint32_t)s * 32u + (uint32_t)r31;
     t = t < m_last ? t : m_last;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      int k = og + (2 * q + half) * NOG;
+    if (XSH & 256) {
+      // (round 6) the 8 x 32 table block as ONE 16-byte-per-lane DMA: lane = slot * 8 + piece of four rows -- a table line
+      // is contiguous in the row; four-byte alignment is enough for the hardware (M_out is arbitrary); rows past M_out
+      // read whatever follows and are overwritten by fix_tail
+      int k = og + (lane >> 3) * NOG;
       k = k < K ? k : og;
-      bdma4(rsN, ((uint32_t)k * (uint32_t)M_out + t) * 4u, hb + q * 64);
+      bdma16(rsN, ((uint32_t)k * (uint32_t)M_out + (uint32_t)s * 32u + (uint32_t)(lane & 7) * 4u) * 4u, hb);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int k = og + (2 * q + half) * NOG;
+        k = k < K ? k : og;
+        bdma4(rsN, ((uint32_t)k * (uint32_t)M_out + t) * 4u, hb + q * 64);
+      }
     }
     bdma4(rsO, t * 4u, hb + GS * 32);
   };
@@ -476,10 +488,423 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
   }
 }
 
-// dW = sum over workgroup slabs in a fixed order: thread (element quad e, slab lane l) adds slabs l, l + 8, ... in
-// ascending order, the 8 lane sums are then added in lane order through LDS (P slabs of a few hundred KB: one thread
-// per quad walking all P slabs left the reduction latency bound at ~11 us)
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the gathered operand straight to registers (spconv_dw3_kernel).
+// In the product dW[k] = X_gathered^T . dY the gathered tile is the A operand with M = input channel: lane (ci, half) of
+// v_mfma_f32_32x32x2_f32 holds X[row][ci] for one row per instruction -- the 32 lanes of a half read 32 CONSECUTIVE floats
+// of one gathered row.  A plain `buffer_load_dword` per instruction is therefore fully coalesced (two 128-byte lines, one
+// per half) and lands in the fragment layout: no LDS-DMA (four instructions of 100-185 cycles each to issue),
+// no X-tile ring in LDS, no 16 transposed `ds_read_b32` per step.  (The forward / dIn products cannot do this: their
+// gathered tile is the operand with M = row, a row per lane = four cache lines per quad, measured in round 5.)
+// Per step: the 16 row ids of the lane's half come from the slice header in LDS by four broadcast `ds_read_b128`
+// (instruction s pairs rows s and 16 + s instead of 2s and 2s + 1 -- any pairing is a valid order of the k-sum as long as
+// the dY fragments use the same), one v_mad_u32_u24 per row turns them into byte offsets (a missing pair, -1, lands
+// beyond the tensor and reads zeros: dw3_fits checks that for the pitch), 16 loads fill the OTHER of two static register
+// sets while the 16 MFMAs of the current step run on this one -- the loads ride the gaps of the dependent MFMA chain.
+// Everything else is dw2's: a wave owns up to 8 offsets of one (Cin chunk, Cout block), streams its share of the slices,
+// keeps the dY tile of a slice as 16 fragment registers (LDS-DMA once per slice), header of the next slice a slice ahead,
+// same slabs, same fixed-order slab sum.  The order of additions inside a 32-row tile differs from dw2 (row pairing), so
+// the two kernels agree to rounding, each bit-reproducible.
+constexpr int HDR3_INTS = GS * 32 + 64;
+constexpr int HDR3 = HDR3_INTS * 4;
+constexpr int WAVE_LDS3 = 4 * TILE + 256;      // the epilogue adds four accumulators per wave through LDS; the loop uses
+                                               // 2 headers + the dY tile (6.6 KB) at its start
+
+template <bool DIAG>
+__global__ __launch_bounds__(WGW * 64, 2) void spconv_dw3_kernel(const float* __restrict__ X, const int32_t* __restrict__ nbrS,
+                                                                 const int32_t* __restrict__ order,
+                                                                 const float* __restrict__ dY, float* __restrict__ partial,
+                                                                 int64_t M_in, int64_t M_out, int K, int Cin, int Cout, int NOG,
+                                                                 int h16, unsigned long long* dbg) {
+  unsigned long long t_start = 0, t_loop = 0, t_end_loop = 0;
+  unsigned n_steps = 0, n_slices_done = 0;
+  unsigned long long d_wait = 0, d_top = 0, d_chain = 0, d_bot = 0, t_prev = 0;
+  if (DIAG) t_start = __builtin_readcyclecounter();
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r31 = lane & 31, half = lane >> 5;
+  unsigned char* const my = lds + wave * WAVE_LDS3;
+  int32_t* const hdr0 = reinterpret_cast<int32_t*>(my);
+  unsigned char* const Bt = my + 2 * HDR3;
+
+  const int nchunk = Cin >> 5, nblk = (Cout + 31) >> 5;
+  int combo = blockIdx.y;
+  const int cb = combo % nblk;
+  combo /= nblk;
+  const int c = combo % nchunk;
+  const int og = combo / nchunk;
+  const int64_t n_slices = (M_out + 31) >> 5;
+  const int64_t stride = (int64_t)gridDim.x * WGW;
+  const int64_t first = (int64_t)blockIdx.x * WGW + wave;
+  const int64_t n_pos = n_slices;
+  auto slice_of = [&](int64_t pos) -> int64_t {      // (dw2's snake over full rounds of `stride`)
+    const int64_t n = pos / stride;
+    if ((n & 1) && (n + 1) * stride <= n_pos) return n * stride + (stride - 1 - (pos - n * stride));
+    return pos;
+  };
+
+  f32x16 acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    acc0[i] = acc1[i] = acc2[i] = acc3[i] = acc4[i] = acc5[i] = acc6[i] = acc7[i] = 0.0f;
+
+  const uint32_t x_pitch = (uint32_t)Cin * 4u, y_pitch = (uint32_t)Cout * 4u;
+  const rsrc_t rsX = make_rsrc(reinterpret_cast<const char*>(X) + c * 128, (uint32_t)(M_in * x_pitch) - c * 128);
+  const rsrc_t rsY = make_rsrc(reinterpret_cast<const char*>(dY) + cb * 128, (uint32_t)(M_out * y_pitch) - cb * 128);
+  const rsrc_t rsN = make_rsrc(nbrS, (uint32_t)((int64_t)K * M_out * 4));
+  const rsrc_t rsO = make_rsrc(order, (uint32_t)(M_out * 4));
+  const int d_row = lane >> 3;
+  const uint32_t d_po = (uint32_t)(lane & 7) * 16u;
+  const uint32_t m_last = (uint32_t)(M_out - 1);
+  const bool y_piece_ok = (uint32_t)cb * 128u + d_po < y_pitch;
+  const uint32_t a_col = (uint32_t)r31 * 4u;
+
+  const bool dense = nbrS == nullptr;
+  // header of a slice: nb[slot][row] of this worker's offsets + the slice's own rows.  h16: the 8 x 32 table block is ONE
+  // 16-byte-per-lane DMA (lane = slot * 8 + piece of four rows; a table line is contiguous in the row) instead of four
+  // 4-byte ones; rows past M_out read whatever follows and are overwritten by fix_tail, slots past K are masked
+  auto issueH = [&](int64_t s, int32_t* hb) {
+    if (dense) {
+      const int64_t tt = s * 32 + r31;
+      const int32_t v = tt < M_out ? (int32_t)tt : -1;
+      hb[r31] = v;
+      hb[GS * 32 + r31] = v;
+      return;
+    }
+    uint32_t t = (uint32_t)s * 32u + (uint32_t)r31;
+    t = t < m_last ? t : m_last;
+    if (h16) {
+      int k = og + (lane >> 3) * NOG;
+      k = k < K ? k : og;
+      bdma16(rsN, ((uint32_t)k * (uint32_t)M_out + (uint32_t)s * 32u + (uint32_t)(lane & 7) * 4u) * 4u, hb);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int k = og + (2 * q + half) * NOG;
+        k = k < K ? k : og;
+        bdma4(rsN, ((uint32_t)k * (uint32_t)M_out + t) * 4u, hb + q * 64);
+      }
+    }
+    bdma4(rsO, t * 4u, hb + GS * 32);
+  };
+  auto fix_tail = [&](int32_t* hb, int64_t s) {
+    if (s * 32 + 32 <= M_out) return;
+    const int64_t t0 = s * 32 + (lane & 7) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (t0 + e >= M_out) hb[lane * 4 + e] = -1;
+    if (lane < 32 && s * 32 + lane >= M_out) hb[GS * 32 + lane] = -1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  auto readmask = [&](const int32_t* hb) -> uint32_t {
+    const int4 v = *reinterpret_cast<const int4*>(hb + lane * 4);
+    const bool any = (og + (lane >> 3) * NOG < K) & ((v.x & v.y & v.z & v.w) >= 0);
+    unsigned long long b = __ballot(any);
+    b |= b >> 4;
+    b |= b >> 2;
+    b |= b >> 1;
+    uint32_t m = 0u;
+#pragma unroll
+    for (int j = 0; j < GS; ++j) m |= (uint32_t)((b >> (8 * j)) & 1ull) << j;
+    return m;
+  };
+  const uint32_t y_ok_mask = y_piece_ok ? 0xffffffffu : 0u;
+  auto issueB = [&](const int32_t* hb, unsigned char* dst) {
+    const int32_t* p = hb + GS * 32 + d_row;
+    const int32_t r0 = p[0], r1 = p[8], r2 = p[16], r3 = p[24];
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t o0 = (((uint32_t)r0 * y_pitch + d_po) & y_ok_mask) | (0xffffff00u & ~y_ok_mask);
+    const uint32_t o1 = (((uint32_t)r1 * y_pitch + d_po) & y_ok_mask) | (0xffffff00u & ~y_ok_mask);
+    const uint32_t o2 = (((uint32_t)r2 * y_pitch + d_po) & y_ok_mask) | (0xffffff00u & ~y_ok_mask);
+    const uint32_t o3 = (((uint32_t)r3 * y_pitch + d_po) & y_ok_mask) | (0xffffff00u & ~y_ok_mask);
+    __builtin_amdgcn_sched_barrier(0);
+    bdma16(rsY, o0, dst);
+    bdma16(rsY, o1, dst + 1024);
+    bdma16(rsY, o2, dst + 2048);
+    bdma16(rsY, o3, dst + 3072);
+  };
+  // the dY fragments of a slice: instruction s takes rows s (lower half wave) and 16 + s (upper)
+  auto readfragB = [&](float (&f)[16]) {
+    const float* p = reinterpret_cast<const float*>(Bt) + half * 16 * 32 + r31;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) f[s] = p[s * 32];
+  };
+  // row ids of the 16 gathered rows of this lane's half for offset slot j of header hb (nullptr: nothing to gather -- -1:
+  // sixteen loads beyond the tensor: zeros, no traffic)
+  auto rowids = [&](const int32_t* hb, int j, int4 (&q)[4]) {
+    if (!hb) {
+      q[0] = q[1] = q[2] = q[3] = make_int4(-1, -1, -1, -1);
+      return;
+    }
+    const int4* p = reinterpret_cast<const int4*>(hb + j * 32 + half * 16);
+    q[0] = p[0];
+    q[1] = p[1];
+    q[2] = p[2];
+    q[3] = p[3];
+  };
+  auto idof = [&](const int4 (&q)[4], int s) -> int32_t {
+    const int4& v = q[s >> 2];
+    return (s & 3) == 0 ? v.x : (s & 3) == 1 ? v.y : (s & 3) == 2 ? v.z : v.w;
+  };
+  auto loadA = [&](int32_t id) -> float {      // (v_mad_u32_u24: one VALU instruction per gathered row)
+    const uint32_t off = __umul24((uint32_t)id, x_pitch) + a_col;
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, (int)off, 0, 0));
+  };
+
+  // ONE register set for the gathered operand: a[s] is read by MFMA s of this step and, right behind it, becomes the
+  // destination of the load for MFMA s of the NEXT step -- a prefetch distance of exactly one step (16 MFMAs, ~1,040
+  // cycles) with 16 registers.  The waits in front of the MFMAs are the compiler's (plain loads: it counts them).
+  float a[16], bfr[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) a[s] = bfr[s] = 0.0f;
+
+  if (first < n_pos) {
+    int64_t g_pos = first;
+    int64_t g_slice = slice_of(g_pos);
+    uint32_t c_mask = 0u;
+    for (;;) {      // first slice with work for this worker, loaded synchronously
+      issueH(g_slice, hdr0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      fix_tail(hdr0, g_slice);
+      c_mask = readmask(hdr0);
+      if (c_mask || g_pos + stride >= n_pos) break;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      g_pos += stride;
+      g_slice = slice_of(g_pos);
+    }
+    if (c_mask) {
+      int hb = 0;                                        // header buffer of the slice whose tiles are being issued
+      bool has_next = g_pos + stride < n_pos;            // a header for the position after it is in flight / has landed
+      if (has_next) issueH(slice_of(g_pos + stride), hdr0 + HDR3_INTS);
+      issueB(hdr0, Bt);
+      uint32_t g_rem = c_mask & (c_mask - 1u);           // slots of that slice not yet handed out
+      uint32_t mask_next = 0u;
+      bool more = false;                                 // another slice follows the one being computed
+      {
+        int4 q[4];
+        rowids(hdr0, __builtin_ctz(c_mask), q);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a[s] = loadA(idof(q, s));
+      }
+      bool new_slice = true;
+      if (DIAG) t_loop = __builtin_readcyclecounter();
+
+      // one (slice, offset slot) step: find the next step's tile (a slice advance where the current slice is used up:
+      // mask of the next header, its dY tile, the header after it), then 16 MFMAs with the 16 loads of the next step
+      // between them
+      auto step = [&](f32x16& acc) {
+        unsigned long long ta = 0, tb = 0, tc = 0, td = 0;
+        if (DIAG) { ta = __builtin_readcyclecounter(); if (t_prev) d_bot += ta - t_prev; }
+        if (new_slice) {
+          // everything but the 16 loads of this step's tile has landed: the dY tile (issued at the advance, a step ago)
+          asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+          readfragB(bfr);
+          new_slice = false;
+          if (DIAG) ++n_slices_done;
+        }
+        if (DIAG) tb = __builtin_readcyclecounter();
+        const int32_t* nh = nullptr;
+        int nj = 0;
+        if (g_rem) {
+          nh = hdr0 + hb * HDR3_INTS;
+          nj = __builtin_ctz(g_rem);
+          g_rem &= g_rem - 1u;
+        } else if (has_next) {
+          // the next header was issued a slice ago: older than the 16 loads in flight
+          asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");      // (dY fragments in registers before Bt is reused)
+          int32_t* const hn = hdr0 + (hb ^ 1) * HDR3_INTS;
+          g_pos += stride;
+          g_slice = slice_of(g_pos);
+          fix_tail(hn, g_slice);
+          uint32_t m = readmask(hn);
+          while (m == 0u && g_pos + stride < n_pos) {             // rare: a slice without pairs for this worker
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            g_pos += stride;
+            g_slice = slice_of(g_pos);
+            issueH(g_slice, hn);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fix_tail(hn, g_slice);
+            m = readmask(hn);
+          }
+          if (m) {
+            has_next = g_pos + stride < n_pos;
+            if (has_next) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              issueH(slice_of(g_pos + stride), hdr0 + hb * HDR3_INTS);      // into the header the finished slice leaves
+            }
+            issueB(hn, Bt);
+            hb ^= 1;
+            nh = hn;
+            nj = __builtin_ctz(m);
+            g_rem = m & (m - 1u);
+            mask_next = m;
+            more = true;
+          } else {
+            has_next = false;
+          }
+        }
+        int4 q[4];
+        rowids(nh, nj, q);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (DIAG) tc = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bfr[s], acc, 0, 0, 0);
+          a[s] = loadA(idof(q, s));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (DIAG) { td = __builtin_readcyclecounter(); d_wait += tb - ta; d_top += tc - tb; d_chain += td - tc; t_prev = td; ++n_steps; }
+      };
+      for (;;) {
+        more = false;
+        if (c_mask & 1u) step(acc0);
+        if (c_mask & 2u) step(acc1);
+        if (c_mask & 4u) step(acc2);
+        if (c_mask & 8u) step(acc3);
+        if (c_mask & 16u) step(acc4);
+        if (c_mask & 32u) step(acc5);
+        if (c_mask & 64u) step(acc6);
+        if (c_mask & 128u) step(acc7);
+        if (!more) break;
+        c_mask = mask_next;
+        new_slice = true;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  if (DIAG) t_end_loop = __builtin_readcyclecounter();
+  __syncthreads();
+
+  // ---- epilogue: dw2's (four offset slots at a time through LDS, added in wave order, one slab per workgroup)
+  float* const red = reinterpret_cast<float*>(lds);
+  float* const slab = partial + (int64_t)blockIdx.x * K * Cin * Cout;
+  auto put = [&](const f32x16& acc, int q) {
+    float* mine = red + wave * (WAVE_LDS3 / 4) + q * 1024;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+      mine[ci * 32 + r31] = acc[reg];
+    }
+  };
+  auto flush4 = [&](const f32x16& q0, const f32x16& q1, const f32x16& q2, const f32x16& q3, int jbase) {
+    if (og + jbase * NOG >= K) return;
+    put(q0, 0);
+    put(q1, 1);
+    put(q2, 2);
+    put(q3, 3);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4096; e += WGW * 64) {
+      const int k = og + (jbase + (e >> 10)) * NOG;
+      if (k >= K) break;
+      float v = red[e];
+#pragma unroll
+      for (int w = 1; w < WGW; ++w) v += red[w * (WAVE_LDS3 / 4) + e];
+      const int ci = (e >> 5) & 31, co = e & 31;
+      if (cb * 32 + co < Cout) slab[((int64_t)k * Cin + c * 32 + ci) * Cout + cb * 32 + co] = v;
+    }
+    __syncthreads();
+  };
+  flush4(acc0, acc1, acc2, acc3, 0);
+  flush4(acc4, acc5, acc6, acc7, 4);
+  if (DIAG && lane == 0) {
+    unsigned long long* d = dbg + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * WGW + wave) * 10;
+    d[0] = t_start; d[1] = t_loop; d[2] = t_end_loop; d[3] = __builtin_readcyclecounter(); d[4] = n_steps; d[5] = n_slices_done;
+    d[6] = d_wait; d[7] = d_top; d[8] = d_chain; d[9] = d_bot;
+  }
+}
+
+// dW = sum over workgroup slabs in a fixed order.  A workgroup of 256 threads covers QW = 256 / SL element quads; thread
+// (quad el, slab lane sl of SL) adds slabs sl, sl + SL, ... in ascending order -- every load of a thread in flight at once
+// (P / SL <= 8 for the plans of dw2_P_plan) -- and the SL lane sums are then added in lane order through LDS.  SL follows
+// P alone (dw2_reduce_lanes), so the order of additions of an element is a function of the slab count: bit-reproducible,
+// the same whether a product is finished by its own launch (dw2_reduce_kernel) or by the batched launch of a whole
+// backward pass (dw2_reduce_batch_kernel).  Round 5's form (8 slab lanes, 32 quads per workgroup, a walk of P / 8 dependent
+// trips of 4) left a level-0 launch of four scenes at 216 workgroups of 16 sequential loads: 30 us for 14 MB.
+template <int SL>
+__device__ __forceinline__ void dw2_reduce_body(const float4* __restrict__ partial, float4* __restrict__ dW, int64_t total4,
+                                                int P, int64_t block, float4* red) {
+  constexpr int QW = 256 / SL;
+  const int el = threadIdx.x % QW, sl = threadIdx.x / QW;
+  const int64_t t = block * QW + el;
+  float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (t < total4) {
+    const float4* src = partial + t;
+    int p = sl;
+    for (; p + 3 * SL < P; p += 4 * SL) {            // four slabs of this lane per trip, all loads issued before the adds
+      const float4 v0 = src[(int64_t)p * total4], v1 = src[(int64_t)(p + SL) * total4];
+      const float4 v2 = src[(int64_t)(p + 2 * SL) * total4], v3 = src[(int64_t)(p + 3 * SL) * total4];
+      s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+      s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+      s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+      s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+    }
+    for (; p < P; p += SL) {
+      const float4 v = src[(int64_t)p * total4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  if (SL > 1) {
+    red[sl * (QW + 1) + el] = s;                      // [SL][QW + 1] of the workgroup's DW2_RED_F4 float4s
+    __syncthreads();
+    if (sl == 0 && t < total4) {
+#pragma unroll
+      for (int l = 1; l < SL; ++l) {
+        const float4 v = red[l * (QW + 1) + el];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      dW[t] = s;
+    }
+    __syncthreads();                                  // (the batched form walks several blocks per workgroup)
+  } else if (t < total4) {
+    dW[t] = s;
+  }
+}
+__host__ __device__ inline int dw2_reduce_lanes(int P) { return P >= 64 ? 32 : P >= 16 ? 16 : P >= 8 ? 8 : P >= 2 ? 2 : 1; }
+__host__ __device__ inline int64_t dw2_reduce_blocks(int64_t total4, int P) {
+  const int qw = 256 / dw2_reduce_lanes(P);
+  return (total4 + qw - 1) / qw;
+}
+constexpr int DW2_RED_F4 = 32 * 9;      // SL (QW + 1) at its largest (SL = 32)
+__device__ __forceinline__ void dw2_reduce_any(const float4* partial, float4* dW, int64_t total4, int P, int64_t block,
+                                               float4* red) {
+  switch (dw2_reduce_lanes(P)) {
+    case 32: dw2_reduce_body<32>(partial, dW, total4, P, block, red); break;
+    case 16: dw2_reduce_body<16>(partial, dW, total4, P, block, red); break;
+    case 8: dw2_reduce_body<8>(partial, dW, total4, P, block, red); break;
+    case 2: dw2_reduce_body<2>(partial, dW, total4, P, block, red); break;
+    default: dw2_reduce_body<1>(partial, dW, total4, P, block, red); break;
+  }
+}
 __global__ __launch_bounds__(256) void dw2_reduce_kernel(const float4* __restrict__ partial, float4* __restrict__ dW,
+                                                         int64_t total4, int P) {
+  __shared__ float4 red[DW2_RED_F4];
+  dw2_reduce_any(partial, dW, total4, P, blockIdx.x, red);
+}
+
+// every deferred slab sum of (a part of) a backward pass in ONE launch: workgroup b finishes block b - first[i] of
+// product i -- the body, and with it the order of additions, of dw2_reduce_kernel
+constexpr int DW2_BATCH = 64;
+struct DwRedBatch {
+  const float4* partial[DW2_BATCH];
+  float4* dW[DW2_BATCH];
+  int64_t total4[DW2_BATCH];
+  int32_t P[DW2_BATCH];
+  int32_t first[DW2_BATCH + 1];
+  int32_t n;
+};
+__global__ __launch_bounds__(256) void dw2_reduce_batch_kernel(const DwRedBatch b) {
+  __shared__ float4 red[DW2_RED_F4];
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.first[i + 1]) ++i;
+  dw2_reduce_any(b.partial[i], b.dW[i], b.total4[i], b.P[i], (int64_t)((int)blockIdx.x - b.first[i]), red);
+}
+
+#if WSIS_EXPERIMENTAL
+// round 5's slab sum (8 slab lanes, 32 quads per workgroup), kept for the in-process A/B (WSIS_DW2_RED=0)
+__global__ __launch_bounds__(256) void dw2_reduce_r5_kernel(const float4* __restrict__ partial, float4* __restrict__ dW,
                                                          int64_t total4, int P) {
   __shared__ float4 red[8][32];
   const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
@@ -504,9 +929,24 @@ __global__ __launch_bounds__(256) void dw2_reduce_kernel(const float4* __restric
   }
 }
 
+#endif
+
 int dw2_env(const char* name, int dflt) {      // (launch-plan knobs: live in the EXPERIMENTAL build)
   const char* e = tune_env(name);
   return e ? atoi(e) : dflt;
+}
+
+// the fixed-order slab sum that finishes a product (EXPERIMENTAL build: WSIS_DW2_RED=0 selects round 5's kernel)
+void dw2_launch_reduce(const float* partial, float* d_dW, int64_t total4, int P, hipStream_t st) {
+#if WSIS_EXPERIMENTAL
+  if (dw2_env("WSIS_DW2_RED", 1) == 0) {
+    hipLaunchKernelGGL(dw2_reduce_r5_kernel, dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(d_dW), total4, P);
+    return;
+  }
+#endif
+  hipLaunchKernelGGL(dw2_reduce_kernel, dim3((unsigned)dw2_reduce_blocks(total4, P)), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(d_dW), total4, P);
 }
 
 // workgroups per combination (= slabs): ~target waves over the launch, never more than there are slices
@@ -558,6 +998,43 @@ int64_t dw2_workspace_bytes(int64_t M_out, int K, int Cin, int Cout) {      // (
 
 void dw2_set_batch_rows(int64_t rows) { g_batch_rows.store(rows, std::memory_order_relaxed); }
 
+static thread_local DwRedRec* t_defer = nullptr;
+void dw2_set_defer(DwRedRec* slot) { t_defer = slot; }
+
+int dw2_reduce_batch(const DwRedRec* recs, int n, hipStream_t st) {
+  int i = 0;
+  while (i < n) {
+    DwRedBatch b;
+    b.n = 0;
+    int64_t blocks = 0;
+    for (; i < n && b.n < DW2_BATCH; ++i) {
+      const DwRedRec& r = recs[i];
+      if (!r.partial) continue;
+      const int64_t nb = dw2_reduce_blocks(r.total4, r.P);
+      if (blocks + nb > ((int64_t)1 << 30)) break;
+      b.partial[b.n] = reinterpret_cast<const float4*>(r.partial);
+      b.dW[b.n] = reinterpret_cast<float4*>(r.dW);
+      b.total4[b.n] = r.total4;
+      b.P[b.n] = r.P;
+      b.first[b.n] = (int32_t)blocks;
+      blocks += nb;
+      ++b.n;
+    }
+    if (b.n == 0) continue;
+    b.first[b.n] = (int32_t)blocks;
+    for (int j = b.n; j < DW2_BATCH; ++j) {      // (defined values in the unused tail of the argument block)
+      b.partial[j] = nullptr;
+      b.dW[j] = nullptr;
+      b.total4[j] = 0;
+      b.P[j] = 0;
+      b.first[j + 1] = (int32_t)blocks;
+    }
+    hipLaunchKernelGGL(dw2_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, b);
+    WSIS_LAUNCH_CHECK();
+  }
+  return WSIS_OK;
+}
+
 // the own-rows form (kernel SWAP): conv input x [M_in, Cin] normalised on the fly, gathered conv dY [M_out, Cout] through
 // the dIn table (rows = conv inputs); writes dW [K, Cin, Cout] exactly like dw2_launch
 int dw2_launch_swapped(const float* d_X, const float* d_mean, const float* d_var, const float* d_gamma, const float* d_beta,
@@ -589,11 +1066,39 @@ int dw2_launch_swapped(const float* d_X, const float* d_mean, const float* d_var
   prof.stop();
   WSIS_LAUNCH_CHECK();
   const int64_t total4 = (int64_t)K * Cin * Cout / 4;
-  hipLaunchKernelGGL(dw2_reduce_kernel, dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, st,
-                     reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(d_dW), total4, P);
+  if (t_defer) {      // the executor finishes this product with the other slab sums of its pass (dw2_reduce_batch)
+    t_defer->partial = partial;
+    t_defer->dW = d_dW;
+    t_defer->total4 = total4;
+    t_defer->P = P;
+    return WSIS_OK;
+  }
+  dw2_launch_reduce(partial, d_dW, total4, P, st);
   prof.tail();
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
+}
+
+// the register-gather kernel applies when row ids fit 24 bits (v_mad_u32_u24) and a missing pair's offset
+// (0xFFFFFF x pitch mod 2^32) lies beyond the gathered tensor, so that it reads zeros
+bool dw3_fits(int64_t M_in, int Cin) {
+  const uint64_t p = (uint64_t)Cin * 4u;
+  const uint32_t w = (uint32_t)(0xFFFFFFull * p);
+  return M_in < (1 << 24) - 1 && (uint64_t)w >= (uint64_t)M_in * p && w <= 0xFFFFFF00u;
+}
+// WSIS_DW3 (read per call): 1 = spconv_dw3_kernel where it fits, 0 (default) = spconv_dw2_kernel everywhere -- measured at
+// parity (profiles/r06_dw3.txt: level 0 76.7 vs 71.4 us, levels 1-3 57.7 / 45.8 / 27.8 vs 58.0 / 46.4 / 29.0; the step
+// 20.40 vs 20.35 ms at four scenes): the loads stretch the MFMA chain by 12 cycles a slot and the slice advance, not
+// the gather, is what a step waits for
+int dw3_mode() {
+  const char* e = getenv("WSIS_DW3");
+  return e ? atoi(e) : 0;
+}
+// header table block by ONE 16-byte DMA (both kernels): WSIS_DW_H16 = 1 always (default), 2 only where every table line is
+// 16-byte aligned, 0 never (EXPERIMENTAL build: live)
+bool dw3_h16(int64_t M_out) {
+  const int m = dw2_env("WSIS_DW_H16", 1);
+  return m == 1 || (m == 2 && (M_out & 3) == 0);
 }
 
 int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY, float* d_dW,
@@ -602,6 +1107,32 @@ int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, c
   const int P = dw2_P(M_out, K, Cin, Cout);
   float* partial = static_cast<float*>(d_ws);
   const dim3 grid((unsigned)P, (unsigned)(NOG * (Cin / 32) * ((Cout + 31) / 32)), 1);
+  if (dw3_mode() && dw3_fits(M_in, Cin)) {
+    const size_t ldsb3 = (size_t)WAVE_LDS3 * WGW;
+    static bool attr3_set = false;
+    if (!attr3_set) {
+      WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_dw3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)ldsb3));
+      attr3_set = true;
+    }
+    ProfScope prof(1, st);
+    hipLaunchKernelGGL((spconv_dw3_kernel<false>), grid, dim3(WGW * 64), ldsb3, st, d_X, d_nbr, d_order, d_dY, partial, M_in,
+                       M_out, K, Cin, Cout, NOG, dw3_h16(M_out) ? 1 : 0, (unsigned long long*)nullptr);
+    prof.stop();
+    WSIS_LAUNCH_CHECK();
+    const int64_t total4 = (int64_t)K * Cin * Cout / 4;
+    if (t_defer) {
+      t_defer->partial = partial;
+      t_defer->dW = d_dW;
+      t_defer->total4 = total4;
+      t_defer->P = P;
+      return WSIS_OK;
+    }
+    dw2_launch_reduce(partial, d_dW, total4, P, st);
+    prof.tail();
+    WSIS_LAUNCH_CHECK();
+    return WSIS_OK;
+  }
   const size_t ldsb = (size_t)WAVE_LDS * WGW;
   static bool attr_set = false;
   if (!attr_set) {
@@ -611,11 +1142,11 @@ int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, c
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
     attr_set = true;
   }
-  static int xcd_on = -1, xsh = XSH_DEFAULT;
-  if (xcd_on < 0) {
-    xcd_on = dw2_env("WSIS_DW2_XCD", 0);     // measured: no gain at level 0, slower below (chunk imbalance)
-    xsh = dw2_env("WSIS_DW2_XSH", XSH_DEFAULT);
-  }
+  // (read per call: in-process A/Bs flip them) XCD-aware dealing of the slices: rows >= WSIS_DW2_XCD (0 = never)
+  const int64_t xcd_rows = dw2_env("WSIS_DW2_XCD", 0);     // measured at one scene: no gain at level 0, slower below (chunk imbalance)
+  const bool xcd_on = xcd_rows > 0 && M_out >= xcd_rows;
+  // (bit 8 of the kernel's XSH argument: the header's table block by one 16-byte DMA instead of four 4-byte ones)
+  const int xsh = dw2_env("WSIS_DW2_XSH", XSH_DEFAULT) | (dw3_h16(M_out) ? 256 : 0);
   ProfScope prof(1, st);
   if (xcd_on && P % 8 == 0)
     hipLaunchKernelGGL((spconv_dw2_kernel<false, true>), grid, dim3(WGW * 64), ldsb, st, d_X, d_nbr, d_order,
@@ -626,8 +1157,14 @@ int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, c
   prof.stop();
   WSIS_LAUNCH_CHECK();
   const int64_t total4 = (int64_t)K * Cin * Cout / 4;
-  hipLaunchKernelGGL(dw2_reduce_kernel, dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, st,
-                     reinterpret_cast<const float4*>(partial), reinterpret_cast<float4*>(d_dW), total4, P);
+  if (t_defer) {      // the executor finishes this product with the other slab sums of its pass (dw2_reduce_batch)
+    t_defer->partial = partial;
+    t_defer->dW = d_dW;
+    t_defer->total4 = total4;
+    t_defer->P = P;
+    return WSIS_OK;
+  }
+  dw2_launch_reduce(partial, d_dW, total4, P, st);
   prof.tail();
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;
@@ -648,6 +1185,17 @@ extern "C" int wsis_debug_dw2_diag(const void* d_X, const void* d_nbr, const voi
   const dim3 grid((unsigned)P, (unsigned)(NOG * (Cin / 32) * ((Cout + 31) / 32)), 1);
   *n_waves = (int64_t)grid.x * grid.y * WGW;
   WSIS_REQUIRE(dbg_bytes >= *n_waves * 80, "stamp buffer too small");
+  if (wsis::dw3_mode() && wsis::dw3_fits(M_in, Cin)) {      // the register-gather kernel's stamps (same record layout)
+    const size_t ldsb3 = (size_t)WAVE_LDS3 * WGW;
+    WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_dw3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)ldsb3));
+    hipLaunchKernelGGL((spconv_dw3_kernel<true>), grid, dim3(WGW * 64), ldsb3, wsis::as_stream(stream),
+                       static_cast<const float*>(d_X), static_cast<const int32_t*>(d_nbr),
+                       static_cast<const int32_t*>(d_order), static_cast<const float*>(d_dY), static_cast<float*>(d_ws),
+                       M_in, M_out, K, Cin, Cout, NOG, wsis::dw3_h16(M_out) ? 1 : 0, static_cast<unsigned long long*>(d_dbg));
+    WSIS_LAUNCH_CHECK();
+    return WSIS_OK;
+  }
   WSIS_REQUIRE(P % 8 == 0, "diagnostic build is the XCD-aware variant");
   const size_t ldsb = (size_t)WAVE_LDS * WGW;
   WSIS_HIP_CHECK(hipFuncSetAttribute((const void*)spconv_dw2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -655,7 +1203,7 @@ extern "C" int wsis_debug_dw2_diag(const void* d_X, const void* d_nbr, const voi
   hipLaunchKernelGGL((spconv_dw2_kernel<true, true>), grid, dim3(WGW * 64), ldsb, wsis::as_stream(stream),
                      static_cast<const float*>(d_X), static_cast<const int32_t*>(d_nbr),
                      static_cast<const int32_t*>(d_order), static_cast<const float*>(d_dY), static_cast<float*>(d_ws),
-                     M_in, M_out, K, Cin, Cout, NOG, dw2_env("WSIS_DW2_XSH", XSH_DEFAULT),
+                     M_in, M_out, K, Cin, Cout, NOG, dw2_env("WSIS_DW2_XSH", XSH_DEFAULT) | (wsis::dw3_h16(M_out) ? 256 : 0),
                      static_cast<unsigned long long*>(d_dbg));
   WSIS_LAUNCH_CHECK();
   return WSIS_OK;

@@ -281,7 +281,7 @@ class UNetProgram(object):
         src = self._stats_src.get(x) if training else None
         have_parts = src is not None and sum(c for _, c, _ in src) == C and len(src) <= 2
         stats_done = False
-        if have_parts and self._fuse_fin and all(rec.rows[r][10][4] == 0 for _, _, r in src):
+        if have_parts and self._fuse_fin and lvl >= self._fuse_fin_lvl and all(rec.rows[r][10][4] == 0 for _, _, r in src):
             # every producer finishes its channel range of this BatchNorm's statistics inside its own launch
             c0 = 0
             rm = _ptr(bn.running_mean) if update else 0
@@ -437,6 +437,7 @@ class UNetProgram(object):
         # inside the producing convolution or apply them inside the consuming one leave no such op, so a program
         # compiled with them must never serve a synced pass (and the other way round)
         return (need_dx, self.bn_sync is not None, _fuse_stats_enabled(), _fuse_fin_enabled(), _fuse_apply_level(),
+                os.environ.get("WSIS_FUSE_BN_FIN_LVL", "0"),
                 os.environ.get("WSIS_FWD2", "1"), tuple(bn.training for bn in self.bns), tuple(p.data_ptr() for p in self.params),
                 tuple(bn.running_mean.data_ptr() if bn.running_mean is not None else 0 for bn in self.bns))
 
@@ -455,6 +456,7 @@ class UNetProgram(object):
         self._stats_src, self._fuse_stats = {}, _fuse_stats_enabled()
         self._virt, self._fuse_apply_lvl = {}, _fuse_apply_level()
         self._fuse_fin = _fuse_fin_enabled() and self._fuse_stats
+        self._fuse_fin_lvl = int(os.environ.get("WSIS_FUSE_BN_FIN_LVL", "0"))      # (EXPERIMENTAL build: from this level on)
         if self.bn_sync is not None:      # every BatchNorm layer stays an op of its own: _run_synced runs it between parts
             self._fuse_fin, self._fuse_apply_lvl = False, 99
         y, b_in = self._conv(rec, _EXT | 0, net.input_conv[0], _subm(0), 0, 0)
@@ -834,7 +836,7 @@ _EXPERIMENTAL_SWITCHES = ("WSIS_DEEP", "WSIS_FWD2P", "WSIS_RING", "WSIS_GRAPH", 
 # to their measured defaults in the default library (tests/test_abi.py keeps this list equal to the sources)
 TUNE_KNOBS = (
     "WSIS_BN_APPLY_PT", "WSIS_BN_FUSED_GRID", "WSIS_BN_TICKET", "WSIS_DW2", "WSIS_DW2_HI", "WSIS_DW2_LO",
-    "WSIS_DW2_WAVES", "WSIS_DW2_XCD", "WSIS_DW2_XSH", "WSIS_DW_DIV", "WSIS_DW_THREAD", "WSIS_FWD2P_MIN",
+    "WSIS_DW2_WAVES", "WSIS_DW2_XCD", "WSIS_DW2_XSH", "WSIS_DW2_RED", "WSIS_DW_H16", "WSIS_DW_DIV", "WSIS_DW_THREAD", "WSIS_FWD2P_MIN",
     "WSIS_FWD2_BD", "WSIS_FWD2_DA_NW4", "WSIS_FWD2_DEAL", "WSIS_FWD2_NOSLAB", "WSIS_FWD2_NW", "WSIS_FWD2_NW_MAX",
     "WSIS_FWD2_NW_MAX_NOSLAB", "WSIS_FWD2_RG", "WSIS_FWD2_RGH", "WSIS_FWD2_RGH_LATE", "WSIS_FWD2_SNAKE",
     "WSIS_FWD2_TR", "WSIS_FWD2_TR_DA", "WSIS_FWD2_WAVES", "WSIS_FWD2_XCD", "WSIS_FWD2_ZS", "WSIS_FWD_NB_SMALL",

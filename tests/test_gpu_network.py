@@ -227,6 +227,36 @@ def test_native_unet_executor_is_bit_identical_to_the_module_walk(monkeypatch, t
     assert [n for n in s0 if not torch.equal(s0[n], s1[n])] == []
 
 
+@pytest.mark.parametrize("dw_stream", ["1", "0"])
+def test_batched_slab_sums_give_the_bits_of_the_per_product_sums(monkeypatch, dw_stream):
+    """round 6: the executor finishes the weight gradients of a backward pass with ONE dw2_reduce_batch launch per part
+    (WSIS_DW_BATCH_REDUCE=1; opt-in: measured slower in the step; every product's slabs in a region of their own) instead
+    of one slab-sum launch per product (=0, default: what the module walk and a direct caller of wsis_spconv_dw get): same body, same order of additions --
+    every gradient EQUAL, on the side stream with the worker thread and on the caller's stream."""
+    cfg = harness.default_cfg()
+    monkeypatch.setenv("WSIS_DW_STREAM", dw_stream)
+    batch_host = harness.collate([harness.make_scene(s, room=(1.7, 1.3, 1.0), n_box=2) for s in (41, 42)])
+    cfg.batch_size = 2
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("WSIS_DW_BATCH_REDUCE", mode)
+        batch = harness.to_device(batch_host, "cuda")
+        model, crit, opt = harness.build_model(cfg, "cuda")
+        model.train()
+        losses = []
+        for _ in range(2):                      # (the second pass reuses the program's persistent gradient buffer)
+            model.zero_grad(set_to_none=True)
+            loss, _ = harness.forward_loss(model, crit, batch, cfg)
+            loss.backward()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        res[mode] = (losses, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert res["0"][0] == res["1"][0]
+    g0, g1 = res["0"][1], res["1"][1]
+    assert set(g0) == set(g1) and len(g0) > 150
+    assert [n for n in g0 if not torch.equal(g0[n], g1[n])] == []
+
+
 def test_training_over_scenes_of_varying_size_is_reproducible():
     """36 optimizer steps cycling over 9 batches of very different sizes (1.8 m room ... 8 m room, one batch of three
     scenes), twice from the same seed: identical loss sequences, no NaN.  Every launch plan, the slice queues of the

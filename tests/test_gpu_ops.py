@@ -168,6 +168,33 @@ def test_other_kernel_volumes(kind, cin, cout):
     _conv_case(kind, cin, cout, (14, 12, 10), 0.3, 27)
 
 
+@pytest.mark.parametrize("kind,cin,cout,shape,density", [("subm", 32, 32, (12, 11, 10), 0.25), ("subm", 64, 32, (12, 11, 10), 0.25),
+                                                         ("subm", 96, 96, (23, 19, 9), 0.3), ("subm", 160, 160, (12, 11, 10), 0.25),
+                                                         ("subm", 32, 20, (17, 13, 11), 0.3), ("down", 64, 96, (13, 12, 11), 0.3),
+                                                         ("subm1", 256, 128, (10, 10, 10), 0.3)])
+def test_register_gather_weight_gradient_kernel(monkeypatch, kind, cin, cout, shape, density):
+    """round 6: spconv_dw3_kernel (WSIS_DW3=1; the gathered operand by coalesced loads straight into MFMA fragments, no
+    LDS staging) against the same fp64 autograd as the default spconv_dw2_kernel -- row counts that are not multiples
+    of 4 (the header's 16-byte DMA from a 4-byte-aligned table line), a partial output block, the strided and the
+    dense 1x1 form -- and bit-reproducible run to run"""
+    monkeypatch.setenv("WSIS_DW3", "1")
+    _, inp, mod = _conv_case(kind, cin, cout, shape, density, 29)
+    g1 = mod.weight.grad.clone()
+    mod.weight.grad = None
+    out = mod(spconv.SparseConvTensor(inp.features.detach().clone().requires_grad_(True), inp.indices,
+                                      inp.spatial_shape, inp.batch_size))
+    torch.manual_seed(5)
+    go = torch.randn_like(out.features)
+    out.features.backward(go)
+    a = mod.weight.grad.clone()
+    mod.weight.grad = None
+    out = mod(spconv.SparseConvTensor(inp.features.detach().clone().requires_grad_(True), inp.indices,
+                                      inp.spatial_shape, inp.batch_size))
+    out.features.backward(go)
+    assert torch.equal(a, mod.weight.grad)
+    assert g1.shape == a.shape
+
+
 @pytest.mark.parametrize("cin,cout", [(64, 32), (256, 128), (192, 96)])
 def test_1x1_conv(cin, cout):
     _conv_case("subm1", cin, cout, (10, 10, 10), 0.3, 24)
