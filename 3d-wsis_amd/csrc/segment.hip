@@ -299,6 +299,145 @@ __global__ void csrb_offsets_kernel(CsrBatch b, const uint64_t* __restrict__ sor
   }
 }
 
+}  // extern "C"  (a template follows)
+namespace {
+// ---- the same CSRs WITHOUT a sort (round 6).  The keys are (table, segment id) pairs of bounded range and the wanted order
+// inside a segment is the original position, so "stable sort by key" is a counting sort whose segments are then put in
+// order: count per (table, segment) -> exclusive scan per table (= the offsets) -> place every row at an atomic cursor of
+// its segment (any order) -> order every segment's slice by value (the rows ARE their original positions: ascending
+// values = the stable order).  4 launches + 1 fill instead of rocPRIM's merge sort of ~0.5 M 64-bit keys (~23 launches);
+// identical perm / offsets.  OPT-IN (WSIS_CSR_COUNTING=1): measured slower than the sort, see wsis_segment_csr_batch.  Out-of-range ids (negative or >= S) share one extra bucket behind the last segment, as the
+// sort leaves them behind offsets[S].
+struct CsrCount {
+  CsrBatch b;
+  int64_t cbase[CSRB_MAX + 1];     // first counter word of table t (S_t + 2 words each: buckets 0 .. S_t, one spare)
+};
+__device__ __forceinline__ int csrc_table(const CsrBatch& b, int64_t i) {
+  int t = 0;
+  while (t + 1 < b.n && i >= b.base[t + 1]) ++t;
+  return t;
+}
+__global__ void csrc_count_kernel(CsrCount c, int32_t* __restrict__ cnt) {
+  const int64_t N = c.b.base[c.b.n];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = csrc_table(c.b, i);
+    const int64_t v = c.b.index[t][i - c.b.base[t]];
+    const int64_t bucket = (v < 0 || v > c.b.S[t]) ? c.b.S[t] : v;
+    atomicAdd(cnt + c.cbase[t] + bucket, 1);
+  }
+}
+// one workgroup per table: exclusive scan of its S + 1 buckets -> offsets [S + 1] and the placement cursors (in place)
+__global__ __launch_bounds__(1024) void csrc_scan_kernel(CsrCount c, int32_t* __restrict__ cnt, int32_t* __restrict__ offsets) {
+  __shared__ int32_t wsum[16];
+  __shared__ int32_t carry_s;
+  const int t = blockIdx.x;
+  const int64_t n = c.b.S[t] + 1;
+  int32_t* cn = cnt + c.cbase[t];
+  int32_t* off = offsets + c.b.obase[t];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t i0 = 0; i0 < n; i0 += 1024) {
+    const int64_t i = i0 + threadIdx.x;
+    const int32_t v = i < n ? cn[i] : 0;
+    int32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int32_t base = carry_s;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    const int32_t excl = base + x - v;
+    if (i < n) {
+      off[i] = excl;
+      cn[i] = excl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = base + x;
+    __syncthreads();
+  }
+}
+__global__ void csrc_place_kernel(CsrCount c, int32_t* __restrict__ cursor, int32_t* __restrict__ perm) {
+  const int64_t N = c.b.base[c.b.n];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = csrc_table(c.b, i);
+    const int64_t r = i - c.b.base[t];
+    const int64_t v = c.b.index[t][r];
+    const int64_t bucket = (v < 0 || v > c.b.S[t]) ? c.b.S[t] : v;
+    const int32_t pos = atomicAdd(cursor + c.cbase[t] + bucket, 1);
+    perm[c.b.base[t] + pos] = (int32_t)r;
+  }
+}
+// one wavefront per (table, bucket): its slice of perm in ascending order.  <= 64 rows: every lane counts the values below
+// its own (values are distinct); <= CSRC_LDS rows: bitonic network in the wave's LDS region; more: the same network on
+// the slice in memory (a degenerate input -- one segment holding thousands of rows; slow and correct).  All merges are
+// "minimum to the lower index", so the virtual +inf padding up to a power of two never moves.
+constexpr int CSRC_LDS = 2048;
+template <bool GLOBAL>
+__device__ __forceinline__ void csrc_bitonic(int32_t* a, int n, int lane) {
+  int p2 = 1;
+  while (p2 < n) p2 <<= 1;
+  for (int k = 2; k <= p2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const bool flip = j == (k >> 1);
+      for (int i = lane; i < p2; i += 64) {
+        const int q = flip ? (i ^ (k - 1)) : (i ^ j);
+        if (q > i && q < n) {
+          const int32_t x = a[i], y = a[q];
+          if (x > y) {
+            a[i] = y;
+            a[q] = x;
+          }
+        }
+      }
+      if (GLOBAL) __threadfence();      // (another lane reads these words next: through L2, not a stale L1 line)
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+__global__ __launch_bounds__(256) void csrc_order_kernel(CsrCount c, const int32_t* __restrict__ offsets, int32_t* __restrict__ perm) {
+  __shared__ int32_t stage[4][CSRC_LDS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t total = 0;
+  for (int t = 0; t < c.b.n; ++t) total += c.b.S[t] + 1;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t u = (int64_t)blockIdx.x * 4 + wave; u < total; u += nw) {
+    int t = 0;
+    int64_t s = u;
+    while (s >= c.b.S[t] + 1) {
+      s -= c.b.S[t] + 1;
+      ++t;
+    }
+    const int64_t n_t = c.b.base[t + 1] - c.b.base[t];
+    const int32_t* off = offsets + c.b.obase[t];
+    const int32_t beg = off[s];
+    const int32_t end = s < c.b.S[t] ? off[s + 1] : (int32_t)n_t;      // (the last bucket: out-of-range ids)
+    const int n = end - beg;
+    if (n < 2) continue;
+    int32_t* a = perm + c.b.base[t] + beg;
+    if (n <= 64) {
+      const int32_t v = lane < n ? a[lane] : 0x7fffffff;
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += __builtin_amdgcn_readlane(v, j) < v ? 1 : 0;
+      if (lane < n) a[rank] = v;
+    } else if (n <= CSRC_LDS) {
+      int32_t* l = stage[wave];
+      for (int i = lane; i < n; i += 64) l[i] = a[i];
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      csrc_bitonic<false>(l, n, lane);
+      for (int i = lane; i < n; i += 64) a[i] = l[i];
+    } else {
+      csrc_bitonic<true>(a, n, lane);
+    }
+  }
+}
+}  // namespace
+extern "C" {
+
 int64_t wsis_segment_csr_batch_workspace_bytes(int64_t N_all) {
   if (N_all < 0) return -1;
   if (N_all == 0) return 256;
@@ -334,6 +473,33 @@ int wsis_segment_csr_batch(int32_t n, const void* const* h_index, const int64_t*
   if (N == 0) return WSIS_OK;
   WSIS_REQUIRE(d_perm_all && d_ws, "null pointer");
   char* ws = static_cast<char*>(d_ws);
+  {
+    // counting form (WSIS_CSR_COUNTING=1; opt-in) where its counters fit the workspace.  Measured (tools/r06_csr.sh,
+    // profiles/r06_ab_csr.txt): identical CSRs, 5 launches instead of ~23 -- and 288 us of kernels instead of ~130 (the
+    // per-segment ordering pass walks 165 k segments with two dependent loads each: 162 us; count and place serialise on
+    // the atomics of 2.3 k superpoint counters: 45 us each): the step 7.81 -> 7.89 ms, four scenes 20.28 -> 20.50.
+    const char* ce = getenv("WSIS_CSR_COUNTING");
+    CsrCount c;
+    c.b = b;
+    c.cbase[0] = 0;
+    for (int t = 0; t < n; ++t) c.cbase[t + 1] = c.cbase[t] + h_S[t] + 2;
+    const int64_t words = c.cbase[n];
+    if (ce && atoi(ce) != 0 && words * 4 + 256 <= ws_bytes) {
+      int32_t* cnt = reinterpret_cast<int32_t*>(ws);
+      WSIS_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)words * 4, st));
+      hipLaunchKernelGGL(csrc_count_kernel, dim3(grid_for(N, 256)), dim3(256), 0, st, c, cnt);
+      hipLaunchKernelGGL(csrc_scan_kernel, dim3((unsigned)n), dim3(1024), 0, st, c, cnt, d_offsets_all);
+      hipLaunchKernelGGL(csrc_place_kernel, dim3(grid_for(N, 256)), dim3(256), 0, st, c, cnt, d_perm_all);
+      int64_t segs = 0;
+      for (int t = 0; t < n; ++t) segs += h_S[t] + 1;
+      int64_t g = (segs + 3) / 4;
+      if (g > 1024) g = 1024;
+      if (g < 1) g = 1;
+      hipLaunchKernelGGL(csrc_order_kernel, dim3((unsigned)g), dim3(256), 0, st, c, d_offsets_all, d_perm_all);
+      WSIS_LAUNCH_CHECK();
+      return WSIS_OK;
+    }
+  }
   const size_t a8 = align256((size_t)N * 8), a4 = align256((size_t)N * 4);
   WSIS_REQUIRE((int64_t)(2 * a8 + a4) < ws_bytes, "workspace too small");
   uint64_t* keys = reinterpret_cast<uint64_t*>(ws);

@@ -100,3 +100,36 @@ def test_batched_csr_build_equals_the_single_builds():
         if c.N:
             assert torch.equal(c.perm[:c.N], ref.perm[:ref.N])
         assert torch.equal(c.index, ref.index)
+
+
+@pytest.mark.parametrize("counting", ["1", "0"])
+def test_counting_csr_build_handles_every_segment_size(monkeypatch, counting):
+    """round 6: the batched CSRs by counting (count per segment, scan, place at an atomic cursor, order every segment's
+    slice by value) against the single-table sort: segments of one row, of 65 .. 2,048 rows (bitonic network in LDS), one
+    of 9,000 rows (the network on the slice in memory), empty segments, ids outside [0, S) (one bucket behind the last
+    segment: never visible through the offsets) -- and the sort path (WSIS_CSR_COUNTING=0, the default: the counting form
+    measured slower in the step) stays what it was"""
+    from torch_scatter import SegmentCSR, segment_csr_batch
+    monkeypatch.setenv("WSIS_CSR_COUNTING", counting)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    big = torch.cat([torch.full((9000,), 3, device=DEV), torch.randint(0, 40, (6000,), device=DEV, generator=g)])
+    big = big[torch.randperm(big.numel(), device=DEV, generator=g)]
+    mid = torch.randint(0, 12, (9000,), device=DEV, generator=g)                  # ~750 rows per segment
+    sparse = torch.randint(0, 200000, (150000,), device=DEV, generator=g)         # mostly empty / one-row segments
+    bad = torch.randint(0, 50, (4000,), device=DEV, generator=g)                  # ids below S only are segments
+    pairs = [(big, 40), (mid, 12), (sparse, 200000), (bad, 30), (torch.zeros(1, dtype=torch.int64, device=DEV), 1)]
+    got = segment_csr_batch(pairs)
+    torch.cuda.synchronize()
+    for (index, S), c in zip(pairs, got):
+        assert sorted(c.perm[:c.N].tolist()) == list(range(c.N))      # a permutation of all rows
+        if index is bad:
+            if counting == "1":       # (ids >= S are a caller error: the counting form keeps them behind offsets[S])
+                ok = index < S
+                want = torch.argsort(index[ok], stable=True)
+                rows = torch.nonzero(ok).flatten()[want]
+                n_in = int(ok.sum())
+                assert int(c.offsets[-1]) == n_in and torch.equal(c.perm[:n_in].long(), rows)
+            continue
+        ref = SegmentCSR(index, S)
+        assert torch.equal(c.offsets, ref.offsets)
+        assert torch.equal(c.perm[:c.N], ref.perm[:ref.N])

@@ -3,7 +3,7 @@
 # ranks on the one GPU (per-rank statistics, --sync-bn), and the aten / host trace with and without a process group.
 #   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/dist_lines.sh'
 set -x
-R=${R:-r05}
+R=${R:-r06}
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 WSIS_FORCE_DIST=1 timeout -k 10 240 python bench.py --gpus 1 --steps 40 --warmup 5 --no-cpu-baseline --no-stages > $O/${R}_bench_rccl1.json 2> $O/${R}_bench_rccl1.err

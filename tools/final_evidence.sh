@@ -3,7 +3,7 @@
 # rocprofv3 summaries / timeline / PMC traffic (tools/refresh_profiles.sh), the distributed lines (tools/dist_lines.sh).
 #   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/final_evidence.sh'
 cd $GRAFT_REPO_ROOT
-R=${R:-r05}
+R=${R:-r06}
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${R}_smoke.log 2>&1; tail -1 gpurun_out/${R}_smoke.log
 timeout -k 10 700 python -m pytest tests -m gpu -q > gpurun_out/${R}_gputests_default.log 2>&1; tail -2 gpurun_out/${R}_gputests_default.log
 R=$R bash tools/refresh_profiles.sh > gpurun_out/${R}_refresh.log 2>&1; tail -c 300 gpurun_out/${R}_bench_default.json; echo
