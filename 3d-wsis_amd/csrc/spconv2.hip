@@ -365,8 +365,7 @@ static int spconv_fwd_t_impl(const float* d_X, const int32_t* d_nbr, const int32
   const char* deal_env = tune_env("WSIS_FWD2_DEAL");
   // (wave priorities by step count -- s_setprio 1..3 for waves with many steps, the launch lasts as long as its longest
   // wave -- measured neutral on every level: not kept)
-  const int flip_deal = (flip ? 1 : 0) | (((deal_env ? atoi(deal_env) : 0) != 0 && p.ZS == 1) ? 2 : 0) |
-                        (tune_int("WSIS_FWD2_PRIO", 0) ? 64 : 0);
+  const int flip_deal = (flip ? 1 : 0) | (((deal_env ? atoi(deal_env) : 0) != 0 && p.ZS == 1) ? 2 : 0);
   ProfScope prof(0, st, /*exact_events=*/true);
 #if WSIS_EXPERIMENTAL
   // role-split ring form (spconv3.hip): the levels with many work items

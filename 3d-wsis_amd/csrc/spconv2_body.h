@@ -276,9 +276,6 @@ __device__ __forceinline__ void fwd2_body(
   // ACTIVE offsets round-robin (see the ownership block below)
   const int flip = flip_deal & 1;
   const bool deal_active = (flip_deal & 2) != 0;
-  // bit 6 (round 6 probe, WSIS_FWD2_PRIO): the waves of this product take instruction-arbiter priority 3 -- above the
-  // weight-gradient waves (priority 0) that share their SIMDs on the side stream
-  if (flip_deal & 64) __builtin_amdgcn_s_setprio(3);
   // stats (optional, final pass only): per-slice BatchNorm partials of the FINISHED output rows (bias and residual
   // included), stats[(slice * 2 + {0: sum, 1: sum of squared deviations from the SLICE mean}) * Cout + channel] -- the
   // statistics pass of the BatchNorm that consumes this tensor (sparse_unet3d.py:128-137) without re-reading it.
