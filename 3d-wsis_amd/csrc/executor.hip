@@ -297,6 +297,19 @@ bool dw_batch_reduce_enabled() {
   return (e ? atoi(e) != 0 : false) && !g_prof_on;
 }
 
+// The weight gradient of the LAST op of a pass that has no dIn product of its own (the input convolution: its dY is the
+// final result of the main stream's chain) goes on the CALLER's stream: the main stream has nothing left to run, so the
+// product overlaps the previous layer's weight gradient still running on the side stream instead of queueing behind it
+// -- the tail of a backward pass that nothing hides (one scene: ~55 us of a 7.8 ms step).  Its slabs use the op workspace
+// (free: the op issues nothing else).  WSIS_DW_TAIL_MAIN=0 (read per pass): everything on the side stream.
+bool dw_tail_main_enabled() {
+  const char* e = getenv("WSIS_DW_TAIL_MAIN");
+  return e ? atoi(e) != 0 : true;
+}
+inline bool dw_tail_on_main(const wsis_op* ops, int n, int i) {
+  return i == n - 1 && ops[i].kind == WSIS_OP_CONV_BWD && ops[i].out[1] && !ops[i].out[0];
+}
+
 bool dw_stream_enabled() {   // read per pass: bench.py switches it off for its event-instrumented roofline steps
   const char* e = getenv("WSIS_DW_STREAM");
   return e ? atoi(e) != 0 : true;
@@ -676,8 +689,9 @@ int64_t wsis_run_ops_workspace_bytes(const wsis_op* ops, int32_t n) {
   int64_t need = ALIGN, wt = 0, dw = 0, dw_sum = 0;
   const bool on = fwd2_enabled();
   for (int i = 0; i < n; ++i) {
-    const int64_t b = op_ws_bytes(ops[i], on);
+    int64_t b = op_ws_bytes(ops[i], on);
     if (b < 0) return -1;
+    if (dw_tail_on_main(ops, n, i)) b = std::max(b, dw_ws_of(ops[i]));      // (its slabs live in the op workspace)
     if (b > need) need = b;
     if (needs_wt(ops[i], on)) wt += wt_bytes_of(ops[i]);
     if (ops[i].kind == WSIS_OP_CONV_BWD && ops[i].out[1]) {
@@ -835,6 +849,7 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   // dW region (shared by the dW launches, which are ordered among themselves on one stream)
   // ... or, with deferred slab sums, one region per product: its slabs live until the batched launch that sums them
   const bool dw_defer = dw_batch_reduce_enabled();
+  const bool tail_main = dw_tail_main_enabled();
   int64_t dw_bytes = 0, dw_sum = 0;
   int n_dw = 0;
   for (int i = 0; i < n; ++i)
@@ -1179,7 +1194,14 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
           if (rc != WSIS_OK) break;
         }
       din_done:
-        if (op.out[1]) rc = dw_issue(op);
+        if (op.out[1]) {
+          if (tail_main && side && dw_tail_on_main(ops, n, i)) {
+            // (never deferred: the batched slab sum runs on the side stream, these slabs are written on this one)
+            rc = issue_dw(op, ws, ws_bytes, stream, nullptr);
+          } else {
+            rc = dw_issue(op);
+          }
+        }
         break;
       }
       case WSIS_OP_BN_RELU_BWD:
