@@ -507,8 +507,10 @@ __global__ __launch_bounds__(WGW * 64, 8 / WGW) void spconv_dw2_kernel(const flo
 // the two kernels agree to rounding, each bit-reproducible.
 constexpr int HDR3_INTS = GS * 32 + 64;
 constexpr int HDR3 = HDR3_INTS * 4;
-constexpr int WAVE_LDS3 = 4 * TILE + 256;      // the epilogue adds four accumulators per wave through LDS; the loop uses
-                                               // 2 headers + the dY tile (6.6 KB) at its start
+constexpr int WAVE_LDS3 = 2 * HDR3 + TILE;      // 6.4 KB per wave: two headers + the dY tile; the epilogue adds ONE accumulator
+                                               // per wave at a time through the same bytes (4 KB per wave).  25.6 KB per
+                                               // workgroup against dw2's 77 KB: the dIn items that share the CU from the main
+                                               // stream (37 KB each at levels 1-2, 8.4 KB at level 0) keep their occupancy
 
 template <bool DIAG>
 __global__ __launch_bounds__(WGW * 64, 2) void spconv_dw3_kernel(const float* __restrict__ X, const int32_t* __restrict__ nbrS,
@@ -778,37 +780,36 @@ __global__ __launch_bounds__(WGW * 64, 2) void spconv_dw3_kernel(const float* __
   if (DIAG) t_end_loop = __builtin_readcyclecounter();
   __syncthreads();
 
-  // ---- epilogue: dw2's (four offset slots at a time through LDS, added in wave order, one slab per workgroup)
+  // ---- epilogue: one offset slot at a time through LDS (4 KB per wave), added in wave order, one slab per workgroup
   float* const red = reinterpret_cast<float*>(lds);
   float* const slab = partial + (int64_t)blockIdx.x * K * Cin * Cout;
-  auto put = [&](const f32x16& acc, int q) {
-    float* mine = red + wave * (WAVE_LDS3 / 4) + q * 1024;
+  auto flush1 = [&](const f32x16& acc, int j) {
+    const int k = og + j * NOG;
+    if (k >= K) return;                              // uniform over the workgroup
+    float* mine = red + wave * 1024;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int ci = (reg & 3) + 8 * (reg >> 2) + 4 * half;
       mine[ci * 32 + r31] = acc[reg];
     }
-  };
-  auto flush4 = [&](const f32x16& q0, const f32x16& q1, const f32x16& q2, const f32x16& q3, int jbase) {
-    if (og + jbase * NOG >= K) return;
-    put(q0, 0);
-    put(q1, 1);
-    put(q2, 2);
-    put(q3, 3);
     __syncthreads();
-    for (int e = threadIdx.x; e < 4096; e += WGW * 64) {
-      const int k = og + (jbase + (e >> 10)) * NOG;
-      if (k >= K) break;
+    for (int e = threadIdx.x; e < 1024; e += WGW * 64) {
       float v = red[e];
 #pragma unroll
-      for (int w = 1; w < WGW; ++w) v += red[w * (WAVE_LDS3 / 4) + e];
-      const int ci = (e >> 5) & 31, co = e & 31;
+      for (int w = 1; w < WGW; ++w) v += red[w * 1024 + e];
+      const int ci = e >> 5, co = e & 31;
       if (cb * 32 + co < Cout) slab[((int64_t)k * Cin + c * 32 + ci) * Cout + cb * 32 + co] = v;
     }
     __syncthreads();
   };
-  flush4(acc0, acc1, acc2, acc3, 0);
-  flush4(acc4, acc5, acc6, acc7, 4);
+  flush1(acc0, 0);
+  flush1(acc1, 1);
+  flush1(acc2, 2);
+  flush1(acc3, 3);
+  flush1(acc4, 4);
+  flush1(acc5, 5);
+  flush1(acc6, 6);
+  flush1(acc7, 7);
   if (DIAG && lane == 0) {
     unsigned long long* d = dbg + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * WGW + wave) * 10;
     d[0] = t_start; d[1] = t_loop; d[2] = t_end_loop; d[3] = __builtin_readcyclecounter(); d[4] = n_steps; d[5] = n_slices_done;
@@ -1086,13 +1087,14 @@ bool dw3_fits(int64_t M_in, int Cin) {
   const uint32_t w = (uint32_t)(0xFFFFFFull * p);
   return M_in < (1 << 24) - 1 && (uint64_t)w >= (uint64_t)M_in * p && w <= 0xFFFFFF00u;
 }
-// WSIS_DW3 (read per call): 1 = spconv_dw3_kernel where it fits, 0 (default) = spconv_dw2_kernel everywhere -- measured at
-// parity (profiles/r06_dw3.txt: level 0 76.7 vs 71.4 us, levels 1-3 57.7 / 45.8 / 27.8 vs 58.0 / 46.4 / 29.0; the step
-// 20.40 vs 20.35 ms at four scenes): the loads stretch the MFMA chain by 12 cycles a slot and the slice advance, not
-// the gather, is what a step waits for
+// WSIS_DW3 (read per call): 1 (default) = spconv_dw3_kernel where it fits, 0 = spconv_dw2_kernel everywhere.  Alone on the
+// GPU the two kernels are at parity (profiles/r06_dw3.txt); IN THE STEP the register-gather kernel wins because of what it
+// does not occupy: 26 KB of LDS per workgroup instead of 77 KB -- the dIn items that share its CU from the main stream
+// (37 KB each at levels 1-2, 8.4 KB at level 0) keep their occupancy: 7.77 -> 7.66 ms at one scene, 11.75 -> 11.67 at two,
+// 20.37 -> 20.06 at four (profiles/r06_ab_dw3_lds.txt; with a 66 KB epilogue the same kernel measured 20.40 vs 20.35)
 int dw3_mode() {
   const char* e = getenv("WSIS_DW3");
-  return e ? atoi(e) : 0;
+  return e ? atoi(e) : 1;
 }
 // header table block by ONE 16-byte DMA (both kernels): WSIS_DW_H16 = 1 always (default), 2 only where every table line is
 // 16-byte aligned, 0 never (EXPERIMENTAL build: live)
