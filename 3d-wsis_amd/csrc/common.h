@@ -200,6 +200,7 @@ bool dw2_supported(int K, int Cin, int Cout);
 bool dw2_fits(int64_t M_in, int64_t M_out, int K, int Cin, int Cout);   // 32-bit buffer offsets
 int64_t dw2_workspace_bytes(int64_t M_out, int K, int Cin, int Cout);
 void dw2_set_batch_rows(int64_t rows);      // launch-plan hint of the weight-gradient launches (wsis_hint_batch_rows)
+int64_t dw2_batch_rows();                   // the hint as last set (0: none)
 // Deferred slab sums (the op-list executor, round 6): with a record slot set for the calling thread, dw2_launch /
 // dw2_launch_swapped issue the main kernel only and describe the fixed-order slab sum that finishes the product in the
 // slot; the executor finishes all products of (a part of) a backward pass with ONE dw2_reduce_batch launch -- same

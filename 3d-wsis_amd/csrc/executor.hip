@@ -850,6 +850,13 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   // ... or, with deferred slab sums, one region per product: its slabs live until the batched launch that sums them
   const bool dw_defer = dw_batch_reduce_enabled();
   const bool tail_main = dw_tail_main_enabled();
+  // (measured in-process: 7.69 -> 7.50 ms at one scene per step, 11.70 -> 11.50 at two, 20.11 -> 20.22 at four -- with a
+  // batch that fills the GPU the early product takes from the dIn launch beside it what it gains at the tail; default:
+  // by the batch hint, below WSIS_DW_EARLY_ROWS active voxels)
+  const char* early_env = getenv("WSIS_DW_EARLY");
+  const char* early_rows_env = getenv("WSIS_DW_EARLY_ROWS");
+  const int64_t early_rows = early_rows_env ? atoll(early_rows_env) : 500000;
+  const bool dw_early = early_env ? atoi(early_env) != 0 : dw2_batch_rows() < early_rows;
   int64_t dw_bytes = 0, dw_sum = 0;
   int n_dw = 0;
   for (int i = 0; i < n; ++i)
@@ -1147,6 +1154,16 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
         // in: X, W, dY, nbr_f, order_f, nbr_b, order_b ; out: dX (optional), dW (optional)
         char* rest = ws;
         const int64_t rest_bytes = ws_bytes;
+        // The weight gradient needs X (saved by the forward pass) and dY -- complete once everything enqueued so far has
+        // run -- but NOT this op's own dIn product: forked in front of it (round 6), it starts beside the dIn launch that
+        // reads the same dY instead of behind it, and the side stream runs one product further ahead all the way to the
+        // tail of the pass.  WSIS_DW_EARLY=0 (read per pass): forked behind the dIn launch as before.
+        bool dw_forked = false;
+        if (dw_early && op.out[1] && op.out[0] && side) {
+          rc = dw_issue(op);
+          dw_forked = true;
+          if (rc != WSIS_OK) break;
+        }
         if (op.out[0]) {
           if (wt_off[i] >= 0 && (op.flags & WSIS_OPF_STATS)) {
             rc = fail(WSIS_ERR_ARG, "op %d: BatchNorm partials requested from a dIn pass that is not on wsis_spconv_fwd_t", i);
@@ -1194,7 +1211,7 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
           if (rc != WSIS_OK) break;
         }
       din_done:
-        if (op.out[1]) {
+        if (op.out[1] && !dw_forked) {
           if (tail_main && side && dw_tail_on_main(ops, n, i)) {
             // (never deferred: the batched slab sum runs on the side stream, these slabs are written on this one)
             rc = issue_dw(op, ws, ws_bytes, stream, nullptr);

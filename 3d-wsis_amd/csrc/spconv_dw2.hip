@@ -998,6 +998,7 @@ int64_t dw2_workspace_bytes(int64_t M_out, int K, int Cin, int Cout) {      // (
 }
 
 void dw2_set_batch_rows(int64_t rows) { g_batch_rows.store(rows, std::memory_order_relaxed); }
+int64_t dw2_batch_rows() { return g_batch_rows.load(std::memory_order_relaxed); }
 
 static thread_local DwRedRec* t_defer = nullptr;
 void dw2_set_defer(DwRedRec* slot) { t_defer = slot; }
