@@ -967,6 +967,11 @@ int dw2_P_plan(int64_t M_out, int K, int Cin, int Cout, bool wide) {
   const int NOG = (K + GS - 1) / GS;
   const int64_t combos = (int64_t)NOG * (Cin / 32) * ((Cout + 31) / 32);
   int64_t P = (target / WGW + combos - 1) / combos;
+  // dense products with many output blocks (K = 1: the shared filter weights of the GNN, 32 x 2,080 over 7 x S rows):
+  // the wave target leaves a combination 4 workgroups, i.e. ~30 slices per wave, each a slice advance -- and the launch runs
+  // in the GNN phase of the step, alone on the GPU.  Up to 32 workgroups per combination while a wave keeps >= 4 slices
+  // (in-process: the step 7.471 -> 7.451 ms at one scene, 20.148 -> 20.044 at four; profiles/r06_ab_densewg.txt).
+  if (K == 1) P = std::max(P, std::min<int64_t>(n_slices / (4 * WGW), dw2_env("WSIS_DW2_DENSE_WG", 32)));
   const int64_t cap = (n_slices + WGW - 1) / WGW;
   if (P > cap) P = cap;
   if (P >= 8) P &= ~(int64_t)7;     // multiple of 8: blockIdx.x % 8 is the XCD for every blockIdx.y
