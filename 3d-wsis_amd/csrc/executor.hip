@@ -137,6 +137,7 @@ struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t join = nullptr;
   hipEvent_t mark_main = nullptr, mark_side = nullptr;   // milestone of wsis_run_ops_marked
+  hipEvent_t wt_fork = nullptr, wt_done = nullptr;       // the pass's weight transposes on the side stream (run_ops_impl)
   std::vector<hipEvent_t> fork;
   size_t next = 0;
 };
@@ -154,6 +155,8 @@ SideStream* side_stream_for(hipStream_t main) {
     if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.mark_main, hipEventDisableTiming) != hipSuccess) return nullptr;
     if (hipEventCreateWithFlags(&s.mark_side, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.wt_fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.wt_done, hipEventDisableTiming) != hipSuccess) return nullptr;
   }
   return &s;
 }
@@ -808,13 +811,36 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   const bool on = fwd2_enabled();
   std::vector<int64_t> wt_off(n, -1);
   int64_t wt_total = 0;
+  // The transposes (one launch, 28 us at the top of a forward pass) depend on the weights alone: they go to the library's
+  // side stream behind an event of the caller's stream, and the caller's stream waits for them in front of the first op
+  // that reads a transposed weight -- the 6-channel input convolution and its BatchNorm run meanwhile.
+  // WSIS_WT_SIDE=0 (read per pass): on the caller's stream as before.
+  SideStream* wt_side = nullptr;
+  bool wt_pending = false;
+  {
+    const char* we = getenv("WSIS_WT_SIDE");
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool cap = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    bool any_wt = false, first_needs = n > 0 && needs_wt(ops[0], on);
+    for (int i = 0; i < n && !any_wt; ++i) any_wt = needs_wt(ops[i], on);
+    // (not with the resident deep-level launches of the EXPERIMENTAL build: a run of ops is issued as one launch there)
+    if ((we ? atoi(we) != 0 : true) && dw_stream_enabled() && !cap && any_wt && !first_needs && !g_prof_on &&
+        deep_ws_bytes(ops, n, on) == 0)
+      wt_side = side_stream_for(st);
+    if (wt_side) {
+      hipError_t e = hipEventRecord(wt_side->wt_fork, st);
+      if (e == hipSuccess) e = hipStreamWaitEvent(wt_side->stream, wt_side->wt_fork, 0);
+      if (e != hipSuccess) return fail(WSIS_ERR_HIP, "weight-transpose fork failed: %s", hipGetErrorString(e));
+    }
+  }
+  hipStream_t wt_st = wt_side ? wt_side->stream : st;
   {
     WtBatch b;
     b.n = 0;
     b.start[0] = 0;
     auto flush = [&]() -> int {
       if (b.n == 0) return WSIS_OK;
-      hipLaunchKernelGGL(weight_transpose_batch_kernel, dim3(b.start[b.n]), dim3(256), 0, st, b);
+      hipLaunchKernelGGL(weight_transpose_batch_kernel, dim3(b.start[b.n]), dim3(256), 0, wt_st, b);
       WSIS_LAUNCH_CHECK();
       b.n = 0;
       return WSIS_OK;
@@ -842,6 +868,11 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
     }
     const int rc = flush();
     if (rc != WSIS_OK) return rc;
+    if (wt_side) {
+      const hipError_t e = hipEventRecord(wt_side->wt_done, wt_side->stream);
+      if (e != hipSuccess) return fail(WSIS_ERR_HIP, "weight-transpose event failed: %s", hipGetErrorString(e));
+      wt_pending = true;
+    }
   }
   ws += wt_total;
   ws_bytes -= wt_total;
@@ -972,6 +1003,14 @@ static int run_ops_impl(const wsis_op* ops, int32_t n, void* d_ws, int64_t ws_by
   std::vector<char> bn_unfused(n, 0);     // BatchNorm backward ops whose dIn pass did not write partials this run
   for (int i = 0; i < n; ++i) {
     int rc = WSIS_OK;
+    if (wt_pending && wt_off[i] >= 0) {      // the first reader of a transposed weight
+      wt_pending = false;
+      const hipError_t e = hipStreamWaitEvent(st, wt_side->wt_done, 0);
+      if (e != hipSuccess) {
+        first_err = fail(WSIS_ERR_HIP, "weight-transpose join failed: %s", hipGetErrorString(e));
+        break;
+      }
+    }
 #if WSIS_EXPERIMENTAL
     if (deep_on && deep_op_ok(ops, n, i, on)) {
       const int i1 = deep_run_end(ops, n, i, mark_op >= i ? mark_op : -1, on);
