@@ -683,7 +683,13 @@ int wsis_adamw_step(const void* d_segments, const int32_t* d_blocks, int64_t n_b
  *                M_in = rows of X / dX, M_out = rows of dY     (weight_transpose + wsis_spconv_fwd + wsis_spconv_dw)
  *   BN_RELU_BWD  in: x, dy, mean, var, gamma, beta, addend     out: dx, dgamma, dbeta      (wsis_bn_bwd)
  * BN ops use M_in rows and Cin channels.  d_ws from wsis_run_ops_workspace_bytes (max over the ops); d_sync: a
- * zero-filled block of wsis_sync_bytes() bytes (may be NULL: multi-launch forms). */
+ * zero-filled block of wsis_sync_bytes() bytes (may be NULL: multi-launch forms).
+ * Streams: everything the caller's later work depends on is ordered on `stream` when the call returns.  Work that the
+ * chain of ops does not wait for runs on a library-owned side stream of `stream`, forked and joined with events inside
+ * the call: the weight gradients of CONV_BWD ops (WSIS_DW_STREAM=0: on `stream`; forked in FRONT of their op's dIn launch
+ * below WSIS_DW_EARLY_ROWS active voxels per batch -- they need X and dY, not dX; the weight gradient of a pass's last op
+ * goes on `stream` itself, WSIS_DW_TAIL_MAIN) and the pass's weight transposes (WSIS_WT_SIDE; joined in front of the
+ * first op that reads one).  Same kernels on either stream: the results do not depend on these switches. */
 enum {
   WSIS_OP_CONV = 1, WSIS_OP_BN_RELU = 2, WSIS_OP_CAT = 3, WSIS_OP_SPLIT = 4, WSIS_OP_ADD = 5, WSIS_OP_CONV_BWD = 6,
   WSIS_OP_BN_RELU_BWD = 7

@@ -257,6 +257,40 @@ def test_batched_slab_sums_give_the_bits_of_the_per_product_sums(monkeypatch, dw
     assert [n for n in g0 if not torch.equal(g0[n], g1[n])] == []
 
 
+def test_scheduling_switches_of_the_executor_do_not_change_a_bit(monkeypatch):
+    """round 6: WHEN and on WHICH stream the executor issues a weight gradient (forked in front of its op's dIn launch,
+    the last one of a pass on the caller's stream) and the pass's weight transposes (side stream, joined in front of the
+    first reader) changed; the kernels did not.  Loss and every gradient of two passes are EQUAL with each switch off."""
+    cfg = harness.default_cfg()
+    batch_host = harness.collate([harness.make_scene(s, room=(1.6, 1.3, 1.0), n_box=2) for s in (51, 52)])
+    cfg.batch_size = 2
+
+    def run(env):
+        for k in ("WSIS_DW_EARLY", "WSIS_DW_TAIL_MAIN", "WSIS_WT_SIDE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(0)
+        batch = harness.to_device(batch_host, "cuda")
+        model, crit, opt = harness.build_model(cfg, "cuda")
+        model.train()
+        losses = []
+        for _ in range(2):
+            model.zero_grad(set_to_none=True)
+            loss, _ = harness.forward_loss(model, crit, batch, cfg)
+            loss.backward()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        return losses, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    base_l, base_g = run({})
+    for env in ({"WSIS_DW_EARLY": "0"}, {"WSIS_DW_EARLY": "1"}, {"WSIS_DW_TAIL_MAIN": "0"}, {"WSIS_WT_SIDE": "0"},
+                {"WSIS_DW_EARLY": "0", "WSIS_DW_TAIL_MAIN": "0", "WSIS_WT_SIDE": "0"}):
+        l, g = run(env)
+        assert l == base_l, env
+        assert [n for n in base_g if not torch.equal(base_g[n], g[n])] == [], env
+
+
 def test_training_over_scenes_of_varying_size_is_reproducible():
     """36 optimizer steps cycling over 9 batches of very different sizes (1.8 m room ... 8 m room, one batch of three
     scenes), twice from the same seed: identical loss sequences, no NaN.  Every launch plan, the slice queues of the
