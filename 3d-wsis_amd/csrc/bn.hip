@@ -750,37 +750,54 @@ constexpr int BN_SF_ROWS = 256;      // rows per workgroup (32 rows x 8 float4 l
 __global__ __launch_bounds__(256) void bn_small_finish_apply_kernel(
     const float* __restrict__ partial, int nblk, int C, int64_t M, float* __restrict__ mean, float* __restrict__ var,
     float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, const float* __restrict__ x,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu, float* __restrict__ y) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int relu, float* __restrict__ y, int G) {
   __shared__ double red[3][8][33];
   __shared__ float s_mu[32], s_sc[32], s_bt[32];
   const int cgi = blockIdx.y;
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = cgi * 32 + cl;
-  double s = 0.0, q = 0.0, w = 0.0;
-  if (c < C) {
+  // G chunks of `per` partial rows (round 6: G <= 8, the arithmetic of the two-level reduction: the chunk sums of
+  // bn_chunk_centred_stage -- lane pl walks rows lo + pl, + 8, ..., the eight lane sums added in lane order -- then the
+  // chunk sums added in chunk order, which is what the last-arriving workgroup of that stage does with one chunk per lane)
+  const int per = (nblk + G - 1) / G;
+  double S = 0.0, Q = 0.0, W = 0.0;
+  for (int g = 0; g < G; ++g) {
+    const int lo = g * per;
+    const int hi = lo + per < nblk ? lo + per : nblk;
+    double s = 0.0, q = 0.0, w = 0.0;
+    if (c < C) {
 #pragma unroll 4
-    for (int b = pl; b < nblk; b += 8) {
-      const float sf = partial[(int64_t)b * 2 * C + c];
-      const float qf = partial[(int64_t)b * 2 * C + C + c];
-      const int64_t left = M - (int64_t)b * 32;
-      const double si = sf;
-      s += si;
-      q += qf;
-      w += si * si * (left < 32 ? 1.0 / (double)left : 0.03125);
+      for (int b = lo + pl; b < hi; b += 8) {
+        const float sf = partial[(int64_t)b * 2 * C + c];
+        const float qf = partial[(int64_t)b * 2 * C + C + c];
+        const int64_t left = M - (int64_t)b * 32;
+        const double si = sf;
+        s += si;
+        q += qf;
+        w += si * si * (left < 32 ? 1.0 / (double)left : 0.03125);
+      }
+    }
+    if (g) __syncthreads();            // (the previous chunk's lane sums have been read)
+    red[0][pl][cl] = s;
+    red[1][pl][cl] = q;
+    red[2][pl][cl] = w;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+      double Sg = 0.0, Qg = 0.0, Wg = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {      // fixed order
+        Sg += red[0][j][cl];
+        Qg += red[1][j][cl];
+        Wg += red[2][j][cl];
+      }
+      if (G == 1) {
+        S = Sg; Q = Qg; W = Wg;
+      } else {                           // (0.0 + chunk 0 + chunk 1 + ...: the order of the stage's second level)
+        S += Sg; Q += Qg; W += Wg;
+      }
     }
   }
-  red[0][pl][cl] = s;
-  red[1][pl][cl] = q;
-  red[2][pl][cl] = w;
-  __syncthreads();
   if (pl == 0 && c < C) {
-    double S = 0.0, Q = 0.0, W = 0.0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {      // fixed order
-      S += red[0][j][cl];
-      Q += red[1][j][cl];
-      W += red[2][j][cl];
-    }
     const double n = (double)M;        // (bn_finish_centred)
     const double mu = S / n;
     double v = (Q + (W - n * mu * mu)) / n;
@@ -832,30 +849,44 @@ __global__ __launch_bounds__(256) void bn_small_bwd_finish_apply_kernel(
     const float* __restrict__ partial, int nblk, int C, int64_t M, const float* __restrict__ x,
     const float* __restrict__ dy, const float* __restrict__ mean, const float* __restrict__ var,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ addend, float eps, int relu,
-    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int G) {
   __shared__ double red[2][8][33];
   __shared__ float s_k1[32], s_k2[32];
   const int cgi = blockIdx.y;
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = cgi * 32 + cl;
-  double a = 0.0, b = 0.0;
-  if (c < C) {
+  const int per = (nblk + G - 1) / G;      // (G chunks: the two levels of bn_sum_chunk_stage, see the forward kernel)
+  double A = 0.0, B = 0.0;
+  for (int g = 0; g < G; ++g) {
+    const int lo = g * per;
+    const int hi = lo + per < nblk ? lo + per : nblk;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
 #pragma unroll 4
-    for (int k = pl; k < nblk; k += 8) {
-      a += partial[(int64_t)k * 2 * C + c];
-      b += partial[(int64_t)k * 2 * C + C + c];
+      for (int k = lo + pl; k < hi; k += 8) {
+        a += partial[(int64_t)k * 2 * C + c];
+        b += partial[(int64_t)k * 2 * C + C + c];
+      }
+    }
+    if (g) __syncthreads();
+    red[0][pl][cl] = a;
+    red[1][pl][cl] = b;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+      double Ag = 0.0, Bg = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {      // fixed order
+        Ag += red[0][j][cl];
+        Bg += red[1][j][cl];
+      }
+      if (G == 1) {
+        A = Ag; B = Bg;
+      } else {
+        A += Ag; B += Bg;
+      }
     }
   }
-  red[0][pl][cl] = a;
-  red[1][pl][cl] = b;
-  __syncthreads();
   if (pl == 0 && c < C) {
-    double A = 0.0, B = 0.0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {      // fixed order
-      A += red[0][j][cl];
-      B += red[1][j][cl];
-    }
     const float db = (float)A, dg = (float)B;
     if (blockIdx.x == 0) {
       dbeta[c] = db;
@@ -905,6 +936,16 @@ __global__ __launch_bounds__(256) void bn_small_bwd_finish_apply_kernel(
   }
 }
 
+// chunks up to which a level takes finish + apply as ONE launch in which every workgroup redoes the (chunked) finish of its
+// channel group: G = 1 is round 5's form (rows < 4,096); round 6: up to WSIS_BN_SMALL_G chunks (default 4: rows < ~10,240 --
+// level 2 of a scene, level 3 of four) -- a workgroup re-reads <= 320 partial rows of 32 channels (80 KB from L2) instead
+// of the step paying a launch + a kernel boundary per layer and direction.  Same bits as the two launches (the chunk order
+// of the ticketed second level).  Read per call.
+static int bn_small_gmax() {
+  const char* e = getenv("WSIS_BN_SMALL_G");
+  const int g = e ? atoi(e) : 4;
+  return g < 1 ? 1 : g > 8 ? 8 : g;
+}
 static bool bn_small_fused_on() {      // WSIS_BN_SMALL_FUSED=0 (read per call): the two launches
   const char* e = getenv("WSIS_BN_SMALL_FUSED");
   return !e || atoi(e) != 0;
@@ -1272,11 +1313,12 @@ int wsis_bn_stats_finalize_apply(const float* d_partials, int64_t n_part, int64_
   // the one-launch form needs: a sync slot (tickets + flag), every workgroup resident, vector rows
   const int grid = tickets ? bn_fused_grid(M, C, G * CG) : 0;
   const bool fused = grid > 0;
-  if (G == 1 && (C & 3) == 0 && bn_small_fused_on() && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 &&
-      (reinterpret_cast<uintptr_t>(d_y) & 15) == 0) {      // one chunk: finish + apply without any hand-off
+  if (G <= bn_small_gmax() && (G == 1 || tickets) && (C & 3) == 0 && bn_small_fused_on() &&
+      (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(d_y) & 15) == 0) {      // few chunks: finish + apply without any hand-off
     hipLaunchKernelGGL(bn_small_finish_apply_kernel, dim3((unsigned)ceil_div(M, BN_SF_ROWS), (unsigned)CG), dim3(256), 0,
                        st, d_partials, (int)n_part, (int)C, M, d_mean, d_var, d_running_mean, d_running_var, momentum, d_x,
-                       d_gamma, d_beta, eps, (int)relu, d_y);
+                       d_gamma, d_beta, eps, (int)relu, d_y, G);
     WSIS_LAUNCH_CHECK();
     return WSIS_OK;
   }
@@ -1346,12 +1388,13 @@ int wsis_bn_bwd_from_partials(const float* d_partials, int64_t n_part, const flo
   hipStream_t st = as_stream(stream);
   WSIS_REQUIRE(C <= 512, "more than 512 channels");
   unsigned* tickets = bn_tickets(d_sync);
-  if (d_dx && G == 1 && (C & 3) == 0 && bn_small_fused_on() && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 &&
+  if (d_dx && G <= bn_small_gmax() && (G == 1 || tickets) && (C & 3) == 0 && bn_small_fused_on() &&
+      (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(d_dy) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_dx) & 15) == 0 &&
       (reinterpret_cast<uintptr_t>(d_addend) & 15) == 0) {
     hipLaunchKernelGGL(bn_small_bwd_finish_apply_kernel, dim3((unsigned)ceil_div(M, BN_SF_ROWS), (unsigned)((C + 31) / 32)),
                        dim3(256), 0, st, d_partials, (int)n_part, (int)C, M, d_x, d_dy, d_mean, d_var, d_gamma, d_beta,
-                       d_addend, eps, (int)relu, d_dx, d_dgamma, d_dbeta);
+                       d_addend, eps, (int)relu, d_dx, d_dgamma, d_dbeta, G);
     WSIS_LAUNCH_CHECK();
     return WSIS_OK;
   }

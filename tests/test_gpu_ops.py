@@ -1476,11 +1476,60 @@ def test_fused_batchnorm_launches_on_two_streams_concurrently_do_not_interfere(m
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,C,addend", [(3300, 128, True), (1100, 160, False), (70, 32, True), (344, 160, True)])
+@pytest.mark.parametrize("M,C", [(3300, 128), (344, 160), (70, 32), (4100, 32), (6572, 96), (9000, 128), (10007, 64), (10240, 32)])
+def test_small_level_batchnorm_forward_finish_and_apply_in_one_launch(M, C, monkeypatch):
+    """wsis_bn_stats_finalize_apply on levels of up to four chunks of slice partials (bn_small_finish_apply_kernel: every
+    workgroup redoes the chunked finish of its channel group, then applies) against the two launches
+    (WSIS_BN_SMALL_FUSED=0: ticketed chunk stage + apply pass): mean, var, running statistics and y bit for bit, and
+    y against torch; 10,240 rows = five chunks: the two launches either way"""
+    import wsis_native as _n
+    lib = _n.hip()
+    g = torch.Generator(device=DEV).manual_seed(M + 3 * C)
+    x = torch.randn(M, C, device=DEV, generator=g) * 1.7 + 0.3
+    gamma, beta = torch.rand(C, device=DEV, generator=g) + 0.5, torch.randn(C, device=DEV, generator=g)
+    n_part = (M + 31) // 32
+    pad = n_part * 32 - M
+    xp = torch.cat([x, torch.zeros(pad, C, device=DEV)]) if pad else x
+    blocks = xp.view(n_part, 32, C)
+    cnt = torch.full((n_part, 1), 32.0, device=DEV)
+    cnt[-1] = 32 - pad
+    sm = blocks.sum(1)
+    mask = (torch.arange(n_part * 32, device=DEV) < M).view(n_part, 32, 1).float()
+    q = (((blocks - (sm / cnt).unsqueeze(1)) * mask) ** 2).sum(1)
+    partial = torch.stack([sm, q], 1).contiguous()
+    ws_bytes = lib.wsis_bn_stats_finalize_workspace_bytes(n_part, C)
+
+    def run():
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+        mean, var = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        y = torch.empty_like(x)
+        _n.check(lib.wsis_bn_stats_finalize_apply(_n.ptr(partial), n_part, M, C, _n.ptr(mean), _n.ptr(var), _n.ptr(rm),
+                                                  _n.ptr(rv), 0.1, _n.ptr(x), _n.ptr(gamma), _n.ptr(beta), 1e-4, 1,
+                                                  _n.ptr(y), _n.ptr(ws), ws_bytes, _n.ptr(_n.sync_block()), _n.stream_ptr()),
+                 "finalize_apply")
+        torch.cuda.synchronize()
+        return mean, var, rm, rv, y
+
+    one = run()
+    again = run()
+    monkeypatch.setenv("WSIS_BN_SMALL_FUSED", "0")
+    two = run()
+    for a, b, c in zip(one, again, two):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    want = torch.relu(torch.nn.functional.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-4))
+    assert torch.allclose(one[4], want, rtol=1e-4, atol=1e-4)
+    assert not _n.sync_block()[:64 * 4096].any(), "every launch must leave its sync slot zero"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,C,addend", [(3300, 128, True), (1100, 160, False), (70, 32, True), (344, 160, True),
+                                        (6572, 96, True), (9000, 128, False), (10007, 64, True), (4100, 32, False)])
 def test_small_level_batchnorm_backward_finish_and_apply_in_one_launch(M, C, addend, monkeypatch):
-    """fewer than 4,096 rows (one chunk of slice partials): wsis_bn_bwd_from_partials runs the reduction finish and the
-    apply pass as ONE launch without any hand-off between workgroups (bn_small_bwd_finish_apply_kernel) -- dx, dgamma,
-    dbeta bit for bit equal to the two launches (WSIS_BN_SMALL_FUSED=0), and dx equal to autograd through BatchNorm+ReLU"""
+    """up to four chunks of slice partials (fewer than ~10,240 rows; round 5: one chunk, 4,096 rows): wsis_bn_bwd_from_partials
+    runs the reduction finish and the apply pass as ONE launch without any hand-off between workgroups
+    (bn_small_bwd_finish_apply_kernel: every workgroup redoes the chunked finish of its channel group) -- dx, dgamma, dbeta
+    bit for bit equal to the two launches (WSIS_BN_SMALL_FUSED=0), and dx equal to autograd through BatchNorm+ReLU"""
     import wsis_native as _n
     lib = _n.hip()
     g = torch.Generator(device=DEV).manual_seed(M * 7 + C)
