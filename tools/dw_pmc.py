@@ -6,7 +6,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--parse":
     acc = {}
     for f in glob.glob(os.path.join(sys.argv[2], "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            for kn in ("spconv_dw2_kernel", "dw2_reduce_kernel"):
+            for kn in ("spconv_dw3_kernel", "spconv_dw2_kernel", "dw2_reduce_kernel"):
                 if kn in r["Kernel_Name"]:
                     acc.setdefault((kn, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     for k, v in sorted(acc.items()):
