@@ -540,10 +540,12 @@ __global__ __launch_bounds__(WGW * 64, 2) void spconv_dw3_kernel(const float* __
   const int64_t stride = (int64_t)gridDim.x * WGW;
   const int64_t first = (int64_t)blockIdx.x * WGW + wave;
   const int64_t n_pos = n_slices;
-  auto slice_of = [&](int64_t pos) -> int64_t {      // (dw2's snake over full rounds of `stride`)
-    const int64_t n = pos / stride;
-    if ((n & 1) && (n + 1) * stride <= n_pos) return n * stride + (stride - 1 - (pos - n * stride));
-    return pos;
+  // dw2's snake over full rounds of `stride`, by ROUND: this worker's position in round r is first + r * stride, so the
+  // round of a position never has to be divided out (a 64-bit division per call -- two per slice advance -- was ~500 of
+  // the ~3,000 cycles an advance costs: profiles/r06_dw3_advance_probe.txt)
+  auto slice_at = [&](int64_t r) -> int64_t {
+    if ((r & 1) && (r + 1) * stride <= n_pos) return r * stride + (stride - 1 - first);
+    return first + r * stride;
   };
 
   f32x16 acc0, acc1, acc2, acc3, acc4, acc5, acc6, acc7;
@@ -606,10 +608,10 @@ __global__ __launch_bounds__(WGW * 64, 2) void spconv_dw3_kernel(const float* __
     b |= b >> 4;
     b |= b >> 2;
     b |= b >> 1;
-    uint32_t m = 0u;
-#pragma unroll
-    for (int j = 0; j < GS; ++j) m |= (uint32_t)((b >> (8 * j)) & 1ull) << j;
-    return m;
+    // bit 8j of b = slot j has a pair; the eight bits gathered into one byte by a multiplication (bit 8j x bit 7(8 - j)
+    // lands on bit 56 + j, all 64 partial products on distinct bits: no carries)
+    static_assert(GS == 8, "the gather below is for eight slots");
+    return (uint32_t)(((b & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
   };
   const uint32_t y_ok_mask = y_piece_ok ? 0xffffffffu : 0u;
   auto issueB = [&](const int32_t* hb, unsigned char* dst) {
@@ -662,8 +664,8 @@ __global__ __launch_bounds__(WGW * 64, 2) void spconv_dw3_kernel(const float* __
   for (int s = 0; s < 16; ++s) a[s] = bfr[s] = 0.0f;
 
   if (first < n_pos) {
-    int64_t g_pos = first;
-    int64_t g_slice = slice_of(g_pos);
+    int64_t g_pos = first, g_round = 0;
+    int64_t g_slice = slice_at(g_round);
     uint32_t c_mask = 0u;
     for (;;) {      // first slice with work for this worker, loaded synchronously
       issueH(g_slice, hdr0);
@@ -673,12 +675,12 @@ __global__ __launch_bounds__(WGW * 64, 2) void spconv_dw3_kernel(const float* __
       if (c_mask || g_pos + stride >= n_pos) break;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       g_pos += stride;
-      g_slice = slice_of(g_pos);
+      g_slice = slice_at(++g_round);
     }
     if (c_mask) {
       int hb = 0;                                        // header buffer of the slice whose tiles are being issued
       bool has_next = g_pos + stride < n_pos;            // a header for the position after it is in flight / has landed
-      if (has_next) issueH(slice_of(g_pos + stride), hdr0 + HDR3_INTS);
+      if (has_next) issueH(slice_at(g_round + 1), hdr0 + HDR3_INTS);
       issueB(hdr0, Bt);
       uint32_t g_rem = c_mask & (c_mask - 1u);           // slots of that slice not yet handed out
       uint32_t mask_next = 0u;
@@ -718,13 +720,13 @@ __global__ __launch_bounds__(WGW * 64, 2) void spconv_dw3_kernel(const float* __
           asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");      // (dY fragments in registers before Bt is reused)
           int32_t* const hn = hdr0 + (hb ^ 1) * HDR3_INTS;
           g_pos += stride;
-          g_slice = slice_of(g_pos);
+          g_slice = slice_at(++g_round);
           fix_tail(hn, g_slice);
           uint32_t m = readmask(hn);
           while (m == 0u && g_pos + stride < n_pos) {             // rare: a slice without pairs for this worker
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             g_pos += stride;
-            g_slice = slice_of(g_pos);
+            g_slice = slice_at(++g_round);
             issueH(g_slice, hn);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             fix_tail(hn, g_slice);
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(WGW * 64, 2) void spconv_dw3_kernel(const float* __
             has_next = g_pos + stride < n_pos;
             if (has_next) {
               asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-              issueH(slice_of(g_pos + stride), hdr0 + hb * HDR3_INTS);      // into the header the finished slice leaves
+              issueH(slice_at(g_round + 1), hdr0 + hb * HDR3_INTS);      // into the header the finished slice leaves
             }
             issueB(hn, Bt);
             hb ^= 1;
