@@ -517,12 +517,14 @@ __global__ __launch_bounds__(WGW * 64, 2) void spconv_dw3_kernel(const float* __
                                                                  const int32_t* __restrict__ order,
                                                                  const float* __restrict__ dY, float* __restrict__ partial,
                                                                  int64_t M_in, int64_t M_out, int K, int Cin, int Cout, int NOG,
-                                                                 int h16, unsigned long long* dbg) {
+                                                                 int flags, unsigned long long* dbg) {
   unsigned long long t_start = 0, t_loop = 0, t_end_loop = 0;
   unsigned n_steps = 0, n_slices_done = 0;
   unsigned long long d_wait = 0, d_top = 0, d_chain = 0, d_bot = 0, t_prev = 0;
   if (DIAG) t_start = __builtin_readcyclecounter();
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int h16 = flags & 1;                 // header table block by one 16-byte DMA
+  const bool balanced = (flags & 2) != 0;    // offset groups of a 3 x 3 x 3 product balanced by activity (below)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r31 = lane & 31, half = lane >> 5;
@@ -536,6 +538,24 @@ __global__ __launch_bounds__(WGW * 64, 2) void spconv_dw3_kernel(const float* __
   combo /= nblk;
   const int c = combo % nchunk;
   const int og = combo / nchunk;
+  // offset of slot j of this workgroup's offset group.  3 x 3 x 3: a partition balanced by ACTIVITY -- every slice has its
+  // centre offset, ~70 % of the slices a given face offset, ~40 % an edge offset, ~5 % (level 0) a corner offset, and an
+  // axis-aligned surface has exactly centre + 4 faces + 4 edges.  Grouped by k mod 4 (rounds 2-6) the group of the centre
+  // held six edge offsets as well: 1.29 x the mean number of steps at level 0 (1.24 / 1.17 at levels 1 / 2) and the launch
+  // lasts as long as its busiest workgroups.  This partition (centre + 1 face + 2 edges + 3 corners | 6 edges + 1 corner |
+  // 2 faces + 3 edges + 1 corner | 3 faces + 1 edge + 3 corners; no group takes more than 3 of the 9 offsets of an axis
+  // plane) is within 1.03 x of the mean on the measured and on the class-symmetrised activity of levels 0-3
+  // (tools/dw_balance.py, profiles/r06_dw_balance.txt).  Which workgroup owns an offset does not enter the arithmetic: the
+  // slices a wave walks and the slab order are those of before, the result is the same bit for bit.  Other kernel sizes
+  // (and WSIS_DW_BAL=0 in the EXPERIMENTAL build): slot j = offset og + j * NOG.
+  const unsigned long long ktab =
+      !(K == 27 && balanced) ? 0ull
+      : og == 0 ? 0xff1a13110d0c0602ull      //  2  6 12 13 17 19 26
+      : og == 1 ? 0xff17150b07050100ull      //  0  1  5  7 11 21 23
+      : og == 2 ? 0xffff19140f0a0403ull      //  3  4 10 15 20 25
+                : 0xff181612100e0908ull;     //  8  9 14 16 18 22 24
+  auto kof = [&](int j) -> int { return ktab ? (int)((ktab >> (8 * j)) & 0xffull) : og + j * NOG; };
+  const int k_first = kof(0);
   const int64_t n_slices = (M_out + 31) >> 5;
   const int64_t stride = (int64_t)gridDim.x * WGW;
   const int64_t first = (int64_t)blockIdx.x * WGW + wave;
@@ -579,14 +599,14 @@ __global__ __launch_bounds__(WGW * 64, 2) void spconv_dw3_kernel(const float* __
     uint32_t t = (uint32_t)s * 32u + (uint32_t)r31;
     t = t < m_last ? t : m_last;
     if (h16) {
-      int k = og + (lane >> 3) * NOG;
-      k = k < K ? k : og;
+      int k = kof(lane >> 3);
+      k = k < K ? k : k_first;
       bdma16(rsN, ((uint32_t)k * (uint32_t)M_out + (uint32_t)s * 32u + (uint32_t)(lane & 7) * 4u) * 4u, hb);
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        int k = og + (2 * q + half) * NOG;
-        k = k < K ? k : og;
+        int k = kof(2 * q + half);
+        k = k < K ? k : k_first;
         bdma4(rsN, ((uint32_t)k * (uint32_t)M_out + t) * 4u, hb + q * 64);
       }
     }
@@ -603,7 +623,7 @@ __global__ __launch_bounds__(WGW * 64, 2) void spconv_dw3_kernel(const float* __
   };
   auto readmask = [&](const int32_t* hb) -> uint32_t {
     const int4 v = *reinterpret_cast<const int4*>(hb + lane * 4);
-    const bool any = (og + (lane >> 3) * NOG < K) & ((v.x & v.y & v.z & v.w) >= 0);
+    const bool any = (kof(lane >> 3) < K) & ((v.x & v.y & v.z & v.w) >= 0);
     unsigned long long b = __ballot(any);
     b |= b >> 4;
     b |= b >> 2;
@@ -786,7 +806,7 @@ __global__ __launch_bounds__(WGW * 64, 2) void spconv_dw3_kernel(const float* __
   float* const red = reinterpret_cast<float*>(lds);
   float* const slab = partial + (int64_t)blockIdx.x * K * Cin * Cout;
   auto flush1 = [&](const f32x16& acc, int j) {
-    const int k = og + j * NOG;
+    const int k = kof(j);
     if (k >= K) return;                              // uniform over the workgroup
     float* mine = red + wave * 1024;
 #pragma unroll
@@ -969,6 +989,11 @@ int dw2_P_plan(int64_t M_out, int K, int Cin, int Cout, bool wide) {
   const int NOG = (K + GS - 1) / GS;
   const int64_t combos = (int64_t)NOG * (Cin / 32) * ((Cout + 31) / 32);
   int64_t P = (target / WGW + combos - 1) / combos;
+  // where rounding up overshoots the workgroup target (36 combinations at 96 channels: 8 x 36 = 288 workgroups for 256
+  // CUs -- 32 CUs take two, and the launch lasts as long as those), round down instead (7 x 36 = 252: one workgroup per
+  // CU): level 2 46.3 -> 42.8 us, level 4 23.5 -> 21.0 alone; with the balanced offset groups the one-scene step
+  // 7.458 -> 7.438 ms in-process (profiles/r06_dw_bal2.txt).  WSIS_DW2_PFLOOR=0 (EXPERIMENTAL build): round up
+  if (dw2_env("WSIS_DW2_PFLOOR", 1) && K != 1 && P * combos > target / WGW && P > 1) --P;
   // dense products with many output blocks (K = 1: the shared filter weights of the GNN, 32 x 2,080 over 7 x S rows):
   // the wave target leaves a combination 4 workgroups, i.e. ~30 slices per wave, each a slice advance -- and the launch runs
   // in the GNN phase of the step, alone on the GPU.  Up to 32 workgroups per combination while a wave keeps >= 4 slices
@@ -1110,6 +1135,7 @@ bool dw3_h16(int64_t M_out) {
   const int m = dw2_env("WSIS_DW_H16", 1);
   return m == 1 || (m == 2 && (M_out & 3) == 0);
 }
+int dw3_flags(int64_t M_out) { return (dw3_h16(M_out) ? 1 : 0) | (dw2_env("WSIS_DW_BAL", 1) ? 2 : 0); }
 
 int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, const float* d_dY, float* d_dW,
                int64_t M_in, int64_t M_out, int K, int Cin, int Cout, void* d_ws, hipStream_t st) {
@@ -1127,7 +1153,7 @@ int dw2_launch(const float* d_X, const int32_t* d_nbr, const int32_t* d_order, c
     }
     ProfScope prof(1, st);
     hipLaunchKernelGGL((spconv_dw3_kernel<false>), grid, dim3(WGW * 64), ldsb3, st, d_X, d_nbr, d_order, d_dY, partial, M_in,
-                       M_out, K, Cin, Cout, NOG, dw3_h16(M_out) ? 1 : 0, (unsigned long long*)nullptr);
+                       M_out, K, Cin, Cout, NOG, dw3_flags(M_out), (unsigned long long*)nullptr);
     prof.stop();
     WSIS_LAUNCH_CHECK();
     const int64_t total4 = (int64_t)K * Cin * Cout / 4;
@@ -1202,7 +1228,7 @@ extern "C" int wsis_debug_dw2_diag(const void* d_X, const void* d_nbr, const voi
     hipLaunchKernelGGL((spconv_dw3_kernel<true>), grid, dim3(WGW * 64), ldsb3, wsis::as_stream(stream),
                        static_cast<const float*>(d_X), static_cast<const int32_t*>(d_nbr),
                        static_cast<const int32_t*>(d_order), static_cast<const float*>(d_dY), static_cast<float*>(d_ws),
-                       M_in, M_out, K, Cin, Cout, NOG, wsis::dw3_h16(M_out) ? 1 : 0, static_cast<unsigned long long*>(d_dbg));
+                       M_in, M_out, K, Cin, Cout, NOG, wsis::dw3_flags(M_out), static_cast<unsigned long long*>(d_dbg));
     WSIS_LAUNCH_CHECK();
     return WSIS_OK;
   }

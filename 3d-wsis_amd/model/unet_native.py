@@ -836,7 +836,7 @@ _EXPERIMENTAL_SWITCHES = ("WSIS_DEEP", "WSIS_FWD2P", "WSIS_RING", "WSIS_GRAPH", 
 # to their measured defaults in the default library (tests/test_abi.py keeps this list equal to the sources)
 TUNE_KNOBS = (
     "WSIS_BN_APPLY_PT", "WSIS_BN_FUSED_GRID", "WSIS_BN_TICKET", "WSIS_DW2", "WSIS_DW2_HI", "WSIS_DW2_LO",
-    "WSIS_DW2_WAVES", "WSIS_DW2_XCD", "WSIS_DW2_XSH", "WSIS_DW2_DENSE_WG", "WSIS_DW2_RED", "WSIS_DW_H16", "WSIS_DW_DIV", "WSIS_DW_THREAD", "WSIS_FWD2P_MIN",
+    "WSIS_DW2_WAVES", "WSIS_DW2_XCD", "WSIS_DW2_XSH", "WSIS_DW2_DENSE_WG", "WSIS_DW2_RED", "WSIS_DW2_PFLOOR", "WSIS_DW_BAL", "WSIS_DW_H16", "WSIS_DW_DIV", "WSIS_DW_THREAD", "WSIS_FWD2P_MIN",
     "WSIS_FWD2_BD", "WSIS_FWD2_DA_NW4", "WSIS_FWD2_DEAL", "WSIS_FWD2_NOSLAB", "WSIS_FWD2_NW", "WSIS_FWD2_NW_MAX",
     "WSIS_FWD2_NW_MAX_NOSLAB", "WSIS_FWD2_RG", "WSIS_FWD2_RGH", "WSIS_FWD2_RGH_LATE", "WSIS_FWD2_SNAKE",
     "WSIS_FWD2_TR", "WSIS_FWD2_TR_DA", "WSIS_FWD2_WAVES", "WSIS_FWD2_XCD", "WSIS_FWD2_ZS", "WSIS_FWD_NB_SMALL",

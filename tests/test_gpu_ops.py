@@ -195,6 +195,21 @@ def test_register_gather_weight_gradient_kernel(monkeypatch, kind, cin, cout, sh
     assert g1.shape == a.shape
 
 
+@pytest.mark.experimental
+@pytest.mark.parametrize("cin,cout,shape", [(32, 32, (24, 21, 12)), (96, 96, (23, 19, 9)), (64, 32, (12, 11, 10))])
+def test_offset_groups_of_the_weight_gradient_kernel_do_not_enter_the_arithmetic(monkeypatch, cin, cout, shape):
+    """round 6: which workgroup owns which of the 27 offsets (grouped by index, WSIS_DW_BAL=0, or the activity-balanced
+    partition, the default) and how many slabs a product is split into by the round-down rule (WSIS_DW2_PFLOOR) change
+    the schedule only: with the same slab count the weight gradient is the same bit for bit"""
+    grads = {}
+    for bal in ("0", "1"):
+        monkeypatch.setenv("WSIS_DW_BAL", bal)
+        monkeypatch.setenv("WSIS_DW2_PFLOOR", "0")
+        _, inp, mod = _conv_case("subm", cin, cout, shape, 0.3, 31)
+        grads[bal] = mod.weight.grad.clone()
+    assert torch.equal(grads["0"], grads["1"])
+
+
 @pytest.mark.parametrize("cin,cout", [(64, 32), (256, 128), (192, 96)])
 def test_1x1_conv(cin, cout):
     _conv_case("subm1", cin, cout, (10, 10, 10), 0.3, 24)
