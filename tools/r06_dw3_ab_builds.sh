@@ -1,3 +1,4 @@
+# (needs the build under test as libwsis_hip_new.so and the build before it as libwsis_hip_old.so beside libwsis_hip.so)
 # dw3 with the activity-balanced offset partition (new) against the build before it (old): two default-flavour libraries swapped
 # between runs on one box.  Values (fp64 tests), per-layer times alone, the step at one and four scenes (A B A B).
 cd $GRAFT_REPO_ROOT

@@ -1,3 +1,4 @@
+# (needs EBATCH = 16 in csrc/ecc.hip built as libwsis_hip_new.so and the committed build as libwsis_hip_old.so)
 # in-edges staged per trip of the ECC contraction kernels: 8 (old build) against 16 (new build), two default-flavour
 # libraries swapped on one box: kernel times (tools/ecc_bench.py), the GNN tests, the step
 cd $GRAFT_REPO_ROOT

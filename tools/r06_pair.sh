@@ -1,3 +1,4 @@
+# (needs profiles/r06_pair_kernel.patch applied: the paired launch was measured and not kept)
 # Paired launch of the one-wave level-0 items (WSIS_FWD2_PAIR; EXPERIMENTAL build: the knob is live): per layer, bit
 # identity, then the step in-process
 cd $GRAFT_REPO_ROOT
